@@ -1,0 +1,19 @@
+"""galah_amd -- MI355X-native finch-precluster / ANI hot path of wwood/galah.
+
+Host-side mirror of the reference's plugin interface for this path:
+  FinchPreclusterer            <- src/finch.rs (PreclusterDistanceFinder)
+  HipAniClusterer              <- src/skani.rs SkaniClusterer (ClusterDistanceFinder)
+  SortedPairGenomeDistanceCache<- src/sorted_pair_genome_distance_cache.rs
+  cluster                      <- src/clusterer.rs::cluster
+Everything computes in libgalah_hip.so (include/galah_hip.h); importing the package does not
+load the library, using it does -- and raises if the HIP extension has not been built.
+"""
+from .cache import SortedPairGenomeDistanceCache
+from .engine import Context, cluster_pairs, device_count
+from .finch import FinchPreclusterer, distances
+from .ani import HipAniClusterer
+from .clusterer import cluster
+from ._lib import GalahHipError, PAIR_DTYPE
+
+__all__ = ["SortedPairGenomeDistanceCache", "Context", "cluster_pairs", "device_count", "FinchPreclusterer",
+           "distances", "HipAniClusterer", "cluster", "GalahHipError", "PAIR_DTYPE"]

@@ -1,0 +1,97 @@
+"""ctypes binding of the C-ABI drop-in library libgalah_hip.so (include/galah_hip.h).
+
+Fails loudly when the HIP extension is missing: there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgalah_hip.so")
+
+PAIR_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("common", "<u4"), ("total", "<u4"), ("ani", "<f4")])
+
+GHIP_OK = 0
+ERROR_NAMES = {1: "GHIP_EINVAL", 2: "GHIP_EIO", 3: "GHIP_EHIP", 4: "GHIP_ENOMEM", 5: "GHIP_EUNSUPPORTED"}
+
+ANI_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
+
+
+class GalahHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+# every symbol include/galah_hip.h declares: (restype, argtypes)
+_vp, _sz, _u32, _u64, _f32, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_float, C.c_int
+_pp = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "ghip_abi_version": (_int, []),
+    "ghip_device_count": (_int, []),
+    "ghip_init": (_int, [_int, _pp]),
+    "ghip_destroy": (None, [_vp]),
+    "ghip_last_error": (C.c_char_p, [_vp]),
+    "ghip_set_stream": (_int, [_vp, _vp]),
+    "ghip_synchronize": (_int, [_vp]),
+    "ghip_profile_enable": (_int, [_vp, _int]),
+    "ghip_profile_reset": (_int, [_vp]),
+    "ghip_kernel_stats": (_int, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "ghip_genomes_from_files": (_int, [_vp, C.POINTER(C.c_char_p), _sz, _int, _pp]),
+    "ghip_genomes_from_host": (_int, [_vp, _vp, _vp, _sz, _pp]),
+    "ghip_genomes_synthetic": (_int, [_vp, _u64, _u32, _u32, _u64, C.c_double, _pp]),
+    "ghip_genomes_count": (_sz, [_vp]),
+    "ghip_genomes_total_bases": (_u64, [_vp]),
+    "ghip_genomes_length": (_u64, [_vp, _sz]),
+    "ghip_genomes_to_host": (_int, [_vp, _vp, _sz, _vp]),
+    "ghip_genomes_free": (None, [_vp]),
+    "ghip_sketch_genomes": (_int, [_vp, _vp, _u32, _u32, _u64, _pp]),
+    "ghip_sketch_files": (_int, [_vp, C.POINTER(C.c_char_p), _sz, _u32, _u32, _u64, _int, _pp]),
+    "ghip_sketches_from_host": (_int, [_vp, _vp, _vp, _sz, _u32, _u32, _pp]),
+    "ghip_sketches_wrap_device": (_int, [_vp, _vp, _vp, _sz, _u32, _u32, _pp]),
+    "ghip_sketches_to_host": (_int, [_vp, _vp, _vp, _vp]),
+    "ghip_sketches_count": (_sz, [_vp]),
+    "ghip_sketches_size": (_u32, [_vp]),
+    "ghip_sketches_kmer": (_u32, [_vp]),
+    "ghip_sketches_device_hashes": (_vp, [_vp]),
+    "ghip_sketches_device_lens": (_vp, [_vp]),
+    "ghip_sketches_free": (None, [_vp]),
+    "ghip_precluster": (_int, [_vp, _vp, _f32, _pp, C.POINTER(_sz)]),
+    "ghip_precluster_shard": (_int, [_vp, _vp, _f32, _u32, _u32, _pp, C.POINTER(_sz)]),
+    "ghip_last_pairs_compared": (_u64, [_vp]),
+    "ghip_ani_index_build": (_int, [_vp, _vp, _u32, _u32, _u32, _pp]),
+    "ghip_ani_pairs": (_int, [_vp, _vp, _vp, _sz, _f32, _vp, _vp]),
+    "ghip_ani_index_free": (None, [_vp]),
+    "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
+    "ghip_free": (None, [_vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgalah_hip.so; raise (never fall back) when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C galah_amd/csrc). "
+            "galah_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError if the library does not export it
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int, ctx_handle=None):
+    if rc != GHIP_OK:
+        msg = lib().ghip_last_error(ctx_handle)
+        raise GalahHipError(rc, msg.decode() if msg else "")

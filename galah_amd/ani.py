@@ -1,0 +1,75 @@
+"""ClusterDistanceFinder mirror for the batched GPU ANI stage.
+
+Mirrors SkaniClusterer (reference src/skani.rs:689-716): initialise() asserts a percent
+threshold, calculate_ani(fasta1, fasta2) -> Some(percent f32) with 0.0 below the aligned-fraction
+gate.  Instead of one `skani dist` subprocess per pair (src/skani.rs:718-788) the genomes are
+sketched once into an HBM-resident FracMinHash index and pairs are answered in batches.
+The estimator is build-defined; skani parity is unpinned (DESIGN.md "ANI").
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .engine import AniIndex, Context
+
+ANI_K = 15
+ANI_CHUNK = 20000
+
+
+class HipAniClusterer:
+    def __init__(self, threshold: float, min_aligned_threshold: float = 0.15, small_genomes: bool = False,
+                 ctx: Optional[Context] = None, io_threads: int = 1):
+        self.threshold = np.float32(threshold)                       # percent (skani.rs:203-209)
+        self.min_aligned_threshold = np.float32(min_aligned_threshold)  # fraction (skani.rs:734: * 100 for the CLI)
+        self.small_genomes = small_genomes
+        self._ctx = ctx
+        self.io_threads = io_threads
+        self._index: Optional[AniIndex] = None
+        self._genomes = None
+        self._path_index: Dict[str, int] = {}
+
+    @property
+    def seed_compression(self) -> int:
+        return 30 if self.small_genomes else 125  # skani --small-genomes ~ -c 30
+
+    def _context(self) -> Context:
+        if self._ctx is None:
+            self._ctx = Context(0)
+        return self._ctx
+
+    def initialise(self) -> None:
+        assert self.threshold > 1.0  # skani.rs:696-698
+
+    def method_name(self) -> str:
+        return "hipani"
+
+    def get_ani_threshold(self) -> np.float32:
+        return self.threshold
+
+    # ---- batched interface used by galah_amd.clusterer.cluster
+    def prepare(self, genome_fasta_paths: Sequence[str]) -> None:
+        ctx = self._context()
+        if self._index is not None:
+            self._index.free()
+        self._genomes = ctx.genomes_from_files(list(genome_fasta_paths), self.io_threads)
+        self._index = ctx.ani_index_build(self._genomes, ANI_K, self.seed_compression, ANI_CHUNK)
+        self._path_index = {p: i for i, p in enumerate(genome_fasta_paths)}
+
+    def prepare_from_genomes(self, genomes, names: Optional[Sequence[str]] = None) -> None:
+        ctx = self._context()
+        self._genomes = genomes
+        self._index = ctx.ani_index_build(genomes, ANI_K, self.seed_compression, ANI_CHUNK)
+        self._path_index = {p: i for i, p in enumerate(names)} if names is not None else {}
+
+    def calculate_ani_indices(self, pairs: np.ndarray) -> np.ndarray:
+        assert self._index is not None, "call prepare() first"
+        return self._context().ani_pairs(self._index, pairs, float(self.min_aligned_threshold))
+
+    # ---- the trait method
+    def calculate_ani(self, fasta1: str, fasta2: str) -> Optional[np.float32]:
+        if fasta1 not in self._path_index or fasta2 not in self._path_index:
+            self.prepare(list(dict.fromkeys(list(self._path_index) + [fasta1, fasta2])))
+        pair = np.array([[self._path_index[fasta1], self._path_index[fasta2]]], dtype=np.uint32)
+        return np.float32(self.calculate_ani_indices(pair)[0])  # always Some(..) (skani.rs:709)

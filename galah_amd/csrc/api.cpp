@@ -1,0 +1,657 @@
+// C-ABI of libgalah_hip.so (include/galah_hip.h): context, ingest, sketch, precluster, ANI.
+// Host orchestration only -- all data-parallel work is in sketch.hip / pairs.hip / ani.hip.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "ghip_internal.h"
+
+int ghip_read_fasta_streams(const char *const *paths, size_t n, int threads,
+                            std::vector<std::vector<uint8_t>> &streams, std::string &err);
+
+static thread_local std::string g_init_error;
+
+int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_init_error = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------ profiling
+static void drain_events(ghip_ctx *ctx) {
+    for (auto &pe : ctx->pending) {
+        hipEventSynchronize(pe.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+            auto &st = ctx->stats[pe.name];
+            st.launches++;
+            st.total_ms += ms;
+        }
+        hipEventDestroy(pe.start);
+        hipEventDestroy(pe.stop);
+    }
+    ctx->pending.clear();
+}
+
+void ghip_prof_begin(ghip_ctx *ctx, const char *name) {
+    if (!ctx->profile) return;
+    ghip_pending_event pe;
+    pe.name = name;
+    hipEventCreate(&pe.start);
+    hipEventCreate(&pe.stop);
+    hipEventRecord(pe.start, ctx->stream);
+    ctx->pending.push_back(pe);
+}
+
+void ghip_prof_end(ghip_ctx *ctx) {
+    if (!ctx->profile || ctx->pending.empty()) return;
+    hipEventRecord(ctx->pending.back().stop, ctx->stream);
+}
+
+namespace {
+
+template <typename T>
+int dmalloc(ghip_ctx *ctx, T **p, size_t count) {
+    *p = nullptr;
+    GHIP_HIP_CHECK(ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return GHIP_OK;
+}
+
+template <typename T>
+int h2d(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
+    if (count == 0) return GHIP_OK;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // src may be pageable / short-lived
+    return GHIP_OK;
+}
+
+template <typename T>
+int d2h(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
+    if (count == 0) return GHIP_OK;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GHIP_OK;
+}
+
+uint32_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return (uint32_t)p;
+}
+
+// 1 - mash_distance exactly as the reference computes it (src/finch.rs:78-86 with finch's
+// jaccard = common/total, mash = -ln(2j/(1+j))/k clamped to [0,1]; Rust f64::max/min drop NaN).
+double finch_ani(uint64_t common, uint64_t total, uint32_t k) {
+    double j = (double)common / (double)total;
+    double mash = -1.0 * std::log((2.0 * j) / (1.0 + j)) / (double)k;
+    double lo = std::isnan(mash) ? 0.0 : (mash > 0.0 ? mash : 0.0);  // f64::max(0, mash)
+    double cl = lo < 1.0 ? lo : 1.0;                                   // f64::min(1, .)
+    return 1.0 - cl;
+}
+
+struct DeviceFree {
+    std::vector<void *> ptrs;
+    ~DeviceFree() { for (void *p : ptrs) if (p) hipFree(p); }
+    template <typename T> void add(T *p) { ptrs.push_back((void *)p); }
+};
+
+int build_work(ghip_ctx *ctx, ghip_genomes *g) {
+    std::vector<ghip_sketch_work> work;
+    for (size_t i = 0; i < g->n; i++) {
+        uint64_t chunks = (g->lens[i] + GHIP_SKETCH_CHUNK - 1) / GHIP_SKETCH_CHUNK;
+        for (uint64_t c = 0; c < chunks; c++) work.push_back({(uint32_t)i, (uint32_t)c});
+    }
+    g->n_work = work.size();
+    int rc = dmalloc(ctx, &g->d_work, work.size());
+    if (rc) return rc;
+    rc = h2d(ctx, g->d_work, work.data(), work.size());
+    if (rc) return rc;
+    std::vector<uint32_t> ident(g->n);
+    for (size_t i = 0; i < g->n; i++) ident[i] = (uint32_t)i;
+    rc = dmalloc(ctx, &g->d_identity, g->n);
+    if (rc) return rc;
+    return h2d(ctx, g->d_identity, ident.data(), g->n);
+}
+
+// lays genomes out with 16-B aligned starts and GHIP_TAIL_PAD bytes of 'N' after each
+int layout_genomes(ghip_ctx *ctx, ghip_genomes *g, const std::vector<uint64_t> &lens) {
+    g->n = lens.size();
+    g->lens = lens;
+    g->starts.resize(g->n);
+    uint64_t off = 0;
+    g->total_bases = 0;
+    for (size_t i = 0; i < g->n; i++) {
+        g->starts[i] = off;
+        off += (lens[i] + GHIP_TAIL_PAD + 15) / 16 * 16;
+        g->total_bases += lens[i];
+    }
+    g->total_alloc = off + 256;
+    int rc = dmalloc(ctx, &g->d_bytes, g->total_alloc);
+    if (rc) return rc;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(g->d_bytes, 'N', g->total_alloc, ctx->stream));
+    if ((rc = dmalloc(ctx, &g->d_starts, g->n))) return rc;
+    if ((rc = dmalloc(ctx, &g->d_lens, g->n))) return rc;
+    if ((rc = h2d(ctx, g->d_starts, g->starts.data(), g->n))) return rc;
+    if ((rc = h2d(ctx, g->d_lens, g->lens.data(), g->n))) return rc;
+    return build_work(ctx, g);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ context
+extern "C" int ghip_abi_version(void) { return GHIP_ABI_VERSION; }
+
+extern "C" int ghip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ghip_init(int device, ghip_ctx **out) {
+    if (!out) return GHIP_EINVAL;
+    *out = nullptr;
+    int n = ghip_device_count();
+    if (n <= 0) return ghip_set_error(nullptr, GHIP_EHIP, "no HIP device visible: the galah HIP back-end needs an AMD GPU");
+    if (device < 0 || device >= n) return ghip_set_error(nullptr, GHIP_EINVAL, "device ordinal out of range");
+    if (hipSetDevice(device) != hipSuccess) return ghip_set_error(nullptr, GHIP_EHIP, "hipSetDevice failed");
+    ghip_ctx *ctx = new ghip_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ghip_set_error(nullptr, GHIP_EHIP, "hipStreamCreate failed");
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return GHIP_OK;
+}
+
+extern "C" void ghip_destroy(ghip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    drain_events(ctx);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char *ghip_last_error(const ghip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+extern "C" int ghip_set_stream(ghip_ctx *ctx, void *hip_stream) {
+    if (!ctx) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_synchronize(ghip_ctx *ctx) {
+    if (!ctx) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GHIP_OK;
+}
+
+extern "C" int ghip_profile_enable(ghip_ctx *ctx, int enable) {
+    if (!ctx) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!enable) drain_events(ctx);
+    ctx->profile = enable != 0;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_profile_reset(ghip_ctx *ctx) {
+    if (!ctx) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_events(ctx);
+    ctx->stats.clear();
+    return GHIP_OK;
+}
+
+extern "C" int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms) {
+    if (!ctx || !kernel) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_events(ctx);
+    auto it = ctx->stats.find(kernel);
+    if (launches) *launches = it == ctx->stats.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == ctx->stats.end() ? 0.0 : it->second.total_ms;
+    return GHIP_OK;
+}
+
+extern "C" void ghip_free(void *p) { free(p); }
+
+// ------------------------------------------------------------------------------------ genomes
+extern "C" void ghip_genomes_free(ghip_genomes *g) {
+    if (!g) return;
+    hipSetDevice(g->ctx->device);
+    hipFree(g->d_bytes); hipFree(g->d_starts); hipFree(g->d_lens); hipFree(g->d_work); hipFree(g->d_identity);
+    delete g;
+}
+
+extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, size_t n,
+                                      ghip_genomes **out) {
+    if (!ctx || !out || (n && (!bytes || !offsets))) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> lens(n);
+    for (size_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return ghip_set_error(ctx, GHIP_EINVAL, "offsets must be non-decreasing");
+        lens[i] = offsets[i + 1] - offsets[i];
+    }
+    ghip_genomes *g = new ghip_genomes();
+    g->ctx = ctx;
+    int rc = layout_genomes(ctx, g, lens);
+    for (size_t i = 0; i < n && rc == GHIP_OK; i++)
+        if (lens[i]) {
+            hipError_t e = hipMemcpyAsync(g->d_bytes + g->starts[i], bytes + offsets[i], lens[i], hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
+        }
+    if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
+    if (rc != GHIP_OK) { ghip_genomes_free(g); return rc; }
+    *out = g;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
+                                       ghip_genomes **out) {
+    if (!ctx || !out || (n && !paths)) return GHIP_EINVAL;
+    std::vector<std::vector<uint8_t>> streams;
+    std::string err;
+    int rc = ghip_read_fasta_streams(paths, n, io_threads, streams, err);
+    if (rc != GHIP_OK) return ghip_set_error(ctx, rc, err);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> lens(n);
+    for (size_t i = 0; i < n; i++) lens[i] = streams[i].size();
+    ghip_genomes *g = new ghip_genomes();
+    g->ctx = ctx;
+    rc = layout_genomes(ctx, g, lens);
+    for (size_t i = 0; i < n && rc == GHIP_OK; i++)
+        if (lens[i]) {
+            hipError_t e = hipMemcpyAsync(g->d_bytes + g->starts[i], streams[i].data(), lens[i], hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
+        }
+    if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
+    if (rc != GHIP_OK) { ghip_genomes_free(g); return rc; }
+    *out = g;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_genomes_synthetic(ghip_ctx *ctx, uint64_t seed, uint32_t n_species, uint32_t members,
+                                      uint64_t length, double sub_rate, ghip_genomes **out) {
+    if (!ctx || !out || n_species == 0 || members == 0 || length == 0) return GHIP_EINVAL;
+    if ((uint64_t)n_species * members > 65535) return ghip_set_error(ctx, GHIP_EINVAL, "at most 65535 synthetic genomes per call");
+    if (!(sub_rate >= 0.0 && sub_rate < 1.0)) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> lens((size_t)n_species * members, length);
+    ghip_genomes *g = new ghip_genomes();
+    g->ctx = ctx;
+    int rc = layout_genomes(ctx, g, lens);
+    if (rc != GHIP_OK) { ghip_genomes_free(g); return rc; }
+    ghip_launch_synth(ctx, g->d_bytes, g->d_starts, length, n_species, members, seed, (uint32_t)(sub_rate * 4294967296.0));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ghip_genomes_free(g); return ghip_set_error(ctx, GHIP_EHIP, "synth_genomes failed"); }
+    *out = g;
+    return GHIP_OK;
+}
+
+extern "C" size_t ghip_genomes_count(const ghip_genomes *g) { return g ? g->n : 0; }
+extern "C" uint64_t ghip_genomes_total_bases(const ghip_genomes *g) { return g ? g->total_bases : 0; }
+extern "C" uint64_t ghip_genomes_length(const ghip_genomes *g, size_t idx) { return (g && idx < g->n) ? g->lens[idx] : 0; }
+
+extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t idx, uint8_t *outp) {
+    if (!ctx || !g || idx >= g->n || !outp) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return d2h(ctx, outp, g->d_bytes + g->starts[idx], g->lens[idx]);
+}
+
+// ------------------------------------------------------------------------------------ sketches
+extern "C" void ghip_sketches_free(ghip_sketches *sk) {
+    if (!sk) return;
+    if (sk->owned) { hipSetDevice(sk->ctx->device); hipFree(sk->d_hashes); hipFree(sk->d_lens); }
+    delete sk;
+}
+
+extern "C" size_t ghip_sketches_count(const ghip_sketches *sk) { return sk ? sk->n : 0; }
+extern "C" uint32_t ghip_sketches_size(const ghip_sketches *sk) { return sk ? sk->s : 0; }
+extern "C" uint32_t ghip_sketches_kmer(const ghip_sketches *sk) { return sk ? sk->k : 0; }
+extern "C" void *ghip_sketches_device_hashes(const ghip_sketches *sk) { return sk ? sk->d_hashes : nullptr; }
+extern "C" void *ghip_sketches_device_lens(const ghip_sketches *sk) { return sk ? sk->d_lens : nullptr; }
+
+extern "C" int ghip_sketches_from_host(ghip_ctx *ctx, const uint64_t *hashes, const uint32_t *lens, size_t n,
+                                       uint32_t s, uint32_t k, ghip_sketches **out) {
+    if (!ctx || !out || s == 0 || (n && (!hashes || !lens))) return GHIP_EINVAL;
+    for (size_t i = 0; i < n; i++) {
+        if (lens[i] > s) return ghip_set_error(ctx, GHIP_EINVAL, "sketch length exceeds sketch size");
+        for (uint32_t e = 1; e < lens[i]; e++)
+            if (hashes[i * s + e] <= hashes[i * s + e - 1]) return ghip_set_error(ctx, GHIP_EINVAL, "sketch hashes must be strictly ascending");
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ghip_sketches *sk = new ghip_sketches();
+    sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
+    std::vector<uint64_t> padded(hashes, hashes + n * (size_t)s);
+    for (size_t i = 0; i < n; i++) for (uint32_t e = lens[i]; e < s; e++) padded[i * s + e] = ~0ull;
+    int rc = dmalloc(ctx, &sk->d_hashes, n * (size_t)s);
+    if (!rc) rc = dmalloc(ctx, &sk->d_lens, n);
+    if (!rc) rc = h2d(ctx, sk->d_hashes, padded.data(), n * (size_t)s);
+    if (!rc) rc = h2d(ctx, sk->d_lens, lens, n);
+    if (rc) { ghip_sketches_free(sk); return rc; }
+    *out = sk;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_sketches_wrap_device(ghip_ctx *ctx, void *d_hashes, void *d_lens, size_t n, uint32_t s,
+                                         uint32_t k, ghip_sketches **out) {
+    if (!ctx || !out || s == 0 || (n && (!d_hashes || !d_lens))) return GHIP_EINVAL;
+    ghip_sketches *sk = new ghip_sketches();
+    sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
+    sk->d_hashes = (uint64_t *)d_hashes; sk->d_lens = (uint32_t *)d_lens; sk->owned = false;
+    *out = sk;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_sketches_to_host(ghip_ctx *ctx, const ghip_sketches *sk, uint64_t *hashes, uint32_t *lens) {
+    if (!ctx || !sk) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = GHIP_OK;
+    if (hashes) rc = d2h(ctx, hashes, sk->d_hashes, sk->n * (size_t)sk->s);
+    if (!rc && lens) rc = d2h(ctx, lens, sk->d_lens, sk->n);
+    return rc;
+}
+
+// finch::sketch_files replacement.  Exactness: a genome is accepted only when its candidate
+// list did not overflow and held >= s distinct hashes (or the threshold was already 2^64-1).
+extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
+                                   ghip_sketches **out) {
+    if (!ctx || !g || !out) return GHIP_EINVAL;
+    if (k < 1 || k > 32) return ghip_set_error(ctx, GHIP_EINVAL, "kmer_length must be in 1..=32");
+    if (s < 1 || s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "num_kmers must be in 1..=4096");
+    if (seed > 0xffffffffull) return ghip_set_error(ctx, GHIP_EINVAL, "hash_seed must fit 32 bits (murmurhash3 seed)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n = g->n;
+    ghip_sketches *sk = new ghip_sketches();
+    sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
+    int rc = dmalloc(ctx, &sk->d_hashes, n * (size_t)s);
+    if (!rc) rc = dmalloc(ctx, &sk->d_lens, n);
+    if (rc) { ghip_sketches_free(sk); return rc; }
+
+    // pending slots: initially every genome, with threshold ~ 2.5*s expected survivors
+    std::vector<uint32_t> slot_genome(n);
+    std::vector<uint64_t> slot_thr(n);
+    std::vector<uint32_t> slot_cap(n);
+    const uint32_t cap0 = next_pow2(4ull * s);
+    for (size_t i = 0; i < n; i++) {
+        slot_genome[i] = (uint32_t)i;
+        uint64_t nk = g->lens[i] >= k ? g->lens[i] - k + 1 : 1;
+        unsigned __int128 want = ((unsigned __int128)(5ull * s / 2 + 1)) << 64;
+        unsigned __int128 t = want / nk;
+        slot_thr[i] = (t >> 64) ? ~0ull : (uint64_t)t;
+        slot_cap[i] = cap0;
+    }
+    bool first = true;
+    int iter = 0;
+    while (!slot_genome.empty()) {
+        if (++iter > 80) { ghip_sketches_free(sk); return ghip_set_error(ctx, GHIP_EHIP, "sketch selection did not converge"); }
+        const size_t ns = slot_genome.size();
+        std::vector<uint64_t> cand_start(ns);
+        uint64_t total_cand = 0;
+        for (size_t i = 0; i < ns; i++) { cand_start[i] = total_cand; total_cand += slot_cap[i]; }
+        DeviceFree tmp;
+        uint32_t *d_slot_genome = nullptr, *d_cap = nullptr, *d_count = nullptr, *d_status = nullptr;
+        uint64_t *d_thr = nullptr, *d_cstart = nullptr, *d_cand = nullptr;
+        ghip_sketch_work *d_work = nullptr;
+        size_t n_work = 0;
+        if ((rc = dmalloc(ctx, &d_thr, ns))) break; tmp.add(d_thr);
+        if ((rc = dmalloc(ctx, &d_cstart, ns))) break; tmp.add(d_cstart);
+        if ((rc = dmalloc(ctx, &d_cap, ns))) break; tmp.add(d_cap);
+        if ((rc = dmalloc(ctx, &d_count, ns))) break; tmp.add(d_count);
+        if ((rc = dmalloc(ctx, &d_status, ns))) break; tmp.add(d_status);
+        if ((rc = dmalloc(ctx, &d_cand, total_cand))) break; tmp.add(d_cand);
+        if (first) {
+            d_slot_genome = g->d_identity;
+            d_work = g->d_work;
+            n_work = g->n_work;
+        } else {
+            std::vector<ghip_sketch_work> work;
+            for (size_t i = 0; i < ns; i++) {
+                uint64_t chunks = (g->lens[slot_genome[i]] + GHIP_SKETCH_CHUNK - 1) / GHIP_SKETCH_CHUNK;
+                for (uint64_t c = 0; c < chunks; c++) work.push_back({(uint32_t)i, (uint32_t)c});
+            }
+            n_work = work.size();
+            if ((rc = dmalloc(ctx, &d_slot_genome, ns))) break; tmp.add(d_slot_genome);
+            if ((rc = dmalloc(ctx, &d_work, n_work))) break; tmp.add(d_work);
+            if ((rc = h2d(ctx, d_slot_genome, slot_genome.data(), ns))) break;
+            if ((rc = h2d(ctx, d_work, work.data(), n_work))) break;
+        }
+        if ((rc = h2d(ctx, d_thr, slot_thr.data(), ns))) break;
+        if ((rc = h2d(ctx, d_cstart, cand_start.data(), ns))) break;
+        if ((rc = h2d(ctx, d_cap, slot_cap.data(), ns))) break;
+        if (hipMemsetAsync(d_count, 0, ns * sizeof(uint32_t), ctx->stream) != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed"); break; }
+        ghip_launch_sketch_kmers(ctx, g->d_bytes, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
+                                 d_work, n_work, k, (uint32_t)seed, d_cand, d_count);
+        ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, s, sk->d_hashes,
+                                  sk->d_lens, d_status);
+        std::vector<uint32_t> status(ns), count(ns);
+        if ((rc = d2h(ctx, status.data(), d_status, ns))) break;
+        if ((rc = d2h(ctx, count.data(), d_count, ns))) break;
+        { hipError_t e = hipGetLastError(); if (e != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, std::string("sketch kernels: ") + hipGetErrorString(e)); break; } }
+        std::vector<uint32_t> ng; std::vector<uint64_t> nthr; std::vector<uint32_t> ncap;
+        for (size_t i = 0; i < ns; i++) {
+            if (status[i] & 1u) {  // overflow: same threshold, list as large as the survivor count
+                ng.push_back(slot_genome[i]); nthr.push_back(slot_thr[i]); ncap.push_back(next_pow2(count[i]));
+            } else if ((status[i] & 2u) && slot_thr[i] != ~0ull) {  // too few distinct: widen 8x
+                uint64_t t = slot_thr[i];
+                ng.push_back(slot_genome[i]);
+                nthr.push_back(t > (~0ull >> 3) ? ~0ull : t << 3);
+                ncap.push_back(std::max<uint32_t>(slot_cap[i], next_pow2(8ull * count[i] + 64)));
+            }
+        }
+        slot_genome.swap(ng); slot_thr.swap(nthr); slot_cap.swap(ncap);
+        first = false;
+    }
+    if (rc) { ghip_sketches_free(sk); return rc; }
+    *out = sk;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_sketch_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s,
+                                 uint64_t seed, int io_threads, ghip_sketches **out) {
+    ghip_genomes *g = nullptr;
+    int rc = ghip_genomes_from_files(ctx, paths, n, io_threads, &g);
+    if (rc) return rc;
+    rc = ghip_sketch_genomes(ctx, g, k, s, seed, out);
+    ghip_genomes_free(g);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ precluster
+extern "C" uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx) { return ctx ? ctx->last_pairs : 0; }
+
+extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
+                                     uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
+    if (!ctx || !sk || !out_pairs || !out_n || world == 0 || rank >= world) return GHIP_EINVAL;
+    if (sk->s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "sketch size above 4096 is not supported");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    *out_pairs = nullptr; *out_n = 0;
+    const size_t n = sk->n;
+    const uint32_t s = sk->s, k = sk->k;
+    ctx->last_pairs = 0;
+    if (n < 2) return GHIP_OK;
+
+    // cmin[total] = smallest common whose reference ANI clears the threshold (src/finch.rs:91:
+    // `distance >= min_ani as f64`).  The device filter only has to be a superset; the exact
+    // test is repeated on the host for every emitted pair.
+    const double thr = (double)min_ani;
+    const uint32_t max_total = 2 * s;
+    std::vector<uint16_t> cmin(max_total + 2, 0xffff);
+    for (uint32_t total = 0; total <= max_total; total++) {
+        uint32_t cmax = std::min(total, s);
+        for (uint32_t c = 0; c <= cmax; c++)
+            if (finch_ani(c, total, k) >= thr) { cmin[total] = (uint16_t)c; break; }
+    }
+    DeviceFree tmp;
+    uint16_t *d_cmin = nullptr;
+    int rc = dmalloc(ctx, &d_cmin, cmin.size());
+    if (rc) return rc;
+    tmp.add(d_cmin);
+    if ((rc = h2d(ctx, d_cmin, cmin.data(), cmin.size()))) return rc;
+
+    const uint64_t P = (uint64_t)n * (n - 1) / 2;
+    uint64_t cap = std::min<uint64_t>(P, std::max<uint64_t>(1u << 20, 64ull * n));
+    unsigned long long *d_count = nullptr;
+    if ((rc = dmalloc(ctx, &d_count, 1))) return rc;
+    tmp.add(d_count);
+    std::vector<ghip_pair> host;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ghip_pair *d_out = nullptr;
+        if ((rc = dmalloc(ctx, &d_out, cap))) return rc;
+        DeviceFree t2; t2.add(d_out);
+        GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+        uint64_t compared = 0;
+        ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, rank, world, d_out, d_count, cap, &compared);
+        ctx->last_pairs = compared;
+        unsigned long long cnt = 0;
+        if ((rc = d2h(ctx, &cnt, d_count, 1))) return rc;
+        { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("pair_intersect_tile: ") + hipGetErrorString(e)); }
+        if (cnt > cap) { cap = cnt; continue; }  // list overflowed: rerun with room for every hit
+        host.resize(cnt);
+        if ((rc = d2h(ctx, host.data(), d_out, cnt))) return rc;
+        break;
+    }
+    // exact reference arithmetic on the host: f64 ANI, threshold, `as f32`
+    size_t m = 0;
+    for (size_t i = 0; i < host.size(); i++) {
+        double ani = finch_ani(host[i].common, host[i].total, k);
+        if (ani >= thr) { host[i].ani = (float)ani; host[m++] = host[i]; }
+    }
+    host.resize(m);
+    std::sort(host.begin(), host.end(), [](const ghip_pair &a, const ghip_pair &b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
+    ghip_pair *res = (ghip_pair *)malloc(std::max<size_t>(m, 1) * sizeof(ghip_pair));
+    if (!res) return ghip_set_error(ctx, GHIP_ENOMEM, "out of host memory");
+    memcpy(res, host.data(), m * sizeof(ghip_pair));
+    *out_pairs = res; *out_n = m;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, ghip_pair **out_pairs, size_t *out_n) {
+    return ghip_precluster_shard(ctx, sk, min_ani, 0, 1, out_pairs, out_n);
+}
+
+// ------------------------------------------------------------------------------------ ANI
+extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
+    if (!idx) return;
+    hipSetDevice(idx->ctx->device);
+    hipFree(idx->d_seed_hash); hipFree(idx->d_seed_chunk); hipFree(idx->d_seed_start); hipFree(idx->d_seed_count);
+    hipFree(idx->d_table); hipFree(idx->d_table_start); hipFree(idx->d_chunk_total); hipFree(idx->d_chunk_start);
+    hipFree(idx->d_glen);
+    delete idx;
+}
+
+extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
+                                    ghip_ani_index **out) {
+    if (!ctx || !g || !out) return GHIP_EINVAL;
+    if (k < 1 || k > 32 || c < 1 || chunk < 1) return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n = g->n;
+    ghip_ani_index *idx = new ghip_ani_index();
+    idx->ctx = ctx; idx->n = n; idx->k = k; idx->c = c; idx->chunk = chunk;
+    idx->glen = g->lens;
+    idx->chunk_start.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t nch = (g->lens[i] + chunk - 1) / chunk;
+        idx->max_chunks = (uint32_t)std::max<uint64_t>(idx->max_chunks, nch);
+        idx->chunk_start[i + 1] = idx->chunk_start[i] + nch;
+    }
+    int rc = GHIP_OK;
+    if (idx->max_chunks > 32768) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (max 32768 chunks)");
+    std::vector<uint64_t> cap(n);
+    for (size_t i = 0; i < n; i++) cap[i] = g->lens[i] / c + g->lens[i] / (2 * (uint64_t)c) + 1024;
+    for (int attempt = 0; attempt < 2 && rc == GHIP_OK; attempt++) {
+        idx->seed_start.assign(n + 1, 0);
+        for (size_t i = 0; i < n; i++) idx->seed_start[i + 1] = idx->seed_start[i] + cap[i];
+        hipFree(idx->d_seed_hash); hipFree(idx->d_seed_chunk); hipFree(idx->d_seed_start); hipFree(idx->d_seed_count);
+        hipFree(idx->d_chunk_total); hipFree(idx->d_chunk_start); hipFree(idx->d_glen);
+        idx->d_seed_hash = nullptr; idx->d_seed_chunk = nullptr; idx->d_seed_start = nullptr; idx->d_seed_count = nullptr;
+        idx->d_chunk_total = nullptr; idx->d_chunk_start = nullptr; idx->d_glen = nullptr;
+        if ((rc = dmalloc(ctx, &idx->d_seed_hash, idx->seed_start[n]))) break;
+        if ((rc = dmalloc(ctx, &idx->d_seed_chunk, idx->seed_start[n]))) break;
+        if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) break;
+        if ((rc = dmalloc(ctx, &idx->d_seed_count, n))) break;
+        if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) break;
+        if ((rc = dmalloc(ctx, &idx->d_chunk_start, n + 1))) break;
+        if ((rc = dmalloc(ctx, &idx->d_glen, n))) break;
+        if ((rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) break;
+        if ((rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) break;
+        if ((rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) break;
+        hipMemsetAsync(idx->d_seed_count, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), ctx->stream);
+        hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream);
+        ghip_launch_ani_seeds(ctx, g, k, c, chunk, idx->d_seed_hash, idx->d_seed_chunk, idx->d_seed_start,
+                              idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
+        idx->seed_count.assign(n, 0);
+        if ((rc = d2h(ctx, idx->seed_count.data(), idx->d_seed_count, n))) break;
+        bool overflow = false;
+        for (size_t i = 0; i < n; i++) if (idx->seed_count[i] > cap[i]) { overflow = true; cap[i] = idx->seed_count[i]; }
+        if (!overflow) break;
+        if (attempt == 1) rc = ghip_set_error(ctx, GHIP_EHIP, "ANI seed list overflowed twice");
+    }
+    if (rc == GHIP_OK) {
+        idx->table_start.assign(n + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            uint64_t sz = idx->seed_count[i] ? next_pow2(2ull * idx->seed_count[i]) : 0;
+            idx->table_start[i + 1] = idx->table_start[i] + sz;
+        }
+        if (!(rc = dmalloc(ctx, &idx->d_table, idx->table_start[n])) && !(rc = dmalloc(ctx, &idx->d_table_start, n + 1)) &&
+            !(rc = h2d(ctx, idx->d_table_start, idx->table_start.data(), n + 1))) {
+            hipMemsetAsync(idx->d_table, 0xff, std::max<uint64_t>(idx->table_start[n], 1) * sizeof(uint64_t), ctx->stream);
+            ghip_launch_ani_table(ctx, n, idx->d_seed_hash, idx->d_seed_start, idx->d_seed_count, idx->d_table, idx->d_table_start);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+                rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
+        }
+    }
+    if (rc) { ghip_ani_index_free(idx); return rc; }
+    *out = idx;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, size_t n,
+                              float min_af, float *out_ani, float *out_af) {
+    if (!ctx || !idx || !out_ani || (n && !pairs)) return GHIP_EINVAL;
+    for (size_t i = 0; i < 2 * n; i++) if (pairs[i] >= idx->n) return ghip_set_error(ctx, GHIP_EINVAL, "genome index out of range");
+    if (n == 0) return GHIP_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DeviceFree tmp;
+    uint32_t *d_pairs = nullptr;
+    uint64_t *d_out = nullptr;
+    int rc;
+    if ((rc = dmalloc(ctx, &d_pairs, 2 * n))) return rc;
+    tmp.add(d_pairs);
+    if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
+    tmp.add(d_out);
+    if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
+    ghip_launch_ani_pairs(ctx, idx, d_pairs, n, std::max<uint32_t>(idx->max_chunks, 1), d_out);
+    std::vector<uint64_t> res(6 * n);
+    if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
+    { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
+    for (size_t p = 0; p < n; p++) {
+        const uint64_t M = res[6 * p] + res[6 * p + 3], T = res[6 * p + 1] + res[6 * p + 4];
+        const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1];
+        const double afq = idx->glen[q] ? (double)res[6 * p + 2] / (double)idx->glen[q] : 0.0;
+        const double afr = idx->glen[r] ? (double)res[6 * p + 5] / (double)idx->glen[r] : 0.0;
+        if (out_af) { out_af[2 * p] = (float)afq; out_af[2 * p + 1] = (float)afr; }
+        float v = 0.0f;
+        if (T != 0 && M != 0 && !(afq < (double)min_af && afr < (double)min_af)) {
+            // skani prints ANI with two decimals and galah parses that text as f32 (src/skani.rs:770)
+            double ani = 100.0 * std::pow((double)M / (double)T, 1.0 / (double)idx->k);
+            char txt[64];
+            snprintf(txt, sizeof txt, "%.2f", ani);
+            v = strtof(txt, nullptr);
+        }
+        out_ani[p] = v;
+    }
+    return GHIP_OK;
+}

@@ -1,0 +1,195 @@
+// Host clusterer: clusterer::cluster from the precluster cache onwards
+// (reference src/clusterer.rs:56-152, 182-259, 350-487), on the sorted edge list the GPU
+// pair stage returns instead of a BTreeMap probed O(N^2) times:
+//   partition_sketches          -> union-find over the E edges
+//   transform_ids               -> per-precluster adjacency lists
+//   find_precluster_cluster_representatives / _memberships -> same decisions, same tie rules
+// Result semantics follow the reference with --threads 1: preclusters in disjoint-set order
+// (first element ascending) stable-sorted by size descending; within a precluster clusters in
+// representative order; representative first, members ascending.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "ghip_internal.h"
+
+namespace {
+
+struct Adj {
+    uint32_t nbr;   // local index of the neighbour
+    uint32_t edge;  // index into the global pair list
+};
+
+struct Dsu {
+    std::vector<uint32_t> p;
+    explicit Dsu(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0u); }
+    uint32_t find(uint32_t x) {
+        while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; }
+        return x;
+    }
+    void join(uint32_t a, uint32_t b) {
+        a = find(a); b = find(b);
+        if (a == b) return;
+        if (a < b) p[b] = a; else p[a] = b;  // root = smallest member
+    }
+};
+
+}  // namespace
+
+extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
+                            int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, void *user,
+                            uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters) {
+    if (!out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
+    if (n_pairs && !pairs) return GHIP_EINVAL;
+    if (!skip_clusterer && !pair_ani && !ani_cb) return GHIP_EINVAL;
+    for (size_t e = 0; e < n_pairs; e++)
+        if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return GHIP_EINVAL;
+
+    // ---- partition_sketches (clusterer.rs:452-487): single linkage over cache keys ----
+    Dsu dsu(n);
+    for (size_t e = 0; e < n_pairs; e++) dsu.join(pairs[e].i, pairs[e].j);
+    // sets enumerated by first element; members ascending (clusterer.rs:67-76)
+    std::vector<uint32_t> set_of(n), set_size;
+    {
+        std::vector<uint32_t> root_set(n, UINT32_MAX);
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t r = dsu.find(i);
+            if (root_set[r] == UINT32_MAX) { root_set[r] = (uint32_t)set_size.size(); set_size.push_back(0); }
+            set_of[i] = root_set[r];
+            set_size[set_of[i]]++;
+        }
+    }
+    const size_t nsets = set_size.size();
+    std::vector<uint64_t> set_start(nsets + 1, 0);
+    for (size_t s = 0; s < nsets; s++) set_start[s + 1] = set_start[s] + set_size[s];
+    std::vector<uint32_t> members(n), local(n);
+    {
+        std::vector<uint64_t> fill(set_start.begin(), set_start.end() - 1);
+        for (uint32_t i = 0; i < n; i++) {
+            uint64_t pos = fill[set_of[i]]++;
+            members[pos] = i;
+            local[i] = (uint32_t)(pos - set_start[set_of[i]]);
+        }
+    }
+    // bigger preclusters first (clusterer.rs:79), stable
+    std::vector<uint32_t> order(nsets);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return set_size[a] > set_size[b]; });
+
+    // adjacency in CSR form over local indices (== transform_ids, cache.rs:47-58)
+    std::vector<uint64_t> adj_start(n + 1, 0);
+    for (size_t e = 0; e < n_pairs; e++) { adj_start[pairs[e].i + 1]++; adj_start[pairs[e].j + 1]++; }
+    for (size_t i = 0; i < n; i++) adj_start[i + 1] += adj_start[i];
+    std::vector<Adj> adj(2 * n_pairs);
+    {
+        std::vector<uint64_t> fill(adj_start.begin(), adj_start.end() - 1);
+        for (size_t e = 0; e < n_pairs; e++) {
+            adj[fill[pairs[e].i]++] = {local[pairs[e].j], (uint32_t)e};
+            adj[fill[pairs[e].j]++] = {local[pairs[e].i], (uint32_t)e};
+        }
+    }
+    // a duplicate key would be a BTreeMap overwrite; the GPU stage never emits one
+    // clusterer ANI per edge: state 0 = not computed, 1 = None, 2 = Some(value)
+    std::vector<uint8_t> ani_state(n_pairs, 0);
+    std::vector<float> ani_val(n_pairs, 0.0f);
+    if (skip_clusterer) {
+        for (size_t e = 0; e < n_pairs; e++) { ani_state[e] = 2; ani_val[e] = pairs[e].ani; }
+    } else if (pair_ani) {
+        for (size_t e = 0; e < n_pairs; e++) {
+            if (std::isnan(pair_ani[e])) ani_state[e] = 1;
+            else { ani_state[e] = 2; ani_val[e] = pair_ani[e]; }
+        }
+    }
+    auto edge_ani = [&](uint32_t e, uint32_t rep_genome, uint32_t genome) {
+        if (ani_state[e] == 0) {  // ClusterDistanceFinder::calculate_ani(rep, genome)
+            float v = 0.0f;
+            int has = ani_cb(user, rep_genome, genome, &v);
+            ani_state[e] = has ? 2 : 1;
+            ani_val[e] = v;
+        }
+    };
+
+    std::vector<uint32_t> out_m;
+    std::vector<uint64_t> out_o{0};
+    out_m.reserve(n);
+    std::vector<uint8_t> is_rep(n, 0);       // indexed by genome
+    std::vector<uint32_t> assign(n, 0);      // genome -> representative genome
+    struct Cand { uint32_t nbr_local; uint32_t edge; float pre; };
+    std::vector<Cand> cand;
+
+    for (size_t oi = 0; oi < nsets; oi++) {
+        const uint32_t s = order[oi];
+        const uint32_t *orig = members.data() + set_start[s];
+        const uint32_t m = set_size[s];
+        // ---- find_precluster_cluster_representatives (clusterer.rs:182-259) ----
+        for (uint32_t li = 0; li < m; li++) {
+            const uint32_t gi = orig[li];
+            cand.clear();
+            for (uint64_t a = adj_start[gi]; a < adj_start[gi + 1]; a++) {
+                const uint32_t lj = adj[a].nbr;
+                if (lj < li && is_rep[orig[lj]]) cand.push_back({lj, adj[a].edge, pairs[adj[a].edge].ani});
+            }
+            // ascending by precluster ANI (clusterer.rs:200; sort_unstable -> ties by index here)
+            std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) {
+                if (x.pre != y.pre) return x.pre < y.pre;
+                return x.nbr_local < y.nbr_local;
+            });
+            bool rep = true;
+            for (const Cand &c : cand) {
+                edge_ani(c.edge, orig[c.nbr_local], gi);
+                if (ani_state[c.edge] == 2 && ani_val[c.edge] >= ani_threshold) {
+                    rep = false;
+                    if (!skip_clusterer && !pair_ani) break;  // find_any stops on the first hit
+                }
+            }
+            is_rep[gi] = rep ? 1 : 0;
+        }
+        // ---- find_precluster_cluster_memberships (clusterer.rs:350-449) ----
+        for (uint32_t li = 0; li < m; li++) {
+            const uint32_t gi = orig[li];
+            if (is_rep[gi]) { assign[gi] = gi; continue; }
+            bool have = false;
+            float best = 0.0f;
+            uint32_t best_local = 0;
+            for (uint64_t a = adj_start[gi]; a < adj_start[gi + 1]; a++) {
+                const uint32_t lj = adj[a].nbr;
+                if (!is_rep[orig[lj]]) continue;
+                edge_ani(adj[a].edge, orig[lj], gi);
+                if (ani_state[adj[a].edge] != 2) continue;
+                const float v = ani_val[adj[a].edge];
+                // reps are visited in ascending order by the reference; strictly-greater wins,
+                // so among equal ANIs the lowest-index representative is kept.
+                if (!have || v > best || (v == best && lj < best_local)) { have = true; best = v; best_local = lj; }
+            }
+            if (!have) return GHIP_EINVAL;  // reference: best_rep.unwrap() panics (clusterer.rs:444)
+            assign[gi] = orig[best_local];
+        }
+        // clusters of this precluster: representative first, then members ascending
+        const size_t base = out_m.size();
+        std::vector<uint32_t> rep_pos(m, UINT32_MAX), cnt;
+        uint32_t nreps = 0;
+        for (uint32_t li = 0; li < m; li++) if (is_rep[orig[li]]) { rep_pos[li] = nreps++; }
+        cnt.assign(nreps, 0);
+        for (uint32_t li = 0; li < m; li++) cnt[rep_pos[local[assign[orig[li]]]]]++;
+        std::vector<uint64_t> cstart(nreps + 1, 0);
+        for (uint32_t r = 0; r < nreps; r++) cstart[r + 1] = cstart[r] + cnt[r];
+        out_m.resize(base + m);
+        std::vector<uint64_t> fill(cstart.begin(), cstart.end() - 1);
+        for (uint32_t li = 0; li < m; li++)  // representatives first
+            if (is_rep[orig[li]]) out_m[base + fill[rep_pos[li]]++] = orig[li];
+        for (uint32_t li = 0; li < m; li++)
+            if (!is_rep[orig[li]]) out_m[base + fill[rep_pos[local[assign[orig[li]]]]]++] = orig[li];
+        for (uint32_t r = 0; r < nreps; r++) out_o.push_back(base + cstart[r + 1]);
+    }
+
+    uint32_t *om = (uint32_t *)malloc(std::max<size_t>(out_m.size(), 1) * sizeof(uint32_t));
+    uint64_t *oo = (uint64_t *)malloc(out_o.size() * sizeof(uint64_t));
+    if (!om || !oo) { free(om); free(oo); return GHIP_ENOMEM; }
+    memcpy(om, out_m.data(), out_m.size() * sizeof(uint32_t));
+    memcpy(oo, out_o.data(), out_o.size() * sizeof(uint64_t));
+    *out_members = om;
+    *out_offsets = oo;
+    *out_n_clusters = out_o.size() - 1;
+    return GHIP_OK;
+}

@@ -1,0 +1,135 @@
+// Internal declarations shared by the host API and the HIP kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/galah_hip.h"
+
+struct ghip_kstat {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct ghip_pending_event {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+struct ghip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::mutex mu;  // serialises API calls on this ctx (ghip_ani_pairs is called from rayon workers)
+    bool profile = false;
+    std::unordered_map<std::string, ghip_kstat> stats;
+    std::vector<ghip_pending_event> pending;
+    uint64_t last_pairs = 0;
+    int num_cus = 256;
+};
+
+struct ghip_sketch_work {  // one block of the k-mer pass
+    uint32_t slot;   // index into the pending-genome arrays
+    uint32_t chunk;  // chunk index within the genome
+};
+
+struct ghip_genomes {
+    ghip_ctx *ctx = nullptr;
+    size_t n = 0;
+    uint8_t *d_bytes = nullptr;        // all streams; each genome starts 16-B aligned, 'N' padded
+    uint64_t *d_starts = nullptr;      // [n] byte offset of genome g
+    uint64_t *d_lens = nullptr;        // [n] stream length L_g
+    std::vector<uint64_t> starts, lens;
+    uint64_t total_alloc = 0;
+    uint64_t total_bases = 0;
+    // cached full-pass work list (one entry per 16384-position chunk of every genome)
+    ghip_sketch_work *d_work = nullptr;
+    size_t n_work = 0;
+    uint32_t *d_identity = nullptr;  // [n] 0..n-1
+};
+
+struct ghip_sketches {
+    ghip_ctx *ctx = nullptr;
+    size_t n = 0;
+    uint32_t s = 0, k = 0;
+    uint64_t *d_hashes = nullptr;  // [n][s]
+    uint32_t *d_lens = nullptr;    // [n]
+    bool owned = true;
+};
+
+struct ghip_ani_index {
+    ghip_ctx *ctx = nullptr;
+    size_t n = 0;
+    uint32_t k = 0, c = 0, chunk = 0;
+    // per-genome seed lists (unordered) and open-addressing membership tables
+    uint64_t *d_seed_hash = nullptr;   // concatenated
+    uint32_t *d_seed_chunk = nullptr;  // concatenated
+    uint64_t *d_seed_start = nullptr;  // [n+1] offsets into seed arrays (capacity layout)
+    uint32_t *d_seed_count = nullptr;  // [n]
+    uint64_t *d_table = nullptr;       // concatenated tables
+    uint64_t *d_table_start = nullptr; // [n+1]
+    uint32_t *d_chunk_total = nullptr; // concatenated per-chunk seed totals T_c
+    uint64_t *d_chunk_start = nullptr; // [n+1]
+    uint64_t *d_glen = nullptr;        // [n] stream lengths
+    std::vector<uint64_t> glen, chunk_start, table_start, seed_start;
+    std::vector<uint32_t> seed_count;
+    uint32_t max_chunks = 0;
+};
+
+#define GHIP_EMPTY_SLOT 0xFFFFFFFFFFFFFFFFull
+
+int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);
+
+#define GHIP_HIP_CHECK(ctx, expr)                                                          \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ghip_set_error((ctx), GHIP_EHIP,                                        \
+                                  std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// RAII-less helpers for per-kernel timing; no-ops unless ctx->profile.
+void ghip_prof_begin(ghip_ctx *ctx, const char *name);
+void ghip_prof_end(ghip_ctx *ctx);
+
+// ---- launchers (defined in the .hip files) ----
+void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
+                       uint32_t n_species, uint32_t members, uint64_t seed, uint32_t sub_thr);
+
+void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
+                              const uint64_t *d_lens, const uint32_t *d_slot_genome,
+                              const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
+                              const uint32_t *d_slot_cand_cap, const ghip_sketch_work *d_work,
+                              size_t n_work, uint32_t k, uint32_t seed, uint64_t *d_cand,
+                              uint32_t *d_cand_count);
+void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, size_t n_slots,
+                               uint64_t *d_cand, const uint32_t *d_cand_count,
+                               const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap,
+                               uint32_t s, uint64_t *d_hashes, uint32_t *d_lens, uint32_t *d_status);
+void ghip_pair_geometry(uint32_t s, uint32_t *s_pad, uint32_t *sp, uint32_t *pt);
+
+void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n,
+                       uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world,
+                       ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
+                       uint64_t *pairs_compared);
+
+void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
+                           uint64_t *d_seed_hash, uint32_t *d_seed_chunk, const uint64_t *d_seed_start,
+                           uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
+                           const ghip_sketch_work *d_work, size_t n_work);
+void ghip_launch_ani_table(ghip_ctx *ctx, size_t n, const uint64_t *d_seed_hash, const uint64_t *d_seed_start,
+                           const uint32_t *d_seed_count, uint64_t *d_table, const uint64_t *d_table_start);
+void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
+                           uint32_t max_chunks, uint64_t *d_out /* [n_pairs][2][3] = M, T, aligned bases */);
+
+constexpr uint32_t GHIP_SKETCH_POS_PER_THREAD = 64;
+constexpr uint32_t GHIP_SKETCH_THREADS = 256;
+constexpr uint32_t GHIP_SKETCH_CHUNK = GHIP_SKETCH_POS_PER_THREAD * GHIP_SKETCH_THREADS;  // positions per block
+constexpr uint32_t GHIP_TAIL_PAD = 128;  // 'N' bytes after every genome (vector loads may over-read)

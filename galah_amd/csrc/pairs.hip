@@ -1,0 +1,180 @@
+// All-vs-all precluster pair stage on gfx950: replaces the serial i<j loop of
+// finch::distances (reference src/finch.rs:74-96) and finch::distance::raw_distance.
+//
+// pair_intersect_tile: one workgroup per (A-tile, B-tile) of the upper triangle.  Both tiles
+// of sorted u64 sketches are staged in LDS (row-padded by one element per 16 so that lanes
+// walking 16-element-strided positions fall on distinct banks); each wavefront then takes
+// one sketch pair at a time and intersects it with a 64-way merge path: every lane binary-
+// searches its diagonal, merges ~(|A|+|B|)/64 steps and counts equal hashes.  The numbers
+// raw_distance would produce follow in closed form:
+//     common = |A n B|,  m = min(max A, max B),  i = #{a <= m},  j = #{b <= m},
+//     total = i + j - common.
+// No floating point on the device: a pair is emitted iff common >= cmin[total], a table the
+// host derives from the reference's f64 formula, and the host recomputes the exact f32 ANI.
+// Pure integer compare work: no MFMA.  Algorithmic bytes: 2*s*8 per pair.
+#include "ghip_internal.h"
+
+namespace {
+
+constexpr int PAIR_WAVES = 16;
+constexpr int PAIR_THREADS = PAIR_WAVES * 64;
+
+__device__ __forceinline__ uint32_t lds_pos(uint32_t e) { return e + (e >> 4); }
+
+// #elements of sorted X[0..n) that are <= x  (all lanes compute the same value)
+__device__ __forceinline__ uint32_t upper_bound_lds(const uint64_t *X, uint32_t n, uint64_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (X[lds_pos(mid)] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
+    const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, uint32_t n, uint32_t s,
+    uint32_t s_pad, uint32_t sp /* LDS elements per sketch */, uint32_t pt /* tile edge */,
+    uint32_t nt /* tiles per dim */, uint64_t n_tilepairs, uint32_t rank, uint32_t world,
+    const uint16_t *__restrict__ cmin, ghip_pair *__restrict__ out,
+    unsigned long long *__restrict__ out_count, uint64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(smem_raw);
+
+    const uint64_t t = (uint64_t)blockIdx.x * world + rank;
+    if (t >= n_tilepairs) return;
+    // t -> (ti, tj), ti <= tj, rows of the upper triangle: row ti holds nt - ti tile pairs
+    uint32_t ti;
+    {
+        double b = 2.0 * nt + 1.0;
+        double r = (b - sqrt(b * b - 8.0 * (double)t)) * 0.5;
+        ti = (uint32_t)r;
+        if (ti >= nt) ti = nt - 1;
+        auto row_off = [&](uint64_t x) { return x * nt - x * (x - 1) / 2; };
+        while (ti > 0 && row_off(ti) > t) ti--;
+        while (ti + 1 < nt && row_off(ti + 1) <= t) ti++;
+    }
+    const uint32_t tj = ti + (uint32_t)(t - ((uint64_t)ti * nt - (uint64_t)ti * (ti - 1) / 2));
+
+    // ---- stage 2*pt sketches into LDS (coalesced 8-B loads; pad rows with 2^64-1) ----
+    for (uint32_t q = 0; q < 2 * pt; q++) {
+        const uint32_t g = (q < pt) ? ti * pt + q : tj * pt + (q - pt);
+        const uint64_t *row = hashes + (uint64_t)g * s;
+        uint64_t *dst = lds + (uint64_t)q * sp;
+        for (uint32_t e = threadIdx.x; e < s_pad; e += PAIR_THREADS) {
+            uint64_t v = (g < n && e < s) ? row[e] : ~0ull;
+            dst[lds_pos(e)] = v;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t p = wave; p < pt * pt; p += PAIR_WAVES) {
+        const uint32_t qa = p / pt, qb = p % pt;
+        const uint32_t gi = ti * pt + qa, gj = tj * pt + qb;
+        if (gi >= n || gj >= n || gi >= gj) continue;
+        const uint64_t *A = lds + (uint64_t)qa * sp;
+        const uint64_t *B = lds + (uint64_t)(pt + qb) * sp;
+        const uint32_t na = lens[gi], nb = lens[gj];
+        const uint32_t tot = na + nb;
+        const uint32_t D = (tot + 63u) >> 6;
+        const uint32_t d0 = min(lane * D, tot), d1 = min(d0 + D, tot);
+
+        // merge-path split of diagonal d0 (ties: a before b)
+        uint32_t lo = d0 > nb ? d0 - nb : 0u, hi = min(d0, na);
+        while (__any(lo < hi)) {
+            if (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                uint64_t a = A[lds_pos(mid)], b = B[lds_pos(d0 - 1 - mid)];
+                if (a <= b) lo = mid + 1; else hi = mid;
+            }
+        }
+        uint32_t ai = lo, bi = d0 - lo;
+        uint64_t a = A[lds_pos(ai)], b = B[lds_pos(bi)];  // slot [len] is padding (2^64-1)
+        uint32_t common = 0;
+        for (uint32_t d = d0; d < d1; d++) {
+            const bool take_a = (ai < na) && ((bi >= nb) || (a <= b));
+            common += (take_a && (bi < nb) && (a == b)) ? 1u : 0u;
+            if (take_a) { ai++; a = A[lds_pos(ai)]; }
+            else        { bi++; b = B[lds_pos(bi)]; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) common += __shfl_xor(common, off, 64);
+
+        uint32_t icnt = 0, jcnt = 0;
+        if (na > 0 && nb > 0) {
+            const uint64_t maxa = A[lds_pos(na - 1)], maxb = B[lds_pos(nb - 1)];
+            if (maxa <= maxb) { icnt = na; jcnt = upper_bound_lds(B, nb, maxa); }
+            else              { icnt = upper_bound_lds(A, na, maxb); jcnt = nb; }
+        }
+        const uint32_t total = icnt + jcnt - common;
+        if (lane == 0 && common >= (uint32_t)cmin[total]) {
+            unsigned long long idx = atomicAdd(out_count, 1ull);
+            if (idx < cap) {
+                ghip_pair r;
+                r.i = gi; r.j = gj; r.common = common; r.total = total; r.ani = 0.0f;
+                out[idx] = r;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Tile geometry shared with the host (ghip_precluster): sp elements of LDS per sketch,
+// pt sketches per tile edge so that 2*pt*sp*8 bytes fit the 160 KiB LDS.
+void ghip_pair_geometry(uint32_t s, uint32_t *s_pad, uint32_t *sp, uint32_t *pt) {
+    uint32_t spad = ((s + 1 + 63) / 64) * 64;  // >= s+1 so slot [len] is always padding
+    uint32_t per = spad + spad / 16;
+    uint32_t fit = (160u * 1024u) / (2u * per * 8u);
+    uint32_t t = fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : 1));
+    *s_pad = spad; *sp = per; *pt = t;
+}
+
+void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n,
+                       uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world,
+                       ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
+                       uint64_t *pairs_compared) {
+    uint32_t s_pad, sp, pt;
+    ghip_pair_geometry(s, &s_pad, &sp, &pt);
+    const uint32_t nt = (uint32_t)((n + pt - 1) / pt);
+    const uint64_t n_tilepairs = (uint64_t)nt * (nt + 1) / 2;
+    const uint64_t my_tiles = n_tilepairs > rank ? (n_tilepairs - rank + world - 1) / world : 0;
+    // pairs this shard compares (for the throughput metric)
+    if (pairs_compared) {
+        uint64_t cnt = 0;
+        if (world == 1) cnt = (uint64_t)n * (n - 1) / 2;
+        else {
+            for (uint64_t t = rank; t < n_tilepairs; t += world) {
+                // same (ti,tj) mapping as the kernel, on the host
+                uint64_t ti = 0, acc = 0;
+                {
+                    double b = 2.0 * nt + 1.0;
+                    double r = (b - __builtin_sqrt(b * b - 8.0 * (double)t)) * 0.5;
+                    ti = (uint64_t)r;
+                    if (ti >= nt) ti = nt - 1;
+                    auto row_off = [&](uint64_t x) { return x * nt - x * (x - 1) / 2; };
+                    while (ti > 0 && row_off(ti) > t) ti--;
+                    while (ti + 1 < nt && row_off(ti + 1) <= t) ti++;
+                    acc = row_off(ti);
+                }
+                uint64_t tj = ti + (t - acc);
+                uint64_t ra = std::min<uint64_t>(pt, n - ti * pt), rb = std::min<uint64_t>(pt, n - tj * pt);
+                cnt += (ti == tj) ? ra * (ra - 1) / 2 : ra * rb;
+            }
+        }
+        *pairs_compared = cnt;
+    }
+    if (my_tiles == 0) return;
+    const size_t lds_bytes = (size_t)2 * pt * sp * sizeof(uint64_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(pair_intersect_tile_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    ghip_prof_begin(ctx, "pair_intersect_tile");
+    hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3((unsigned)my_tiles), dim3(PAIR_THREADS), lds_bytes,
+                       ctx->stream, d_hashes, d_lens, (uint32_t)n, s, s_pad, sp, pt, nt, n_tilepairs, rank,
+                       world, d_cmin, d_out, d_count, cap);
+    ghip_prof_end(ctx);
+}

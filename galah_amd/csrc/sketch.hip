@@ -1,0 +1,398 @@
+// MinHash sketching on gfx950: replaces finch::sketch_files (reference src/finch.rs:55-69).
+//
+//   sketch_kmers  : one pass over the normalised base stream.  Each lane rolls two 2-bit
+//                   encodings of its run of k-mers (forward big-endian for the canonical
+//                   compare, forward little-endian for the hash input; the reverse complement
+//                   is the bitwise complement of the other one), expands the canonical k-mer
+//                   to its ASCII bytes with v_perm_b32, hashes with MurmurHash3_x64_128
+//                   (seed, first u64) and keeps hashes <= a per-genome threshold in a
+//                   candidate list.  VALU-integer bound (~150 ops per base), not HBM bound.
+//   sketch_select : per genome, sort the candidates (bitonic, LDS), drop duplicates, write the
+//                   s smallest into the packed u64[n][s] matrix.  Exact: the host re-runs a
+//                   genome with a wider threshold / larger list if fewer than s distinct
+//                   hashes survived or the list overflowed.
+//   synth_genomes : counter-based synthetic genomes written straight into HBM (bench input).
+#include "ghip_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+// MurmurHash3_x64_128(key, len=K, seed).h1 where the key is given as little-endian u64 words
+// w[0..3] (bytes beyond K are zero).  K <= 32.
+template <int K>
+__device__ __forceinline__ uint64_t murmur3_h1(const uint64_t (&w)[4], uint32_t seed) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    constexpr int nblocks = K / 16;
+#pragma unroll
+    for (int b = 0; b < nblocks; b++) {
+        uint64_t k1 = w[2 * b], k2 = w[2 * b + 1];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    constexpr int tail = K & 15;
+    if (tail > 8) {
+        uint64_t k2 = w[2 * nblocks + 1];
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (tail > 0) {
+        uint64_t k1 = w[2 * nblocks];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
+// 8 bases (2 bits each, base j at bits [2j+1:2j]) -> 8 ASCII bytes, base j in byte j.
+__device__ __forceinline__ uint64_t expand8(uint32_t f16) {
+    const uint32_t lut = 0x54474341u;  // 'A','C','G','T' in bytes 0..3
+    uint32_t lo = f16 & 0xffu, hi = (f16 >> 8) & 0xffu;
+    lo = (lo | (lo << 12)) & 0x000f000fu;
+    lo = (lo | (lo << 6)) & 0x03030303u;
+    hi = (hi | (hi << 12)) & 0x000f000fu;
+    hi = (hi | (hi << 6)) & 0x03030303u;
+    uint32_t alo = __builtin_amdgcn_perm(lut, lut, lo);
+    uint32_t ahi = __builtin_amdgcn_perm(lut, lut, hi);
+    return ((uint64_t)ahi << 32) | alo;
+}
+
+template <int K>
+__device__ __forceinline__ uint64_t hash_canonical(uint64_t code_le, uint32_t seed) {
+    uint64_t w[4] = {0, 0, 0, 0};
+    constexpr int nw = (K + 7) / 8;
+#pragma unroll
+    for (int i = 0; i < nw; i++) {
+        uint64_t x = expand8((uint32_t)(code_le >> (16 * i)) & 0xffffu);
+        constexpr int dummy = 0;
+        (void)dummy;
+        int nb = K - 8 * i;  // bases in this word
+        if (nb < 8) x &= (nb <= 0) ? 0ull : ((1ull << (8 * nb)) - 1);
+        w[i] = x;
+    }
+    return murmur3_h1<K>(w, seed);
+}
+
+// A..T -> 0..3, anything else -> 4
+__device__ __forceinline__ uint32_t base_code(uint32_t c) {
+    uint32_t d = c - 0x41u;
+    bool ok = d < 20u && ((0x80045u >> d) & 1u);
+    return ok ? (((c >> 1) ^ (c >> 2)) & 3u) : 4u;
+}
+
+template <int K>
+__global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
+    const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
+    const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
+    const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
+    const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
+    uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count) {
+    const ghip_sketch_work wk = work[blockIdx.x];
+    const uint32_t slot = wk.slot;
+    const uint32_t g = slot_genome[slot];
+    const uint64_t L = lens[g];
+    const uint64_t p0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    if (p0 >= L) return;
+    const uint64_t thr = slot_thr[slot];
+    const uint64_t cstart = slot_cand_start[slot];
+    const uint32_t ccap = slot_cand_cap[slot];
+    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);  // 16-B aligned
+
+    constexpr uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
+    uint64_t fwd_be = 0, fwd_le = 0;
+    uint32_t good = 0;
+    // bytes b = 0 .. 63+K-1; the k-mer ending at byte b starts at b-K+1 and is ours iff that
+    // start is in [0, 64) -- i.e. b >= K-1.
+    constexpr int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
+    constexpr int NV = (NB + 15) / 16;
+    uint4 nxt = src[0];
+#pragma unroll 1
+    for (int v = 0; v < NV; v++) {
+        uint4 cur = nxt;
+        if (v + 1 < NV) nxt = src[v + 1];
+        uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int b = v * 16 + j;
+            if (b >= NB) break;
+            uint32_t c = (words[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            uint32_t code = base_code(c);
+            if (code > 3u) { good = 0; continue; }
+            fwd_be = ((fwd_be << 2) | code) & mask;
+            fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
+            good++;
+            if (b < K - 1 || good < (uint32_t)K) continue;
+            if (p0 + (uint64_t)(b - (K - 1)) + K > L) continue;  // window runs past the stream
+            // reverse complement: rc_be = ~fwd_le, rc_le = ~fwd_be (complement = 3 - code)
+            uint64_t rc_be = (~fwd_le) & mask;
+            uint64_t canon_le = (rc_be < fwd_be) ? ((~fwd_be) & mask) : fwd_le;
+            uint64_t h = hash_canonical<K>(canon_le, seed);
+            if (h <= thr) {
+                uint32_t idx = atomicAdd(&cand_count[slot], 1u);
+                if (idx < ccap) cand[cstart + idx] = h;
+            }
+        }
+    }
+}
+
+// Generic-k fallback (k in [1,32], not 21): same algorithm, runtime k.
+__device__ __forceinline__ uint64_t murmur3_h1_rt(const uint64_t (&w)[4], int K, uint32_t seed) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    int nblocks = K / 16;
+    for (int b = 0; b < nblocks; b++) {
+        uint64_t k1 = w[2 * b], k2 = w[2 * b + 1];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    int tail = K & 15;
+    if (tail > 8) {
+        uint64_t k2 = w[(2 * nblocks + 1) & 3];
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (tail > 0) {
+        uint64_t k1 = w[(2 * nblocks) & 3];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
+__global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel_rt(
+    const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
+    const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
+    const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
+    const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
+    int K, uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count) {
+    const ghip_sketch_work wk = work[blockIdx.x];
+    const uint32_t slot = wk.slot;
+    const uint32_t g = slot_genome[slot];
+    const uint64_t L = lens[g];
+    const uint64_t p0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    if (p0 >= L) return;
+    const uint64_t thr = slot_thr[slot];
+    const uint64_t cstart = slot_cand_start[slot];
+    const uint32_t ccap = slot_cand_cap[slot];
+    const uint8_t *src = bytes + starts[g] + p0;
+    const uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
+    uint64_t fwd_be = 0, fwd_le = 0;
+    uint32_t good = 0;
+    const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
+    for (int b = 0; b < NB; b++) {
+        uint32_t code = base_code(src[b]);
+        if (code > 3u) { good = 0; continue; }
+        fwd_be = ((fwd_be << 2) | code) & mask;
+        fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
+        good++;
+        if (b < K - 1 || good < (uint32_t)K) continue;
+        if (p0 + (uint64_t)(b - (K - 1)) + K > L) continue;
+        uint64_t rc_be = (~fwd_le) & mask;
+        uint64_t canon_le = (rc_be < fwd_be) ? ((~fwd_be) & mask) : fwd_le;
+        uint64_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            int nb = K - 8 * i;
+            if (nb <= 0) break;
+            uint64_t x = expand8((uint32_t)(canon_le >> (16 * i)) & 0xffffu);
+            if (nb < 8) x &= (1ull << (8 * nb)) - 1;
+            w[i] = x;
+        }
+        uint64_t h = murmur3_h1_rt(w, K, seed);
+        if (h <= thr) {
+            uint32_t idx = atomicAdd(&cand_count[slot], 1u);
+            if (idx < ccap) cand[cstart + idx] = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sketch_select: one 1024-thread block per pending genome.
+// status bits: 1 = candidate list overflowed (count > cap), 2 = fewer than s distinct hashes.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SELECT_THREADS = 1024;
+constexpr uint32_t SELECT_LDS_ELEMS = 8192;  // 64 KiB
+
+__device__ __forceinline__ void bitonic_sort(uint64_t *buf, uint32_t m /* pow2 */) {
+    for (uint32_t size = 2; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                uint32_t lo = 2 * t - (t & (stride - 1));
+                uint32_t hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                uint64_t a = buf[lo], b = buf[hi];
+                if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SELECT_THREADS) void sketch_select_kernel(
+    const uint32_t *__restrict__ slot_genome, uint64_t *__restrict__ cand,
+    const uint32_t *__restrict__ cand_count, const uint64_t *__restrict__ slot_cand_start,
+    const uint32_t *__restrict__ slot_cand_cap, uint32_t s, uint64_t *__restrict__ hashes,
+    uint32_t *__restrict__ out_lens, uint32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(smem_raw);
+    __shared__ uint32_t wave_tot[SELECT_THREADS / 64];
+
+    const uint32_t slot = blockIdx.x;
+    const uint32_t g = slot_genome[slot];
+    const uint32_t cap = slot_cand_cap[slot];
+    const uint32_t count = cand_count[slot];
+    uint64_t *gbuf = cand + slot_cand_start[slot];
+    if (count > cap) {  // host re-runs this genome with cap >= count
+        if (threadIdx.x == 0) status[slot] = 1u;
+        return;
+    }
+    uint32_t m = 1;
+    while (m < count) m <<= 1;
+    if (m < 2) m = 2;
+    uint64_t *buf;
+    if (m <= SELECT_LDS_ELEMS) {
+        buf = lds;
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) buf[i] = (i < count) ? gbuf[i] : ~0ull;
+    } else {
+        buf = gbuf;  // cap is a power of two >= m on this path
+        for (uint32_t i = count + threadIdx.x; i < m; i += blockDim.x) buf[i] = ~0ull;
+    }
+    bitonic_sort(buf, m);
+
+    // distinct rank of every element; first s distinct go to the output row
+    const uint32_t per = (m + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = threadIdx.x * per;
+    uint32_t local = 0;
+    for (uint32_t i = i0; i < i0 + per && i < count; i++) local += (i == 0 || buf[i] != buf[i - 1]) ? 1u : 0u;
+    // block exclusive scan of `local`
+    uint32_t incl = local;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; w++) {
+        uint32_t t = wave_tot[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    uint32_t rank = base + incl - local;
+    uint64_t *row = hashes + (uint64_t)g * s;
+    for (uint32_t i = i0; i < i0 + per && i < count; i++) {
+        if (i == 0 || buf[i] != buf[i - 1]) {
+            if (rank < s) row[rank] = buf[i];
+            rank++;
+        }
+    }
+    const uint32_t len = total < s ? total : s;
+    for (uint32_t i = len + threadIdx.x; i < s; i += blockDim.x) row[i] = ~0ull;
+    if (threadIdx.x == 0) {
+        out_lens[g] = len;
+        status[slot] = (total < s) ? 2u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synth_genomes: same definition as oracle go_synth_genome (build-defined).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint32_t species, uint32_t stream) {
+    return splitmix64(splitmix64(seed ^ ((uint64_t)species << 20)) ^ ((uint64_t)stream * 0xd1b54a32d192ed03ULL));
+}
+
+// each thread writes 16 bases (one 16-B store)
+__global__ __launch_bounds__(256) void synth_genomes_kernel(uint8_t *__restrict__ bytes,
+                                                            const uint64_t *__restrict__ starts,
+                                                            uint64_t length, uint32_t members,
+                                                            uint64_t seed, uint32_t sub_thr) {
+    const uint32_t g = blockIdx.y;
+    const uint32_t species = g / members, member = g % members;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (p0 >= length) return;
+    const uint64_t ka = synth_key(seed, species, 0), km = synth_key(seed, species, member + 1);
+    const uint64_t w = splitmix64(ka + (p0 >> 5));
+    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint64_t p = p0 + j;
+        uint32_t base = (uint32_t)(w >> (2 * (p & 31))) & 3u;
+        uint64_t u = splitmix64(km + p);
+        if ((uint32_t)(u >> 32) < sub_thr) base = (base + 1 + (uint32_t)((u >> 8) % 3)) & 3u;
+        uint32_t ch = (0x54474341u >> (8 * base)) & 0xffu;
+        if (p >= length) ch = 'N';
+        out[j >> 2] |= ch << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint4 *>(bytes + starts[g] + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+}  // namespace
+
+void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
+                       uint32_t n_species, uint32_t members, uint64_t seed, uint32_t sub_thr) {
+    uint64_t threads = (length + 15) / 16;
+    dim3 grid((unsigned)((threads + 255) / 256), n_species * members);
+    ghip_prof_begin(ctx, "synth_genomes");
+    hipLaunchKernelGGL(synth_genomes_kernel, grid, dim3(256), 0, ctx->stream, d_bytes, d_starts, length, members, seed, sub_thr);
+    ghip_prof_end(ctx);
+}
+
+void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
+                              const uint64_t *d_lens, const uint32_t *d_slot_genome,
+                              const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
+                              const uint32_t *d_slot_cand_cap, const ghip_sketch_work *d_work,
+                              size_t n_work, uint32_t k, uint32_t seed, uint64_t *d_cand,
+                              uint32_t *d_cand_count) {
+    if (n_work == 0) return;
+    ghip_prof_begin(ctx, "sketch_kmers");
+    if (k == 21) {
+        hipLaunchKernelGGL(sketch_kmers_kernel<21>, dim3((unsigned)n_work), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
+                           d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
+                           d_slot_cand_cap, d_work, seed, d_cand, d_cand_count);
+    } else {
+        hipLaunchKernelGGL(sketch_kmers_kernel_rt, dim3((unsigned)n_work), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
+                           d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
+                           d_slot_cand_cap, d_work, (int)k, seed, d_cand, d_cand_count);
+    }
+    ghip_prof_end(ctx);
+}
+
+void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, size_t n_slots,
+                               uint64_t *d_cand, const uint32_t *d_cand_count,
+                               const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap,
+                               uint32_t s, uint64_t *d_hashes, uint32_t *d_lens, uint32_t *d_status) {
+    if (n_slots == 0) return;
+    ghip_prof_begin(ctx, "sketch_select");
+    hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)n_slots), dim3(SELECT_THREADS),
+                       SELECT_LDS_ELEMS * sizeof(uint64_t), ctx->stream, d_slot_genome, d_cand, d_cand_count,
+                       d_slot_cand_start, d_slot_cand_cap, s, d_hashes, d_lens, d_status);
+    ghip_prof_end(ctx);
+}

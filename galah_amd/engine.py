@@ -1,0 +1,250 @@
+"""Thin object layer over the C ABI: one Context per (process, GPU).
+
+Plumbing only -- every call goes straight to libgalah_hip.so; nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PAIR_DTYPE, GalahHipError, check
+
+KERNELS = ("sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_table", "ani_pairs",
+           "synth_genomes")
+
+
+def device_count() -> int:
+    return int(_lib.lib().ghip_device_count())
+
+
+class _Handle:
+    _free_name = ""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx = ctx
+        self._h = handle
+
+    def free(self):
+        if self._h:
+            getattr(_lib.lib(), self._free_name)(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Genomes(_Handle):
+    _free_name = "ghip_genomes_free"
+
+    def __len__(self):
+        return int(_lib.lib().ghip_genomes_count(self._h))
+
+    @property
+    def total_bases(self) -> int:
+        return int(_lib.lib().ghip_genomes_total_bases(self._h))
+
+    def length(self, idx: int) -> int:
+        return int(_lib.lib().ghip_genomes_length(self._h, idx))
+
+    def to_host(self, idx: int) -> np.ndarray:
+        out = np.empty(self.length(idx), dtype=np.uint8)
+        check(_lib.lib().ghip_genomes_to_host(self.ctx._h, self._h, idx, out.ctypes.data), self.ctx._h)
+        return out
+
+
+class Sketches(_Handle):
+    _free_name = "ghip_sketches_free"
+
+    def __len__(self):
+        return int(_lib.lib().ghip_sketches_count(self._h))
+
+    @property
+    def size(self) -> int:
+        return int(_lib.lib().ghip_sketches_size(self._h))
+
+    @property
+    def kmer(self) -> int:
+        return int(_lib.lib().ghip_sketches_kmer(self._h))
+
+    @property
+    def device_hashes(self) -> int:
+        return int(_lib.lib().ghip_sketches_device_hashes(self._h) or 0)
+
+    @property
+    def device_lens(self) -> int:
+        return int(_lib.lib().ghip_sketches_device_lens(self._h) or 0)
+
+    def to_host(self) -> Tuple[np.ndarray, np.ndarray]:
+        n, s = len(self), self.size
+        hashes = np.empty((n, s), dtype=np.uint64)
+        lens = np.empty(n, dtype=np.uint32)
+        check(_lib.lib().ghip_sketches_to_host(self.ctx._h, self._h, hashes.ctypes.data, lens.ctypes.data), self.ctx._h)
+        return hashes, lens
+
+
+class AniIndex(_Handle):
+    _free_name = "ghip_ani_index_free"
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        L = _lib.lib()
+        h = C.c_void_p()
+        rc = L.ghip_init(device, C.byref(h))
+        if rc != 0:
+            msg = L.ghip_last_error(None)
+            raise GalahHipError(rc, msg.decode() if msg else "")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _lib.lib().ghip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing
+    def set_stream(self, hip_stream: Optional[int]):
+        check(_lib.lib().ghip_set_stream(self._h, C.c_void_p(hip_stream or 0)), self._h)
+
+    def synchronize(self):
+        check(_lib.lib().ghip_synchronize(self._h), self._h)
+
+    def profile(self, enable: bool = True):
+        check(_lib.lib().ghip_profile_enable(self._h, 1 if enable else 0), self._h)
+
+    def profile_reset(self):
+        check(_lib.lib().ghip_profile_reset(self._h), self._h)
+
+    def kernel_stats(self) -> Dict[str, Tuple[int, float]]:
+        out = {}
+        for k in KERNELS:
+            n, ms = C.c_uint64(0), C.c_double(0)
+            check(_lib.lib().ghip_kernel_stats(self._h, k.encode(), C.byref(n), C.byref(ms)), self._h)
+            out[k] = (int(n.value), float(ms.value))
+        return out
+
+    # ---- ingest
+    def genomes_from_files(self, paths: Sequence[str], io_threads: int = 1) -> Genomes:
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        check(_lib.lib().ghip_genomes_from_files(self._h, arr, len(paths), io_threads, C.byref(h)), self._h)
+        return Genomes(self, h)
+
+    def genomes_from_host(self, streams: Sequence[bytes | np.ndarray]) -> Genomes:
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        offsets = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        for i, a in enumerate(arrs):
+            offsets[i + 1] = offsets[i] + a.size
+        flat = np.concatenate(arrs) if arrs else np.empty(0, dtype=np.uint8)
+        flat = np.ascontiguousarray(flat)
+        h = C.c_void_p()
+        check(_lib.lib().ghip_genomes_from_host(self._h, flat.ctypes.data, offsets.ctypes.data, len(arrs), C.byref(h)), self._h)
+        return Genomes(self, h)
+
+    def genomes_synthetic(self, seed: int, n_species: int, members: int, length: int, sub_rate: float) -> Genomes:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_genomes_synthetic(self._h, seed, n_species, members, length, sub_rate, C.byref(h)), self._h)
+        return Genomes(self, h)
+
+    # ---- sketching
+    def sketch_genomes(self, g: Genomes, k: int = 21, s: int = 1000, seed: int = 0) -> Sketches:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_sketch_genomes(self._h, g._h, k, s, seed, C.byref(h)), self._h)
+        return Sketches(self, h)
+
+    def sketch_files(self, paths: Sequence[str], k: int = 21, s: int = 1000, seed: int = 0, io_threads: int = 1) -> Sketches:
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        check(_lib.lib().ghip_sketch_files(self._h, arr, len(paths), k, s, seed, io_threads, C.byref(h)), self._h)
+        return Sketches(self, h)
+
+    def sketches_from_host(self, hashes: np.ndarray, lens: np.ndarray, k: int = 21) -> Sketches:
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n, s = hashes.shape
+        h = C.c_void_p()
+        check(_lib.lib().ghip_sketches_from_host(self._h, hashes.ctypes.data, lens.ctypes.data, n, s, k, C.byref(h)), self._h)
+        return Sketches(self, h)
+
+    def sketches_wrap_device(self, d_hashes: int, d_lens: int, n: int, s: int, k: int = 21) -> Sketches:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_sketches_wrap_device(self._h, C.c_void_p(d_hashes), C.c_void_p(d_lens), n, s, k, C.byref(h)), self._h)
+        return Sketches(self, h)
+
+    # ---- precluster
+    def precluster(self, sk: Sketches, min_ani: float, rank: int = 0, world: int = 1) -> np.ndarray:
+        p = C.c_void_p()
+        n = C.c_size_t(0)
+        check(_lib.lib().ghip_precluster_shard(self._h, sk._h, np.float32(min_ani), rank, world, C.byref(p), C.byref(n)), self._h)
+        try:
+            if n.value == 0:
+                return np.empty(0, dtype=PAIR_DTYPE)
+            buf = (C.c_char * (n.value * PAIR_DTYPE.itemsize)).from_address(p.value)
+            return np.frombuffer(buf, dtype=PAIR_DTYPE).copy()
+        finally:
+            _lib.lib().ghip_free(p)
+
+    @property
+    def last_pairs_compared(self) -> int:
+        return int(_lib.lib().ghip_last_pairs_compared(self._h))
+
+    # ---- ANI
+    def ani_index_build(self, g: Genomes, k: int = 15, c: int = 125, chunk: int = 20000) -> AniIndex:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_ani_index_build(self._h, g._h, k, c, chunk, C.byref(h)), self._h)
+        return AniIndex(self, h)
+
+    def ani_pairs(self, idx: AniIndex, pairs: np.ndarray, min_af: float = 0.15, want_af: bool = False):
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        n = pairs.shape[0]
+        out = np.zeros(n, dtype=np.float32)
+        af = np.zeros((n, 2), dtype=np.float32) if want_af else None
+        check(_lib.lib().ghip_ani_pairs(self._h, idx._h, pairs.ctypes.data, n, np.float32(min_af), out.ctypes.data,
+                                        af.ctypes.data if want_af else None), self._h)
+        return (out, af) if want_af else out
+
+
+def cluster_pairs(n_genomes: int, pairs: np.ndarray, ani_threshold: float, pair_ani: Optional[np.ndarray] = None,
+                  skip_clusterer: bool = False, ani_callback=None) -> List[List[int]]:
+    """ghip_cluster: clusterer::cluster from the precluster cache onwards (host, no GPU needed)."""
+    L = _lib.lib()
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    pa = None
+    if pair_ani is not None:
+        pa = np.ascontiguousarray(pair_ani, dtype=np.float32)
+        assert pa.shape[0] == pairs.shape[0]
+
+    def _cb(_user, a, b, out):
+        r = ani_callback(int(a), int(b))
+        if r is None:
+            return 0
+        out[0] = np.float32(r)
+        return 1
+
+    cb = _lib.ANI_CALLBACK(_cb) if ani_callback is not None else C.cast(None, _lib.ANI_CALLBACK)
+    members, offsets, nc = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+    rc = L.ghip_cluster(n_genomes, pairs.ctypes.data, pairs.shape[0], pa.ctypes.data if pa is not None else None,
+                        1 if skip_clusterer else 0, np.float32(ani_threshold), cb, None,
+                        C.byref(members), C.byref(offsets), C.byref(nc))
+    if rc != 0:
+        raise GalahHipError(rc, "ghip_cluster failed (no representative with a known ANI, or bad input)")
+    try:
+        off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), shape=(nc.value + 1,)).copy()
+        total = int(off[-1])
+        mem = np.ctypeslib.as_array(C.cast(members, C.POINTER(C.c_uint32)), shape=(max(total, 1),)).copy()
+    finally:
+        L.ghip_free(members)
+        L.ghip_free(offsets)
+    return [[int(x) for x in mem[off[c]:off[c + 1]]] for c in range(nc.value)]

@@ -1,0 +1,150 @@
+/*
+ * galah_hip.h -- C ABI of the MI355X-native galah precluster/ANI hot path (libgalah_hip.so).
+ *
+ * This is the drop-in boundary a galah maintainer binds from Rust (see INTEGRATION.md for the
+ * `extern "C"` block and the `impl PreclusterDistanceFinder` / `impl ClusterDistanceFinder`
+ * shims).  Plain pointers and sizes only; no unwinding, no callbacks except the optional ANI
+ * callback of ghip_cluster; every function returns 0 on success or a GHIP_E* code, and
+ * ghip_last_error() gives the text the Rust shim turns into the reference's panic!().
+ *
+ * Reference interfaces replaced (paths into wwood/galah @ v0.5.1):
+ *   trait PreclusterDistanceFinder::distances      src/lib.rs:29-30, impl src/finch.rs:13-24
+ *   finch::sketch_files call                        src/finch.rs:55-69
+ *   finch::distance::distance pair loop             src/finch.rs:74-96
+ *   trait ClusterDistanceFinder::calculate_ani      src/lib.rs:47-55, impl src/skani.rs:695-716
+ *   SortedPairGenomeDistanceCache                   src/sorted_pair_genome_distance_cache.rs:5-59
+ *   clusterer::cluster                              src/clusterer.rs:14-152
+ *
+ * Index space of every result = positions in the input path/genome list (src/finch.rs:75-92).
+ */
+#ifndef GALAH_HIP_H
+#define GALAH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GHIP_OK 0
+#define GHIP_EINVAL 1   /* bad argument */
+#define GHIP_EIO 2      /* file could not be read / is not FASTA */
+#define GHIP_EHIP 3     /* HIP runtime error (no device, OOM, launch failure) */
+#define GHIP_ENOMEM 4   /* host allocation failure */
+#define GHIP_EUNSUPPORTED 5 /* mode the finch back-end refuses (src/finch.rs:14-15,26-41) */
+
+#define GHIP_ABI_VERSION 1
+
+typedef struct ghip_ctx ghip_ctx;           /* one per (process, GPU) */
+typedef struct ghip_genomes ghip_genomes;   /* normalised base streams resident in HBM */
+typedef struct ghip_sketches ghip_sketches; /* packed MinHash sketch matrix resident in HBM */
+typedef struct ghip_ani_index ghip_ani_index; /* FracMinHash seed index resident in HBM */
+
+/* One surviving precluster pair: what src/finch.rs:91-93 inserts into the cache.
+ * i < j; common/total are raw_distance's integers; ani = (1.0 - mash_distance) as f32. */
+typedef struct {
+    uint32_t i, j;
+    uint32_t common, total;
+    float ani;
+} ghip_pair;
+
+/* ---------------------------------------------------------------- context */
+int ghip_abi_version(void);
+int ghip_device_count(void);                       /* 0 when no GPU is visible */
+int ghip_init(int device, ghip_ctx **out);         /* device ordinal (LOCAL_RANK) */
+void ghip_destroy(ghip_ctx *ctx);
+const char *ghip_last_error(const ghip_ctx *ctx);  /* ctx may be NULL: last ghip_init error */
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own stream. */
+int ghip_set_stream(ghip_ctx *ctx, void *hip_stream);
+int ghip_synchronize(ghip_ctx *ctx);
+
+/* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:
+ * "sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_table", "ani_pairs",
+ * "synth_genomes".  enable=1 starts collecting, ghip_kernel_stats drains finished events. */
+int ghip_profile_enable(ghip_ctx *ctx, int enable);
+int ghip_profile_reset(ghip_ctx *ctx);
+int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
+
+/* ---------------------------------------------------------------- genome ingest
+ * Device format of one genome: stream G = for each FASTA record, needletail-normalised bytes
+ * followed by one 'N' (k-mers never span records, src/finch.rs:69 -> finch sketch_stream).
+ * Any byte other than A,C,G,T breaks k-mers. */
+int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
+                            ghip_genomes **out);
+/* Host streams already in device format: genome g = bytes[offsets[g] .. offsets[g+1]). */
+int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, size_t n,
+                           ghip_genomes **out);
+/* Counter-based synthetic genomes generated directly in HBM (bench/test input):
+ * genome index g = species * members + member. */
+int ghip_genomes_synthetic(ghip_ctx *ctx, uint64_t seed, uint32_t n_species, uint32_t members,
+                           uint64_t length, double sub_rate, ghip_genomes **out);
+size_t ghip_genomes_count(const ghip_genomes *g);
+uint64_t ghip_genomes_total_bases(const ghip_genomes *g);
+uint64_t ghip_genomes_length(const ghip_genomes *g, size_t idx);
+int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t idx, uint8_t *out);
+void ghip_genomes_free(ghip_genomes *g);
+
+/* ---------------------------------------------------------------- MinHash sketching
+ * Replaces finch::sketch_files (src/finch.rs:55-69): the s smallest distinct
+ * murmurhash3_x64_128(canonical k-mer ASCII, seed).0, ascending; fewer than s allowed
+ * (no_strict).  Layout: u64 hashes[n][s] row-major, rows padded with UINT64_MAX; u32 len[n]. */
+int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s,
+                        uint64_t seed, ghip_sketches **out);
+int ghip_sketch_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s,
+                      uint64_t seed, int io_threads, ghip_sketches **out);
+int ghip_sketches_from_host(ghip_ctx *ctx, const uint64_t *hashes, const uint32_t *lens, size_t n,
+                            uint32_t s, uint32_t k, ghip_sketches **out);
+/* Borrow device memory owned by the caller (e.g. the output of an RCCL all-gather). */
+int ghip_sketches_wrap_device(ghip_ctx *ctx, void *d_hashes, void *d_lens, size_t n, uint32_t s,
+                              uint32_t k, ghip_sketches **out);
+int ghip_sketches_to_host(ghip_ctx *ctx, const ghip_sketches *sk, uint64_t *hashes, uint32_t *lens);
+size_t ghip_sketches_count(const ghip_sketches *sk);
+uint32_t ghip_sketches_size(const ghip_sketches *sk);     /* s */
+uint32_t ghip_sketches_kmer(const ghip_sketches *sk);     /* k */
+void *ghip_sketches_device_hashes(const ghip_sketches *sk); /* u64[n][s] in HBM */
+void *ghip_sketches_device_lens(const ghip_sketches *sk);   /* u32[n] in HBM */
+void ghip_sketches_free(ghip_sketches *sk);
+
+/* ---------------------------------------------------------------- precluster pairs
+ * Replaces the i<j loop of finch::distances (src/finch.rs:74-96).  Output sorted by (i, j).
+ * min_ani_fraction is FinchPreclusterer::min_ani (a fraction, src/finch.rs:5-6).
+ * The caller frees *out_pairs with ghip_free(). */
+int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
+                    ghip_pair **out_pairs, size_t *out_n);
+/* Multi-GPU share: only the upper-triangle tiles t with t % world == rank (block-cyclic). */
+int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
+                          uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n);
+/* Number of genome pairs the last ghip_precluster[_shard] call on this ctx compared. */
+uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
+
+/* ---------------------------------------------------------------- ANI on candidate pairs
+ * Replaces SkaniClusterer::calculate_ani (src/skani.rs:708-716 -> calculate_skani :718-788),
+ * batched.  Returns PERCENT, 0.0 when below the aligned-fraction gate (skani prints no row).
+ * Build-defined estimator, skani parity unpinned: see DESIGN.md "ANI". Thread-safe. */
+int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c,
+                         uint32_t chunk, ghip_ani_index **out);
+int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */,
+                   size_t n, float min_aligned_fraction, float *out_ani_percent,
+                   float *out_af /* nullable, [n][2] */);
+void ghip_ani_index_free(ghip_ani_index *idx);
+
+/* ---------------------------------------------------------------- host clusterer
+ * clusterer::cluster from the precluster cache onwards (src/clusterer.rs:56-152):
+ * partition_sketches, find_precluster_cluster_representatives, ..._memberships.
+ * pair_ani (nullable) = clusterer ANI per precluster pair, same order as `pairs`, in the
+ * clusterer's unit (percent for skani); NaN = None.  When pair_ani is NULL and skip_clusterer
+ * is 0, `ani_cb` is called like ClusterDistanceFinder::calculate_ani(genome_a, genome_b).
+ * Output: clusters as members[offsets[c] .. offsets[c+1]), representative first
+ * (src/cluster_argument_parsing.rs:730); free both with ghip_free(). */
+typedef int (*ghip_ani_callback)(void *user, uint32_t genome_a, uint32_t genome_b, float *ani);
+int ghip_cluster(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
+                 int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, void *user,
+                 uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters);
+
+void ghip_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def fasta(name: str) -> str:
+    return os.path.join(GOLDEN, "fasta", name + ".fna.gz")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(GOLDEN, "golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_sketches():
+    return dict(np.load(os.path.join(GOLDEN, "sketches.npz")))
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import galah_amd
+    if galah_amd.device_count() == 0:
+        pytest.fail("gpu test selected but no HIP device is visible (no CPU fallback exists)")
+    c = galah_amd.Context(0)
+    yield c
+    c.close()
+
+
+def random_sketches(rng, n, s, shared_groups=0, min_len=None):
+    """Random strictly-ascending u64 sketches; members of a group share a fraction of hashes."""
+    hashes = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint32)
+    pools = [rng.integers(0, 2**63, size=3 * s, dtype=np.uint64) for _ in range(max(shared_groups, 1))]
+    for i in range(n):
+        ln = s if min_len is None else int(rng.integers(min_len, s + 1))
+        if shared_groups and rng.random() < 0.8:
+            pool = pools[i % shared_groups]
+            take = rng.choice(pool, size=min(len(pool), ln), replace=False)
+            extra = rng.integers(0, 2**63, size=ln, dtype=np.uint64)
+            mix = np.where(rng.random(ln) < 0.6, take[:ln], extra)
+        else:
+            mix = rng.integers(0, 2**64 - 2, size=ln, dtype=np.uint64)
+        u = np.unique(mix)
+        # scale differently so maxima differ (exercises the i/j rank logic)
+        hashes[i, : len(u)] = u
+        lens[i] = len(u)
+    return hashes, lens

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the reference's own test data (run in the authoring container,
+where /root/reference exists; the GPU box only sees the committed outputs).
+
+Fixtures are DATA only:
+  * FASTA inputs the reference's tests use (tests/data/set1, set2, abisko4 subset, antonio_mags),
+    gzip-compressed copies -- inputs, not reference source code;
+  * golden.json: for each genome pair of the reference's finch-path tests, the integers
+    (i, j, common, total) and the f32 ANI.  Row "set1" is REFERENCE-EMITTED
+    (src/finch.rs:111-119 asserts Some(0.9808188)); every other row is ORACLE-DERIVED
+    (oracle/galah_oracle.c), consistent with the membership asserts of src/clusterer.rs:538-690.
+  * sketches.npz: the oracle's MinHash sketches (k=21, s=1000, seed 0) of every fixture genome.
+"""
+import gzip
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+REF = "/root/reference/tests/data"
+GENOMES = {
+    "set1_1mbp": "set1/1mbp.fna",
+    "set1_500kb": "set1/500kb.fna",
+    "set2_1mbp": "set2/1mbp.fna",
+    "set2_half": "set2/1mbp.half_aligned.fna",
+    "abisko_S1X13": "abisko4/73.20120800_S1X.13.fna",
+    "abisko_S2D19": "abisko4/73.20120600_S2D.19.fna",
+    "abisko_S3X12": "abisko4/73.20120700_S3X.12.fna",
+    "abisko_S2D13": "abisko4/73.20110800_S2D.13.fna",
+    "antonio_MAG52": "antonio_mags/BE_RX_R2_MAG52.fna",
+    "antonio_MAG189": "antonio_mags/BE_RX_R3_MAG189.fna",
+    "clash_500kb": "set1_name_clash/500kb.fna",
+}
+PAIRS = [("set1_1mbp", "set1_500kb"), ("abisko_S1X13", "abisko_S2D19"), ("abisko_S1X13", "abisko_S3X12"),
+         ("abisko_S1X13", "abisko_S2D13"), ("abisko_S2D19", "abisko_S3X12"), ("abisko_S2D19", "abisko_S2D13"),
+         ("abisko_S3X12", "abisko_S2D13"), ("antonio_MAG52", "antonio_MAG189"), ("set2_1mbp", "set2_half"),
+         ("set1_500kb", "clash_500kb"), ("abisko_S1X13", "antonio_MAG52")]
+
+
+def main():
+    fasta_dir = os.path.join(HERE, "fasta")
+    os.makedirs(fasta_dir, exist_ok=True)
+    sketches = {}
+    for name, rel in GENOMES.items():
+        src = os.path.join(REF, rel)
+        dst = os.path.join(fasta_dir, name + ".fna.gz")
+        with open(src, "rb") as f, gzip.GzipFile(dst, "wb", compresslevel=9, mtime=0) as g:
+            shutil.copyfileobj(f, g)
+        sk_plain = oracle.sketch_file(src)
+        sk_gz = oracle.sketch_file(dst)
+        assert np.array_equal(sk_plain, sk_gz), name
+        sketches[name] = sk_plain
+    np.savez_compressed(os.path.join(HERE, "sketches.npz"), **sketches)
+    rows = []
+    for a, b in PAIRS:
+        common, total = oracle.raw_distance(sketches[a], sketches[b])
+        c2, t2 = oracle.raw_distance(sketches[a], sketches[b], closed_form=True)
+        assert (common, total) == (c2, t2)
+        ani = np.float32(oracle.mash_ani(common, total, 21)) if total else None
+        rows.append({"a": a, "b": b, "len_a": int(len(sketches[a])), "len_b": int(len(sketches[b])),
+                     "common": common, "total": total,
+                     "ani_f32": None if ani is None else float(ani),
+                     "ani_f32_bits": None if ani is None else int(np.float32(ani).view(np.uint32)),
+                     "source": "reference src/finch.rs:111-119" if (a, b) == PAIRS[0] else "oracle-derived"})
+    assert rows[0]["ani_f32_bits"] == int(np.float32(0.9808188).view(np.uint32)), rows[0]
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump({"k": 21, "s": 1000, "seed": 0, "pairs": rows}, f, indent=1)
+    for r in rows:
+        print(r)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""The C-ABI library loads, exports every symbol include/galah_hip.h declares, refuses to run
+without a GPU, and its host clusterer (ghip_cluster, no GPU involved) matches the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import galah_amd
+import oracle
+from galah_amd import _lib, PAIR_DTYPE, cluster_pairs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "galah_hip.h")).read()
+    declared = set(re.findall(r"\b(ghip_[a-z_0-9]+)\s*\(", header))
+    declared -= {"ghip_ani_callback"}
+    assert len(declared) >= 35
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in galah_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert L.ghip_abi_version() == 1
+
+
+@pytest.mark.skipif(galah_amd.device_count() > 0, reason="only meaningful without a GPU")
+def test_no_gpu_fails_loudly():
+    with pytest.raises(galah_amd.GalahHipError) as e:
+        galah_amd.Context(0)
+    assert "no HIP device" in str(e.value)
+    with pytest.raises(Exception):
+        galah_amd.distances(["a.fna", "b.fna"], 0.9, 1000, 21)
+
+
+def _random_graph(rng, n, density, groups):
+    rows = []
+    for i in range(n):
+        for j in range(i + 1, n):
+            same = (i % groups) == (j % groups)
+            if rng.random() < (density if same else density * 0.02):
+                rows.append((i, j, 0, 0, np.float32(rng.uniform(0.9, 1.0))))
+    return np.array(rows, dtype=PAIR_DTYPE) if rows else np.zeros(0, dtype=PAIR_DTYPE)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_host_clusterer_matches_oracle(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 120))
+    pairs = _random_graph(rng, n, rng.uniform(0.2, 0.9), int(rng.integers(1, 8)))
+    # clusterer ANI in percent, deterministic function of the pair; some ties, some zeros
+    vals = np.round(rng.uniform(90, 100, size=(n, n)), 1).astype(np.float32)
+    vals = np.minimum(vals, vals.T)
+    vals[rng.random((n, n)) < 0.05] = 0.0
+    vals = np.minimum(vals, vals.T)
+    pair_ani = np.array([vals[p["i"], p["j"]] for p in pairs], dtype=np.float32)
+    thr = np.float32(95.0)
+    want = oracle.cluster(n, oracle.Cache.from_pairs(pairs), thr, lambda a, b: float(vals[a, b]))
+    assert cluster_pairs(n, pairs, thr, pair_ani) == want
+    # callback form (ClusterDistanceFinder::calculate_ani per pair) gives the same clusters
+    assert cluster_pairs(n, pairs, thr, None, False, ani_callback=lambda a, b: float(vals[a, b])) == want
+    # skip_clusterer: precluster ANI reused (clusterer.rs:32-36)
+    thr2 = np.float32(0.95)
+    assert cluster_pairs(n, pairs, thr2, None, True) == oracle.cluster(n, oracle.Cache.from_pairs(pairs), thr2, None, True)
+    flat = sorted(x for c in want for x in c)
+    assert flat == list(range(n))
+
+
+def test_cluster_semantics_rep_first_and_ties():
+    # 0 and 2 are reps (not linked); 1 is equally close to both -> lowest-index rep wins (clusterer.rs:436-441)
+    pairs = np.array([(0, 1, 0, 0, 0.97), (1, 2, 0, 0, 0.98)], dtype=PAIR_DTYPE)
+    ani = np.array([96.0, 96.0], dtype=np.float32)
+    assert cluster_pairs(3, pairs, np.float32(95.0), ani) == [[0, 1], [2]]
+    # below threshold everywhere -> every genome its own representative
+    assert cluster_pairs(3, pairs, np.float32(99.0), ani) == [[0], [1], [2]]
+    # singletons come after bigger preclusters (clusterer.rs:79)
+    pairs = np.array([(2, 3, 0, 0, 0.97)], dtype=PAIR_DTYPE)
+    assert cluster_pairs(4, pairs, np.float32(95.0), np.array([99.0], np.float32)) == [[2, 3], [0], [1]]
+
+
+def test_cluster_mirror_refuses_like_reference():
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21)
+    assert pre.method_name() == "finch"
+    assert len(pre.distances_contigs([], [])) == 0          # finch.rs:26-33
+    with pytest.raises(RuntimeError, match="Reference genome clustering"):
+        pre.distances_with_references([], [])               # finch.rs:40
+    with pytest.raises(RuntimeError, match="Low-memory"):
+        galah_amd.FinchPreclusterer(0.9, low_memory=True).distances(["x"])  # finch.rs:15
+    cl = galah_amd.HipAniClusterer(95.0)
+    with pytest.raises(RuntimeError, match="finch does not support contig comparisons"):
+        galah_amd.cluster(["a"], pre, cl, cluster_contigs=True, contig_names=["c"])  # clusterer.rs:38-41
+    with pytest.raises(AssertionError):
+        galah_amd.HipAniClusterer(0.95).initialise()        # skani.rs:696-698 (threshold is percent)

@@ -1,0 +1,191 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import numpy as np
+import pytest
+
+import galah_amd
+import oracle
+from conftest import fasta, random_sketches
+
+pytestmark = pytest.mark.gpu
+
+ALL = ["set1_1mbp", "set1_500kb", "set2_1mbp", "set2_half", "abisko_S1X13", "abisko_S2D19", "abisko_S3X12",
+       "abisko_S2D13", "antonio_MAG52", "antonio_MAG189", "clash_500kb"]
+
+
+def test_reference_golden_through_hip(ctx):
+    # src/finch.rs:111-128 run through FinchPreclusterer.distances on the GPU
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx)
+    got = pre.distances([fasta("set1_1mbp"), fasta("set1_500kb")])
+    want = galah_amd.SortedPairGenomeDistanceCache()
+    want.insert((0, 1), 0.9808188)
+    assert got == want
+    assert repr(got) == "SortedPairGenomeDistanceCache { internal: {(0, 1): Some(0.9808188)} }"
+    empty = galah_amd.FinchPreclusterer(0.99, 1000, 21, ctx=ctx).distances([fasta("set1_1mbp"), fasta("set1_500kb")])
+    assert empty == galah_amd.SortedPairGenomeDistanceCache()
+
+
+def test_sketches_bit_exact_on_fixture_genomes(ctx, golden_sketches):
+    sk = ctx.sketch_files([fasta(n) for n in ALL], 21, 1000, 0, io_threads=4)
+    hashes, lens = sk.to_host()
+    for i, name in enumerate(ALL):
+        want = golden_sketches[name]
+        assert lens[i] == len(want)
+        assert np.array_equal(hashes[i, : lens[i]], want), name
+        assert np.all(hashes[i, lens[i]:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+
+
+def test_precluster_golden_table(ctx, golden):
+    sk = ctx.sketch_files([fasta(n) for n in ALL], 21, 1000, 0, io_threads=4)
+    pairs = ctx.precluster(sk, np.float32(0.0))  # threshold 0: every pair comes back
+    assert len(pairs) == len(ALL) * (len(ALL) - 1) // 2
+    look = {(int(p["i"]), int(p["j"])): p for p in pairs}
+    for row in golden["pairs"]:
+        i, j = ALL.index(row["a"]), ALL.index(row["b"])
+        p = look[(min(i, j), max(i, j))]
+        assert (int(p["common"]), int(p["total"])) == (row["common"], row["total"])
+        assert int(p["ani"].view(np.uint32)) == row["ani_f32_bits"]
+    hashes, lens = sk.to_host()
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.0))
+    assert pairs.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n,s,min_len,thr", [(37, 1000, None, 0.9), (64, 1000, 1, 0.0), (130, 256, 1, 0.8),
+                                               (9, 64, 0, 0.0), (2, 1000, None, 0.0), (100, 1024, 900, 0.95),
+                                               (33, 2000, 1500, 0.9)])
+def test_pairs_random_sketches_vs_oracle(ctx, n, s, min_len, thr):
+    rng = np.random.default_rng(n * 1000 + s)
+    hashes, lens = random_sketches(rng, n, s, shared_groups=5, min_len=min_len)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    got = ctx.precluster(sk, np.float32(thr))
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(thr))
+    assert got.tobytes() == want.tobytes()
+    assert ctx.last_pairs_compared == n * (n - 1) // 2
+
+
+def test_pairs_edge_cases(ctx):
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    s = 8
+    hashes = np.full((5, s), M, dtype=np.uint64)
+    lens = np.array([0, 0, 3, 8, 8], dtype=np.uint32)  # two empty sketches, ragged, full
+    hashes[2, :3] = [5, 9, 11]
+    hashes[3] = [1, 5, 9, 11, 20, 30, 40, 50]
+    hashes[4] = [5, 9, 11, 12, 13, 14, 15, 2**64 - 2]
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    got = ctx.precluster(sk, np.float32(0.0))
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.0))
+    assert got.tobytes() == want.tobytes()
+    # empty vs empty: total 0 -> NaN dropped by f64::max/min -> ANI 1.0 (documented reference quirk)
+    assert float(got[0]["ani"]) == 1.0 and int(got[0]["total"]) == 0
+
+
+def test_pair_shards_partition_the_triangle(ctx):
+    rng = np.random.default_rng(3)
+    hashes, lens = random_sketches(rng, 77, 1000, shared_groups=4)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    full = ctx.precluster(sk, np.float32(0.0))
+    for world in (2, 3, 8):
+        parts, compared = [], 0
+        for r in range(world):
+            parts.append(ctx.precluster(sk, np.float32(0.0), r, world))
+            compared += ctx.last_pairs_compared
+        assert compared == 77 * 76 // 2
+        merged = np.sort(np.concatenate(parts), order=["i", "j"])
+        assert merged.tobytes() == full.tobytes()
+
+
+def _streams():
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = rng.choice(acgt, size=300_000)
+    out = {"plain": base.copy()}
+    withn = base.copy()
+    withn[rng.integers(0, len(base), 300)] = ord("N")
+    withn[5000:5100] = ord("N")
+    withn[70000] = ord("-")
+    out["with_N_runs"] = withn
+    out["shorter_than_k"] = base[:20].copy()
+    out["exactly_k"] = base[:21].copy()
+    out["tiny_lt_s_kmers"] = base[:700].copy()
+    out["empty"] = np.zeros(0, dtype=np.uint8)
+    out["all_N"] = np.full(5000, ord("N"), dtype=np.uint8)
+    out["repetitive"] = np.tile(base[:1500], 400)          # 600 kb, only ~1500 distinct k-mers
+    out["homopolymer"] = np.full(100_000, ord("A"), dtype=np.uint8)
+    out["chunk_boundary"] = base[:16384 + 21].copy()       # one k-mer straddles two blocks
+    out["lowish"] = rng.choice(acgt, size=70_000)
+    return out
+
+
+def test_sketch_edge_cases_vs_oracle(ctx):
+    streams = _streams()
+    names = list(streams)
+    for k, s in ((21, 1000), (21, 64), (15, 500), (32, 1000), (11, 256)):
+        g = ctx.genomes_from_host([streams[n] for n in names])
+        sk = ctx.sketch_genomes(g, k, s, 0)
+        hashes, lens = sk.to_host()
+        for i, n in enumerate(names):
+            want = oracle.sketch_bytes(streams[n], k, s, 0)
+            assert lens[i] == len(want), (n, k, s, lens[i], len(want))
+            assert np.array_equal(hashes[i, : lens[i]], want), (n, k, s)
+
+
+def test_sketch_nonzero_seed(ctx):
+    rng = np.random.default_rng(2)
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=50_000)
+    g = ctx.genomes_from_host([seq])
+    for seed in (1, 42, 0xFFFFFFFF):
+        hashes, lens = ctx.sketch_genomes(g, 21, 200, seed).to_host()
+        assert np.array_equal(hashes[0, : lens[0]], oracle.sketch_bytes(seq, 21, 200, seed))
+
+
+def test_synthetic_generator_matches_oracle(ctx):
+    g = ctx.genomes_synthetic(42, 2, 3, 100_003, 0.0253)
+    for i in range(6):
+        assert np.array_equal(g.to_host(i), oracle.synth_genome(42, i // 3, i % 3, 100_003, 0.0253))
+
+
+def test_ani_pairs_vs_oracle(ctx):
+    seed, n_species, members, length = 9, 2, 4, 400_000
+    g = ctx.genomes_synthetic(seed, n_species, members, length, 0.0253)
+    n = n_species * members
+    idx = ctx.ani_index_build(g)
+    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.uint32)
+    ani, af = ctx.ani_pairs(idx, pairs, 0.15, want_af=True)
+    osk = [oracle.AniSketch.from_bytes(g.to_host(i)) for i in range(n)]
+    for x, (a, b) in enumerate(pairs):
+        o, afq, afr = oracle.ani_pair(osk[a], osk[b], 0.15)
+        assert np.float32(o) == ani[x], (a, b, o, ani[x])
+        assert np.float32(afq) == af[x, 0] and np.float32(afr) == af[x, 1]
+    same = [ani[x] for x, (a, b) in enumerate(pairs) if a // members == b // members]
+    diff = [ani[x] for x, (a, b) in enumerate(pairs) if a // members != b // members]
+    assert all(94.0 < v < 96.0 for v in same), same   # members are ~95 % identical by construction
+    assert all(v == 0.0 for v in diff)                # unrelated genomes fail the aligned-fraction gate
+
+
+def test_ani_on_fixture_files_vs_oracle(ctx):
+    names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52"]
+    cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=4)
+    paths = [fasta(n) for n in names]
+    cl.prepare(paths)
+    osk = [oracle.AniSketch.from_file(p) for p in paths]
+    for a in range(len(names)):
+        for b in range(len(names)):
+            if a == b:
+                continue
+            got = cl.calculate_ani(paths[a], paths[b])
+            assert got == np.float32(oracle.ani_pair(osk[a], osk[b], 0.15)[0]), (names[a], names[b])
+
+
+def test_cluster_end_to_end_vs_oracle(ctx):
+    names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52", "antonio_MAG189",
+             "set1_1mbp", "set1_500kb"]
+    paths = [fasta(n) for n in names]
+    osk = [oracle.AniSketch.from_file(p) for p in paths]
+    want_pairs = oracle.distances(paths, np.float32(0.9))
+    for thr in (95.0, 98.0, 99.0):
+        pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=4)
+        cl = galah_amd.HipAniClusterer(thr, 0.15, ctx=ctx, io_threads=4)
+        got = galah_amd.cluster(paths, pre, cl)
+        want = oracle.cluster(len(paths), oracle.Cache.from_pairs(want_pairs), thr,
+                              lambda a, b: oracle.ani_pair(osk[a], osk[b], 0.15)[0])
+        assert got == want, (thr, got, want)
+        assert sorted(x for c in got for x in c) == list(range(len(paths)))

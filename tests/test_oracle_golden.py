@@ -1,0 +1,40 @@
+"""Pins the CPU oracle to the reference's golden vectors.  CPU only."""
+import numpy as np
+
+import oracle
+from conftest import fasta
+
+
+def test_reference_golden_finch_rs_111_119():
+    # src/finch.rs:111-119: distances(["set1/1mbp.fna","set1/500kb.fna"], 0.9, 1000, 21)
+    #   == {(0,1): Some(0.9808188)}
+    p = oracle.distances([fasta("set1_1mbp"), fasta("set1_500kb")], 0.9, 1000, 21)
+    assert len(p) == 1
+    assert (p["i"][0], p["j"][0]) == (0, 1)
+    assert p["ani"][0].tobytes() == np.float32(0.9808188).tobytes()
+    assert (p["common"][0], p["total"][0]) == (502, 1000)
+
+
+def test_reference_golden_empty_at_099():
+    # src/finch.rs:121-128
+    assert len(oracle.distances([fasta("set1_1mbp"), fasta("set1_500kb")], 0.99, 1000, 21)) == 0
+
+
+def test_golden_table(golden, golden_sketches):
+    for row in golden["pairs"]:
+        a, b = golden_sketches[row["a"]], golden_sketches[row["b"]]
+        for closed in (False, True):
+            assert oracle.raw_distance(a, b, closed_form=closed) == (row["common"], row["total"])
+        ani = np.float32(oracle.mash_ani(row["common"], row["total"], 21))
+        assert int(ani.view(np.uint32)) == row["ani_f32_bits"]
+
+
+def test_oracle_resketch_matches_committed_sketches(golden_sketches):
+    for name in ("set1_500kb", "abisko_S3X12"):  # single-contig and multi-contig-with-N inputs
+        assert np.array_equal(oracle.sketch_file(fasta(name)), golden_sketches[name])
+
+
+def test_sketch_extremes_from_survey(golden_sketches):
+    assert int(golden_sketches["set1_1mbp"][0]) == 3491212462166
+    assert int(golden_sketches["set1_1mbp"][-1]) == 18302639908299747
+    assert int(golden_sketches["set1_500kb"][-1]) == 38405002408362914
