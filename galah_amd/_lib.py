@@ -37,12 +37,14 @@ SIGNATURES = {
     "ghip_last_error": (C.c_char_p, [_vp]),
     "ghip_set_stream": (_int, [_vp, _vp]),
     "ghip_synchronize": (_int, [_vp]),
+    "ghip_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
     "ghip_profile_enable": (_int, [_vp, _int]),
     "ghip_profile_reset": (_int, [_vp]),
     "ghip_kernel_stats": (_int, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "ghip_genomes_from_files": (_int, [_vp, C.POINTER(C.c_char_p), _sz, _int, _pp]),
     "ghip_genomes_from_host": (_int, [_vp, _vp, _vp, _sz, _pp]),
     "ghip_genomes_synthetic": (_int, [_vp, _u64, _u32, _u32, _u64, C.c_double, _pp]),
+    "ghip_genomes_synthetic_range": (_int, [_vp, _u64, _u32, _u64, _u64, _u64, C.c_double, _pp]),
     "ghip_genomes_count": (_sz, [_vp]),
     "ghip_genomes_total_bases": (_u64, [_vp]),
     "ghip_genomes_length": (_u64, [_vp, _sz]),
@@ -53,6 +55,7 @@ SIGNATURES = {
     "ghip_sketches_from_host": (_int, [_vp, _vp, _vp, _sz, _u32, _u32, _pp]),
     "ghip_sketches_wrap_device": (_int, [_vp, _vp, _vp, _sz, _u32, _u32, _pp]),
     "ghip_sketches_to_host": (_int, [_vp, _vp, _vp, _vp]),
+    "ghip_sketches_copy_into": (_int, [_vp, _vp, _vp, _vp]),
     "ghip_sketches_count": (_sz, [_vp]),
     "ghip_sketches_size": (_u32, [_vp]),
     "ghip_sketches_kmer": (_u32, [_vp]),
@@ -65,9 +68,20 @@ SIGNATURES = {
     "ghip_ani_index_build": (_int, [_vp, _vp, _u32, _u32, _u32, _pp]),
     "ghip_ani_pairs": (_int, [_vp, _vp, _vp, _sz, _f32, _vp, _vp]),
     "ghip_ani_index_free": (None, [_vp]),
+    "ghip_ani_index_layout": (_int, [_vp, _vp]),
+    "ghip_ani_index_meta": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ghip_ani_index_wrap_device": (_int, [_vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp]),
     "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
     "ghip_free": (None, [_vp]),
 }
+
+
+
+class AniLayout(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("n_seed_slots", C.c_uint64), ("n_table_slots", C.c_uint64),
+                ("n_chunk_slots", C.c_uint64), ("d_seed_hash", C.c_void_p), ("d_seed_chunk", C.c_void_p),
+                ("d_table", C.c_void_p), ("d_chunk_total", C.c_void_p)]
+
 
 _lib = None
 

@@ -31,47 +31,82 @@ __device__ __forceinline__ uint32_t base_code(uint32_t c) {
     return ok ? (((c >> 1) ^ (c >> 2)) & 3u) : 4u;
 }
 
+constexpr uint32_t SEED_LDS_CAP = 1024;   // seeds buffered per block (expected 16384/c ~ 131)
+constexpr uint32_t SEED_LDS_CHUNKS = 64;  // per-block chunk counters
+
+// Seeds are rare (1/c of the k-mers), so they are collected in LDS and flushed with ONE global
+// atomic per block: a per-genome counter bumped once per seed serialises at the L2 (4e7
+// same-address atomics at N=1000).
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const ghip_sketch_work *__restrict__ work, uint32_t K,
     uint64_t thr, uint32_t chunk, uint64_t *__restrict__ seed_hash, uint32_t *__restrict__ seed_chunk,
     const uint64_t *__restrict__ seed_start, uint32_t *__restrict__ seed_count,
     uint32_t *__restrict__ chunk_total, const uint64_t *__restrict__ chunk_start) {
+    __shared__ uint64_t l_hash[SEED_LDS_CAP];
+    __shared__ uint32_t l_chunk[SEED_LDS_CAP];
+    __shared__ uint32_t l_ctot[SEED_LDS_CHUNKS];
+    __shared__ uint32_t l_n, l_base;
+
     const ghip_sketch_work wk = work[blockIdx.x];
     const uint32_t g = wk.slot;
     const uint64_t L = lens[g];
-    const uint64_t p0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
-    if (p0 >= L) return;
-    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);
-    const uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
+    const uint64_t blk0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK;
+    const uint64_t p0 = blk0 + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    const uint32_t ch_first = (uint32_t)(blk0 / chunk);
     const uint64_t sstart = seed_start[g];
     const uint32_t scap = (uint32_t)(seed_start[g + 1] - sstart);
-    uint64_t fwd = 0, rev = 0;
-    uint32_t good = 0;
-    const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
-    const int NV = (NB + 15) / 16;
-    for (int v = 0; v < NV; v++) {
-        uint4 cur = src[v];
-        uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+    uint32_t *ctot = chunk_total + chunk_start[g];
+    if (threadIdx.x < SEED_LDS_CHUNKS) l_ctot[threadIdx.x] = 0;
+    if (threadIdx.x == 0) l_n = 0;
+    __syncthreads();
+
+    if (p0 < L) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);
+        const uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
+        uint64_t fwd = 0, rev = 0;
+        uint32_t good = 0;
+        const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
+        const int NV = (NB + 15) / 16;
+        for (int v = 0; v < NV; v++) {
+            uint4 cur = src[v];
+            uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int b = v * 16 + j;
-            if (b >= NB) break;
-            uint32_t code = base_code((words[j >> 2] >> (8 * (j & 3))) & 0xffu);
-            if (code > 3u) { good = 0; fwd = rev = 0; continue; }
-            fwd = ((fwd << 2) | code) & mask;
-            rev = (rev >> 2) | ((uint64_t)(3u - code) << (2 * (K - 1)));
-            good++;
-            if (b < (int)K - 1 || good < K) continue;
-            uint64_t h = mm_hash64(fwd < rev ? fwd : rev);
-            if (h >= thr) continue;
-            const uint64_t pos = p0 + (uint64_t)(b - ((int)K - 1));
-            const uint32_t ch = (uint32_t)(pos / chunk);
-            uint32_t idx = atomicAdd(&seed_count[g], 1u);
-            if (idx < scap) { seed_hash[sstart + idx] = h; seed_chunk[sstart + idx] = ch; }
-            atomicAdd(&chunk_total[chunk_start[g] + ch], 1u);
+            for (int j = 0; j < 16; j++) {
+                const int b = v * 16 + j;
+                uint32_t code = base_code((words[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                const bool valid = code <= 3u;
+                code &= 3u;
+                fwd = ((fwd << 2) | code) & mask;
+                rev = (rev >> 2) | ((uint64_t)(3u - code) << (2 * (K - 1)));
+                good = valid ? good + 1 : 0;
+                const uint64_t h = mm_hash64(fwd < rev ? fwd : rev);
+                if (b < NB && b >= (int)K - 1 && good >= K && h < thr) {
+                    const uint64_t pos = p0 + (uint64_t)(b - ((int)K - 1));
+                    const uint32_t ch = (uint32_t)(pos / chunk);
+                    const uint32_t li = atomicAdd(&l_n, 1u);
+                    if (li < SEED_LDS_CAP) { l_hash[li] = h; l_chunk[li] = ch; }
+                    else {  // LDS buffer full (never at c=125): straight to the global list
+                        uint32_t idx = atomicAdd(&seed_count[g], 1u);
+                        if (idx < scap) { seed_hash[sstart + idx] = h; seed_chunk[sstart + idx] = ch; }
+                    }
+                    const uint32_t rel = ch - ch_first;
+                    if (rel < SEED_LDS_CHUNKS) atomicAdd(&l_ctot[rel], 1u);
+                    else atomicAdd(&ctot[ch], 1u);
+                }
+            }
         }
     }
+    __syncthreads();
+    const uint32_t nloc = min(l_n, SEED_LDS_CAP);
+    if (threadIdx.x == 0) l_base = nloc ? atomicAdd(&seed_count[g], nloc) : 0u;
+    __syncthreads();
+    const uint32_t base = l_base;
+    for (uint32_t i = threadIdx.x; i < nloc; i += blockDim.x) {
+        const uint32_t idx = base + i;
+        if (idx < scap) { seed_hash[sstart + idx] = l_hash[i]; seed_chunk[sstart + idx] = l_chunk[i]; }
+    }
+    if (threadIdx.x < SEED_LDS_CHUNKS && l_ctot[threadIdx.x]) atomicAdd(&ctot[ch_first + threadIdx.x], l_ctot[threadIdx.x]);
 }
 
 // one block per genome; table size is a power of two >= 2*count; slot = low bits of the hash
@@ -98,8 +133,6 @@ __global__ __launch_bounds__(256) void ani_table_kernel(const uint64_t *__restri
         }
     }
 }
-
-constexpr uint32_t ANI_MAX_LDS_CHUNKS = 16384;  // 64 KiB of u32 match counters
 
 __global__ __launch_bounds__(256) void ani_pairs_kernel(
     const uint32_t *__restrict__ pairs, const uint64_t *__restrict__ seed_hash,

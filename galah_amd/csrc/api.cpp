@@ -16,6 +16,44 @@ int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
+// ------------------------------------------------------------------------------------ memory pool
+void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes) {
+    bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+    ghip_pool_block *best = nullptr;
+    for (auto &b : ctx->pool)
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->used = true; return best->p; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // release cached blocks and retry once
+        for (auto it = ctx->pool.begin(); it != ctx->pool.end();)
+            if (!it->used) { hipFree(it->p); it = ctx->pool.erase(it); } else ++it;
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) { ghip_set_error(ctx, GHIP_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); return nullptr; }
+    ctx->pool.push_back({p, bytes, true});
+    return p;
+}
+
+void ghip_pool_free(ghip_ctx *ctx, void *p) {
+    if (!p) return;
+    for (auto &b : ctx->pool)
+        if (b.p == p) { b.used = false; return; }
+}
+
+static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
+    bool del;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        del = ctx->destroyed && ctx->live_handles == 0;
+    }
+    if (!del) return;
+    hipSetDevice(ctx->device);
+    for (auto &b : ctx->pool) hipFree(b.p);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
 // ------------------------------------------------------------------------------------ profiling
 static void drain_events(ghip_ctx *ctx) {
     for (auto &pe : ctx->pending) {
@@ -51,9 +89,8 @@ namespace {
 
 template <typename T>
 int dmalloc(ghip_ctx *ctx, T **p, size_t count) {
-    *p = nullptr;
-    GHIP_HIP_CHECK(ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
-    return GHIP_OK;
+    *p = (T *)ghip_pool_alloc(ctx, std::max<size_t>(count, 1) * sizeof(T));
+    return *p ? GHIP_OK : GHIP_EHIP;
 }
 
 template <typename T>
@@ -88,9 +125,11 @@ double finch_ani(uint64_t common, uint64_t total, uint32_t k) {
     return 1.0 - cl;
 }
 
-struct DeviceFree {
+struct DeviceFree {  // scratch buffers go back to the pool; ctx->mu is held by the caller
+    ghip_ctx *ctx;
     std::vector<void *> ptrs;
-    ~DeviceFree() { for (void *p : ptrs) if (p) hipFree(p); }
+    explicit DeviceFree(ghip_ctx *c) : ctx(c) {}
+    ~DeviceFree() { for (void *p : ptrs) ghip_pool_free(ctx, p); }
     template <typename T> void add(T *p) { ptrs.push_back((void *)p); }
 };
 
@@ -168,10 +207,14 @@ extern "C" int ghip_init(int device, ghip_ctx **out) {
 
 extern "C" void ghip_destroy(ghip_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    drain_events(ctx);
-    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
-    delete ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        drain_events(ctx);
+        ctx->destroyed = true;
+    }
+    ctx_release(ctx);  // deferred until the last genomes/sketches/index handle is freed
 }
 
 extern "C" const char *ghip_last_error(const ghip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
@@ -187,6 +230,14 @@ extern "C" int ghip_synchronize(ghip_ctx *ctx) {
     if (!ctx) return GHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GHIP_OK;
+}
+
+extern "C" int ghip_memcpy_d2d(ghip_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes) {
+    if (!ctx || (nbytes && (!d_dst || !d_src))) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (nbytes) GHIP_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
     return GHIP_OK;
 }
 
@@ -219,11 +270,23 @@ extern "C" int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *la
 extern "C" void ghip_free(void *p) { free(p); }
 
 // ------------------------------------------------------------------------------------ genomes
+static void free_genomes_locked(ghip_genomes *g) {  // ctx->mu held
+    ghip_ctx *ctx = g->ctx;
+    ghip_pool_free(ctx, g->d_bytes); ghip_pool_free(ctx, g->d_starts); ghip_pool_free(ctx, g->d_lens);
+    ghip_pool_free(ctx, g->d_work); ghip_pool_free(ctx, g->d_identity);
+    ctx->live_handles--;
+    delete g;
+}
+
 extern "C" void ghip_genomes_free(ghip_genomes *g) {
     if (!g) return;
-    hipSetDevice(g->ctx->device);
-    hipFree(g->d_bytes); hipFree(g->d_starts); hipFree(g->d_lens); hipFree(g->d_work); hipFree(g->d_identity);
-    delete g;
+    ghip_ctx *ctx = g->ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipStreamSynchronize(ctx->stream);  // nothing in flight may still read the recycled blocks
+        free_genomes_locked(g);
+    }
+    ctx_release(ctx);
 }
 
 extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, size_t n,
@@ -238,6 +301,7 @@ extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const
     }
     ghip_genomes *g = new ghip_genomes();
     g->ctx = ctx;
+    ctx->live_handles++;
     int rc = layout_genomes(ctx, g, lens);
     for (size_t i = 0; i < n && rc == GHIP_OK; i++)
         if (lens[i]) {
@@ -245,7 +309,7 @@ extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const
             if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
         }
     if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
-    if (rc != GHIP_OK) { ghip_genomes_free(g); return rc; }
+    if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
     *out = g;
     return GHIP_OK;
 }
@@ -263,6 +327,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
     for (size_t i = 0; i < n; i++) lens[i] = streams[i].size();
     ghip_genomes *g = new ghip_genomes();
     g->ctx = ctx;
+    ctx->live_handles++;
     rc = layout_genomes(ctx, g, lens);
     for (size_t i = 0; i < n && rc == GHIP_OK; i++)
         if (lens[i]) {
@@ -270,25 +335,35 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
             if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
         }
     if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
-    if (rc != GHIP_OK) { ghip_genomes_free(g); return rc; }
+    if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
     *out = g;
     return GHIP_OK;
 }
 
+extern "C" int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32_t members, uint64_t first,
+                                            uint64_t count, uint64_t length, double sub_rate, ghip_genomes **out);
+
 extern "C" int ghip_genomes_synthetic(ghip_ctx *ctx, uint64_t seed, uint32_t n_species, uint32_t members,
                                       uint64_t length, double sub_rate, ghip_genomes **out) {
-    if (!ctx || !out || n_species == 0 || members == 0 || length == 0) return GHIP_EINVAL;
-    if ((uint64_t)n_species * members > 65535) return ghip_set_error(ctx, GHIP_EINVAL, "at most 65535 synthetic genomes per call");
+    if (n_species == 0) return GHIP_EINVAL;
+    return ghip_genomes_synthetic_range(ctx, seed, members, 0, (uint64_t)n_species * members, length, sub_rate, out);
+}
+
+extern "C" int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32_t members, uint64_t first,
+                                            uint64_t count, uint64_t length, double sub_rate, ghip_genomes **out) {
+    if (!ctx || !out || members == 0 || length == 0) return GHIP_EINVAL;
+    if (count > 65535) return ghip_set_error(ctx, GHIP_EINVAL, "at most 65535 synthetic genomes per call");
     if (!(sub_rate >= 0.0 && sub_rate < 1.0)) return GHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    std::vector<uint64_t> lens((size_t)n_species * members, length);
+    std::vector<uint64_t> lens((size_t)count, length);
     ghip_genomes *g = new ghip_genomes();
     g->ctx = ctx;
+    ctx->live_handles++;
     int rc = layout_genomes(ctx, g, lens);
-    if (rc != GHIP_OK) { ghip_genomes_free(g); return rc; }
-    ghip_launch_synth(ctx, g->d_bytes, g->d_starts, length, n_species, members, seed, (uint32_t)(sub_rate * 4294967296.0));
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ghip_genomes_free(g); return ghip_set_error(ctx, GHIP_EHIP, "synth_genomes failed"); }
+    if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
+    if (count) ghip_launch_synth(ctx, g->d_bytes, g->d_starts, length, (uint32_t)first, (uint32_t)count, members, seed, (uint32_t)(sub_rate * 4294967296.0));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_genomes_locked(g); return ghip_set_error(ctx, GHIP_EHIP, "synth_genomes failed"); }
     *out = g;
     return GHIP_OK;
 }
@@ -305,10 +380,22 @@ extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t
 }
 
 // ------------------------------------------------------------------------------------ sketches
+static void free_sketches_locked(ghip_sketches *sk) {  // ctx->mu held
+    ghip_ctx *ctx = sk->ctx;
+    if (sk->owned) { ghip_pool_free(ctx, sk->d_hashes); ghip_pool_free(ctx, sk->d_lens); }
+    ctx->live_handles--;
+    delete sk;
+}
+
 extern "C" void ghip_sketches_free(ghip_sketches *sk) {
     if (!sk) return;
-    if (sk->owned) { hipSetDevice(sk->ctx->device); hipFree(sk->d_hashes); hipFree(sk->d_lens); }
-    delete sk;
+    ghip_ctx *ctx = sk->ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipStreamSynchronize(ctx->stream);
+        free_sketches_locked(sk);
+    }
+    ctx_release(ctx);
 }
 
 extern "C" size_t ghip_sketches_count(const ghip_sketches *sk) { return sk ? sk->n : 0; }
@@ -328,6 +415,7 @@ extern "C" int ghip_sketches_from_host(ghip_ctx *ctx, const uint64_t *hashes, co
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ghip_sketches *sk = new ghip_sketches();
+    ctx->live_handles++;
     sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
     std::vector<uint64_t> padded(hashes, hashes + n * (size_t)s);
     for (size_t i = 0; i < n; i++) for (uint32_t e = lens[i]; e < s; e++) padded[i * s + e] = ~0ull;
@@ -335,7 +423,7 @@ extern "C" int ghip_sketches_from_host(ghip_ctx *ctx, const uint64_t *hashes, co
     if (!rc) rc = dmalloc(ctx, &sk->d_lens, n);
     if (!rc) rc = h2d(ctx, sk->d_hashes, padded.data(), n * (size_t)s);
     if (!rc) rc = h2d(ctx, sk->d_lens, lens, n);
-    if (rc) { ghip_sketches_free(sk); return rc; }
+    if (rc) { free_sketches_locked(sk); return rc; }
     *out = sk;
     return GHIP_OK;
 }
@@ -343,7 +431,9 @@ extern "C" int ghip_sketches_from_host(ghip_ctx *ctx, const uint64_t *hashes, co
 extern "C" int ghip_sketches_wrap_device(ghip_ctx *ctx, void *d_hashes, void *d_lens, size_t n, uint32_t s,
                                          uint32_t k, ghip_sketches **out) {
     if (!ctx || !out || s == 0 || (n && (!d_hashes || !d_lens))) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     ghip_sketches *sk = new ghip_sketches();
+    ctx->live_handles++;
     sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
     sk->d_hashes = (uint64_t *)d_hashes; sk->d_lens = (uint32_t *)d_lens; sk->owned = false;
     *out = sk;
@@ -360,6 +450,17 @@ extern "C" int ghip_sketches_to_host(ghip_ctx *ctx, const ghip_sketches *sk, uin
     return rc;
 }
 
+extern "C" int ghip_sketches_copy_into(ghip_ctx *ctx, const ghip_sketches *sk, void *d_hashes_dst, void *d_lens_dst) {
+    if (!ctx || !sk || !d_hashes_dst || !d_lens_dst) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (sk->n) {
+        GHIP_HIP_CHECK(ctx, hipMemcpyAsync(d_hashes_dst, sk->d_hashes, sk->n * (size_t)sk->s * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        GHIP_HIP_CHECK(ctx, hipMemcpyAsync(d_lens_dst, sk->d_lens, sk->n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return GHIP_OK;
+}
+
 // finch::sketch_files replacement.  Exactness: a genome is accepted only when its candidate
 // list did not overflow and held >= s distinct hashes (or the threshold was already 2^64-1).
 extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
@@ -372,10 +473,11 @@ extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = g->n;
     ghip_sketches *sk = new ghip_sketches();
+    ctx->live_handles++;
     sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
     int rc = dmalloc(ctx, &sk->d_hashes, n * (size_t)s);
     if (!rc) rc = dmalloc(ctx, &sk->d_lens, n);
-    if (rc) { ghip_sketches_free(sk); return rc; }
+    if (rc) { free_sketches_locked(sk); return rc; }
 
     // pending slots: initially every genome, with threshold ~ 2.5*s expected survivors
     std::vector<uint32_t> slot_genome(n);
@@ -393,12 +495,12 @@ extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_
     bool first = true;
     int iter = 0;
     while (!slot_genome.empty()) {
-        if (++iter > 80) { ghip_sketches_free(sk); return ghip_set_error(ctx, GHIP_EHIP, "sketch selection did not converge"); }
+        if (++iter > 80) { free_sketches_locked(sk); return ghip_set_error(ctx, GHIP_EHIP, "sketch selection did not converge"); }
         const size_t ns = slot_genome.size();
         std::vector<uint64_t> cand_start(ns);
         uint64_t total_cand = 0;
         for (size_t i = 0; i < ns; i++) { cand_start[i] = total_cand; total_cand += slot_cap[i]; }
-        DeviceFree tmp;
+        DeviceFree tmp(ctx);
         uint32_t *d_slot_genome = nullptr, *d_cap = nullptr, *d_count = nullptr, *d_status = nullptr;
         uint64_t *d_thr = nullptr, *d_cstart = nullptr, *d_cand = nullptr;
         ghip_sketch_work *d_work = nullptr;
@@ -451,7 +553,7 @@ extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_
         slot_genome.swap(ng); slot_thr.swap(nthr); slot_cap.swap(ncap);
         first = false;
     }
-    if (rc) { ghip_sketches_free(sk); return rc; }
+    if (rc) { free_sketches_locked(sk); return rc; }
     *out = sk;
     return GHIP_OK;
 }
@@ -485,19 +587,25 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, flo
     // `distance >= min_ani as f64`).  The device filter only has to be a superset; the exact
     // test is repeated on the host for every emitted pair.
     const double thr = (double)min_ani;
-    const uint32_t max_total = 2 * s;
-    std::vector<uint16_t> cmin(max_total + 2, 0xffff);
-    for (uint32_t total = 0; total <= max_total; total++) {
-        uint32_t cmax = std::min(total, s);
-        for (uint32_t c = 0; c <= cmax; c++)
-            if (finch_ani(c, total, k) >= thr) { cmin[total] = (uint16_t)c; break; }
+    uint32_t ani_bits;
+    memcpy(&ani_bits, &min_ani, 4);
+    DeviceFree tmp(ctx);
+    int rc = GHIP_OK;
+    if (!(ctx->cmin.valid && ctx->cmin.ani_bits == ani_bits && ctx->cmin.s == s && ctx->cmin.k == k)) {
+        const uint32_t max_total = 2 * s;
+        std::vector<uint16_t> cmin(max_total + 2, 0xffff);
+        for (uint32_t total = 0; total <= max_total; total++) {
+            uint32_t cmax = std::min(total, s);
+            for (uint32_t c = 0; c <= cmax; c++)
+                if (finch_ani(c, total, k) >= thr) { cmin[total] = (uint16_t)c; break; }
+        }
+        if (ctx->cmin.d_cmin) ghip_pool_free(ctx, ctx->cmin.d_cmin);
+        ctx->cmin.valid = false;
+        if ((rc = dmalloc(ctx, &ctx->cmin.d_cmin, cmin.size()))) return rc;
+        if ((rc = h2d(ctx, ctx->cmin.d_cmin, cmin.data(), cmin.size()))) return rc;
+        ctx->cmin.ani_bits = ani_bits; ctx->cmin.s = s; ctx->cmin.k = k; ctx->cmin.valid = true;
     }
-    DeviceFree tmp;
-    uint16_t *d_cmin = nullptr;
-    int rc = dmalloc(ctx, &d_cmin, cmin.size());
-    if (rc) return rc;
-    tmp.add(d_cmin);
-    if ((rc = h2d(ctx, d_cmin, cmin.data(), cmin.size()))) return rc;
+    uint16_t *d_cmin = ctx->cmin.d_cmin;
 
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     uint64_t cap = std::min<uint64_t>(P, std::max<uint64_t>(1u << 20, 64ull * n));
@@ -508,7 +616,7 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, flo
     for (int attempt = 0; attempt < 2; attempt++) {
         ghip_pair *d_out = nullptr;
         if ((rc = dmalloc(ctx, &d_out, cap))) return rc;
-        DeviceFree t2; t2.add(d_out);
+        DeviceFree t2(ctx); t2.add(d_out);
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         uint64_t compared = 0;
         ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, rank, world, d_out, d_count, cap, &compared);
@@ -541,13 +649,35 @@ extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min
 }
 
 // ------------------------------------------------------------------------------------ ANI
+static void free_index_arrays_locked(ghip_ani_index *idx) {
+    ghip_ctx *ctx = idx->ctx;
+    if (idx->owned) {
+        ghip_pool_free(ctx, idx->d_seed_hash); ghip_pool_free(ctx, idx->d_seed_chunk);
+        ghip_pool_free(ctx, idx->d_table); ghip_pool_free(ctx, idx->d_chunk_total);
+    }
+    ghip_pool_free(ctx, idx->d_seed_start); ghip_pool_free(ctx, idx->d_seed_count);
+    ghip_pool_free(ctx, idx->d_table_start); ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen);
+    idx->d_seed_hash = nullptr; idx->d_seed_chunk = nullptr; idx->d_table = nullptr; idx->d_chunk_total = nullptr;
+    idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_table_start = nullptr; idx->d_chunk_start = nullptr;
+    idx->d_glen = nullptr;
+}
+
+static void free_index_locked(ghip_ani_index *idx) {  // ctx->mu held
+    ghip_ctx *ctx = idx->ctx;
+    free_index_arrays_locked(idx);
+    ctx->live_handles--;
+    delete idx;
+}
+
 extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
     if (!idx) return;
-    hipSetDevice(idx->ctx->device);
-    hipFree(idx->d_seed_hash); hipFree(idx->d_seed_chunk); hipFree(idx->d_seed_start); hipFree(idx->d_seed_count);
-    hipFree(idx->d_table); hipFree(idx->d_table_start); hipFree(idx->d_chunk_total); hipFree(idx->d_chunk_start);
-    hipFree(idx->d_glen);
-    delete idx;
+    ghip_ctx *ctx = idx->ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipStreamSynchronize(ctx->stream);
+        free_index_locked(idx);
+    }
+    ctx_release(ctx);
 }
 
 extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
@@ -558,6 +688,7 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = g->n;
     ghip_ani_index *idx = new ghip_ani_index();
+    ctx->live_handles++;
     idx->ctx = ctx; idx->n = n; idx->k = k; idx->c = c; idx->chunk = chunk;
     idx->glen = g->lens;
     idx->chunk_start.assign(n + 1, 0);
@@ -573,10 +704,8 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
     for (int attempt = 0; attempt < 2 && rc == GHIP_OK; attempt++) {
         idx->seed_start.assign(n + 1, 0);
         for (size_t i = 0; i < n; i++) idx->seed_start[i + 1] = idx->seed_start[i] + cap[i];
-        hipFree(idx->d_seed_hash); hipFree(idx->d_seed_chunk); hipFree(idx->d_seed_start); hipFree(idx->d_seed_count);
-        hipFree(idx->d_chunk_total); hipFree(idx->d_chunk_start); hipFree(idx->d_glen);
-        idx->d_seed_hash = nullptr; idx->d_seed_chunk = nullptr; idx->d_seed_start = nullptr; idx->d_seed_count = nullptr;
-        idx->d_chunk_total = nullptr; idx->d_chunk_start = nullptr; idx->d_glen = nullptr;
+        if (attempt) hipStreamSynchronize(ctx->stream);
+        free_index_arrays_locked(idx);
         if ((rc = dmalloc(ctx, &idx->d_seed_hash, idx->seed_start[n]))) break;
         if ((rc = dmalloc(ctx, &idx->d_seed_chunk, idx->seed_start[n]))) break;
         if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) break;
@@ -601,7 +730,7 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
     if (rc == GHIP_OK) {
         idx->table_start.assign(n + 1, 0);
         for (size_t i = 0; i < n; i++) {
-            uint64_t sz = idx->seed_count[i] ? next_pow2(2ull * idx->seed_count[i]) : 0;
+            uint64_t sz = next_pow2(2ull * cap[i]);  // from the capacity, so shards agree on the layout
             idx->table_start[i + 1] = idx->table_start[i] + sz;
         }
         if (!(rc = dmalloc(ctx, &idx->d_table, idx->table_start[n])) && !(rc = dmalloc(ctx, &idx->d_table_start, n + 1)) &&
@@ -612,7 +741,7 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
                 rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
         }
     }
-    if (rc) { ghip_ani_index_free(idx); return rc; }
+    if (rc) { free_index_locked(idx); return rc; }
     *out = idx;
     return GHIP_OK;
 }
@@ -624,7 +753,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if (n == 0) return GHIP_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    DeviceFree tmp;
+    DeviceFree tmp(ctx);
     uint32_t *d_pairs = nullptr;
     uint64_t *d_out = nullptr;
     int rc;
@@ -653,5 +782,69 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
         }
         out_ani[p] = v;
     }
+    return GHIP_OK;
+}
+
+extern "C" int ghip_ani_index_layout(const ghip_ani_index *idx, ghip_ani_layout *out) {
+    if (!idx || !out) return GHIP_EINVAL;
+    out->n = idx->n;
+    out->n_seed_slots = idx->seed_start[idx->n];
+    out->n_table_slots = idx->table_start[idx->n];
+    out->n_chunk_slots = idx->chunk_start[idx->n];
+    out->d_seed_hash = idx->d_seed_hash; out->d_seed_chunk = idx->d_seed_chunk;
+    out->d_table = idx->d_table; out->d_chunk_total = idx->d_chunk_total;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_len, uint64_t *seed_cap,
+                                   uint32_t *seed_count, uint64_t *table_size) {
+    if (!idx) return GHIP_EINVAL;
+    for (size_t i = 0; i < idx->n; i++) {
+        if (genome_len) genome_len[i] = idx->glen[i];
+        if (seed_cap) seed_cap[i] = idx->seed_start[i + 1] - idx->seed_start[i];
+        if (seed_count) seed_count[i] = idx->seed_count[i];
+        if (table_size) table_size[i] = idx->table_start[i + 1] - idx->table_start[i];
+    }
+    return GHIP_OK;
+}
+
+extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, uint32_t chunk,
+                                          const uint64_t *genome_len, const uint64_t *seed_cap,
+                                          const uint32_t *seed_count, const uint64_t *table_size,
+                                          void *d_seed_hash, void *d_seed_chunk, void *d_table,
+                                          void *d_chunk_total, ghip_ani_index **out) {
+    if (!ctx || !out || chunk == 0 || (n && (!genome_len || !seed_cap || !seed_count || !table_size))) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ghip_ani_index *idx = new ghip_ani_index();
+    ctx->live_handles++;
+    idx->ctx = ctx; idx->n = n; idx->k = k; idx->c = c; idx->chunk = chunk; idx->owned = false;
+    idx->glen.assign(genome_len, genome_len + n);
+    idx->seed_count.assign(seed_count, seed_count + n);
+    idx->seed_start.assign(n + 1, 0); idx->table_start.assign(n + 1, 0); idx->chunk_start.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (seed_count[i] > seed_cap[i] || (table_size[i] & (table_size[i] - 1))) { free_index_locked(idx); return ghip_set_error(ctx, GHIP_EINVAL, "inconsistent ANI index metadata"); }
+        uint64_t nch = (genome_len[i] + chunk - 1) / chunk;
+        idx->max_chunks = (uint32_t)std::max<uint64_t>(idx->max_chunks, nch);
+        idx->seed_start[i + 1] = idx->seed_start[i] + seed_cap[i];
+        idx->table_start[i + 1] = idx->table_start[i] + table_size[i];
+        idx->chunk_start[i + 1] = idx->chunk_start[i] + nch;
+    }
+    idx->d_seed_hash = (uint64_t *)d_seed_hash; idx->d_seed_chunk = (uint32_t *)d_seed_chunk;
+    idx->d_table = (uint64_t *)d_table; idx->d_chunk_total = (uint32_t *)d_chunk_total;
+    int rc = GHIP_OK;
+    if (idx->max_chunks > 32768) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (max 32768 chunks)");
+    if (!rc) rc = dmalloc(ctx, &idx->d_seed_start, n + 1);
+    if (!rc) rc = dmalloc(ctx, &idx->d_seed_count, n);
+    if (!rc) rc = dmalloc(ctx, &idx->d_table_start, n + 1);
+    if (!rc) rc = dmalloc(ctx, &idx->d_chunk_start, n + 1);
+    if (!rc) rc = dmalloc(ctx, &idx->d_glen, n);
+    if (!rc) rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1);
+    if (!rc) rc = h2d(ctx, idx->d_seed_count, idx->seed_count.data(), n);
+    if (!rc) rc = h2d(ctx, idx->d_table_start, idx->table_start.data(), n + 1);
+    if (!rc) rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1);
+    if (!rc) rc = h2d(ctx, idx->d_glen, idx->glen.data(), n);
+    if (rc) { free_index_locked(idx); return rc; }
+    *out = idx;
     return GHIP_OK;
 }

@@ -22,6 +22,18 @@ struct ghip_pending_event {
     hipEvent_t start, stop;
 };
 
+struct ghip_pool_block {
+    void *p;
+    size_t bytes;
+    bool used;
+};
+
+struct ghip_cmin_cache {  // device filter table of ghip_precluster, keyed by (min_ani bits, s, k)
+    uint32_t ani_bits = 0, s = 0, k = 0;
+    uint16_t *d_cmin = nullptr;
+    bool valid = false;
+};
+
 struct ghip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -33,7 +45,15 @@ struct ghip_ctx {
     std::vector<ghip_pending_event> pending;
     uint64_t last_pairs = 0;
     int num_cus = 256;
+    // device-memory pool: hipMalloc/hipFree synchronise the device, so blocks are recycled
+    std::vector<ghip_pool_block> pool;
+    ghip_cmin_cache cmin;
+    int live_handles = 0;   // genomes / sketches / ani indexes still alive
+    bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };
+
+void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes);  // nullptr on failure (ctx->err set); ctx->mu held
+void ghip_pool_free(ghip_ctx *ctx, void *p);         // ctx->mu held
 
 struct ghip_sketch_work {  // one block of the k-mer pass
     uint32_t slot;   // index into the pending-genome arrays
@@ -81,6 +101,7 @@ struct ghip_ani_index {
     std::vector<uint64_t> glen, chunk_start, table_start, seed_start;
     std::vector<uint32_t> seed_count;
     uint32_t max_chunks = 0;
+    bool owned = true;  // false: the four flat arrays are borrowed (ghip_ani_index_wrap_device)
 };
 
 #define GHIP_EMPTY_SLOT 0xFFFFFFFFFFFFFFFFull
@@ -101,7 +122,7 @@ void ghip_prof_end(ghip_ctx *ctx);
 
 // ---- launchers (defined in the .hip files) ----
 void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
-                       uint32_t n_species, uint32_t members, uint64_t seed, uint32_t sub_thr);
+                       uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr);
 
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,

@@ -131,17 +131,20 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
             if (b >= NB) break;
             uint32_t c = (words[j >> 2] >> (8 * (j & 3))) & 0xffu;
             uint32_t code = base_code(c);
-            if (code > 3u) { good = 0; continue; }
+            // branch-free state update; an invalid byte enters as 'A' and resets the run length,
+            // so its bits have left both registers before `good` reaches K again.  Bytes past
+            // the stream end are 'N' padding (ghip_genomes layout), hence no bounds test.
+            const bool valid = code <= 3u;
+            code &= 3u;
             fwd_be = ((fwd_be << 2) | code) & mask;
             fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
-            good++;
-            if (b < K - 1 || good < (uint32_t)K) continue;
-            if (p0 + (uint64_t)(b - (K - 1)) + K > L) continue;  // window runs past the stream
+            good = valid ? good + 1 : 0;
+            if (b < K - 1) continue;  // compile-time: warm-up bytes only roll the state
             // reverse complement: rc_be = ~fwd_le, rc_le = ~fwd_be (complement = 3 - code)
             uint64_t rc_be = (~fwd_le) & mask;
             uint64_t canon_le = (rc_be < fwd_be) ? ((~fwd_be) & mask) : fwd_le;
             uint64_t h = hash_canonical<K>(canon_le, seed);
-            if (h <= thr) {
+            if (good >= (uint32_t)K && h <= thr) {  // rare: ~2.5*s survivors per genome
                 uint32_t idx = atomicAdd(&cand_count[slot], 1u);
                 if (idx < ccap) cand[cstart + idx] = h;
             }
@@ -332,10 +335,11 @@ __device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint32_t species, u
 // each thread writes 16 bases (one 16-B store)
 __global__ __launch_bounds__(256) void synth_genomes_kernel(uint8_t *__restrict__ bytes,
                                                             const uint64_t *__restrict__ starts,
-                                                            uint64_t length, uint32_t members,
-                                                            uint64_t seed, uint32_t sub_thr) {
-    const uint32_t g = blockIdx.y;
-    const uint32_t species = g / members, member = g % members;
+                                                            uint64_t length, uint32_t first,
+                                                            uint32_t members, uint64_t seed,
+                                                            uint32_t sub_thr) {
+    const uint32_t g = blockIdx.y;  // local index; the series index is first + g
+    const uint32_t species = (first + g) / members, member = (first + g) % members;
     const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (p0 >= length) return;
     const uint64_t ka = synth_key(seed, species, 0), km = synth_key(seed, species, member + 1);
@@ -357,11 +361,11 @@ __global__ __launch_bounds__(256) void synth_genomes_kernel(uint8_t *__restrict_
 }  // namespace
 
 void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
-                       uint32_t n_species, uint32_t members, uint64_t seed, uint32_t sub_thr) {
+                       uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr) {
     uint64_t threads = (length + 15) / 16;
-    dim3 grid((unsigned)((threads + 255) / 256), n_species * members);
+    dim3 grid((unsigned)((threads + 255) / 256), count);
     ghip_prof_begin(ctx, "synth_genomes");
-    hipLaunchKernelGGL(synth_genomes_kernel, grid, dim3(256), 0, ctx->stream, d_bytes, d_starts, length, members, seed, sub_thr);
+    hipLaunchKernelGGL(synth_genomes_kernel, grid, dim3(256), 0, ctx->stream, d_bytes, d_starts, length, first, members, seed, sub_thr);
     ghip_prof_end(ctx);
 }
 

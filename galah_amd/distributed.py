@@ -1,0 +1,270 @@
+"""Multi-GPU orchestration of one dereplication job: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) for the two real exchange steps of the path.
+
+  rank r owns genomes [r*B, min((r+1)*B, N)),  B = ceil(N / world)           (contiguous blocks)
+  1. sketch the local genomes                     -> u64[B][s] + u32[B]      (no communication)
+  2. ALL-GATHER the packed sketch matrix          -> u64[N][s] on every rank (N*s*8 bytes, once)
+  3. pair tiles t with t % world == rank          -> local candidate list    (no communication)
+  4. build the local ANI seed index, ALL-GATHER its flat arrays; ANI for the local candidates
+  5. gather (pairs, ANI) on rank 0; greedy clustering on the host            (src/clusterer.rs)
+
+With world == 1 the same code runs with the exchange steps skipped.  The compute engine is
+pluggable so the exchange logic can be exercised on CPU (gloo) in tests; the product engine is
+HipEngine (libgalah_hip.so) -- there is no CPU compute path in this package.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from ._lib import PAIR_DTYPE
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(first, count, block) of rank's contiguous genome block."""
+    block = (n + world - 1) // world
+    first = min(rank * block, n)
+    return first, min(block, n - first), block
+
+
+def tile_pairs_of_rank(n: int, pt: int, rank: int, world: int) -> List[Tuple[int, int]]:
+    """Host restatement of the kernel's block-cyclic tile deal (pairs.hip): upper-triangle tile
+    pairs in row-major order, tile t goes to rank t % world."""
+    nt = (n + pt - 1) // pt
+    out, t = [], 0
+    for ti in range(nt):
+        for tj in range(ti, nt):
+            if t % world == rank:
+                out.append((ti, tj))
+            t += 1
+    return out
+
+
+class Exchange:
+    """torch.distributed plumbing; tensors live wherever the engine puts them (HBM or host)."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+
+    def all_gather_blocks(self, local, n_total: int):
+        """local: [block, ...] tensor (same block on every rank) -> [n_total, ...]."""
+        import torch
+        if self.world == 1:
+            return local[:n_total]
+        out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(out, local.contiguous())
+        return out[:n_total]
+
+    def all_gather_flat(self, local, sizes: List[int]):
+        """1-D tensors of per-rank length sizes[r] -> their concatenation on every rank."""
+        import torch
+        if self.world == 1:
+            return local
+        m = max(sizes)
+        padded = torch.zeros(m, dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+        out = torch.empty(self.world * m, dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(out, padded)
+        if all(sz == m for sz in sizes):
+            return out
+        return torch.cat([out[r * m: r * m + sizes[r]] for r in range(self.world)])
+
+    def all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def gather_object(self, obj, dst: int = 0):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world if self.rank == dst else None
+        self.dist.gather_object(obj, out, dst=dst)
+        return out
+
+
+class HipEngine:
+    """The product engine: every method is a thin call into libgalah_hip.so."""
+
+    def __init__(self, ctx, kmer: int, sketch_size: int, ani_k: int = 15, ani_c: int = 125, ani_chunk: int = 20000):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.device = torch.device("cuda", ctx.device)
+        self.kmer, self.s = kmer, sketch_size
+        self.ani_k, self.ani_c, self.ani_chunk = ani_k, ani_c, ani_chunk
+        self.genomes = None
+        self._keep = []
+
+    # ---- inputs
+    def load_synthetic(self, seed, members, first, count, length, sub_rate):
+        self.genomes = self.ctx.genomes_synthetic_range(seed, members, first, count, length, sub_rate)
+
+    def load_files(self, paths, io_threads=8):
+        self.genomes = self.ctx.genomes_from_files(paths, io_threads)
+
+    @property
+    def local_bases(self) -> int:
+        return self.genomes.total_bases
+
+    # ---- stage 1/2
+    def sketch_local(self, block: int):
+        """-> (int64[block][s], int32[block]) device tensors, rows past the local count padded."""
+        t = self.torch
+        sk = self.ctx.sketch_genomes(self.genomes, self.kmer, self.s, 0)
+        hashes = t.full((block, self.s), -1, dtype=t.int64, device=self.device)  # -1 == 2^64-1
+        lens = t.zeros(block, dtype=t.int32, device=self.device)
+        t.cuda.current_stream().synchronize()
+        self.ctx.sketches_copy_into(sk, hashes.data_ptr(), lens.data_ptr())
+        self.ctx.synchronize()
+        sk.free()
+        return hashes, lens
+
+    def precluster(self, hashes, lens, n: int, min_ani, rank: int, world: int) -> np.ndarray:
+        self.torch.cuda.current_stream().synchronize()
+        sk = self.ctx.sketches_wrap_device(hashes.data_ptr(), lens.data_ptr(), n, self.s, self.kmer)
+        pairs = self.ctx.precluster(sk, min_ani, rank, world)
+        self.last_pairs_compared = self.ctx.last_pairs_compared
+        sk.free()
+        return pairs
+
+    def sketches_to_host(self, hashes, lens):
+        return hashes.cpu().numpy().view(np.uint64), lens.cpu().numpy().view(np.uint32)
+
+    # ---- stage 4
+    def ani_build_local(self):
+        """-> (meta dict of host arrays, dict of flat device tensors)."""
+        t = self.torch
+        idx = self.ctx.ani_index_build(self.genomes, self.ani_k, self.ani_c, self.ani_chunk)
+        glen, cap, cnt, tsz = idx.meta()
+        lay = idx.layout()
+        self._local_index = idx
+        return idx, {"glen": glen, "cap": cap, "cnt": cnt, "tsz": tsz}, lay
+
+    def ani_export(self, idx, lay):
+        t = self.torch
+        arrs = {
+            "seed_hash": t.empty(int(lay.n_seed_slots), dtype=t.int64, device=self.device),
+            "seed_chunk": t.empty(int(lay.n_seed_slots), dtype=t.int32, device=self.device),
+            "table": t.empty(int(lay.n_table_slots), dtype=t.int64, device=self.device),
+            "chunk_total": t.empty(int(lay.n_chunk_slots), dtype=t.int32, device=self.device),
+        }
+        t.cuda.current_stream().synchronize()
+        self.ctx.memcpy_d2d(arrs["seed_hash"].data_ptr(), lay.d_seed_hash, int(lay.n_seed_slots) * 8)
+        self.ctx.memcpy_d2d(arrs["seed_chunk"].data_ptr(), lay.d_seed_chunk, int(lay.n_seed_slots) * 4)
+        self.ctx.memcpy_d2d(arrs["table"].data_ptr(), lay.d_table, int(lay.n_table_slots) * 8)
+        self.ctx.memcpy_d2d(arrs["chunk_total"].data_ptr(), lay.d_chunk_total, int(lay.n_chunk_slots) * 4)
+        self.ctx.synchronize()
+        return arrs
+
+    def ani_wrap(self, meta, arrs):
+        self.torch.cuda.current_stream().synchronize()
+        self._keep = [arrs]  # the wrapped index borrows these tensors
+        return self.ctx.ani_index_wrap_device(self.ani_k, self.ani_c, self.ani_chunk, meta["glen"], meta["cap"],
+                                              meta["cnt"], meta["tsz"], arrs["seed_hash"].data_ptr(),
+                                              arrs["seed_chunk"].data_ptr(), arrs["table"].data_ptr(),
+                                              arrs["chunk_total"].data_ptr())
+
+    def ani_pairs(self, idx, pairs: np.ndarray, min_af: float) -> np.ndarray:
+        if len(pairs) == 0:
+            return np.zeros(0, dtype=np.float32)
+        pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32)
+        return self.ctx.ani_pairs(idx, pi, min_af)
+
+    def cluster(self, n, pairs, pair_ani, ani_threshold):
+        from .engine import cluster_pairs
+        return cluster_pairs(n, pairs, ani_threshold, pair_ani, False)
+
+
+class DereplicationJob:
+    def __init__(self, ctx, rank: int, world: int, n_genomes: int, kmer: int = 21, sketch_size: int = 1000,
+                 min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af: float = 0.15, engine=None):
+        self.rank, self.world, self.n = rank, world, n_genomes
+        self.min_ani, self.ani_threshold, self.min_af = np.float32(min_ani), np.float32(ani_threshold), float(min_af)
+        self.engine = engine if engine is not None else HipEngine(ctx, kmer, sketch_size)
+        self.ex = Exchange(rank, world)
+        self.first, self.count, self.block = shard_range(n_genomes, rank, world)
+        self._stage = {}
+        self._steps = 0
+        self._full = None
+
+    def load_synthetic(self, seed: int, members: int, length: int, sub_rate: float):
+        self.engine.load_synthetic(seed, members, self.first, self.count, length, sub_rate)
+
+    def load_files(self, paths, io_threads: int = 8):
+        assert len(paths) == self.n
+        self.engine.load_files(list(paths[self.first: self.first + self.count]), io_threads)
+
+    @property
+    def local_bases(self) -> int:
+        return self.engine.local_bases
+
+    @property
+    def last_pairs_compared(self) -> int:
+        return getattr(self.engine, "last_pairs_compared", 0)
+
+    def _tick(self, name: str, t0: float) -> float:
+        t1 = time.perf_counter()
+        self._stage[name] = self._stage.get(name, 0.0) + (t1 - t0)
+        return t1
+
+    def stage_ms(self) -> Dict[str, float]:
+        return {k: v / max(self._steps, 1) * 1e3 for k, v in self._stage.items()}
+
+    def sketches_to_host(self):
+        return self.engine.sketches_to_host(*self._full)
+
+    def step(self) -> Dict:
+        e, ex = self.engine, self.ex
+        t = time.perf_counter()
+        hashes_l, lens_l = e.sketch_local(self.block)
+        t = self._tick("sketch", t)
+        hashes = ex.all_gather_blocks(hashes_l, self.n)
+        lens = ex.all_gather_blocks(lens_l, self.n)
+        self._full = (hashes, lens)
+        t = self._tick("allgather_sketches", t)
+        pairs = e.precluster(hashes, lens, self.n, self.min_ani, self.rank, self.world)
+        t = self._tick("pairs", t)
+        idx_l, meta_l, lay = e.ani_build_local()
+        t = self._tick("ani_index", t)
+        if self.world > 1:
+            arrs_l = e.ani_export(idx_l, lay)
+            metas = ex.all_gather_object({k: v for k, v in meta_l.items()} | {
+                "sizes": (int(lay.n_seed_slots), int(lay.n_table_slots), int(lay.n_chunk_slots))})
+            meta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt", "tsz")}
+            arrs = {
+                "seed_hash": ex.all_gather_flat(arrs_l["seed_hash"], [m["sizes"][0] for m in metas]),
+                "seed_chunk": ex.all_gather_flat(arrs_l["seed_chunk"], [m["sizes"][0] for m in metas]),
+                "table": ex.all_gather_flat(arrs_l["table"], [m["sizes"][1] for m in metas]),
+                "chunk_total": ex.all_gather_flat(arrs_l["chunk_total"], [m["sizes"][2] for m in metas]),
+            }
+            idx = e.ani_wrap(meta, arrs)
+            t = self._tick("allgather_ani_index", t)
+        else:
+            idx = idx_l
+        pair_ani = e.ani_pairs(idx, pairs, self.min_af)
+        t = self._tick("ani_pairs", t)
+        gathered = ex.gather_object((pairs, pair_ani), 0)
+        result = {"n_pairs": 0, "n_clusters": 0, "clusters": None, "pairs": None, "pair_ani": None}
+        if self.rank == 0:
+            allp = np.concatenate([g[0] for g in gathered]) if gathered else np.zeros(0, PAIR_DTYPE)
+            alla = np.concatenate([g[1] for g in gathered]) if gathered else np.zeros(0, np.float32)
+            order = np.argsort(allp, order=["i", "j"], kind="stable") if self.world > 1 else slice(None)
+            allp, alla = allp[order], alla[order]
+            t = self._tick("gather_pairs", t)
+            clusters = e.cluster(self.n, allp, alla, self.ani_threshold)
+            t = self._tick("host_cluster", t)
+            result = {"n_pairs": len(allp), "n_clusters": len(clusters), "clusters": clusters, "pairs": allp,
+                      "pair_ani": alla}
+        if hasattr(idx, "free"):
+            idx.free()
+        if self.world > 1 and hasattr(idx_l, "free"):
+            idx_l.free()
+        self._steps += 1
+        return result

@@ -91,6 +91,20 @@ class Sketches(_Handle):
 class AniIndex(_Handle):
     _free_name = "ghip_ani_index_free"
 
+    def layout(self) -> "_lib.AniLayout":
+        lay = _lib.AniLayout()
+        check(_lib.lib().ghip_ani_index_layout(self._h, C.byref(lay)), self.ctx._h)
+        return lay
+
+    def meta(self):
+        """(genome_len u64[n], seed_cap u64[n], seed_count u32[n], table_size u64[n]) host arrays."""
+        n = self.layout().n
+        glen, cap, tsz = (np.zeros(n, dtype=np.uint64) for _ in range(3))
+        cnt = np.zeros(n, dtype=np.uint32)
+        check(_lib.lib().ghip_ani_index_meta(self._h, glen.ctypes.data, cap.ctypes.data, cnt.ctypes.data,
+                                             tsz.ctypes.data), self.ctx._h)
+        return glen, cap, cnt, tsz
+
 
 class Context:
     def __init__(self, device: int = 0):
@@ -120,6 +134,9 @@ class Context:
 
     def synchronize(self):
         check(_lib.lib().ghip_synchronize(self._h), self._h)
+
+    def memcpy_d2d(self, dst: int, src: int, nbytes: int):
+        check(_lib.lib().ghip_memcpy_d2d(self._h, C.c_void_p(dst), C.c_void_p(src), nbytes), self._h)
 
     def profile(self, enable: bool = True):
         check(_lib.lib().ghip_profile_enable(self._h, 1 if enable else 0), self._h)
@@ -153,6 +170,13 @@ class Context:
         check(_lib.lib().ghip_genomes_from_host(self._h, flat.ctypes.data, offsets.ctypes.data, len(arrs), C.byref(h)), self._h)
         return Genomes(self, h)
 
+    def genomes_synthetic_range(self, seed: int, members: int, first: int, count: int, length: int,
+                                sub_rate: float) -> Genomes:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_genomes_synthetic_range(self._h, seed, members, first, count, length, sub_rate,
+                                                      C.byref(h)), self._h)
+        return Genomes(self, h)
+
     def genomes_synthetic(self, seed: int, n_species: int, members: int, length: int, sub_rate: float) -> Genomes:
         h = C.c_void_p()
         check(_lib.lib().ghip_genomes_synthetic(self._h, seed, n_species, members, length, sub_rate, C.byref(h)), self._h)
@@ -183,6 +207,9 @@ class Context:
         check(_lib.lib().ghip_sketches_wrap_device(self._h, C.c_void_p(d_hashes), C.c_void_p(d_lens), n, s, k, C.byref(h)), self._h)
         return Sketches(self, h)
 
+    def sketches_copy_into(self, sk: Sketches, d_hashes: int, d_lens: int):
+        check(_lib.lib().ghip_sketches_copy_into(self._h, sk._h, C.c_void_p(d_hashes), C.c_void_p(d_lens)), self._h)
+
     # ---- precluster
     def precluster(self, sk: Sketches, min_ani: float, rank: int = 0, world: int = 1) -> np.ndarray:
         p = C.c_void_p()
@@ -204,6 +231,19 @@ class Context:
     def ani_index_build(self, g: Genomes, k: int = 15, c: int = 125, chunk: int = 20000) -> AniIndex:
         h = C.c_void_p()
         check(_lib.lib().ghip_ani_index_build(self._h, g._h, k, c, chunk, C.byref(h)), self._h)
+        return AniIndex(self, h)
+
+    def ani_index_wrap_device(self, k: int, c: int, chunk: int, genome_len, seed_cap, seed_count, table_size,
+                              d_seed_hash: int, d_seed_chunk: int, d_table: int, d_chunk_total: int) -> AniIndex:
+        glen = np.ascontiguousarray(genome_len, dtype=np.uint64)
+        cap = np.ascontiguousarray(seed_cap, dtype=np.uint64)
+        cnt = np.ascontiguousarray(seed_count, dtype=np.uint32)
+        tsz = np.ascontiguousarray(table_size, dtype=np.uint64)
+        h = C.c_void_p()
+        check(_lib.lib().ghip_ani_index_wrap_device(self._h, len(glen), k, c, chunk, glen.ctypes.data, cap.ctypes.data,
+                                                    cnt.ctypes.data, tsz.ctypes.data, C.c_void_p(d_seed_hash),
+                                                    C.c_void_p(d_seed_chunk), C.c_void_p(d_table),
+                                                    C.c_void_p(d_chunk_total), C.byref(h)), self._h)
         return AniIndex(self, h)
 
     def ani_pairs(self, idx: AniIndex, pairs: np.ndarray, min_af: float = 0.15, want_af: bool = False):

@@ -58,6 +58,8 @@ const char *ghip_last_error(const ghip_ctx *ctx);  /* ctx may be NULL: last ghip
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own stream. */
 int ghip_set_stream(ghip_ctx *ctx, void *hip_stream);
 int ghip_synchronize(ghip_ctx *ctx);
+/* Async device-to-device copy on the ctx stream (moves index arrays into exchange buffers). */
+int ghip_memcpy_d2d(ghip_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes);
 
 /* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:
  * "sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_table", "ani_pairs",
@@ -79,6 +81,9 @@ int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const uint64_t *
  * genome index g = species * members + member. */
 int ghip_genomes_synthetic(ghip_ctx *ctx, uint64_t seed, uint32_t n_species, uint32_t members,
                            uint64_t length, double sub_rate, ghip_genomes **out);
+/* Same generator, only genomes [first, first+count) of the series (one shard of a multi-GPU job). */
+int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32_t members, uint64_t first,
+                                 uint64_t count, uint64_t length, double sub_rate, ghip_genomes **out);
 size_t ghip_genomes_count(const ghip_genomes *g);
 uint64_t ghip_genomes_total_bases(const ghip_genomes *g);
 uint64_t ghip_genomes_length(const ghip_genomes *g, size_t idx);
@@ -99,6 +104,8 @@ int ghip_sketches_from_host(ghip_ctx *ctx, const uint64_t *hashes, const uint32_
 int ghip_sketches_wrap_device(ghip_ctx *ctx, void *d_hashes, void *d_lens, size_t n, uint32_t s,
                               uint32_t k, ghip_sketches **out);
 int ghip_sketches_to_host(ghip_ctx *ctx, const ghip_sketches *sk, uint64_t *hashes, uint32_t *lens);
+/* Device-to-device copy into caller-owned HBM (e.g. this rank's slice of an all-gather buffer). */
+int ghip_sketches_copy_into(ghip_ctx *ctx, const ghip_sketches *sk, void *d_hashes_dst, void *d_lens_dst);
 size_t ghip_sketches_count(const ghip_sketches *sk);
 uint32_t ghip_sketches_size(const ghip_sketches *sk);     /* s */
 uint32_t ghip_sketches_kmer(const ghip_sketches *sk);     /* k */
@@ -128,6 +135,26 @@ int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pai
                    size_t n, float min_aligned_fraction, float *out_ani_percent,
                    float *out_af /* nullable, [n][2] */);
 void ghip_ani_index_free(ghip_ani_index *idx);
+/* Exchange of an ANI index between GPUs (RCCL all-gather of the flat arrays): genome g owns
+ * seed slots [sum seed_cap[<g], +seed_cap[g]), table slots [sum table_size[<g], +table_size[g]) and
+ * chunk slots [sum n_chunks[<g], +ceil(genome_len[g]/chunk)); concatenating the arrays of
+ * consecutive shards in genome order gives the index of the union. */
+typedef struct {
+    size_t n;
+    uint64_t n_seed_slots, n_table_slots, n_chunk_slots;
+    void *d_seed_hash;   /* u64[n_seed_slots] */
+    void *d_seed_chunk;  /* u32[n_seed_slots] */
+    void *d_table;       /* u64[n_table_slots], empty = 2^64-1 */
+    void *d_chunk_total; /* u32[n_chunk_slots] */
+} ghip_ani_layout;
+int ghip_ani_index_layout(const ghip_ani_index *idx, ghip_ani_layout *out);
+int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_len, uint64_t *seed_cap,
+                        uint32_t *seed_count, uint64_t *table_size); /* host arrays, each [n] */
+int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, uint32_t chunk,
+                               const uint64_t *genome_len, const uint64_t *seed_cap,
+                               const uint32_t *seed_count, const uint64_t *table_size,
+                               void *d_seed_hash, void *d_seed_chunk, void *d_table,
+                               void *d_chunk_total, ghip_ani_index **out);
 
 /* ---------------------------------------------------------------- host clusterer
  * clusterer::cluster from the precluster cache onwards (src/clusterer.rs:56-152):
