@@ -47,9 +47,21 @@ class Exchange:
 
     def __init__(self, rank: int, world: int):
         self.rank, self.world = rank, world
+        self.stage_on_host = False
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
+            # gloo (CPU tests, or two test ranks sharing one GPU) moves device tensors through the host;
+            # nccl (= RCCL over xGMI, the production path) gathers straight out of HBM.
+            self.stage_on_host = dist.get_backend() == "gloo"
+
+    def _gather(self, out, inp):
+        if self.stage_on_host and inp.is_cuda:
+            o = out.cpu()
+            self.dist.all_gather_into_tensor(o, inp.cpu().contiguous())
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp.contiguous())
 
     def all_gather_blocks(self, local, n_total: int):
         """local: [block, ...] tensor (same block on every rank) -> [n_total, ...]."""
@@ -57,7 +69,7 @@ class Exchange:
         if self.world == 1:
             return local[:n_total]
         out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        self.dist.all_gather_into_tensor(out, local.contiguous())
+        self._gather(out, local)
         return out[:n_total]
 
     def all_gather_flat(self, local, sizes: List[int]):
@@ -69,7 +81,7 @@ class Exchange:
         padded = torch.zeros(m, dtype=local.dtype, device=local.device)
         padded[: local.shape[0]] = local
         out = torch.empty(self.world * m, dtype=local.dtype, device=local.device)
-        self.dist.all_gather_into_tensor(out, padded)
+        self._gather(out, padded)
         if all(sz == m for sz in sizes):
             return out
         return torch.cat([out[r * m: r * m + sizes[r]] for r in range(self.world)])

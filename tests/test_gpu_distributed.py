@@ -1,0 +1,74 @@
+"""The real HipEngine under world_size 2: two processes sharing the one GPU of the test box,
+gloo backend (RCCL refuses two ranks on one device).  Exercises every C-ABI call of the
+sharded path -- synthetic_range, copy_into, wrap_device, precluster_shard, ANI export/wrap --
+and checks the result against the single-process HIP run and the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SEED, MEMBERS, LENGTH, RATE, N = 5, 3, 200_000, 0.0253, 19
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch
+
+    import galah_amd
+    from galah_amd.distributed import DereplicationJob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = galah_amd.Context(0)
+    job = DereplicationJob(ctx, rank, world, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
+    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
+    for _ in range(2):  # twice: the memory pool and the wrapped handles must survive re-use
+        res = job.step()
+    if rank == 0:
+        hashes, lens = job.sketches_to_host()
+        q.put({"clusters": res["clusters"], "pairs": res["pairs"].tobytes(), "ani": res["pair_ani"].tobytes(),
+               "hashes": hashes.tobytes(), "lens": lens.tobytes()})
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_two_ranks_one_gpu_equals_single_rank(ctx):
+    import oracle
+    from galah_amd.distributed import DereplicationJob
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    job = DereplicationJob(ctx, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
+    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
+    want = job.step()
+    hashes, lens = job.sketches_to_host()
+    assert got["hashes"] == hashes.tobytes() and got["lens"] == lens.tobytes()
+    assert got["pairs"] == want["pairs"].tobytes()
+    assert got["ani"] == want["pair_ani"].tobytes()
+    assert got["clusters"] == want["clusters"]
+    # oracle end to end
+    streams = [oracle.synth_genome(SEED, g // MEMBERS, g % MEMBERS, LENGTH, RATE) for g in range(N)]
+    opairs = oracle.distances_from_sketches(hashes, lens, np.float32(0.9))
+    assert want["pairs"].tobytes() == opairs.tobytes()
+    sks = [oracle.AniSketch.from_bytes(s) for s in streams]
+    oc = oracle.cluster(N, oracle.Cache.from_pairs(opairs), 95.0, lambda a, b: oracle.ani_pair(sks[a], sks[b], 0.15)[0])
+    assert want["clusters"] == oc
