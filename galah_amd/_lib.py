@@ -96,6 +96,15 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C galah_amd/csrc). "
             "galah_amd has no CPU fallback.")
+    # Load order matters in this image: the PyTorch-ROCm wheel bundles its own HIP/HSA runtime.  If
+    # /opt/rocm's libamdhip64 is mapped first (by this library) and torch is imported later, torch
+    # ends up with a mixed runtime and reports "No HIP GPUs are available".  Importing torch first
+    # makes both share one runtime, so the plumbing (torch tensors, torch.distributed/RCCL) and
+    # this library see the same device state.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(L, name)  # AttributeError if the library does not export it
