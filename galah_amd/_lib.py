@@ -69,8 +69,8 @@ SIGNATURES = {
     "ghip_ani_pairs": (_int, [_vp, _vp, _vp, _sz, _f32, _vp, _vp]),
     "ghip_ani_index_free": (None, [_vp]),
     "ghip_ani_index_layout": (_int, [_vp, _vp]),
-    "ghip_ani_index_meta": (_int, [_vp, _vp, _vp, _vp, _vp]),
-    "ghip_ani_index_wrap_device": (_int, [_vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp]),
+    "ghip_ani_index_meta": (_int, [_vp, _vp, _vp, _vp]),
+    "ghip_ani_index_wrap_device": (_int, [_vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp]),
     "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
     "ghip_free": (None, [_vp]),
 }
@@ -78,9 +78,9 @@ SIGNATURES = {
 
 
 class AniLayout(C.Structure):
-    _fields_ = [("n", C.c_size_t), ("n_seed_slots", C.c_uint64), ("n_table_slots", C.c_uint64),
-                ("n_chunk_slots", C.c_uint64), ("d_seed_hash", C.c_void_p), ("d_seed_chunk", C.c_void_p),
-                ("d_table", C.c_void_p), ("d_chunk_total", C.c_void_p)]
+    _fields_ = [("n", C.c_size_t), ("n_seed_slots", C.c_uint64), ("n_bin_slots", C.c_uint64),
+                ("n_chunk_slots", C.c_uint64), ("d_seed_code", C.c_void_p), ("d_seed_chunk", C.c_void_p),
+                ("d_bin_start", C.c_void_p), ("d_chunk_total", C.c_void_p)]
 
 
 _lib = None

@@ -4,12 +4,19 @@
 // fraction gate, two-decimal percent) -- skani parity is UNPINNED, see DESIGN.md "ANI".
 // The device does integer work only; the host finishes pow/rounding.
 //
-//   ani_seeds : pass over the base stream; canonical 2-bit k-mer -> invertible 64-bit mix;
-//               seeds with hash < 2^64/c are appended (hash, chunk) and counted per chunk.
-//   ani_table : per genome, insert the seed hashes into an open-addressing table (set).
-//   ani_pairs : one workgroup per (pair, direction): every query seed probes the reference's
-//               table; matches are counted per 20 kb query chunk in LDS; a chunk is aligned
-//               iff M_c*10000 >= 510*T_c; emits sum M_c, sum T_c, aligned bases.
+//   ani_seeds : pass over the base stream; canonical 2-bit k-mer (k <= 16, fits u32) ->
+//               invertible 64-bit mix; seeds with hash < 2^64/c are appended as (code u32,
+//               chunk u16) and counted per chunk.  The mix is invertible, so "same hash" ==
+//               "same code" and the 4-byte code is what is stored and compared.
+//   ani_bin   : per genome, counting sort of the seed list by the top 14 bits of a 32-bit
+//               multiplicative hash of the code; writes the binned list and its bin offsets
+//               (CSR).  Every genome uses the same bin function, so two genomes can be joined
+//               bin by bin -- no hash table, no atomics on the device-wide memory.
+//   ani_pairs : one workgroup per PAIR (both directions at once): lane b joins bin b of the
+//               two genomes (~2.4 x 2.4 seeds), counting matched seeds per 20 kb chunk of
+//               each genome in LDS; a chunk is aligned iff M_c*10000 >= 510*T_c; emits
+//               sum M_c, sum T_c and aligned bases per direction.  All four streams (two
+//               bin-offset arrays, two code arrays) are read front to back, coalesced.
 #include "ghip_internal.h"
 
 namespace {
@@ -34,17 +41,18 @@ __device__ __forceinline__ uint32_t base_code(uint32_t c) {
 constexpr uint32_t SEED_LDS_CAP = 1024;   // seeds buffered per block (expected 16384/c ~ 131)
 constexpr uint32_t SEED_LDS_CHUNKS = 64;  // per-block chunk counters
 
-// Seeds are rare (1/c of the k-mers), so they are collected in LDS and flushed with ONE global
-// atomic per block: a per-genome counter bumped once per seed serialises at the L2 (4e7
-// same-address atomics at N=1000).
+// Seeds are rare (1/c of the k-mers) but with 64 lanes a wave still meets one at ~40 % of the
+// positions, so the per-seed work inside the position loop is kept to one LDS atomic and two LDS
+// stores (code, block-relative position); chunk ids, per-chunk totals and the global append are
+// done afterwards by all threads, with ONE global atomic per block on the genome's counter.
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const ghip_sketch_work *__restrict__ work, uint32_t K,
-    uint64_t thr, uint32_t chunk, uint64_t *__restrict__ seed_hash, uint32_t *__restrict__ seed_chunk,
+    uint64_t thr, uint32_t chunk, uint32_t *__restrict__ seed_code, uint16_t *__restrict__ seed_chunk,
     const uint64_t *__restrict__ seed_start, uint32_t *__restrict__ seed_count,
     uint32_t *__restrict__ chunk_total, const uint64_t *__restrict__ chunk_start) {
-    __shared__ uint64_t l_hash[SEED_LDS_CAP];
-    __shared__ uint32_t l_chunk[SEED_LDS_CAP];
+    __shared__ uint32_t l_code[SEED_LDS_CAP];
+    __shared__ uint16_t l_pos[SEED_LDS_CAP];
     __shared__ uint32_t l_ctot[SEED_LDS_CHUNKS];
     __shared__ uint32_t l_n, l_base;
 
@@ -52,8 +60,10 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint32_t g = wk.slot;
     const uint64_t L = lens[g];
     const uint64_t blk0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK;
-    const uint64_t p0 = blk0 + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    const uint32_t toff = threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    const uint64_t p0 = blk0 + toff;
     const uint32_t ch_first = (uint32_t)(blk0 / chunk);
+    const uint32_t rem_first = (uint32_t)(blk0 - (uint64_t)ch_first * chunk);
     const uint64_t sstart = seed_start[g];
     const uint32_t scap = (uint32_t)(seed_start[g + 1] - sstart);
     uint32_t *ctot = chunk_total + chunk_start[g];
@@ -80,19 +90,18 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 fwd = ((fwd << 2) | code) & mask;
                 rev = (rev >> 2) | ((uint64_t)(3u - code) << (2 * (K - 1)));
                 good = valid ? good + 1 : 0;
-                const uint64_t h = mm_hash64(fwd < rev ? fwd : rev);
+                const uint64_t canon = fwd < rev ? fwd : rev;
+                const uint64_t h = mm_hash64(canon);
                 if (b < NB && b >= (int)K - 1 && good >= K && h < thr) {
-                    const uint64_t pos = p0 + (uint64_t)(b - ((int)K - 1));
-                    const uint32_t ch = (uint32_t)(pos / chunk);
+                    const uint32_t rel = toff + (uint32_t)(b - ((int)K - 1));  // position - blk0 (< 16384)
                     const uint32_t li = atomicAdd(&l_n, 1u);
-                    if (li < SEED_LDS_CAP) { l_hash[li] = h; l_chunk[li] = ch; }
+                    if (li < SEED_LDS_CAP) { l_code[li] = (uint32_t)canon; l_pos[li] = (uint16_t)rel; }
                     else {  // LDS buffer full (never at c=125): straight to the global list
+                        const uint32_t ch = ch_first + (rem_first + rel) / chunk;
                         uint32_t idx = atomicAdd(&seed_count[g], 1u);
-                        if (idx < scap) { seed_hash[sstart + idx] = h; seed_chunk[sstart + idx] = ch; }
+                        if (idx < scap) { seed_code[sstart + idx] = (uint32_t)canon; seed_chunk[sstart + idx] = (uint16_t)ch; }
+                        atomicAdd(&ctot[ch], 1u);
                     }
-                    const uint32_t rel = ch - ch_first;
-                    if (rel < SEED_LDS_CHUNKS) atomicAdd(&l_ctot[rel], 1u);
-                    else atomicAdd(&ctot[ch], 1u);
                 }
             }
         }
@@ -103,87 +112,83 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     __syncthreads();
     const uint32_t base = l_base;
     for (uint32_t i = threadIdx.x; i < nloc; i += blockDim.x) {
+        const uint32_t chrel = (rem_first + l_pos[i]) / chunk;
         const uint32_t idx = base + i;
-        if (idx < scap) { seed_hash[sstart + idx] = l_hash[i]; seed_chunk[sstart + idx] = l_chunk[i]; }
+        if (idx < scap) { seed_code[sstart + idx] = l_code[i]; seed_chunk[sstart + idx] = (uint16_t)(ch_first + chrel); }
+        if (chrel < SEED_LDS_CHUNKS) atomicAdd(&l_ctot[chrel], 1u);
+        else atomicAdd(&ctot[ch_first + chrel], 1u);
     }
+    __syncthreads();
     if (threadIdx.x < SEED_LDS_CHUNKS && l_ctot[threadIdx.x]) atomicAdd(&ctot[ch_first + threadIdx.x], l_ctot[threadIdx.x]);
 }
 
-// one block per genome; table size is a power of two >= 2*count; slot = low bits of the hash
-__global__ __launch_bounds__(256) void ani_table_kernel(const uint64_t *__restrict__ seed_hash,
-                                                        const uint64_t *__restrict__ seed_start,
-                                                        const uint32_t *__restrict__ seed_count,
-                                                        uint64_t *__restrict__ table,
-                                                        const uint64_t *__restrict__ table_start) {
+__device__ __forceinline__ uint32_t code_bin(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - GHIP_ANI_BIN_BITS); }
+
+constexpr uint32_t BIN_COUNT = GHIP_ANI_BIN_COUNT, BIN_THREADS = 1024;
+
+// Counting sort in LDS; the order inside a bin is arbitrary.  bin_start[g][b] is relative to the
+// genome's first seed slot, so shards can be concatenated.
+__global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
+    const uint32_t *__restrict__ in_code, const uint16_t *__restrict__ in_chunk,
+    uint32_t *__restrict__ out_code, uint16_t *__restrict__ out_chunk,
+    const uint64_t *__restrict__ seed_start, const uint32_t *__restrict__ seed_count,
+    uint32_t *__restrict__ bin_start) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);  // BIN_COUNT counters
+    __shared__ uint32_t wave_tot[BIN_THREADS / 64];
     const uint32_t g = blockIdx.x;
-    const uint64_t tstart = table_start[g];
-    const uint64_t tsize = table_start[g + 1] - tstart;
-    if (tsize == 0) return;
-    const uint64_t tmask = tsize - 1;
-    unsigned long long *tab = reinterpret_cast<unsigned long long *>(table + tstart);
-    const uint64_t *src = seed_hash + seed_start[g];
-    const uint32_t n = seed_count[g];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t h = src[i];
-        uint64_t slot = h & tmask;
-        for (;;) {
-            unsigned long long prev = atomicCAS(&tab[slot], (unsigned long long)GHIP_EMPTY_SLOT, (unsigned long long)h);
-            if (prev == GHIP_EMPTY_SLOT || prev == h) break;
-            slot = (slot + 1) & tmask;
-        }
+    const uint64_t s0 = seed_start[g];
+    const uint32_t n = min(seed_count[g], (uint32_t)(seed_start[g + 1] - s0));
+    uint32_t *bstart = bin_start + (uint64_t)g * (BIN_COUNT + 1);
+    for (uint32_t i = threadIdx.x; i < BIN_COUNT; i += BIN_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) atomicAdd(&hist[code_bin(in_code[s0 + i])], 1u);
+    __syncthreads();
+    // exclusive scan of hist: 16 consecutive bins per thread
+    constexpr uint32_t PER = BIN_COUNT / BIN_THREADS;
+    uint32_t local[PER], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) { local[j] = hist[threadIdx.x * PER + j]; sum += local[j]; }
+    uint32_t incl = sum;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        hist[threadIdx.x * PER + j] = run;
+        bstart[threadIdx.x * PER + j] = run;
+        run += local[j];
+    }
+    if (threadIdx.x == BIN_THREADS - 1) bstart[BIN_COUNT] = run;  // == n
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
+        const uint32_t c = in_code[s0 + i];
+        const uint32_t pos = atomicAdd(&hist[code_bin(c)], 1u);
+        out_code[s0 + pos] = c;
+        out_chunk[s0 + pos] = in_chunk[s0 + i];
     }
 }
 
-__global__ __launch_bounds__(256) void ani_pairs_kernel(
-    const uint32_t *__restrict__ pairs, const uint64_t *__restrict__ seed_hash,
-    const uint32_t *__restrict__ seed_chunk, const uint64_t *__restrict__ seed_start,
-    const uint32_t *__restrict__ seed_count, const uint64_t *__restrict__ table,
-    const uint64_t *__restrict__ table_start, const uint32_t *__restrict__ chunk_total,
-    const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, uint32_t chunk,
-    uint64_t *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t *mc = reinterpret_cast<uint32_t *>(smem_raw);
-    __shared__ unsigned long long red[3];
+constexpr uint32_t ANI_PAIR_THREADS = 512;
 
-    const uint32_t pair = blockIdx.x >> 1, dir = blockIdx.x & 1u;
-    const uint32_t q = pairs[2 * pair + dir], r = pairs[2 * pair + (dir ^ 1u)];
-    const uint32_t nch = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
-    for (uint32_t i = threadIdx.x; i < nch; i += blockDim.x) mc[i] = 0;
-    if (threadIdx.x < 3) red[threadIdx.x] = 0;
-    __syncthreads();
-
-    const uint64_t tstart = table_start[r];
-    const uint64_t tsize = table_start[r + 1] - tstart;
-    const uint64_t tmask = tsize - 1;
-    const uint64_t *tab = table + tstart;
-    const uint64_t qs = seed_start[q];
-    const uint32_t nq = seed_count[q];
-    if (tsize != 0) {
-        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
-            const uint64_t h = seed_hash[qs + i];
-            uint64_t slot = h & tmask;
-            bool hit = false;
-            for (;;) {
-                const uint64_t v = tab[slot];
-                if (v == h) { hit = true; break; }
-                if (v == GHIP_EMPTY_SLOT) break;
-                slot = (slot + 1) & tmask;
-            }
-            if (hit) atomicAdd(&mc[seed_chunk[qs + i]], 1u);
-        }
-    }
-    __syncthreads();
-
+__device__ __forceinline__ void reduce_direction(const uint32_t *mc, const uint32_t *tc, uint32_t nch, uint64_t L,
+                                                 uint32_t chunk, unsigned long long *red) {
     unsigned long long M = 0, T = 0, bases = 0;
-    const uint64_t Lq = glen[q];
-    const uint32_t *tc = chunk_total + chunk_start[q];
     for (uint32_t c = threadIdx.x; c < nch; c += blockDim.x) {
         const unsigned long long t = tc[c], m = mc[c];
         if (t >= 1 && m * 10000ull >= 510ull * t) {
             M += m; T += t;
             const uint64_t lo = (uint64_t)c * chunk;
             uint64_t hi = lo + chunk;
-            if (hi > Lq) hi = Lq;
+            if (hi > L) hi = L;
             bases += hi - lo;
         }
     }
@@ -193,50 +198,102 @@ __global__ __launch_bounds__(256) void ani_pairs_kernel(
         T += __shfl_xor(T, off, 64);
         bases += __shfl_xor(bases, off, 64);
     }
-    if ((threadIdx.x & 63u) == 0) {
-        atomicAdd(&red[0], M); atomicAdd(&red[1], T); atomicAdd(&red[2], bases);
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[0], M); atomicAdd(&red[1], T); atomicAdd(&red[2], bases); }
+}
+
+__global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
+    const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ seed_code,
+    const uint16_t *__restrict__ seed_chunk, const uint64_t *__restrict__ seed_start,
+    const uint32_t *__restrict__ bin_start, const uint32_t *__restrict__ chunk_total,
+    const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, uint32_t chunk,
+    uint64_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
+    __shared__ unsigned long long red[6];
+
+    // physical block b runs on XCD b % 8: give each XCD runs of 32 consecutive pairs (one precluster's
+    // genomes are then re-read from that XCD's L2)
+    const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
+    const uint32_t pair = ((slot_in_xcd >> 5) * 8u + xcd) * 32u + (slot_in_xcd & 31u);
+    if (pair >= n_pairs) return;
+    const uint32_t q = pairs[2 * pair], r = pairs[2 * pair + 1];
+    const uint32_t nchq = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
+    const uint32_t nchr = (uint32_t)(chunk_start[r + 1] - chunk_start[r]);
+    uint32_t *mcr = mcq + nchq;
+    for (uint32_t i = threadIdx.x; i < nchq + nchr; i += blockDim.x) mcq[i] = 0;
+    if (threadIdx.x < 6) red[threadIdx.x] = 0;
+    __syncthreads();
+
+    const uint32_t *qb = bin_start + (uint64_t)q * (BIN_COUNT + 1), *rb = bin_start + (uint64_t)r * (BIN_COUNT + 1);
+    const uint32_t *qc = seed_code + seed_start[q], *rc = seed_code + seed_start[r];
+    const uint16_t *qk = seed_chunk + seed_start[q], *rk = seed_chunk + seed_start[r];
+    for (uint32_t b = threadIdx.x; b < BIN_COUNT; b += blockDim.x) {
+        const uint32_t qs = qb[b], qe = qb[b + 1], rs = rb[b], re = rb[b + 1];
+        if (qs == qe || rs == re) continue;
+        for (uint32_t i = qs; i < qe; i++) {       // q seeds that occur in r
+            const uint32_t c = qc[i];
+            bool hit = false;
+            for (uint32_t j = rs; j < re; j++) hit |= (rc[j] == c);
+            if (hit) atomicAdd(&mcq[qk[i]], 1u);
+        }
+        for (uint32_t j = rs; j < re; j++) {       // r seeds that occur in q
+            const uint32_t c = rc[j];
+            bool hit = false;
+            for (uint32_t i = qs; i < qe; i++) hit |= (qc[i] == c);
+            if (hit) atomicAdd(&mcr[rk[j]], 1u);
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 3) out[(uint64_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x];
+    reduce_direction(mcq, chunk_total + chunk_start[q], nchq, glen[q], chunk, red);
+    reduce_direction(mcr, chunk_total + chunk_start[r], nchr, glen[r], chunk, red + 3);
+    __syncthreads();
+    if (threadIdx.x < 6) out[(uint64_t)pair * 6 + threadIdx.x] = red[threadIdx.x];
 }
 
 }  // namespace
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
-                           uint64_t *d_seed_hash, uint32_t *d_seed_chunk, const uint64_t *d_seed_start,
+                           uint32_t *d_seed_code, uint16_t *d_seed_chunk, const uint64_t *d_seed_start,
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
     const uint64_t thr = ~0ull / c;
     ghip_prof_begin(ctx, "ani_seeds");
     hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)n_work), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                       g->d_bytes, g->d_starts, g->d_lens, d_work, k, thr, chunk, d_seed_hash, d_seed_chunk,
+                       g->d_bytes, g->d_starts, g->d_lens, d_work, k, thr, chunk, d_seed_code, d_seed_chunk,
                        d_seed_start, d_seed_count, d_chunk_total, d_chunk_start);
     ghip_prof_end(ctx);
 }
 
-void ghip_launch_ani_table(ghip_ctx *ctx, size_t n, const uint64_t *d_seed_hash, const uint64_t *d_seed_start,
-                           const uint32_t *d_seed_count, uint64_t *d_table, const uint64_t *d_table_start) {
+void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint16_t *in_chunk, uint32_t *out_code,
+                         uint16_t *out_chunk, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
+                         uint32_t *d_bin_start) {
     if (n == 0) return;
-    ghip_prof_begin(ctx, "ani_table");
-    hipLaunchKernelGGL(ani_table_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_seed_hash, d_seed_start,
-                       d_seed_count, d_table, d_table_start);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    ghip_prof_begin(ctx, "ani_bin");
+    hipLaunchKernelGGL(ani_bin_kernel, dim3((unsigned)n), dim3(BIN_THREADS), BIN_COUNT * sizeof(uint32_t), ctx->stream,
+                       in_code, in_chunk, out_code, out_chunk, d_seed_start, d_seed_count, d_bin_start);
     ghip_prof_end(ctx);
 }
 
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out) {
     if (n_pairs == 0) return;
-    const size_t lds = (size_t)max_chunks * sizeof(uint32_t);
+    const size_t lds = (size_t)2 * max_chunks * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         attr_set = true;
     }
     ghip_prof_begin(ctx, "ani_pairs");
-    hipLaunchKernelGGL(ani_pairs_kernel, dim3((unsigned)(2 * n_pairs)), dim3(256), lds, ctx->stream, d_pairs,
-                       idx->d_seed_hash, idx->d_seed_chunk, idx->d_seed_start, idx->d_seed_count, idx->d_table,
-                       idx->d_table_start, idx->d_chunk_total, idx->d_chunk_start, idx->d_glen, idx->chunk, d_out);
+    const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
+    hipLaunchKernelGGL(ani_pairs_kernel, dim3(grid), dim3(ANI_PAIR_THREADS), lds, ctx->stream, d_pairs, (uint32_t)n_pairs,
+                       idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
+                       idx->d_chunk_start, idx->d_glen, idx->chunk, d_out);
     ghip_prof_end(ctx);
 }

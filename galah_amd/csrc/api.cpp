@@ -109,6 +109,9 @@ int d2h(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
     return GHIP_OK;
 }
 
+// Deterministic ANI index layout (shards must agree): Poisson(L/c) seeds, +10 % + 256 slack.
+uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) { return len / c + len / (10ull * c) + 256; }
+
 uint32_t next_pow2(uint64_t x) {
     uint64_t p = 1;
     while (p < x) p <<= 1;
@@ -652,13 +655,13 @@ extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min
 static void free_index_arrays_locked(ghip_ani_index *idx) {
     ghip_ctx *ctx = idx->ctx;
     if (idx->owned) {
-        ghip_pool_free(ctx, idx->d_seed_hash); ghip_pool_free(ctx, idx->d_seed_chunk);
-        ghip_pool_free(ctx, idx->d_table); ghip_pool_free(ctx, idx->d_chunk_total);
+        ghip_pool_free(ctx, idx->d_seed_code); ghip_pool_free(ctx, idx->d_seed_chunk);
+        ghip_pool_free(ctx, idx->d_bin_start); ghip_pool_free(ctx, idx->d_chunk_total);
     }
     ghip_pool_free(ctx, idx->d_seed_start); ghip_pool_free(ctx, idx->d_seed_count);
-    ghip_pool_free(ctx, idx->d_table_start); ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen);
-    idx->d_seed_hash = nullptr; idx->d_seed_chunk = nullptr; idx->d_table = nullptr; idx->d_chunk_total = nullptr;
-    idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_table_start = nullptr; idx->d_chunk_start = nullptr;
+    ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen);
+    idx->d_seed_code = nullptr; idx->d_seed_chunk = nullptr; idx->d_bin_start = nullptr; idx->d_chunk_total = nullptr;
+    idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_chunk_start = nullptr;
     idx->d_glen = nullptr;
 }
 
@@ -683,7 +686,7 @@ extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
 extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
                                     ghip_ani_index **out) {
     if (!ctx || !g || !out) return GHIP_EINVAL;
-    if (k < 1 || k > 32 || c < 1 || chunk < 1) return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters");
+    if (k < 1 || k > 16 || c < 1 || chunk < 1) return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters (k must be 1..=16)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = g->n;
@@ -698,15 +701,15 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
         idx->chunk_start[i + 1] = idx->chunk_start[i] + nch;
     }
     int rc = GHIP_OK;
-    if (idx->max_chunks > 32768) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (max 32768 chunks)");
+    if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");
     std::vector<uint64_t> cap(n);
-    for (size_t i = 0; i < n; i++) cap[i] = g->lens[i] / c + g->lens[i] / (2 * (uint64_t)c) + 1024;
+    for (size_t i = 0; i < n; i++) cap[i] = ghip_ani_seed_capacity(g->lens[i], c);
     for (int attempt = 0; attempt < 2 && rc == GHIP_OK; attempt++) {
         idx->seed_start.assign(n + 1, 0);
         for (size_t i = 0; i < n; i++) idx->seed_start[i + 1] = idx->seed_start[i] + cap[i];
         if (attempt) hipStreamSynchronize(ctx->stream);
         free_index_arrays_locked(idx);
-        if ((rc = dmalloc(ctx, &idx->d_seed_hash, idx->seed_start[n]))) break;
+        if ((rc = dmalloc(ctx, &idx->d_seed_code, idx->seed_start[n]))) break;
         if ((rc = dmalloc(ctx, &idx->d_seed_chunk, idx->seed_start[n]))) break;
         if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) break;
         if ((rc = dmalloc(ctx, &idx->d_seed_count, n))) break;
@@ -718,7 +721,7 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
         if ((rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) break;
         hipMemsetAsync(idx->d_seed_count, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), ctx->stream);
         hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream);
-        ghip_launch_ani_seeds(ctx, g, k, c, chunk, idx->d_seed_hash, idx->d_seed_chunk, idx->d_seed_start,
+        ghip_launch_ani_seeds(ctx, g, k, c, chunk, idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start,
                               idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
         idx->seed_count.assign(n, 0);
         if ((rc = d2h(ctx, idx->seed_count.data(), idx->d_seed_count, n))) break;
@@ -728,18 +731,18 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
         if (attempt == 1) rc = ghip_set_error(ctx, GHIP_EHIP, "ANI seed list overflowed twice");
     }
     if (rc == GHIP_OK) {
-        idx->table_start.assign(n + 1, 0);
-        for (size_t i = 0; i < n; i++) {
-            uint64_t sz = next_pow2(2ull * cap[i]);  // from the capacity, so shards agree on the layout
-            idx->table_start[i + 1] = idx->table_start[i] + sz;
-        }
-        if (!(rc = dmalloc(ctx, &idx->d_table, idx->table_start[n])) && !(rc = dmalloc(ctx, &idx->d_table_start, n + 1)) &&
-            !(rc = h2d(ctx, idx->d_table_start, idx->table_start.data(), n + 1))) {
-            hipMemsetAsync(idx->d_table, 0xff, std::max<uint64_t>(idx->table_start[n], 1) * sizeof(uint64_t), ctx->stream);
-            ghip_launch_ani_table(ctx, n, idx->d_seed_hash, idx->d_seed_start, idx->d_seed_count, idx->d_table, idx->d_table_start);
+        // reorder every genome's seed list by hash bin and record the bin offsets (the join index)
+        uint32_t *d_code2 = nullptr; uint16_t *d_chunk2 = nullptr;
+        if (!(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) &&
+            !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n]))) {
+            ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_chunk, d_code2, d_chunk2, idx->d_seed_start,
+                                idx->d_seed_count, idx->d_bin_start);
+            std::swap(idx->d_seed_code, d_code2);
+            std::swap(idx->d_seed_chunk, d_chunk2);
             if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
                 rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
         }
+        ghip_pool_free(ctx, d_code2); ghip_pool_free(ctx, d_chunk2);  // the unordered lists
     }
     if (rc) { free_index_locked(idx); return rc; }
     *out = idx;
@@ -789,31 +792,28 @@ extern "C" int ghip_ani_index_layout(const ghip_ani_index *idx, ghip_ani_layout 
     if (!idx || !out) return GHIP_EINVAL;
     out->n = idx->n;
     out->n_seed_slots = idx->seed_start[idx->n];
-    out->n_table_slots = idx->table_start[idx->n];
+    out->n_bin_slots = (uint64_t)idx->n * (GHIP_ANI_BIN_COUNT + 1);
     out->n_chunk_slots = idx->chunk_start[idx->n];
-    out->d_seed_hash = idx->d_seed_hash; out->d_seed_chunk = idx->d_seed_chunk;
-    out->d_table = idx->d_table; out->d_chunk_total = idx->d_chunk_total;
+    out->d_seed_code = idx->d_seed_code; out->d_seed_chunk = idx->d_seed_chunk;
+    out->d_bin_start = idx->d_bin_start; out->d_chunk_total = idx->d_chunk_total;
     return GHIP_OK;
 }
 
-extern "C" int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_len, uint64_t *seed_cap,
-                                   uint32_t *seed_count, uint64_t *table_size) {
+extern "C" int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_len, uint64_t *seed_cap, uint32_t *seed_count) {
     if (!idx) return GHIP_EINVAL;
     for (size_t i = 0; i < idx->n; i++) {
         if (genome_len) genome_len[i] = idx->glen[i];
         if (seed_cap) seed_cap[i] = idx->seed_start[i + 1] - idx->seed_start[i];
         if (seed_count) seed_count[i] = idx->seed_count[i];
-        if (table_size) table_size[i] = idx->table_start[i + 1] - idx->table_start[i];
     }
     return GHIP_OK;
 }
 
 extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, uint32_t chunk,
                                           const uint64_t *genome_len, const uint64_t *seed_cap,
-                                          const uint32_t *seed_count, const uint64_t *table_size,
-                                          void *d_seed_hash, void *d_seed_chunk, void *d_table,
-                                          void *d_chunk_total, ghip_ani_index **out) {
-    if (!ctx || !out || chunk == 0 || (n && (!genome_len || !seed_cap || !seed_count || !table_size))) return GHIP_EINVAL;
+                                          const uint32_t *seed_count, void *d_seed_code, void *d_seed_chunk,
+                                          void *d_bin_start, void *d_chunk_total, ghip_ani_index **out) {
+    if (!ctx || !out || chunk == 0 || (n && (!genome_len || !seed_cap || !seed_count))) return GHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ghip_ani_index *idx = new ghip_ani_index();
@@ -821,27 +821,24 @@ extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, u
     idx->ctx = ctx; idx->n = n; idx->k = k; idx->c = c; idx->chunk = chunk; idx->owned = false;
     idx->glen.assign(genome_len, genome_len + n);
     idx->seed_count.assign(seed_count, seed_count + n);
-    idx->seed_start.assign(n + 1, 0); idx->table_start.assign(n + 1, 0); idx->chunk_start.assign(n + 1, 0);
+    idx->seed_start.assign(n + 1, 0); idx->chunk_start.assign(n + 1, 0);
     for (size_t i = 0; i < n; i++) {
-        if (seed_count[i] > seed_cap[i] || (table_size[i] & (table_size[i] - 1))) { free_index_locked(idx); return ghip_set_error(ctx, GHIP_EINVAL, "inconsistent ANI index metadata"); }
+        if (seed_count[i] > seed_cap[i]) { free_index_locked(idx); return ghip_set_error(ctx, GHIP_EINVAL, "inconsistent ANI index metadata"); }
         uint64_t nch = (genome_len[i] + chunk - 1) / chunk;
         idx->max_chunks = (uint32_t)std::max<uint64_t>(idx->max_chunks, nch);
         idx->seed_start[i + 1] = idx->seed_start[i] + seed_cap[i];
-        idx->table_start[i + 1] = idx->table_start[i] + table_size[i];
         idx->chunk_start[i + 1] = idx->chunk_start[i] + nch;
     }
-    idx->d_seed_hash = (uint64_t *)d_seed_hash; idx->d_seed_chunk = (uint32_t *)d_seed_chunk;
-    idx->d_table = (uint64_t *)d_table; idx->d_chunk_total = (uint32_t *)d_chunk_total;
+    idx->d_seed_code = (uint32_t *)d_seed_code; idx->d_seed_chunk = (uint16_t *)d_seed_chunk;
+    idx->d_bin_start = (uint32_t *)d_bin_start; idx->d_chunk_total = (uint32_t *)d_chunk_total;
     int rc = GHIP_OK;
-    if (idx->max_chunks > 32768) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (max 32768 chunks)");
+    if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");
     if (!rc) rc = dmalloc(ctx, &idx->d_seed_start, n + 1);
     if (!rc) rc = dmalloc(ctx, &idx->d_seed_count, n);
-    if (!rc) rc = dmalloc(ctx, &idx->d_table_start, n + 1);
     if (!rc) rc = dmalloc(ctx, &idx->d_chunk_start, n + 1);
     if (!rc) rc = dmalloc(ctx, &idx->d_glen, n);
     if (!rc) rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1);
     if (!rc) rc = h2d(ctx, idx->d_seed_count, idx->seed_count.data(), n);
-    if (!rc) rc = h2d(ctx, idx->d_table_start, idx->table_start.data(), n + 1);
     if (!rc) rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1);
     if (!rc) rc = h2d(ctx, idx->d_glen, idx->glen.data(), n);
     if (rc) { free_index_locked(idx); return rc; }

@@ -89,22 +89,23 @@ struct ghip_ani_index {
     size_t n = 0;
     uint32_t k = 0, c = 0, chunk = 0;
     // per-genome seed lists (unordered) and open-addressing membership tables
-    uint64_t *d_seed_hash = nullptr;   // concatenated
-    uint32_t *d_seed_chunk = nullptr;  // concatenated
+    uint32_t *d_seed_code = nullptr;   // concatenated canonical 2-bit k-mer codes (k <= 16)
+    uint16_t *d_seed_chunk = nullptr;  // concatenated
     uint64_t *d_seed_start = nullptr;  // [n+1] offsets into seed arrays (capacity layout)
     uint32_t *d_seed_count = nullptr;  // [n]
-    uint64_t *d_table = nullptr;       // concatenated tables
-    uint64_t *d_table_start = nullptr; // [n+1]
+    uint32_t *d_bin_start = nullptr;   // [n][GHIP_ANI_BIN_COUNT+1] CSR offsets of the binned seed list
     uint32_t *d_chunk_total = nullptr; // concatenated per-chunk seed totals T_c
     uint64_t *d_chunk_start = nullptr; // [n+1]
     uint64_t *d_glen = nullptr;        // [n] stream lengths
-    std::vector<uint64_t> glen, chunk_start, table_start, seed_start;
+    std::vector<uint64_t> glen, chunk_start, seed_start;
     std::vector<uint32_t> seed_count;
     uint32_t max_chunks = 0;
     bool owned = true;  // false: the four flat arrays are borrowed (ghip_ani_index_wrap_device)
 };
 
-#define GHIP_EMPTY_SLOT 0xFFFFFFFFFFFFFFFFull
+#define GHIP_ANI_BIN_BITS 14
+#define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
+#define GHIP_ANI_MAX_CHUNKS 19000u  // two u32 counter arrays of one pair must fit the 160 KiB LDS
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);
 
@@ -142,11 +143,12 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
                        uint64_t *pairs_compared);
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
-                           uint64_t *d_seed_hash, uint32_t *d_seed_chunk, const uint64_t *d_seed_start,
+                           uint32_t *d_seed_code, uint16_t *d_seed_chunk, const uint64_t *d_seed_start,
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work);
-void ghip_launch_ani_table(ghip_ctx *ctx, size_t n, const uint64_t *d_seed_hash, const uint64_t *d_seed_start,
-                           const uint32_t *d_seed_count, uint64_t *d_table, const uint64_t *d_table_start);
+void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint16_t *in_chunk, uint32_t *out_code,
+                         uint16_t *out_chunk, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
+                         uint32_t *d_bin_start);
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out /* [n_pairs][2][3] = M, T, aligned bases */);
 

@@ -73,18 +73,22 @@ class Exchange:
         return out[:n_total]
 
     def all_gather_flat(self, local, sizes: List[int]):
-        """1-D tensors of per-rank length sizes[r] -> their concatenation on every rank."""
+        """1-D tensors of per-rank length sizes[r] -> their concatenation on every rank.
+        Moved as raw bytes (u8), so any element type works with any backend."""
         import torch
         if self.world == 1:
             return local
-        m = max(sizes)
-        padded = torch.zeros(m, dtype=local.dtype, device=local.device)
-        padded[: local.shape[0]] = local
-        out = torch.empty(self.world * m, dtype=local.dtype, device=local.device)
+        esz = local.element_size()
+        raw = local.contiguous().view(torch.uint8)
+        m = max(sizes) * esz
+        m = (m + 15) // 16 * 16
+        padded = torch.zeros(m, dtype=torch.uint8, device=local.device)
+        padded[: raw.shape[0]] = raw
+        out = torch.empty(self.world * m, dtype=torch.uint8, device=local.device)
         self._gather(out, padded)
-        if all(sz == m for sz in sizes):
-            return out
-        return torch.cat([out[r * m: r * m + sizes[r]] for r in range(self.world)])
+        if all(sz * esz == m for sz in sizes):
+            return out.view(local.dtype)
+        return torch.cat([out[r * m: r * m + sizes[r] * esz] for r in range(self.world)]).view(local.dtype)
 
     def all_gather_object(self, obj):
         if self.world == 1:
@@ -154,23 +158,23 @@ class HipEngine:
         """-> (meta dict of host arrays, dict of flat device tensors)."""
         t = self.torch
         idx = self.ctx.ani_index_build(self.genomes, self.ani_k, self.ani_c, self.ani_chunk)
-        glen, cap, cnt, tsz = idx.meta()
+        glen, cap, cnt = idx.meta()
         lay = idx.layout()
         self._local_index = idx
-        return idx, {"glen": glen, "cap": cap, "cnt": cnt, "tsz": tsz}, lay
+        return idx, {"glen": glen, "cap": cap, "cnt": cnt}, lay
 
     def ani_export(self, idx, lay):
         t = self.torch
         arrs = {
-            "seed_hash": t.empty(int(lay.n_seed_slots), dtype=t.int64, device=self.device),
-            "seed_chunk": t.empty(int(lay.n_seed_slots), dtype=t.int32, device=self.device),
-            "table": t.empty(int(lay.n_table_slots), dtype=t.int64, device=self.device),
+            "seed_code": t.empty(int(lay.n_seed_slots), dtype=t.int32, device=self.device),
+            "seed_chunk": t.empty(int(lay.n_seed_slots), dtype=t.int16, device=self.device),
+            "bin_start": t.empty(int(lay.n_bin_slots), dtype=t.int32, device=self.device),
             "chunk_total": t.empty(int(lay.n_chunk_slots), dtype=t.int32, device=self.device),
         }
         t.cuda.current_stream().synchronize()
-        self.ctx.memcpy_d2d(arrs["seed_hash"].data_ptr(), lay.d_seed_hash, int(lay.n_seed_slots) * 8)
-        self.ctx.memcpy_d2d(arrs["seed_chunk"].data_ptr(), lay.d_seed_chunk, int(lay.n_seed_slots) * 4)
-        self.ctx.memcpy_d2d(arrs["table"].data_ptr(), lay.d_table, int(lay.n_table_slots) * 8)
+        self.ctx.memcpy_d2d(arrs["seed_code"].data_ptr(), lay.d_seed_code, int(lay.n_seed_slots) * 4)
+        self.ctx.memcpy_d2d(arrs["seed_chunk"].data_ptr(), lay.d_seed_chunk, int(lay.n_seed_slots) * 2)
+        self.ctx.memcpy_d2d(arrs["bin_start"].data_ptr(), lay.d_bin_start, int(lay.n_bin_slots) * 4)
         self.ctx.memcpy_d2d(arrs["chunk_total"].data_ptr(), lay.d_chunk_total, int(lay.n_chunk_slots) * 4)
         self.ctx.synchronize()
         return arrs
@@ -179,8 +183,8 @@ class HipEngine:
         self.torch.cuda.current_stream().synchronize()
         self._keep = [arrs]  # the wrapped index borrows these tensors
         return self.ctx.ani_index_wrap_device(self.ani_k, self.ani_c, self.ani_chunk, meta["glen"], meta["cap"],
-                                              meta["cnt"], meta["tsz"], arrs["seed_hash"].data_ptr(),
-                                              arrs["seed_chunk"].data_ptr(), arrs["table"].data_ptr(),
+                                              meta["cnt"], arrs["seed_code"].data_ptr(),
+                                              arrs["seed_chunk"].data_ptr(), arrs["bin_start"].data_ptr(),
                                               arrs["chunk_total"].data_ptr())
 
     def ani_pairs(self, idx, pairs: np.ndarray, min_af: float) -> np.ndarray:
@@ -248,12 +252,12 @@ class DereplicationJob:
         if self.world > 1:
             arrs_l = e.ani_export(idx_l, lay)
             metas = ex.all_gather_object({k: v for k, v in meta_l.items()} | {
-                "sizes": (int(lay.n_seed_slots), int(lay.n_table_slots), int(lay.n_chunk_slots))})
-            meta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt", "tsz")}
+                "sizes": (int(lay.n_seed_slots), int(lay.n_bin_slots), int(lay.n_chunk_slots))})
+            meta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt")}
             arrs = {
-                "seed_hash": ex.all_gather_flat(arrs_l["seed_hash"], [m["sizes"][0] for m in metas]),
+                "seed_code": ex.all_gather_flat(arrs_l["seed_code"], [m["sizes"][0] for m in metas]),
                 "seed_chunk": ex.all_gather_flat(arrs_l["seed_chunk"], [m["sizes"][0] for m in metas]),
-                "table": ex.all_gather_flat(arrs_l["table"], [m["sizes"][1] for m in metas]),
+                "bin_start": ex.all_gather_flat(arrs_l["bin_start"], [m["sizes"][1] for m in metas]),
                 "chunk_total": ex.all_gather_flat(arrs_l["chunk_total"], [m["sizes"][2] for m in metas]),
             }
             idx = e.ani_wrap(meta, arrs)

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import PAIR_DTYPE, GalahHipError, check
 
-KERNELS = ("sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_table", "ani_pairs",
+KERNELS = ("sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_bin", "ani_pairs",
            "synth_genomes")
 
 
@@ -97,13 +97,12 @@ class AniIndex(_Handle):
         return lay
 
     def meta(self):
-        """(genome_len u64[n], seed_cap u64[n], seed_count u32[n], table_size u64[n]) host arrays."""
+        """(genome_len u64[n], seed_cap u64[n], seed_count u32[n]) host arrays."""
         n = self.layout().n
-        glen, cap, tsz = (np.zeros(n, dtype=np.uint64) for _ in range(3))
+        glen, cap = (np.zeros(n, dtype=np.uint64) for _ in range(2))
         cnt = np.zeros(n, dtype=np.uint32)
-        check(_lib.lib().ghip_ani_index_meta(self._h, glen.ctypes.data, cap.ctypes.data, cnt.ctypes.data,
-                                             tsz.ctypes.data), self.ctx._h)
-        return glen, cap, cnt, tsz
+        check(_lib.lib().ghip_ani_index_meta(self._h, glen.ctypes.data, cap.ctypes.data, cnt.ctypes.data), self.ctx._h)
+        return glen, cap, cnt
 
 
 class Context:
@@ -233,16 +232,15 @@ class Context:
         check(_lib.lib().ghip_ani_index_build(self._h, g._h, k, c, chunk, C.byref(h)), self._h)
         return AniIndex(self, h)
 
-    def ani_index_wrap_device(self, k: int, c: int, chunk: int, genome_len, seed_cap, seed_count, table_size,
-                              d_seed_hash: int, d_seed_chunk: int, d_table: int, d_chunk_total: int) -> AniIndex:
+    def ani_index_wrap_device(self, k: int, c: int, chunk: int, genome_len, seed_cap, seed_count,
+                              d_seed_code: int, d_seed_chunk: int, d_bin_start: int, d_chunk_total: int) -> AniIndex:
         glen = np.ascontiguousarray(genome_len, dtype=np.uint64)
         cap = np.ascontiguousarray(seed_cap, dtype=np.uint64)
         cnt = np.ascontiguousarray(seed_count, dtype=np.uint32)
-        tsz = np.ascontiguousarray(table_size, dtype=np.uint64)
         h = C.c_void_p()
         check(_lib.lib().ghip_ani_index_wrap_device(self._h, len(glen), k, c, chunk, glen.ctypes.data, cap.ctypes.data,
-                                                    cnt.ctypes.data, tsz.ctypes.data, C.c_void_p(d_seed_hash),
-                                                    C.c_void_p(d_seed_chunk), C.c_void_p(d_table),
+                                                    cnt.ctypes.data, C.c_void_p(d_seed_code),
+                                                    C.c_void_p(d_seed_chunk), C.c_void_p(d_bin_start),
                                                     C.c_void_p(d_chunk_total), C.byref(h)), self._h)
         return AniIndex(self, h)
 

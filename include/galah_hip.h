@@ -62,7 +62,7 @@ int ghip_synchronize(ghip_ctx *ctx);
 int ghip_memcpy_d2d(ghip_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes);
 
 /* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:
- * "sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_table", "ani_pairs",
+ * "sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_bin", "ani_pairs",
  * "synth_genomes".  enable=1 starts collecting, ghip_kernel_stats drains finished events. */
 int ghip_profile_enable(ghip_ctx *ctx, int enable);
 int ghip_profile_reset(ghip_ctx *ctx);
@@ -136,25 +136,24 @@ int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pai
                    float *out_af /* nullable, [n][2] */);
 void ghip_ani_index_free(ghip_ani_index *idx);
 /* Exchange of an ANI index between GPUs (RCCL all-gather of the flat arrays): genome g owns
- * seed slots [sum seed_cap[<g], +seed_cap[g]), table slots [sum table_size[<g], +table_size[g]) and
- * chunk slots [sum n_chunks[<g], +ceil(genome_len[g]/chunk)); concatenating the arrays of
- * consecutive shards in genome order gives the index of the union. */
+ * seed slots [sum seed_cap[<g], +seed_cap[g]), bin slots [g*16385, +16385) (offsets relative to its
+ * first seed slot) and chunk slots [sum n_chunks[<g], +ceil(genome_len[g]/chunk)); concatenating the
+ * arrays of consecutive shards in genome order gives the index of the union. */
 typedef struct {
     size_t n;
-    uint64_t n_seed_slots, n_table_slots, n_chunk_slots;
-    void *d_seed_hash;   /* u64[n_seed_slots] */
-    void *d_seed_chunk;  /* u32[n_seed_slots] */
-    void *d_table;       /* u64[n_table_slots], empty = 2^64-1 */
+    uint64_t n_seed_slots, n_bin_slots, n_chunk_slots;
+    void *d_seed_code;   /* u32[n_seed_slots]: canonical 2-bit k-mer codes (k <= 16), binned by hash */
+    void *d_seed_chunk;  /* u16[n_seed_slots] */
+    void *d_bin_start;   /* u32[n_bin_slots]: CSR bin offsets, 2^14 + 1 per genome */
     void *d_chunk_total; /* u32[n_chunk_slots] */
 } ghip_ani_layout;
 int ghip_ani_index_layout(const ghip_ani_index *idx, ghip_ani_layout *out);
 int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_len, uint64_t *seed_cap,
-                        uint32_t *seed_count, uint64_t *table_size); /* host arrays, each [n] */
+                        uint32_t *seed_count); /* host arrays, each [n] */
 int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, uint32_t chunk,
                                const uint64_t *genome_len, const uint64_t *seed_cap,
-                               const uint32_t *seed_count, const uint64_t *table_size,
-                               void *d_seed_hash, void *d_seed_chunk, void *d_table,
-                               void *d_chunk_total, ghip_ani_index **out);
+                               const uint32_t *seed_count, void *d_seed_code, void *d_seed_chunk,
+                               void *d_bin_start, void *d_chunk_total, ghip_ani_index **out);
 
 /* ---------------------------------------------------------------- host clusterer
  * clusterer::cluster from the precluster cache onwards (src/clusterer.rs:56-152):

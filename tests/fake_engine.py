@@ -57,43 +57,39 @@ class FakeEngine:
         return np.sort(out, order=["i", "j"])
 
     def ani_build_local(self):
-        caps, cnts, tszs, glens, sh, sc, ct = [], [], [], [], [], [], []
+        caps, cnts, glens, sh, sc, ct = [], [], [], [], [], []
         for st in self.streams:
             a = oracle.AniSketch.from_bytes(st, self.ani_k, self.ani_c, self.ani_chunk)
             h, ch = a.seeds(), a.chunks()
-            cap = len(st) // self.ani_c + len(st) // (2 * self.ani_c) + 1024
+            cap = len(st) // self.ani_c + len(st) // (10 * self.ani_c) + 256
             pad = cap - len(h)
             sh.append(np.concatenate([h, np.zeros(pad, np.uint64)]))
-            sc.append(np.concatenate([ch, np.zeros(pad, np.uint32)]))
+            sc.append(np.concatenate([ch.astype(np.uint16), np.zeros(pad, np.uint16)]))
             nch = (len(st) + self.ani_chunk - 1) // self.ani_chunk
             ct.append(np.bincount(ch, minlength=nch).astype(np.uint32))
             caps.append(cap); cnts.append(len(h)); glens.append(len(st))
-            tsz = 1
-            while tsz < 2 * cap:
-                tsz *= 2
-            tszs.append(tsz)
         meta = {"glen": np.array(glens, np.uint64), "cap": np.array(caps, np.uint64),
-                "cnt": np.array(cnts, np.uint32), "tsz": np.array(tszs, np.uint64)}
+                "cnt": np.array(cnts, np.uint32)}
         arrs = {"seed_hash": np.concatenate(sh) if sh else np.zeros(0, np.uint64),
-                "seed_chunk": np.concatenate(sc) if sc else np.zeros(0, np.uint32),
-                "table": np.zeros(int(sum(tszs)), np.uint64),
+                "seed_chunk": np.concatenate(sc) if sc else np.zeros(0, np.uint16),
+                "bin_start": np.zeros(len(caps) * 16385, np.uint32),
                 "chunk_total": np.concatenate(ct) if ct else np.zeros(0, np.uint32)}
-        lay = types.SimpleNamespace(n_seed_slots=len(arrs["seed_hash"]), n_table_slots=len(arrs["table"]),
+        lay = types.SimpleNamespace(n_seed_slots=len(arrs["seed_hash"]), n_bin_slots=len(arrs["bin_start"]),
                                     n_chunk_slots=len(arrs["chunk_total"]))
         idx = {"meta": meta, "arrs": arrs}
         return idx, meta, lay
 
     def ani_export(self, idx, lay):
         a = idx["arrs"]
-        return {"seed_hash": torch.from_numpy(a["seed_hash"].view(np.int64)),
-                "seed_chunk": torch.from_numpy(a["seed_chunk"].view(np.int32)),
-                "table": torch.from_numpy(a["table"].view(np.int64)),
+        return {"seed_code": torch.from_numpy(a["seed_hash"].view(np.int64)),  # the stand-in keeps the 64-bit hash
+                "seed_chunk": torch.from_numpy(a["seed_chunk"].view(np.int16)),
+                "bin_start": torch.from_numpy(a["bin_start"].view(np.int32)),
                 "chunk_total": torch.from_numpy(a["chunk_total"].view(np.int32))}
 
     def ani_wrap(self, meta, arrs):
-        return {"meta": meta, "arrs": {"seed_hash": arrs["seed_hash"].numpy().view(np.uint64),
-                                        "seed_chunk": arrs["seed_chunk"].numpy().view(np.uint32),
-                                        "table": arrs["table"].numpy().view(np.uint64),
+        return {"meta": meta, "arrs": {"seed_hash": arrs["seed_code"].numpy().view(np.uint64),
+                                        "seed_chunk": arrs["seed_chunk"].numpy().view(np.uint16),
+                                        "bin_start": arrs["bin_start"].numpy().view(np.uint32),
                                         "chunk_total": arrs["chunk_total"].numpy().view(np.uint32)}}
 
     def _genome(self, idx, g):
