@@ -57,7 +57,20 @@ def parse_percentage(x: float) -> np.float32:
     return p
 
 
-def cpu_baseline(args, hashes, lens, n_pairs_total, min_ani):
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (scripts/gpu_pmc.sh +
+    scripts/pmc_summary.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 x2 read correction for
+    16 B/lane streams).  PMC collection cannot run inside the timed bench, hence a recorded figure."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d["kernels"][kernel + "_kernel"]["hbm_bytes_per_launch"]), d.get("tag")
+    except Exception:
+        return None, None
+
+
+def cpu_baseline(args, hashes, lens, n_pairs_total, min_ani, gpu_pairs=None):
     """Times the CPU oracle (a port of src/finch.rs:48-97; the Rust reference cannot be built
     here) on this host's cores, on a bounded sample of the same workload."""
     from concurrent.futures import ThreadPoolExecutor
@@ -82,6 +95,8 @@ def cpu_baseline(args, hashes, lens, n_pairs_total, min_ani):
     par = oracle.distances_from_sketches(hashes, lens, min_ani, args.kmer, threads=cores)
     t_pairs_par = time.perf_counter() - t0
     assert serial.tobytes() == par.tobytes()
+    if gpu_pairs is not None:  # full-size parity: every precluster pair, integers and f32 bits
+        assert gpu_pairs.tobytes() == serial.tobytes(), "GPU precluster pairs differ from the CPU oracle"
     # ANI leg: sketch a sample and time a sample of candidate pairs
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -181,9 +196,13 @@ def main():
                     e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBS
                 kern[k] = e
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
+        traffic, traffic_tag = pmc_traffic(dom) if world == 1 else (None, None)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": None,
-                    "avg_launch_ms": kern[dom]["avg_ms"]}
+                    "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
+                    "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag,
+                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "note": ("sketch_kmers is integer-VALU bound (MurmurHash3 multiplies), not HBM bound; "
+                             "pair_intersect_tile is the HBM-roofline kernel of the path, see 'kernels'")}
         out = {
             "metric": "genome-pairs/sec (MinHash+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -201,7 +220,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             hashes, lens = job.sketches_to_host()
-            out["cpu_baseline"] = cpu_baseline(args, hashes, lens, n_pairs_total, min_ani)
+            out["cpu_baseline"] = cpu_baseline(args, hashes, lens, n_pairs_total, min_ani, result["pairs"])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

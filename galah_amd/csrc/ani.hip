@@ -71,15 +71,24 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     if (threadIdx.x == 0) l_n = 0;
     __syncthreads();
 
-    if (p0 < L) {
+    {
+        // every base is fetched once: own 64 bytes from memory, the K-1 overlap bytes from the next
+        // lane's registers (lane 63: from memory); lanes past the stream end hold 'N'
+        const bool live = p0 < L;
         const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);
+        const uint4 NNNN = make_uint4(0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu);
+        uint4 q0 = live ? src[0] : NNNN, q1 = live ? src[1] : NNNN, q2 = live ? src[2] : NNNN, q3 = live ? src[3] : NNNN;
+        uint4 q4;
+        q4.x = __shfl_down(q0.x, 1, 64); q4.y = __shfl_down(q0.y, 1, 64); q4.z = __shfl_down(q0.z, 1, 64); q4.w = __shfl_down(q0.w, 1, 64);
+        if ((threadIdx.x & 63u) == 63u) q4 = live ? src[4] : NNNN;
         const uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
         uint64_t fwd = 0, rev = 0;
         uint32_t good = 0;
-        const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
+        const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;  // K <= 16 -> at most 79 bytes = 5 vectors
         const int NV = (NB + 15) / 16;
         for (int v = 0; v < NV; v++) {
-            uint4 cur = src[v];
+            const uint4 cur = q0;
+            q0 = q1; q1 = q2; q2 = q3; q3 = q4;
             uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
             for (int j = 0; j < 16; j++) {

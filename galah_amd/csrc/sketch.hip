@@ -106,7 +106,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
     const uint32_t g = slot_genome[slot];
     const uint64_t L = lens[g];
     const uint64_t p0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
-    if (p0 >= L) return;
+    const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's bytes
     const uint64_t thr = slot_thr[slot];
     const uint64_t cstart = slot_cand_start[slot];
     const uint32_t ccap = slot_cand_cap[slot];
@@ -119,11 +119,23 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
     // start is in [0, 64) -- i.e. b >= K-1.
     constexpr int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
     constexpr int NV = (NB + 15) / 16;
-    uint4 nxt = src[0];
+    static_assert(NV <= 6, "the 6-entry byte queue covers 64 + 31 bytes");
+    // Every base is fetched from HBM once: a lane loads only its own 64 bytes; the K-1 bytes that
+    // run into the next lane's range come from that lane's registers (wave shuffle), and only
+    // lane 63 reads them from memory.  Lanes past the stream end hold 'N'.
+    const uint4 NNNN = make_uint4(0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu);
+    uint4 q0 = live ? src[0] : NNNN, q1 = live ? src[1] : NNNN, q2 = live ? src[2] : NNNN, q3 = live ? src[3] : NNNN;
+    uint4 q4, q5;
+    q4.x = __shfl_down(q0.x, 1, 64); q4.y = __shfl_down(q0.y, 1, 64); q4.z = __shfl_down(q0.z, 1, 64); q4.w = __shfl_down(q0.w, 1, 64);
+    q5.x = __shfl_down(q1.x, 1, 64); q5.y = __shfl_down(q1.y, 1, 64); q5.z = __shfl_down(q1.z, 1, 64); q5.w = __shfl_down(q1.w, 1, 64);
+    if ((threadIdx.x & 63u) == 63u) {  // next wave's bytes (or the 'N' tail padding of the genome)
+        q4 = live ? src[4] : NNNN;
+        q5 = live ? src[5] : NNNN;
+    }
 #pragma unroll 1
     for (int v = 0; v < NV; v++) {
-        uint4 cur = nxt;
-        if (v + 1 < NV) nxt = src[v + 1];
+        const uint4 cur = q0;
+        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5;
         uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int j = 0; j < 16; j++) {
