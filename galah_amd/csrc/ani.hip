@@ -21,12 +21,25 @@
 
 namespace {
 
+// D = (a << sh) + b in one VALU op (sh <= 4).  hipcc turns the *265 and *21 steps of the mix into
+// 64-bit multiplies (3 quarter-rate ops each); spelled as shift-adds they are 5 full-rate ops.
+template <int SH>
+__device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
+    return d;
+}
+
+// minimap2 / skani invertible 64-bit mix
 __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
     key = ~key + (key << 21);
     key = key ^ (key >> 24);
-    key = (key + (key << 3)) + (key << 8);
+    {   // key * 265 = key + (key << 3) + (key << 8)
+        const uint64_t t = lshl_add_u64<3>(key, key);
+        key = lshl_add_u64<4>(lshl_add_u64<4>(key, 0ull), t);
+    }
     key = key ^ (key >> 14);
-    key = (key + (key << 2)) + (key << 4);
+    key = lshl_add_u64<4>(key, lshl_add_u64<2>(key, key));  // key * 21
     key = key ^ (key >> 28);
     key = key + (key << 31);
     return key;
@@ -81,8 +94,9 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
         uint4 q4;
         q4.x = __shfl_down(q0.x, 1, 64); q4.y = __shfl_down(q0.y, 1, 64); q4.z = __shfl_down(q0.z, 1, 64); q4.w = __shfl_down(q0.w, 1, 64);
         if ((threadIdx.x & 63u) == 63u) q4 = live ? src[4] : NNNN;
-        const uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
-        uint64_t fwd = 0, rev = 0;
+        const uint32_t mask = (K < 16) ? ((1u << (2 * K)) - 1) : ~0u;  // K <= 16: codes fit 32 bits
+        const uint32_t top = 2 * (K - 1);
+        uint32_t fwd = 0, rev = 0;
         uint32_t good = 0;
         const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;  // K <= 16 -> at most 79 bytes = 5 vectors
         const int NV = (NB + 15) / 16;
@@ -97,18 +111,18 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 const bool valid = code <= 3u;
                 code &= 3u;
                 fwd = ((fwd << 2) | code) & mask;
-                rev = (rev >> 2) | ((uint64_t)(3u - code) << (2 * (K - 1)));
+                rev = (rev >> 2) | ((3u - code) << top);
                 good = valid ? good + 1 : 0;
-                const uint64_t canon = fwd < rev ? fwd : rev;
-                const uint64_t h = mm_hash64(canon);
+                const uint32_t canon = min(fwd, rev);
+                const uint64_t h = mm_hash64((uint64_t)canon);
                 if (b < NB && b >= (int)K - 1 && good >= K && h < thr) {
                     const uint32_t rel = toff + (uint32_t)(b - ((int)K - 1));  // position - blk0 (< 16384)
                     const uint32_t li = atomicAdd(&l_n, 1u);
-                    if (li < SEED_LDS_CAP) { l_code[li] = (uint32_t)canon; l_pos[li] = (uint16_t)rel; }
+                    if (li < SEED_LDS_CAP) { l_code[li] = canon; l_pos[li] = (uint16_t)rel; }
                     else {  // LDS buffer full (never at c=125): straight to the global list
                         const uint32_t ch = ch_first + (rem_first + rel) / chunk;
                         uint32_t idx = atomicAdd(&seed_count[g], 1u);
-                        if (idx < scap) { seed_code[sstart + idx] = (uint32_t)canon; seed_chunk[sstart + idx] = (uint16_t)ch; }
+                        if (idx < scap) { seed_code[sstart + idx] = canon; seed_chunk[sstart + idx] = (uint16_t)ch; }
                         atomicAdd(&ctot[ch], 1u);
                     }
                 }

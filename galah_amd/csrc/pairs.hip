@@ -12,12 +12,15 @@
 // No floating point on the device: a pair is emitted iff common >= cmin[total], a table the
 // host derives from the reference's f64 formula, and the host recomputes the exact f32 ANI.
 // Pure integer compare work: no MFMA.  Algorithmic bytes: 2*s*8 per pair.
+#include <cstdlib>
+
 #include "ghip_internal.h"
 
 namespace {
 
 constexpr int PAIR_WAVES = 16;
 constexpr int PAIR_THREADS = PAIR_WAVES * 64;
+constexpr int PAIR_CHAINS = 4;  // sketch pairs interleaved per wavefront
 
 __device__ __forceinline__ uint32_t lds_pos(uint32_t e) { return e + (e >> 4); }
 
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
     uint32_t s_pad, uint32_t sp /* LDS elements per sketch */, uint32_t pt /* tile edge */,
     uint32_t nt /* tiles per dim */, uint64_t n_tilepairs, uint32_t rank, uint32_t world,
     const uint16_t *__restrict__ cmin, ghip_pair *__restrict__ out,
-    unsigned long long *__restrict__ out_count, uint64_t cap) {
+    unsigned long long *__restrict__ out_count, uint64_t cap, int dbg_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *lds = reinterpret_cast<uint64_t *>(smem_raw);
 
@@ -66,53 +69,101 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
         }
     }
     __syncthreads();
+    if (dbg_mode == 1) {  // GHIP_PAIR_DEBUG=1: staging only (timing experiments)
+        if (threadIdx.x == 0 && lds[lds_pos(5)] == 12345ull) atomicAdd(out_count, 1ull);
+        return;
+    }
 
+    // Each wavefront intersects PAIR_CHAINS sketch pairs at once (independent merge chains are
+    // interleaved per lane; the kernel is instruction-issue bound, so this mostly amortises the
+    // loop and reduction overhead).  One sketch pair is still owned by one wavefront.
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t p = wave; p < pt * pt; p += PAIR_WAVES) {
-        const uint32_t qa = p / pt, qb = p % pt;
-        const uint32_t gi = ti * pt + qa, gj = tj * pt + qb;
-        if (gi >= n || gj >= n || gi >= gj) continue;
-        const uint64_t *A = lds + (uint64_t)qa * sp;
-        const uint64_t *B = lds + (uint64_t)(pt + qb) * sp;
-        const uint32_t na = lens[gi], nb = lens[gj];
-        const uint32_t tot = na + nb;
-        const uint32_t D = (tot + 63u) >> 6;
-        const uint32_t d0 = min(lane * D, tot), d1 = min(d0 + D, tot);
-
-        // merge-path split of diagonal d0 (ties: a before b)
-        uint32_t lo = d0 > nb ? d0 - nb : 0u, hi = min(d0, na);
-        while (__any(lo < hi)) {
-            if (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                uint64_t a = A[lds_pos(mid)], b = B[lds_pos(d0 - 1 - mid)];
-                if (a <= b) lo = mid + 1; else hi = mid;
+    for (uint32_t p0 = wave; p0 < pt * pt; p0 += PAIR_WAVES * PAIR_CHAINS) {
+        const uint64_t *A[PAIR_CHAINS], *B[PAIR_CHAINS];
+        uint32_t na[PAIR_CHAINS], nb[PAIR_CHAINS], gi[PAIR_CHAINS], gj[PAIR_CHAINS];
+        uint32_t d0[PAIR_CHAINS], nstep[PAIR_CHAINS], lo[PAIR_CHAINS], hi[PAIR_CHAINS];
+        uint32_t maxstep = 0;
+#pragma unroll
+        for (int c = 0; c < PAIR_CHAINS; c++) {
+            const uint32_t p = p0 + c * PAIR_WAVES;
+            const uint32_t qa = p / pt, qb = p % pt;
+            gi[c] = ti * pt + qa; gj[c] = tj * pt + qb;
+            const bool ok = p < pt * pt && gi[c] < n && gj[c] < n && gi[c] < gj[c];
+            A[c] = lds + (uint64_t)(ok ? qa : 0u) * sp;
+            B[c] = lds + (uint64_t)(pt + (ok ? qb : 0u)) * sp;
+            na[c] = ok ? lens[gi[c]] : 0u;
+            nb[c] = ok ? lens[gj[c]] : 0u;
+            if (!ok) gi[c] = 0xffffffffu;
+            const uint32_t tot = na[c] + nb[c];
+            const uint32_t D = (tot + 63u) >> 6;
+            d0[c] = min(lane * D, tot);
+            nstep[c] = min(d0[c] + D, tot) - d0[c];
+            maxstep = max(maxstep, D);
+            lo[c] = d0[c] > nb[c] ? d0[c] - nb[c] : 0u;
+            hi[c] = min(d0[c], na[c]);
+        }
+        // merge-path split of diagonal d0 (ties: a before b); <= 11 rounds for 1024-element lists
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int c = 0; c < PAIR_CHAINS; c++) more |= lo[c] < hi[c];
+            if (!__any(more)) break;
+            uint64_t av[PAIR_CHAINS], bv[PAIR_CHAINS];
+#pragma unroll
+            for (int c = 0; c < PAIR_CHAINS; c++) {
+                const uint32_t mid = (lo[c] + hi[c]) >> 1;
+                const bool act = lo[c] < hi[c];
+                av[c] = A[c][lds_pos(act ? mid : 0u)];
+                bv[c] = B[c][lds_pos(act ? d0[c] - 1 - mid : 0u)];
+            }
+#pragma unroll
+            for (int c = 0; c < PAIR_CHAINS; c++) {
+                const uint32_t mid = (lo[c] + hi[c]) >> 1;
+                if (lo[c] < hi[c]) { if (av[c] <= bv[c]) lo[c] = mid + 1; else hi[c] = mid; }
             }
         }
-        uint32_t ai = lo, bi = d0 - lo;
-        uint64_t a = A[lds_pos(ai)], b = B[lds_pos(bi)];  // slot [len] is padding (2^64-1)
-        uint32_t common = 0;
-        for (uint32_t d = d0; d < d1; d++) {
-            const bool take_a = (ai < na) && ((bi >= nb) || (a <= b));
-            common += (take_a && (bi < nb) && (a == b)) ? 1u : 0u;
-            if (take_a) { ai++; a = A[lds_pos(ai)]; }
-            else        { bi++; b = B[lds_pos(bi)]; }
+        uint32_t ai[PAIR_CHAINS], bi[PAIR_CHAINS], common[PAIR_CHAINS];
+        uint64_t a[PAIR_CHAINS], b[PAIR_CHAINS];
+#pragma unroll
+        for (int c = 0; c < PAIR_CHAINS; c++) {
+            ai[c] = lo[c]; bi[c] = d0[c] - lo[c]; common[c] = 0;
+            a[c] = A[c][lds_pos(ai[c])];   // slot [len] is padding (2^64-1)
+            b[c] = B[c][lds_pos(bi[c])];
+        }
+        for (uint32_t st = 0; st < maxstep; st++) {
+#pragma unroll
+            for (int c = 0; c < PAIR_CHAINS; c++) {
+                const bool run = st < nstep[c];
+                const bool take_a = (ai[c] < na[c]) && ((bi[c] >= nb[c]) || (a[c] <= b[c]));
+                common[c] += (run && take_a && (bi[c] < nb[c]) && (a[c] == b[c])) ? 1u : 0u;
+                const bool adv_a = run && take_a, adv_b = run && !take_a;
+                ai[c] += adv_a ? 1u : 0u;
+                bi[c] += adv_b ? 1u : 0u;
+                const uint64_t v = adv_a ? A[c][lds_pos(ai[c])] : B[c][lds_pos(bi[c])];
+                if (adv_a) a[c] = v;
+                if (adv_b) b[c] = v;
+            }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) common += __shfl_xor(common, off, 64);
-
-        uint32_t icnt = 0, jcnt = 0;
-        if (na > 0 && nb > 0) {
-            const uint64_t maxa = A[lds_pos(na - 1)], maxb = B[lds_pos(nb - 1)];
-            if (maxa <= maxb) { icnt = na; jcnt = upper_bound_lds(B, nb, maxa); }
-            else              { icnt = upper_bound_lds(A, na, maxb); jcnt = nb; }
-        }
-        const uint32_t total = icnt + jcnt - common;
-        if (lane == 0 && common >= (uint32_t)cmin[total]) {
-            unsigned long long idx = atomicAdd(out_count, 1ull);
-            if (idx < cap) {
-                ghip_pair r;
-                r.i = gi; r.j = gj; r.common = common; r.total = total; r.ani = 0.0f;
-                out[idx] = r;
+        for (int c = 0; c < PAIR_CHAINS; c++) {
+            uint32_t cm = common[c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cm += __shfl_xor(cm, off, 64);
+            if (gi[c] == 0xffffffffu) continue;
+            uint32_t icnt = 0, jcnt = 0;
+            if (na[c] > 0 && nb[c] > 0) {
+                const uint64_t maxa = A[c][lds_pos(na[c] - 1)], maxb = B[c][lds_pos(nb[c] - 1)];
+                if (maxa <= maxb) { icnt = na[c]; jcnt = upper_bound_lds(B[c], nb[c], maxa); }
+                else              { icnt = upper_bound_lds(A[c], na[c], maxb); jcnt = nb[c]; }
+            }
+            const uint32_t total = icnt + jcnt - cm;
+            if (lane == 0 && cm >= (uint32_t)cmin[total]) {
+                unsigned long long idx = atomicAdd(out_count, 1ull);
+                if (idx < cap) {
+                    ghip_pair r;
+                    r.i = gi[c]; r.j = gj[c]; r.common = cm; r.total = total; r.ani = 0.0f;
+                    out[idx] = r;
+                }
             }
         }
     }
@@ -175,6 +226,6 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
     ghip_prof_begin(ctx, "pair_intersect_tile");
     hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3((unsigned)my_tiles), dim3(PAIR_THREADS), lds_bytes,
                        ctx->stream, d_hashes, d_lens, (uint32_t)n, s, s_pad, sp, pt, nt, n_tilepairs, rank,
-                       world, d_cmin, d_out, d_count, cap);
+                       world, d_cmin, d_out, d_count, cap, getenv("GHIP_PAIR_DEBUG") ? atoi(getenv("GHIP_PAIR_DEBUG")) : 0);
     ghip_prof_end(ctx);
 }

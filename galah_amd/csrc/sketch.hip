@@ -87,6 +87,56 @@ __device__ __forceinline__ uint64_t hash_canonical(uint64_t code_le, uint32_t se
     return murmur3_h1<K>(w, seed);
 }
 
+// ---- K = 21 fast path: the first-stage multiplies of MurmurHash3 by table look-up ----------
+// k1 = bytes 0..7, k2 = bytes 8..15, tail = bytes 16..20 of the canonical k-mer.  A 64-bit
+// multiply is linear mod 2^64:  k1*c1 = A4(x0)*c1 + ((A4(x1)*c1) << 32)  with A4(x) the 4 ASCII
+// bytes of the 8-bit 2-bit-code x.  So 256-entry LDS tables of A4(x)*c1 and A4(x)*c2 replace the
+// 2-bit->ASCII expansion and the two first multiplies, and a 1024-entry table holds the whole
+// tail term rotl(tail*c1,31)*c2.  12 KiB of LDS, built once per block; bit-identical results.
+struct KmerLuts {
+    uint64_t c1[256];    // A4(x) * c1
+    uint64_t c2[256];    // A4(x) * c2
+    uint64_t tail[1024]; // rotl64(A5(x) * c1, 31) * c2
+};
+
+__device__ __forceinline__ uint32_t ascii4(uint32_t x8) {
+    const uint32_t lut = 0x54474341u;
+    uint32_t v = (x8 | (x8 << 12)) & 0x000f000fu;
+    v = (v | (v << 6)) & 0x03030303u;
+    return __builtin_amdgcn_perm(lut, lut, v);
+}
+
+__device__ __forceinline__ void build_kmer_luts(KmerLuts &L) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {
+        const uint64_t a = ascii4(x);
+        L.c1[x] = a * c1;
+        L.c2[x] = a * c2;
+    }
+    for (uint32_t x = threadIdx.x; x < 1024; x += blockDim.x) {
+        const uint64_t a = (uint64_t)ascii4(x & 0xffu) | ((uint64_t)((0x54474341u >> (8 * (x >> 8))) & 0xffu) << 32);
+        L.tail[x] = rotl64(a * c1, 31) * c2;
+    }
+}
+
+__device__ __forceinline__ uint64_t hash_canonical21_lut(uint64_t code_le, uint32_t seed, const KmerLuts &L) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    const uint32_t lo = (uint32_t)code_le, hi = (uint32_t)(code_le >> 32);
+    uint64_t h1 = seed, h2 = seed;
+    uint64_t k1 = L.c1[lo & 0xffu] + ((uint64_t)(uint32_t)L.c1[(lo >> 8) & 0xffu] << 32);    // k1 * c1
+    uint64_t k2 = L.c2[(lo >> 16) & 0xffu] + ((uint64_t)(uint32_t)L.c2[lo >> 24] << 32);     // k2 * c2
+    k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    h1 ^= L.tail[hi & 0x3ffu];
+    h1 ^= 21ull; h2 ^= 21ull;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
 // A..T -> 0..3, anything else -> 4
 __device__ __forceinline__ uint32_t base_code(uint32_t c) {
     uint32_t d = c - 0x41u;
@@ -101,6 +151,11 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
     const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
     const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
     uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count) {
+    __shared__ KmerLuts luts;
+    if (K == 21) {
+        build_kmer_luts(luts);
+        __syncthreads();
+    }
     const ghip_sketch_work wk = work[blockIdx.x];
     const uint32_t slot = wk.slot;
     const uint32_t g = slot_genome[slot];
@@ -155,7 +210,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
             // reverse complement: rc_be = ~fwd_le, rc_le = ~fwd_be (complement = 3 - code)
             uint64_t rc_be = (~fwd_le) & mask;
             uint64_t canon_le = (rc_be < fwd_be) ? ((~fwd_be) & mask) : fwd_le;
-            uint64_t h = hash_canonical<K>(canon_le, seed);
+            uint64_t h = (K == 21) ? hash_canonical21_lut(canon_le, seed, luts) : hash_canonical<K>(canon_le, seed);
             if (good >= (uint32_t)K && h <= thr) {  // rare: ~2.5*s survivors per genome
                 uint32_t idx = atomicAdd(&cand_count[slot], 1u);
                 if (idx < ccap) cand[cstart + idx] = h;
