@@ -13,7 +13,9 @@ from .engine import Context, cluster_pairs, device_count
 from .finch import FinchPreclusterer, distances
 from .ani import HipAniClusterer
 from .clusterer import cluster
+from .quality import parks2020_reduced_score, quality_order_parks2020_reduced
 from ._lib import GalahHipError, PAIR_DTYPE
 
 __all__ = ["SortedPairGenomeDistanceCache", "Context", "cluster_pairs", "device_count", "FinchPreclusterer",
-           "distances", "HipAniClusterer", "cluster", "GalahHipError", "PAIR_DTYPE"]
+           "distances", "HipAniClusterer", "cluster", "GalahHipError", "PAIR_DTYPE", "parks2020_reduced_score",
+           "quality_order_parks2020_reduced"]

@@ -282,9 +282,10 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
     if (n_work == 0) return;
     const uint64_t thr = ~0ull / c;
     ghip_prof_begin(ctx, "ani_seeds");
-    hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)n_work), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                       g->d_bytes, g->d_starts, g->d_lens, d_work, k, thr, chunk, d_seed_code, d_seed_chunk,
-                       d_seed_start, d_seed_count, d_chunk_total, d_chunk_start);
+    for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
+        hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),
+                           dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, g->d_bytes, g->d_starts, g->d_lens, d_work + off, k,
+                           thr, chunk, d_seed_code, d_seed_chunk, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start);
     ghip_prof_end(ctx);
 }
 

@@ -765,7 +765,9 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
     tmp.add(d_out);
     if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
-    ghip_launch_ani_pairs(ctx, idx, d_pairs, n, std::max<uint32_t>(idx->max_chunks, 1), d_out);
+    const size_t batch = (size_t)1 << 22;  // 512 threads per pair: keep each dispatch below 2^32 work-items
+    for (size_t off = 0; off < n; off += batch)
+        ghip_launch_ani_pairs(ctx, idx, d_pairs + 2 * off, std::min(batch, n - off), std::max<uint32_t>(idx->max_chunks, 1), d_out + 6 * off);
     std::vector<uint64_t> res(6 * n);
     if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }

@@ -155,4 +155,5 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
 constexpr uint32_t GHIP_SKETCH_POS_PER_THREAD = 64;
 constexpr uint32_t GHIP_SKETCH_THREADS = 256;
 constexpr uint32_t GHIP_SKETCH_CHUNK = GHIP_SKETCH_POS_PER_THREAD * GHIP_SKETCH_THREADS;  // positions per block
+constexpr size_t GHIP_MAX_GRID = 1u << 21;  // workgroups per dispatch (x <= 1024 threads stays below 2^32 work-items)
 constexpr uint32_t GHIP_TAIL_PAD = 128;  // 'N' bytes after every genome (vector loads may over-read)

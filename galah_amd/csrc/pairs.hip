@@ -43,8 +43,12 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *lds = reinterpret_cast<uint64_t *>(smem_raw);
 
-    const uint64_t t = (uint64_t)blockIdx.x * world + rank;
+    // grid-stride over this rank's tile pairs: an AQL dispatch holds at most 2^32-1 work-items, so
+    // the grid is capped on the host and each workgroup walks several tile pairs.
+    for (uint64_t blk = blockIdx.x;; blk += gridDim.x) {
+    const uint64_t t = blk * world + rank;
     if (t >= n_tilepairs) return;
+    __syncthreads();  // every wave is done with the previous tile pair's LDS image
     // t -> (ti, tj), ti <= tj, rows of the upper triangle: row ti holds nt - ti tile pairs
     uint32_t ti;
     {
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
     __syncthreads();
     if (dbg_mode == 1) {  // GHIP_PAIR_DEBUG=1: staging only (timing experiments)
         if (threadIdx.x == 0 && lds[lds_pos(5)] == 12345ull) atomicAdd(out_count, 1ull);
-        return;
+        continue;
     }
 
     // Each wavefront intersects PAIR_CHAINS sketch pairs at once (independent merge chains are
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
             }
         }
     }
+    }  // grid-stride loop
 }
 
 }  // namespace
@@ -224,7 +229,8 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
         attr_set = true;
     }
     ghip_prof_begin(ctx, "pair_intersect_tile");
-    hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3((unsigned)my_tiles), dim3(PAIR_THREADS), lds_bytes,
+    const unsigned grid = (unsigned)std::min<uint64_t>(my_tiles, 1u << 21);  // x 1024 threads < 2^32 work-items
+    hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3(grid), dim3(PAIR_THREADS), lds_bytes,
                        ctx->stream, d_hashes, d_lens, (uint32_t)n, s, s_pad, sp, pt, nt, n_tilepairs, rank,
                        world, d_cmin, d_out, d_count, cap, getenv("GHIP_PAIR_DEBUG") ? atoi(getenv("GHIP_PAIR_DEBUG")) : 0);
     ghip_prof_end(ctx);

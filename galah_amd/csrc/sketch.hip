@@ -444,14 +444,17 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
                               uint32_t *d_cand_count) {
     if (n_work == 0) return;
     ghip_prof_begin(ctx, "sketch_kmers");
-    if (k == 21) {
-        hipLaunchKernelGGL(sketch_kmers_kernel<21>, dim3((unsigned)n_work), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                           d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
-                           d_slot_cand_cap, d_work, seed, d_cand, d_cand_count);
-    } else {
-        hipLaunchKernelGGL(sketch_kmers_kernel_rt, dim3((unsigned)n_work), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                           d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
-                           d_slot_cand_cap, d_work, (int)k, seed, d_cand, d_cand_count);
+    for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID) {  // one AQL dispatch holds < 2^32 work-items
+        const unsigned grid = (unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID);
+        if (k == 21) {
+            hipLaunchKernelGGL(sketch_kmers_kernel<21>, dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
+                               d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
+                               d_slot_cand_cap, d_work + off, seed, d_cand, d_cand_count);
+        } else {
+            hipLaunchKernelGGL(sketch_kmers_kernel_rt, dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
+                               d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
+                               d_slot_cand_cap, d_work + off, (int)k, seed, d_cand, d_cand_count);
+        }
     }
     ghip_prof_end(ctx);
 }

@@ -1,0 +1,186 @@
+"""BASELINE.json configs as parity-test cases on the GPU (configs[1] is the bench workload; its
+full-size parity check -- all 499 500 pairs and 256 sketches against the oracle -- runs inside
+bench.py's cpu_baseline leg).  Sketch matrices here are planted: families of 10 share a pool of
+hashes, unrelated genomes share nothing, so the exact expected pair list is the union of the
+oracle's per-family lists and scales to any N."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import galah_amd
+import oracle
+from galah_amd import PAIR_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def planted_sketches(n, s, seed, fam=10, q=0.6, hi=2**52):
+    rng = np.random.default_rng(seed)
+    hashes = np.empty((n, s), dtype=np.uint64)
+    lens = np.full(n, s, dtype=np.uint32)
+    nf = (n + fam - 1) // fam
+    for f in range(nf):
+        pool = rng.integers(0, hi, size=s, dtype=np.uint64)
+        for g in range(f * fam, min((f + 1) * fam, n)):
+            own = rng.integers(0, hi, size=s, dtype=np.uint64)
+            u = np.unique(np.where(rng.random(s) < q, pool, own))
+            while len(u) < s:
+                u = np.unique(np.concatenate([u, rng.integers(0, hi, size=s - len(u), dtype=np.uint64)]))
+            hashes[g] = u[:s]
+    return hashes, lens
+
+
+def expected_pairs(hashes, lens, min_ani, fam=10):
+    n = hashes.shape[0]
+    out = []
+    for f0 in range(0, n, fam):
+        p = oracle.distances_from_sketches(hashes[f0:f0 + fam], lens[f0:f0 + fam], np.float32(min_ani))
+        p = p.copy()
+        p["i"] += f0
+        p["j"] += f0
+        out.append(p)
+    return np.concatenate(out) if out else np.zeros(0, PAIR_DTYPE)
+
+
+def test_config3_10k_genomes_pair_stage_full_oracle(ctx):
+    """configs[2]: 10 000 genomes -- the whole 5e7-pair stage against the oracle's pair loop."""
+    n, s = 10_000, 1000
+    hashes, lens = planted_sketches(n, s, 3)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    got = ctx.precluster(sk, np.float32(0.9))
+    assert ctx.last_pairs_compared == n * (n - 1) // 2
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=os.cpu_count())
+    assert got.tobytes() == want.tobytes()
+    assert len(got) == (n // 10) * 45
+    # N x N tiles dealt over 8 ranks: the shards partition the result (what 8 GPUs would each compute)
+    parts = [ctx.precluster(sk, np.float32(0.9), r, 8) for r in range(8)]
+    merged = np.sort(np.concatenate(parts), order=["i", "j"])
+    assert merged.tobytes() == got.tobytes()
+    sizes = [len(p) for p in parts]
+    assert max(sizes) < 2 * (sum(sizes) / 8)  # block-cyclic deal is balanced
+
+
+def test_config4_small_sketch_high_pair_count(ctx):
+    """configs[3]: many short contigs, small sketch (s'=256, build-defined -- finch itself refuses
+    contigs, src/finch.rs:26-33).  4.5e8 pairs; expected list from the planted families."""
+    n, s = 30_000, 256
+    hashes, lens = planted_sketches(n, s, 4, q=0.7)
+    lens[::7] = 100   # ragged: some contigs have fewer than s k-mers
+    for g in range(0, n, 7):
+        hashes[g, 100:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    got = ctx.precluster(sk, np.float32(0.9))
+    want = expected_pairs(hashes, lens, 0.9)
+    assert got.tobytes() == want.tobytes()
+    assert ctx.last_pairs_compared == n * (n - 1) // 2
+
+
+def test_config4_contigs_end_to_end_small_genomes(ctx):
+    """Short contigs (2-20 kb) as individual genomes: sketches, pairs and ANI against the oracle."""
+    rng = np.random.default_rng(8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = []
+    for f in range(40):
+        L = int(np.exp(rng.uniform(np.log(2000), np.log(20000))))
+        anc = rng.choice(acgt, size=L)
+        for m in range(5):
+            c = anc.copy()
+            mut = rng.random(L) < 0.02
+            c[mut] = rng.choice(acgt, size=int(mut.sum()))
+            contigs.append(c)
+    g = ctx.genomes_from_host(contigs)
+    sk = ctx.sketch_genomes(g, 21, 256, 0)
+    hashes, lens = sk.to_host()
+    for i in (0, 1, 57, 199):
+        o = oracle.sketch_bytes(contigs[i], 21, 256, 0)
+        assert lens[i] == len(o) and np.array_equal(hashes[i, : lens[i]], o)
+    got = ctx.precluster(sk, np.float32(0.9))
+    assert got.tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9)).tobytes()
+    idx = ctx.ani_index_build(g, 15, 30, 20000)  # --small-genomes ~ c = 30
+    pi = np.stack([got["i"], got["j"]], axis=1).astype(np.uint32)
+    ani = ctx.ani_pairs(idx, pi, 0.15)
+    sks = {}
+    for x in range(0, len(pi), 37):
+        a, b = int(pi[x, 0]), int(pi[x, 1])
+        for y in (a, b):
+            if y not in sks:
+                sks[y] = oracle.AniSketch.from_bytes(contigs[y], 15, 30, 20000)
+        assert np.float32(oracle.ani_pair(sks[a], sks[b], 0.15)[0]) == ani[x]
+
+
+def test_config5_50k_genomes_quality_order_two_stage(ctx):
+    """configs[4]: 50 000 genomes, CheckM2-style qualities, genomes ordered by Parks2020_reduced
+    (src/cluster_argument_parsing.rs:1078-1092), 90 % precluster / 95 % ANI two-stage clustering."""
+    n, s = 50_000, 1000
+    hashes, lens = planted_sketches(n, s, 5)
+    rng = np.random.default_rng(55)
+    completeness = rng.uniform(70, 100, n).astype(np.float32) / np.float32(100)
+    contamination = rng.uniform(0, 5, n).astype(np.float32) / np.float32(100)
+    num_contigs = rng.integers(1, 400, n)
+    ambiguous = rng.integers(0, 20000, n)
+    order = galah_amd.quality_order_parks2020_reduced(completeness, contamination, num_contigs, ambiguous)
+    score = completeness.astype(np.float64) * 100. - 5. * contamination.astype(np.float64) * 100. \
+        - 5. * num_contigs / 100. - 5. * ambiguous / 100000.
+    assert np.all(np.diff(score[order]) <= 0)  # best genome first -> becomes the representative
+    hashes, lens = hashes[order], lens[order]
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    pairs = ctx.precluster(sk, np.float32(0.9))
+    assert ctx.last_pairs_compared == n * (n - 1) // 2
+    # expected list: families are scattered by the quality order, so build it by original family
+    inv = np.empty(n, dtype=np.int64)
+    inv[order] = np.arange(n)
+    rows = []
+    for f0 in range(0, n, 10):
+        members = np.sort(inv[f0:f0 + 10])
+        p = oracle.distances_from_sketches(hashes[members], lens[members], np.float32(0.9)).copy()
+        p["i"], p["j"] = members[p["i"]], members[p["j"]]
+        rows.append(p)
+    want = np.sort(np.concatenate(rows), order=["i", "j"])
+    assert pairs.tobytes() == want.tobytes()
+    # second stage: a deterministic synthetic ANI per pair; the host clusterer must match the oracle on a
+    # sub-problem and satisfy the greedy invariants on the full one
+    ani = (np.float32(90) + (pairs["common"].astype(np.float32) % np.float32(97)) / np.float32(9.7)).astype(np.float32)
+    clusters = galah_amd.cluster_pairs(n, pairs, np.float32(95.0), ani)
+    assert sorted(x for c in clusters for x in c) == list(range(n))
+    look = {(int(p["i"]), int(p["j"])): a for p, a in zip(pairs, ani)}
+    reps = np.array([c[0] for c in clusters])
+    is_rep = np.zeros(n, bool)
+    is_rep[reps] = True
+    for c in clusters[:3000]:
+        for m in c[1:]:
+            assert look[(min(c[0], m), max(c[0], m))] >= np.float32(95.0)  # members reach their representative
+    for (i, j), a in list(look.items())[:200000]:
+        if is_rep[i] and is_rep[j]:
+            assert a < np.float32(95.0)  # two representatives are never within the threshold
+    sub = 3000
+    keep = (pairs["i"] < sub) & (pairs["j"] < sub)
+    oc = oracle.cluster(sub, oracle.Cache.from_pairs(pairs[keep]), 95.0,
+                        lambda a, b: float(look[(min(a, b), max(a, b))]))
+    assert galah_amd.cluster_pairs(sub, pairs[keep], np.float32(95.0), ani[keep]) == oc
+
+
+def test_config2_full_length_genomes_sample_vs_oracle(ctx):
+    """configs[1] at full genome length (5 Mb) on a sample of 20 genomes: sketches, pairs, ANI."""
+    seed, members, length, rate = 42, 10, 5_000_000, 0.0253
+    g = ctx.genomes_synthetic(seed, 2, members, length, rate)
+    sk = ctx.sketch_genomes(g, 21, 1000, 0)
+    hashes, lens = sk.to_host()
+    streams = [oracle.synth_genome(seed, i // members, i % members, length, rate) for i in range(20)]
+    with ThreadPoolExecutor(min(20, os.cpu_count() or 1)) as ex:
+        osk = list(ex.map(lambda b: oracle.sketch_bytes(b, 21, 1000, 0), streams))
+        ask = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b), streams))
+    for i in range(20):
+        assert lens[i] == 1000 and np.array_equal(hashes[i], osk[i])
+        assert np.all(np.diff(hashes[i].astype(np.float64)) > 0)
+    pairs = ctx.precluster(sk, np.float32(0.9))
+    assert pairs.tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9)).tobytes()
+    assert len(pairs) == 90
+    idx = ctx.ani_index_build(g)
+    pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32)
+    ani = ctx.ani_pairs(idx, pi, 0.15)
+    for x in range(0, 90, 7):
+        a, b = pi[x]
+        assert np.float32(oracle.ani_pair(ask[a], ask[b], 0.15)[0]) == ani[x]
+    assert np.all((ani > 94.5) & (ani < 95.5))
