@@ -386,6 +386,7 @@ extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t
 static void free_sketches_locked(ghip_sketches *sk) {  // ctx->mu held
     ghip_ctx *ctx = sk->ctx;
     if (sk->owned) { ghip_pool_free(ctx, sk->d_hashes); ghip_pool_free(ctx, sk->d_lens); }
+    ghip_pool_free(ctx, sk->d_tables); ghip_pool_free(ctx, sk->d_row_start);
     ctx->live_handles--;
     delete sk;
 }
@@ -574,8 +575,28 @@ extern "C" int ghip_sketch_files(ghip_ctx *ctx, const char *const *paths, size_t
 // ------------------------------------------------------------------------------------ precluster
 extern "C" uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx) { return ctx ? ctx->last_pairs : 0; }
 
-extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
+// Builds the cuckoo sets and the work rows of the probe-form pair kernel once per sketch matrix.
+static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
+    if (sk->probe_ready) return GHIP_OK;
+    const size_t slots = ghip_probe_table_slots(sk->s);
+    int rc;
+    uint32_t *d_flags = nullptr;
+    if ((rc = dmalloc(ctx, &sk->d_tables, sk->n * slots))) return rc;
+    if ((rc = dmalloc(ctx, &d_flags, 1))) return rc;
+    DeviceFree tmp(ctx); tmp.add(d_flags);
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
+    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, d_flags);
+    sk->n_work = ghip_probe_work_rows(sk->n, ctx->num_cus, &sk->probe_cb, sk->row_start);
+    if ((rc = dmalloc(ctx, &sk->d_row_start, sk->row_start.size()))) return rc;
+    if ((rc = h2d(ctx, sk->d_row_start, sk->row_start.data(), sk->row_start.size()))) return rc;
+    if ((rc = d2h(ctx, &sk->probe_flags, d_flags, 1))) return rc;
+    sk->probe_ready = true;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_ani, uint32_t rank,
                                      uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
+    ghip_sketches *sk = const_cast<ghip_sketches *>(sk_in);  // lazily caches the probe-form tables
     if (!ctx || !sk || !out_pairs || !out_n || world == 0 || rank >= world) return GHIP_EINVAL;
     if (sk->s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "sketch size above 4096 is not supported");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -610,6 +631,14 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, flo
     }
     uint16_t *d_cmin = ctx->cmin.d_cmin;
 
+    // s <= 1024: hash-probe form (pairs_probe.hip); otherwise, or if a sketch holds 2^64-1 / a cuckoo
+    // insertion failed, the 64-way merge-path kernel (pairs.hip).  GHIP_PAIR_KERNEL=merge forces the latter.
+    bool use_probe = s <= 1024 && !(getenv("GHIP_PAIR_KERNEL") && !strcmp(getenv("GHIP_PAIR_KERNEL"), "merge"));
+    if (use_probe) {
+        if ((rc = prepare_probe(ctx, sk))) return rc;
+        use_probe = sk->probe_flags == 0;
+    }
+
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     uint64_t cap = std::min<uint64_t>(P, std::max<uint64_t>(1u << 20, 64ull * n));
     unsigned long long *d_count = nullptr;
@@ -622,7 +651,13 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, flo
         DeviceFree t2(ctx); t2.add(d_out);
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         uint64_t compared = 0;
-        ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, rank, world, d_out, d_count, cap, &compared);
+        if (use_probe) {
+            ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, n, s, sk->probe_cb, sk->d_row_start,
+                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, rank, world, d_out, d_count, cap);
+            compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, rank, world);
+        } else {
+            ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, rank, world, d_out, d_count, cap, &compared);
+        }
         ctx->last_pairs = compared;
         unsigned long long cnt = 0;
         if ((rc = d2h(ctx, &cnt, d_count, 1))) return rc;

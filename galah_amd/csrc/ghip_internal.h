@@ -82,6 +82,14 @@ struct ghip_sketches {
     uint64_t *d_hashes = nullptr;  // [n][s]
     uint32_t *d_lens = nullptr;    // [n]
     bool owned = true;
+    // probe-form pair stage (pairs_probe.hip): cuckoo sets + work rows, built on first use
+    bool probe_ready = false;
+    uint32_t probe_flags = 0;          // != 0: fall back to the merge-path kernel
+    uint64_t *d_tables = nullptr;      // [n][2*next_pow2(s)]
+    uint64_t *d_row_start = nullptr;   // [nta+1]
+    std::vector<uint64_t> row_start;
+    uint64_t n_work = 0;
+    uint32_t probe_cb = 64;            // B-sketches per work item
 };
 
 struct ghip_ani_index {
@@ -141,6 +149,16 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
                        uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world,
                        ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
                        uint64_t *pairs_compared);
+
+size_t ghip_probe_table_slots(uint32_t s);
+void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                             uint64_t *d_tables, uint32_t *d_flags);
+uint64_t ghip_probe_work_rows(size_t n, int num_cus, uint32_t *cb_out, std::vector<uint64_t> &row_start);
+uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t cb, const std::vector<uint64_t> &row_start, uint32_t rank, uint32_t world);
+void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
+                             size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
+                             const uint16_t *d_cmin, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                             unsigned long long *d_count, uint64_t cap);
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
                            uint32_t *d_seed_code, uint16_t *d_seed_chunk, const uint64_t *d_seed_start,

@@ -1,0 +1,256 @@
+// Pair stage, hash-probe form (the default for s <= 1024): replaces the serial i<j loop of
+// finch::distances (reference src/finch.rs:74-96) / finch::distance::raw_distance.
+//
+// raw_distance only needs |A n B| and two ranks, so sortedness is not required
+// for the intersection itself.  Every sketch is turned once into a cuckoo set (2 hash positions x
+// 2-slot 16-byte buckets, 2*next_pow2(s) slots, load <= 0.5) by pair_table_build.  Then
+//
+//   pair_intersect_tile (probe form): one workgroup = 8 A-sketches as cuckoo sets in LDS
+//   (8 x 16 KiB) x 64 B-sketches.  One sketch pair per wavefront: the wave holds its B-sketch
+//   in registers (lane l owns elements l, l+64, ...; coalesced 8-byte loads of the packed matrix
+//   row) and probes the A-set with exactly two ds_read_b128 per element -- no sorted merge, no
+//   data-dependent loop.  A B-sketch is loaded once per 8 pairs and an A-set once per 64.
+//       common = #hits;  m = min(max A, max B)
+//       max A <= max B :  i = |A|, j = #{b <= max A}          (counted while probing)
+//       max A >  max B :  j = |B|, i = #{a <= max B}          (64 LDS samples + one 16-element
+//                                                              row segment of the sorted matrix)
+//   ~240 VALU instructions per pair instead of ~1150 for the 64-way merge path; LDS-bound.
+//
+// Integer work only; a pair is emitted iff common >= cmin[total] (host table from the f64
+// formula) and the host recomputes the exact f32.  Exactness guards: a sketch that holds the
+// value 2^64-1 (the empty-slot marker) or whose cuckoo insertion fails makes the host fall back
+// to the merge-path kernel (pairs.hip) for the whole call.
+#include "ghip_internal.h"
+
+namespace {
+
+constexpr int PROBE_TA = 8;        // A-sketches (cuckoo sets) per workgroup
+constexpr int PROBE_CB_MAX = 64;   // B-sketches per workgroup (16 / 32 / 64, chosen so the grid fills the chip)
+constexpr int PROBE_WAVES = 8;
+constexpr int PROBE_THREADS = PROBE_WAVES * 64;
+constexpr uint64_t EMPTY = ~0ull;
+
+__device__ __forceinline__ uint32_t bucket1(uint64_t x, uint32_t mask) { return (uint32_t)x & mask; }
+__device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask) { return (uint32_t)(x >> 20) & mask; }
+
+// ---------------------------------------------------------------------------------------------
+// pair_table_build: one 256-thread block per sketch, cuckoo insertion with 64-bit LDS atomics.
+// flags: bit 0 = some sketch contains 2^64-1, bit 1 = an insertion did not converge.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *__restrict__ hashes,
+                                                               const uint32_t *__restrict__ lens, uint32_t s,
+                                                               uint32_t buckets, uint64_t *__restrict__ tables,
+                                                               uint32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long *tab = reinterpret_cast<unsigned long long *>(smem_raw);
+    const uint32_t g = blockIdx.x;
+    const uint32_t mask = buckets - 1, slots = 2 * buckets;
+    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) tab[i] = EMPTY;
+    __syncthreads();
+    const uint32_t n = lens[g];
+    const uint64_t *row = hashes + (uint64_t)g * s;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        unsigned long long x = row[i];
+        if (x == EMPTY) { atomicOr(flags, 1u); continue; }
+        uint32_t b = bucket1(x, mask);
+        bool placed = false;
+        uint32_t rnd = (uint32_t)(x >> 40) ^ (uint32_t)x ^ (i * 0x9E3779B9u);
+        for (int it = 0; it < 4000 && !placed; it++) {
+            if (atomicCAS(&tab[2 * b], (unsigned long long)EMPTY, x) == EMPTY) { placed = true; break; }
+            if (atomicCAS(&tab[2 * b + 1], (unsigned long long)EMPTY, x) == EMPTY) { placed = true; break; }
+            // random-walk cuckoo: evict a pseudo-randomly chosen resident and carry it to its other
+            // bucket (a fixed slot pattern can ping-pong between two full buckets forever)
+            rnd = rnd * 1664525u + 1013904223u;
+            const unsigned long long y = atomicExch(&tab[2 * b + (rnd >> 31)], x);
+            x = y;
+            if (x == EMPTY) { placed = true; break; }  // a concurrent eviction freed the slot
+            const uint32_t b1 = bucket1(x, mask), b2 = bucket2(x, mask);
+            b = (b == b1) ? b2 : b1;
+        }
+        if (!placed) atomicOr(flags, 2u);
+    }
+    __syncthreads();
+    uint64_t *dst = tables + (uint64_t)g * slots;
+    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) dst[i] = tab[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// probe kernel; NT = 64-element register slices of a B-sketch (s <= 64*NT)
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
+    const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint64_t *__restrict__ tables,
+    uint32_t n, uint32_t s, uint32_t buckets, uint32_t cb, const uint64_t *__restrict__ row_start, uint32_t nta,
+    uint64_t n_work, uint32_t rank, uint32_t world, const uint16_t *__restrict__ cmin,
+    ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *sets = reinterpret_cast<uint4 *>(smem_raw);                                  // [TA][buckets]
+    uint64_t *samp = reinterpret_cast<uint64_t *>(sets + (size_t)PROBE_TA * buckets);   // [TA][64]
+    uint64_t *a_max = samp + PROBE_TA * 64;                                             // [TA]
+    uint32_t *a_len = reinterpret_cast<uint32_t *>(a_max + PROBE_TA);                   // [TA]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t mask = buckets - 1;
+
+    for (uint64_t blk = blockIdx.x;; blk += gridDim.x) {  // grid-stride: a dispatch holds < 2^32 work-items
+        const uint64_t w = blk * world + rank;
+        if (w >= n_work) return;
+        // work item -> (A-tile ti, chunk c): largest ti with row_start[ti] <= w
+        uint32_t lo = 0, hi = nta;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (row_start[mid] <= w) lo = mid; else hi = mid;
+        }
+        const uint32_t ti = lo;
+        const uint32_t j0 = ti * PROBE_TA + (uint32_t)(w - row_start[ti]) * cb;
+        __syncthreads();  // previous work item's LDS image is no longer read
+        // ---- stage the 8 cuckoo sets (linear 16-byte copies), rank samples and lengths ----
+        for (uint32_t q = 0; q < PROBE_TA; q++) {
+            const uint32_t g = ti * PROBE_TA + q;
+            const uint4 *src = reinterpret_cast<const uint4 *>(tables + (uint64_t)g * 2 * buckets);
+            for (uint32_t e = threadIdx.x; e < buckets; e += PROBE_THREADS)
+                sets[(size_t)q * buckets + e] = (g < n) ? src[e] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+        if (threadIdx.x < PROBE_TA * 64) {
+            const uint32_t q = threadIdx.x >> 6, l = threadIdx.x & 63u;
+            const uint32_t g = ti * PROBE_TA + q;
+            const uint32_t na = (g < n) ? lens[g] : 0u;
+            const uint32_t idx = 16 * l + 15;
+            samp[q * 64 + l] = (idx < na) ? hashes[(uint64_t)g * s + idx] : EMPTY;
+            if (l == 0) { a_len[q] = na; a_max[q] = na ? hashes[(uint64_t)g * s + na - 1] : 0ull; }
+        }
+        __syncthreads();
+
+        for (uint32_t jj = wave; jj < cb; jj += PROBE_WAVES) {
+            const uint32_t gj = j0 + jj;
+            if (gj >= n || gj <= ti * PROBE_TA) continue;  // no A of this tile has a smaller index
+            const uint32_t nb = lens[gj];
+            const uint64_t *brow = hashes + (uint64_t)gj * s;
+            uint64_t b[NT];
+            uint32_t vmask = 0;  // bit t: element lane + 64 t exists
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint32_t e = lane + 64u * t;
+                b[t] = (e < s) ? brow[e] : EMPTY;
+                vmask |= (e < nb ? 1u : 0u) << t;
+            }
+            const uint64_t maxb = nb ? brow[nb - 1] : 0ull;
+            for (uint32_t q = 0; q < PROBE_TA; q++) {
+                const uint32_t gi = ti * PROBE_TA + q;
+                if (gi >= gj) break;
+                const uint32_t na = a_len[q];
+                const uint64_t maxa = a_max[q];
+                const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(sets + (size_t)q * buckets);
+                uint32_t packed = 0;  // low 16 bits: hits, high 16 bits: #{b <= max A}
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const uint64_t x = b[t];
+                    const ulonglong2 v1 = set[bucket1(x, mask)];  // both buckets are always read: no
+                    const ulonglong2 v2 = set[bucket2(x, mask)];  // data-dependent branch in the probe
+                    const uint32_t hit = (uint32_t)(v1.x == x) | (uint32_t)(v1.y == x) | (uint32_t)(v2.x == x) | (uint32_t)(v2.y == x);
+                    const uint32_t ok = (vmask >> t) & 1u;
+                    packed += (hit & ok) + (((uint32_t)(x <= maxa) & ok) << 16);
+                    // at most 8 bucket reads (32 VGPRs) in flight: 1024-thread blocks cap a lane at 128 VGPRs
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) packed += __shfl_xor(packed, off, 64);
+                const uint32_t common = packed & 0xffffu;
+                uint32_t icnt = 0, jcnt = 0;
+                if (na > 0 && nb > 0) {
+                    if (maxa <= maxb) {
+                        icnt = na; jcnt = packed >> 16;
+                    } else {  // #{a <= max B}: whole 16-blocks from the LDS samples, the partial block from the row
+                        jcnt = nb;
+                        const uint32_t full = (uint32_t)__popcll(__ballot(samp[q * 64 + lane] <= maxb));
+                        const uint32_t e = 16 * full + (lane & 15u);
+                        const bool in = lane < 16 && e < na && hashes[(uint64_t)gi * s + e] <= maxb;
+                        icnt = 16 * full + (uint32_t)__popcll(__ballot(in));
+                    }
+                }
+                const uint32_t total = icnt + jcnt - common;
+                if (lane == 0 && common >= (uint32_t)cmin[total]) {
+                    unsigned long long idx = atomicAdd(out_count, 1ull);
+                    if (idx < cap) {
+                        ghip_pair r;
+                        r.i = gi; r.j = gj; r.common = common; r.total = total; r.ani = 0.0f;
+                        out[idx] = r;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t ghip_probe_table_slots(uint32_t s) {
+    uint32_t b = 1;
+    while (b < s) b <<= 1;
+    return 2 * (size_t)b;
+}
+
+void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                             uint64_t *d_tables, uint32_t *d_flags) {
+    if (n == 0) return;
+    const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
+    ghip_prof_begin(ctx, "pair_table_build");
+    hipLaunchKernelGGL(pair_table_build_kernel, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
+                       ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_flags);
+    ghip_prof_end(ctx);
+}
+
+// work items: A-tile ti (8 sketches) x chunk of cb B-sketches starting at 8*ti.  cb shrinks for small
+// N so that there are several work items per CU (each stages 128 KiB, amortised over 8*cb pairs).
+uint64_t ghip_probe_work_rows(size_t n, int num_cus, uint32_t *cb_out, std::vector<uint64_t> &row_start) {
+    const size_t nta = (n + PROBE_TA - 1) / PROBE_TA;
+    uint32_t cb = PROBE_CB_MAX;
+    while (cb > 16 && nta * ((n / 2 + cb - 1) / cb) < (size_t)num_cus * 12) cb >>= 1;
+    row_start.assign(nta + 1, 0);
+    for (size_t ti = 0; ti < nta; ti++) {
+        const size_t j0 = ti * PROBE_TA;
+        row_start[ti + 1] = row_start[ti] + (n - j0 + cb - 1) / cb;
+    }
+    *cb_out = cb;
+    return row_start[nta];
+}
+
+uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t PROBE_CB, const std::vector<uint64_t> &row_start, uint32_t rank, uint32_t world) {
+    if (world == 1) return (uint64_t)n * (n - 1) / 2;
+    uint64_t cnt = 0;
+    const size_t nta = row_start.size() - 1;
+    for (size_t ti = 0; ti < nta; ti++)
+        for (uint64_t w = row_start[ti]; w < row_start[ti + 1]; w++) {
+            if (w % world != rank) continue;
+            const uint64_t j0 = ti * PROBE_TA + (w - row_start[ti]) * PROBE_CB;
+            for (uint64_t gi = ti * PROBE_TA; gi < std::min<uint64_t>((ti + 1) * PROBE_TA, n); gi++) {
+                const uint64_t lo = std::max<uint64_t>(j0, gi + 1), hi = std::min<uint64_t>(j0 + PROBE_CB, n);
+                if (hi > lo) cnt += hi - lo;
+            }
+        }
+    return cnt;
+}
+
+void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
+                             size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
+                             const uint16_t *d_cmin, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                             unsigned long long *d_count, uint64_t cap) {
+    const uint64_t mine = n_work > rank ? (n_work - rank + world - 1) / world : 0;
+    if (mine == 0) return;
+    const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
+    const size_t lds = (size_t)PROBE_TA * buckets * 16 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(pair_probe_tile_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(pair_probe_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)std::min<uint64_t>(mine, GHIP_MAX_GRID);
+    ghip_prof_begin(ctx, "pair_intersect_tile");
+    if (s <= 256)
+        hipLaunchKernelGGL(pair_probe_tile_kernel<4>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
+                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, d_cmin, d_out, d_count, cap);
+    else
+        hipLaunchKernelGGL(pair_probe_tile_kernel<16>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
+                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, d_cmin, d_out, d_count, cap);
+    ghip_prof_end(ctx);
+}

@@ -6,7 +6,8 @@
   2. ALL-GATHER the packed sketch matrix          -> u64[N][s] on every rank (N*s*8 bytes, once)
   3. pair tiles t with t % world == rank          -> local candidate list    (no communication)
   4. build the local ANI seed index, ALL-GATHER its flat arrays; ANI for the local candidates
-  5. gather (pairs, ANI) on rank 0; greedy clustering on the host            (src/clusterer.rs)
+  5. all-gather the (small) candidate lists, ANI for an interleaved slice per rank, gather the ANI
+     values on rank 0; greedy clustering on the host                         (src/clusterer.rs)
 
 With world == 1 the same code runs with the exchange steps skipped.  The compute engine is
 pluggable so the exchange logic can be exercised on CPU (gloo) in tests; the product engine is
@@ -264,16 +265,25 @@ class DereplicationJob:
             t = self._tick("allgather_ani_index", t)
         else:
             idx = idx_l
-        pair_ani = e.ani_pairs(idx, pairs, self.min_af)
+        # candidates cluster near the diagonal, so the per-rank lists are uneven: every rank learns the
+        # whole (small) list and computes the ANI of an interleaved slice of it
+        if self.world > 1:
+            parts = ex.all_gather_object(pairs)
+            allp = np.concatenate(parts) if parts else np.zeros(0, PAIR_DTYPE)
+            allp = allp[np.argsort(allp, order=["i", "j"], kind="stable")]
+            t = self._tick("allgather_pairs", t)
+        else:
+            allp = pairs
+        mine = allp[self.rank::self.world]
+        ani_mine = e.ani_pairs(idx, mine, self.min_af)
         t = self._tick("ani_pairs", t)
-        gathered = ex.gather_object((pairs, pair_ani), 0)
+        gathered = ex.gather_object(ani_mine, 0)
         result = {"n_pairs": 0, "n_clusters": 0, "clusters": None, "pairs": None, "pair_ani": None}
         if self.rank == 0:
-            allp = np.concatenate([g[0] for g in gathered]) if gathered else np.zeros(0, PAIR_DTYPE)
-            alla = np.concatenate([g[1] for g in gathered]) if gathered else np.zeros(0, np.float32)
-            order = np.argsort(allp, order=["i", "j"], kind="stable") if self.world > 1 else slice(None)
-            allp, alla = allp[order], alla[order]
-            t = self._tick("gather_pairs", t)
+            alla = np.zeros(len(allp), dtype=np.float32)
+            for r, a in enumerate(gathered):
+                alla[r::self.world] = a
+            t = self._tick("gather_ani", t)
             clusters = e.cluster(self.n, allp, alla, self.ani_threshold)
             t = self._tick("host_cluster", t)
             result = {"n_pairs": len(allp), "n_clusters": len(clusters), "clusters": clusters, "pairs": allp,

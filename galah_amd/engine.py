@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import PAIR_DTYPE, GalahHipError, check
 
-KERNELS = ("sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_bin", "ani_pairs",
+KERNELS = ("sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_tile", "ani_seeds", "ani_bin", "ani_pairs",
            "synth_genomes")
 
 

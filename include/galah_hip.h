@@ -62,7 +62,8 @@ int ghip_synchronize(ghip_ctx *ctx);
 int ghip_memcpy_d2d(ghip_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes);
 
 /* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:
- * "sketch_kmers", "sketch_select", "pair_intersect_tile", "ani_seeds", "ani_bin", "ani_pairs",
+ * "sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_tile", "ani_seeds", "ani_bin",
+ * "ani_pairs",
  * "synth_genomes".  enable=1 starts collecting, ghip_kernel_stats drains finished events. */
 int ghip_profile_enable(ghip_ctx *ctx, int enable);
 int ghip_profile_reset(ghip_ctx *ctx);

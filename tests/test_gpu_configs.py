@@ -55,11 +55,14 @@ def test_config3_10k_genomes_pair_stage_full_oracle(ctx):
     assert got.tobytes() == want.tobytes()
     assert len(got) == (n // 10) * 45
     # N x N tiles dealt over 8 ranks: the shards partition the result (what 8 GPUs would each compute)
-    parts = [ctx.precluster(sk, np.float32(0.9), r, 8) for r in range(8)]
+    parts, compared = [], []
+    for r in range(8):
+        parts.append(ctx.precluster(sk, np.float32(0.9), r, 8))
+        compared.append(ctx.last_pairs_compared)
     merged = np.sort(np.concatenate(parts), order=["i", "j"])
     assert merged.tobytes() == got.tobytes()
-    sizes = [len(p) for p in parts]
-    assert max(sizes) < 2 * (sum(sizes) / 8)  # block-cyclic deal is balanced
+    assert sum(compared) == n * (n - 1) // 2
+    assert max(compared) < 1.02 * min(compared)  # the block-cyclic deal balances the pair work
 
 
 def test_config4_small_sketch_high_pair_count(ctx):
