@@ -189,3 +189,32 @@ def test_cluster_end_to_end_vs_oracle(ctx):
                               lambda a, b: oracle.ani_pair(osk[a], osk[b], 0.15)[0])
         assert got == want, (thr, got, want)
         assert sorted(x for c in got for x in c) == list(range(len(paths)))
+
+
+def test_merge_path_kernel_also_matches_oracle(ctx, monkeypatch):
+    """The 64-way merge-path kernel (fallback form of pair_intersect_tile) on the same inputs."""
+    monkeypatch.setenv("GHIP_PAIR_KERNEL", "merge")
+    for n, s, min_len, thr in ((37, 1000, None, 0.9), (130, 256, 1, 0.8), (64, 1000, 1, 0.0)):
+        rng = np.random.default_rng(n * 7 + s)
+        hashes, lens = random_sketches(rng, n, s, shared_groups=5, min_len=min_len)
+        sk = ctx.sketches_from_host(hashes, lens, 21)
+        got = ctx.precluster(sk, np.float32(thr))
+        assert got.tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(thr)).tobytes()
+        assert ctx.last_pairs_compared == n * (n - 1) // 2
+
+
+def test_sketch_holding_the_empty_marker_falls_back_exactly(ctx):
+    """A real hash equal to 2^64-1 (the cuckoo empty-slot marker / row padding) must not change results:
+    the probe form detects it and the call runs the merge-path kernel with explicit index guards."""
+    rng = np.random.default_rng(99)
+    hashes, lens = random_sketches(rng, 20, 64, shared_groups=2)
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for g in (3, 4, 11):           # same family members share the maximal hash
+        hashes[g, lens[g] - 1] = M
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    got = ctx.precluster(sk, np.float32(0.0))
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.0))
+    assert got.tobytes() == want.tobytes()
+    row = got[(got["i"] == 3) & (got["j"] == 4)][0]
+    a, b = set(hashes[3, : lens[3]].tolist()), set(hashes[4, : lens[4]].tolist())
+    assert int(row["common"]) == len(a & b) and int(M) in (a & b)
