@@ -49,6 +49,7 @@ SIGNATURES = {
     "ghip_genomes_total_bases": (_u64, [_vp]),
     "ghip_genomes_length": (_u64, [_vp, _sz]),
     "ghip_genomes_to_host": (_int, [_vp, _vp, _sz, _vp]),
+    "ghip_genomes_stats": (_int, [_vp, _sz, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "ghip_genomes_free": (None, [_vp]),
     "ghip_sketch_genomes": (_int, [_vp, _vp, _u32, _u32, _u64, _pp]),
     "ghip_sketch_files": (_int, [_vp, C.POINTER(C.c_char_p), _sz, _u32, _u32, _u64, _int, _pp]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "ghip_sketches_wrap_device": (_int, [_vp, _vp, _vp, _sz, _u32, _u32, _pp]),
     "ghip_sketches_to_host": (_int, [_vp, _vp, _vp, _vp]),
     "ghip_sketches_copy_into": (_int, [_vp, _vp, _vp, _vp]),
+    "ghip_sketches_save": (_int, [_vp, _vp, C.c_char_p]),
+    "ghip_sketches_load": (_int, [_vp, C.c_char_p, _pp]),
     "ghip_sketches_count": (_sz, [_vp]),
     "ghip_sketches_size": (_u32, [_vp]),
     "ghip_sketches_kmer": (_u32, [_vp]),

@@ -7,7 +7,8 @@
 #include "ghip_internal.h"
 
 int ghip_read_fasta_streams(const char *const *paths, size_t n, int threads,
-                            std::vector<std::vector<uint8_t>> &streams, std::string &err);
+                            std::vector<std::vector<uint8_t>> &streams, std::vector<ghip_genome_stats> &stats,
+                            std::string &err);
 
 static thread_local std::string g_init_error;
 
@@ -321,8 +322,9 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                                        ghip_genomes **out) {
     if (!ctx || !out || (n && !paths)) return GHIP_EINVAL;
     std::vector<std::vector<uint8_t>> streams;
+    std::vector<ghip_genome_stats> stats;
     std::string err;
-    int rc = ghip_read_fasta_streams(paths, n, io_threads, streams, err);
+    int rc = ghip_read_fasta_streams(paths, n, io_threads, streams, stats, err);
     if (rc != GHIP_OK) return ghip_set_error(ctx, rc, err);
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -330,6 +332,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
     for (size_t i = 0; i < n; i++) lens[i] = streams[i].size();
     ghip_genomes *g = new ghip_genomes();
     g->ctx = ctx;
+    g->stats = stats;
     ctx->live_handles++;
     rc = layout_genomes(ctx, g, lens);
     for (size_t i = 0; i < n && rc == GHIP_OK; i++)
@@ -374,6 +377,16 @@ extern "C" int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32
 extern "C" size_t ghip_genomes_count(const ghip_genomes *g) { return g ? g->n : 0; }
 extern "C" uint64_t ghip_genomes_total_bases(const ghip_genomes *g) { return g ? g->total_bases : 0; }
 extern "C" uint64_t ghip_genomes_length(const ghip_genomes *g, size_t idx) { return (g && idx < g->n) ? g->lens[idx] : 0; }
+
+extern "C" int ghip_genomes_stats(const ghip_genomes *g, size_t idx, uint64_t *num_contigs, uint64_t *num_ambiguous_bases,
+                                  uint64_t *n50) {
+    if (!g || idx >= g->n) return GHIP_EINVAL;
+    if (g->stats.size() != g->n) return GHIP_EUNSUPPORTED;  // only genomes read from FASTA files carry statistics
+    if (num_contigs) *num_contigs = g->stats[idx].num_contigs;
+    if (num_ambiguous_bases) *num_ambiguous_bases = g->stats[idx].num_ambiguous_bases;
+    if (n50) *n50 = g->stats[idx].n50;
+    return GHIP_OK;
+}
 
 extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t idx, uint8_t *outp) {
     if (!ctx || !g || idx >= g->n || !outp) return GHIP_EINVAL;
@@ -463,6 +476,45 @@ extern "C" int ghip_sketches_copy_into(ghip_ctx *ctx, const ghip_sketches *sk, v
         GHIP_HIP_CHECK(ctx, hipMemcpyAsync(d_lens_dst, sk->d_lens, sk->n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     return GHIP_OK;
+}
+
+// On-disk sketch matrix (the reference has no finch counterpart -- skani's
+// --low-memory db dir, src/skani.rs:266-304, is the closest): "GHIPSK01", u32 k, u32 s, u64 n,
+// u32 len[n], u64 hashes[n][s], little-endian.
+extern "C" int ghip_sketches_save(ghip_ctx *ctx, const ghip_sketches *sk, const char *path) {
+    if (!ctx || !sk || !path) return GHIP_EINVAL;
+    std::vector<uint64_t> h(sk->n * (size_t)sk->s);
+    std::vector<uint32_t> l(sk->n);
+    int rc = ghip_sketches_to_host(ctx, sk, h.data(), l.data());
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return ghip_set_error(ctx, GHIP_EIO, std::string("cannot write ") + path);
+    const uint64_t n = sk->n;
+    bool ok = fwrite("GHIPSK01", 1, 8, f) == 8 && fwrite(&sk->k, 4, 1, f) == 1 && fwrite(&sk->s, 4, 1, f) == 1 &&
+              fwrite(&n, 8, 1, f) == 1 && fwrite(l.data(), 4, l.size(), f) == l.size() &&
+              fwrite(h.data(), 8, h.size(), f) == h.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? GHIP_OK : ghip_set_error(ctx, GHIP_EIO, std::string("short write to ") + path);
+}
+
+extern "C" int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches **out) {
+    if (!ctx || !path || !out) return GHIP_EINVAL;
+    FILE *f = fopen(path, "rb");
+    if (!f) return ghip_set_error(ctx, GHIP_EIO, std::string("cannot read ") + path);
+    char magic[8];
+    uint32_t k = 0, s = 0;
+    uint64_t n = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GHIPSK01", 8) && fread(&k, 4, 1, f) == 1 &&
+              fread(&s, 4, 1, f) == 1 && fread(&n, 8, 1, f) == 1 && s >= 1 && s <= 4096 && n < (1ull << 32);
+    std::vector<uint32_t> l;
+    std::vector<uint64_t> h;
+    if (ok) {
+        l.resize(n); h.resize(n * (size_t)s);
+        ok = fread(l.data(), 4, l.size(), f) == l.size() && fread(h.data(), 8, h.size(), f) == h.size();
+    }
+    fclose(f);
+    if (!ok) return ghip_set_error(ctx, GHIP_EIO, std::string("not a sketch matrix file: ") + path);
+    return ghip_sketches_from_host(ctx, h.data(), l.data(), n, s, k, out);  // validates order and lengths
 }
 
 // finch::sketch_files replacement.  Exactness: a genome is accepted only when its candidate

@@ -60,6 +60,10 @@ struct ghip_sketch_work {  // one block of the k-mer pass
     uint32_t chunk;  // chunk index within the genome
 };
 
+struct ghip_genome_stats {  // reference src/genome_stats.rs:5-9
+    uint64_t num_contigs = 0, num_ambiguous_bases = 0, n50 = 0;
+};
+
 struct ghip_genomes {
     ghip_ctx *ctx = nullptr;
     size_t n = 0;
@@ -67,6 +71,7 @@ struct ghip_genomes {
     uint64_t *d_starts = nullptr;      // [n] byte offset of genome g
     uint64_t *d_lens = nullptr;        // [n] stream length L_g
     std::vector<uint64_t> starts, lens;
+    std::vector<ghip_genome_stats> stats;  // filled by ghip_genomes_from_files
     uint64_t total_alloc = 0;
     uint64_t total_bases = 0;
     // cached full-pass work list (one entry per 16384-position chunk of every genome)

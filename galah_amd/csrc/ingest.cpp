@@ -49,8 +49,12 @@ bool slurp(const char *path, std::vector<uint8_t> &buf) {
 
 }  // namespace
 
-// Returns 0 ok, GHIP_EIO on unreadable / non-FASTA input.
-int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, std::string &err) {
+// Returns 0 ok, GHIP_EIO on unreadable / non-FASTA input.  The same pass yields the assembly
+// statistics galah computes in a second read of every file (reference src/genome_stats.rs:11-51):
+// records, raw 'N'/'n' count, N50 over record lengths (bases, line ends excluded).
+int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, ghip_genome_stats &st, std::string &err) {
+    st = ghip_genome_stats();
+    std::vector<uint64_t> contig_lengths;
     std::vector<uint8_t> buf;
     if (!slurp(path, buf)) { err = std::string("Failed to open fasta file ") + path; return GHIP_EIO; }
     const size_t n = buf.size();
@@ -64,22 +68,37 @@ int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, std::str
         while (p < n && buf[p] != '\n') p++;  // header line
         if (p < n) p++;
         bool line_start = true;
+        uint64_t bases = 0;
         while (p < n) {
             const uint8_t c = buf[p];
             if (line_start && c == '>') break;
             line_start = (c == '\n');
+            if (c != '\n' && c != '\r') bases++;
+            if (c == 'N' || c == 'n') st.num_ambiguous_bases++;
             const uint8_t o = kNorm.t[c];
             if (o) out.push_back(o);
             p++;
         }
         out.push_back('N');
+        st.num_contigs++;
+        contig_lengths.push_back(bases);
+    }
+    // genome_stats.rs:33-45: ascending lengths, first running sum >= total/2
+    std::sort(contig_lengths.begin(), contig_lengths.end());
+    uint64_t total = 0, run = 0;
+    for (uint64_t l : contig_lengths) total += l;
+    for (uint64_t l : contig_lengths) {
+        run += l;
+        if (run >= total / 2) { st.n50 = l; break; }
     }
     return GHIP_OK;
 }
 
 int ghip_read_fasta_streams(const char *const *paths, size_t n, int threads,
-                            std::vector<std::vector<uint8_t>> &streams, std::string &err) {
+                            std::vector<std::vector<uint8_t>> &streams, std::vector<ghip_genome_stats> &stats,
+                            std::string &err) {
     streams.assign(n, {});
+    stats.assign(n, ghip_genome_stats());
     if (threads < 1) threads = 1;
     threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n, 1));
     std::atomic<size_t> next{0};
@@ -90,7 +109,7 @@ int ghip_read_fasta_streams(const char *const *paths, size_t n, int threads,
             size_t i = next.fetch_add(1);
             if (i >= n) return;
             std::string e;
-            int r = ghip_read_fasta_stream(paths[i], streams[i], e);
+            int r = ghip_read_fasta_stream(paths[i], streams[i], stats[i], e);
             if (r != GHIP_OK) {
                 std::lock_guard<std::mutex> lk(emu);
                 if (rc.load() == GHIP_OK) { rc = r; err = e; }

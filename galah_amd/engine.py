@@ -52,6 +52,12 @@ class Genomes(_Handle):
     def length(self, idx: int) -> int:
         return int(_lib.lib().ghip_genomes_length(self._h, idx))
 
+    def stats(self, idx: int) -> Tuple[int, int, int]:
+        """(num_contigs, num_ambiguous_bases, n50) -- GenomeAssemblyStats of src/genome_stats.rs."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(_lib.lib().ghip_genomes_stats(self._h, idx, C.byref(a), C.byref(b), C.byref(c)), self.ctx._h)
+        return int(a.value), int(b.value), int(c.value)
+
     def to_host(self, idx: int) -> np.ndarray:
         out = np.empty(self.length(idx), dtype=np.uint8)
         check(_lib.lib().ghip_genomes_to_host(self.ctx._h, self._h, idx, out.ctypes.data), self.ctx._h)
@@ -79,6 +85,9 @@ class Sketches(_Handle):
     @property
     def device_lens(self) -> int:
         return int(_lib.lib().ghip_sketches_device_lens(self._h) or 0)
+
+    def save(self, path: str):
+        check(_lib.lib().ghip_sketches_save(self.ctx._h, self._h, path.encode()), self.ctx._h)
 
     def to_host(self) -> Tuple[np.ndarray, np.ndarray]:
         n, s = len(self), self.size
@@ -199,6 +208,11 @@ class Context:
         n, s = hashes.shape
         h = C.c_void_p()
         check(_lib.lib().ghip_sketches_from_host(self._h, hashes.ctypes.data, lens.ctypes.data, n, s, k, C.byref(h)), self._h)
+        return Sketches(self, h)
+
+    def sketches_load(self, path: str) -> Sketches:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_sketches_load(self._h, path.encode(), C.byref(h)), self._h)
         return Sketches(self, h)
 
     def sketches_wrap_device(self, d_hashes: int, d_lens: int, n: int, s: int, k: int = 21) -> Sketches:

@@ -89,6 +89,10 @@ size_t ghip_genomes_count(const ghip_genomes *g);
 uint64_t ghip_genomes_total_bases(const ghip_genomes *g);
 uint64_t ghip_genomes_length(const ghip_genomes *g, size_t idx);
 int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t idx, uint8_t *out);
+/* Assembly statistics gathered in the same parse (replaces the second file read of
+ * calculate_genome_stats, src/genome_stats.rs:11-51); GHIP_EUNSUPPORTED unless built from files. */
+int ghip_genomes_stats(const ghip_genomes *g, size_t idx, uint64_t *num_contigs,
+                       uint64_t *num_ambiguous_bases, uint64_t *n50);
 void ghip_genomes_free(ghip_genomes *g);
 
 /* ---------------------------------------------------------------- MinHash sketching
@@ -107,6 +111,9 @@ int ghip_sketches_wrap_device(ghip_ctx *ctx, void *d_hashes, void *d_lens, size_
 int ghip_sketches_to_host(ghip_ctx *ctx, const ghip_sketches *sk, uint64_t *hashes, uint32_t *lens);
 /* Device-to-device copy into caller-owned HBM (e.g. this rank's slice of an all-gather buffer). */
 int ghip_sketches_copy_into(ghip_ctx *ctx, const ghip_sketches *sk, void *d_hashes_dst, void *d_lens_dst);
+/* Persisted sketch matrix (incremental dereplication without re-sketching). */
+int ghip_sketches_save(ghip_ctx *ctx, const ghip_sketches *sk, const char *path);
+int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches **out);
 size_t ghip_sketches_count(const ghip_sketches *sk);
 uint32_t ghip_sketches_size(const ghip_sketches *sk);     /* s */
 uint32_t ghip_sketches_kmer(const ghip_sketches *sk);     /* k */

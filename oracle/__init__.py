@@ -83,6 +83,8 @@ def lib():
     L.go_cluster.restype = C.c_size_t
     L.go_cluster.argtypes = [C.c_size_t, C.c_void_p, C.c_int, C.c_float, _ANI_FN, C.c_void_p,
                              C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.go_genome_stats.restype = C.c_int
+    L.go_genome_stats.argtypes = [C.c_char_p, u64p, u64p, u64p]
     L.go_splitmix64.restype = C.c_uint64
     L.go_splitmix64.argtypes = [C.c_uint64]
     L.go_synth_genome.restype = None
@@ -255,6 +257,15 @@ def cluster(n: int, precluster_cache: Cache, ani_threshold: float,
     nc = lib().go_cluster(n, precluster_cache._h, 1 if skip_clusterer else 0, np.float32(ani_threshold),
                           cb, None, members, offsets)
     return [[int(members[x]) for x in range(offsets[c], offsets[c + 1])] for c in range(nc)]
+
+
+def genome_stats(path: str) -> Tuple[int, int, int]:
+    """calculate_genome_stats (src/genome_stats.rs:11-51) -> (num_contigs, num_ambiguous_bases, n50)."""
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    rc = lib().go_genome_stats(path.encode(), C.byref(a), C.byref(b), C.byref(c))
+    if rc != 0:
+        raise RuntimeError(f"oracle: failed to read {path} (rc={rc})")
+    return int(a.value), int(b.value), int(c.value)
 
 
 # ---------------------------------------------------------------- synthetic genomes

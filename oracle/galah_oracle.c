@@ -609,6 +609,40 @@ size_t go_cluster(size_t n, const go_cache *pcache, int skip_clusterer, float an
 }
 
 /* ------------------------------------------------------------------------------------------
+ * calculate_genome_stats (src/genome_stats.rs:11-51): records, 'N'/'n' count, N50.
+ * ------------------------------------------------------------------------------------------ */
+struct stats_ctx { uint64_t contigs, ambiguous; uint64_t *lens; size_t n, cap; };
+static void stats_record_cb(void *vctx, const uint8_t *seq, size_t n) {
+    struct stats_ctx *c = (struct stats_ctx *)vctx;
+    uint64_t bases = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (seq[i] == '\n' || seq[i] == '\r') continue;
+        bases++;
+        if (seq[i] == 'N' || seq[i] == 'n') c->ambiguous++;   /* :27-31 */
+    }
+    if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 64; c->lens = (uint64_t *)realloc(c->lens, c->cap * sizeof(uint64_t)); }
+    c->lens[c->n++] = bases;
+    c->contigs++;
+}
+
+int go_genome_stats(const char *path, uint64_t *num_contigs, uint64_t *num_ambiguous_bases, uint64_t *n50) {
+    size_t n;
+    uint8_t *buf = slurp(path, &n);
+    if (!buf) return -1;
+    struct stats_ctx c = { 0, 0, NULL, 0, 0 };
+    int rc = for_each_fasta_record(buf, n, stats_record_cb, &c);
+    free(buf);
+    if (rc) { free(c.lens); return rc; }
+    qsort(c.lens, c.n, sizeof(uint64_t), cmp_u64);            /* :34 */
+    uint64_t total = 0, run = 0, v = 0;
+    for (size_t i = 0; i < c.n; i++) total += c.lens[i];
+    for (size_t i = 0; i < c.n; i++) { run += c.lens[i]; if (run >= total / 2) { v = c.lens[i]; break; } }   /* :35-44 */
+    *num_contigs = c.contigs; *num_ambiguous_bases = c.ambiguous; *n50 = v;
+    free(c.lens);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic genomes: counter-based, so CPU and GPU produce identical bytes
  * with no storage.  Build-defined (no reference counterpart).
  *   ancestor(species)[p] = 2 bits of splitmix64(key(seed, species, 0) + p/32)

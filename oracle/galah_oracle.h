@@ -86,6 +86,9 @@ size_t go_cluster(size_t n, const go_cache *precluster_cache, int skip_clusterer
                   float ani_threshold, go_ani_fn ani, void *ani_ctx,
                   size_t *out_members, size_t *out_offsets);
 
+/* ---- genome assembly statistics (src/genome_stats.rs:11-51) ---- */
+int go_genome_stats(const char *path, uint64_t *num_contigs, uint64_t *num_ambiguous_bases, uint64_t *n50);
+
 /* ---- synthetic genomes (bench/test input generator; counter-based) ---- */
 uint64_t go_splitmix64(uint64_t x);
 void go_synth_genome(uint64_t seed, uint32_t species, uint32_t member, uint64_t length,

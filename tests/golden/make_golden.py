@@ -37,6 +37,7 @@ GENOMES = {
     "antonio_MAG52": "antonio_mags/BE_RX_R2_MAG52.fna",
     "antonio_MAG189": "antonio_mags/BE_RX_R3_MAG189.fna",
     "clash_500kb": "set1_name_clash/500kb.fna",
+    "abisko_S2D10": "abisko4/73.20110600_S2D.10.fna",   # src/genome_stats.rs:61-73 golden
 }
 PAIRS = [("set1_1mbp", "set1_500kb"), ("abisko_S1X13", "abisko_S2D19"), ("abisko_S1X13", "abisko_S3X12"),
          ("abisko_S1X13", "abisko_S2D13"), ("abisko_S2D19", "abisko_S3X12"), ("abisko_S2D19", "abisko_S2D13"),
@@ -70,8 +71,12 @@ def main():
                      "ani_f32_bits": None if ani is None else int(np.float32(ani).view(np.uint32)),
                      "source": "reference src/finch.rs:111-119" if (a, b) == PAIRS[0] else "oracle-derived"})
     assert rows[0]["ani_f32_bits"] == int(np.float32(0.9808188).view(np.uint32)), rows[0]
+    # genome statistics: both rows are REFERENCE-EMITTED (src/genome_stats.rs:61-86)
+    stats = {"abisko_S2D10": [161, 6506, 8289], "set1_1mbp": [1, 0, 1000000]}
+    for name, want in stats.items():
+        assert list(oracle.genome_stats(os.path.join(fasta_dir, name + ".fna.gz"))) == want, name
     with open(os.path.join(HERE, "golden.json"), "w") as f:
-        json.dump({"k": 21, "s": 1000, "seed": 0, "pairs": rows}, f, indent=1)
+        json.dump({"k": 21, "s": 1000, "seed": 0, "pairs": rows, "genome_stats": stats}, f, indent=1)
     for r in rows:
         print(r)
 

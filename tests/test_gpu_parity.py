@@ -218,3 +218,32 @@ def test_sketch_holding_the_empty_marker_falls_back_exactly(ctx):
     row = got[(got["i"] == 3) & (got["j"] == 4)][0]
     a, b = set(hashes[3, : lens[3]].tolist()), set(hashes[4, : lens[4]].tolist())
     assert int(row["common"]) == len(a & b) and int(M) in (a & b)
+
+
+def test_ingest_yields_reference_genome_stats(ctx):
+    """Assembly statistics come out of the same FASTA parse as the base streams
+    (src/genome_stats.rs:61-86 goldens, plus the oracle on every fixture)."""
+    g = ctx.genomes_from_files([fasta(n) for n in ALL + ["abisko_S2D10"]], io_threads=4)
+    assert g.stats(len(ALL)) == (161, 6506, 8289)
+    assert g.stats(ALL.index("set1_1mbp")) == (1, 0, 1_000_000)
+    for i, n in enumerate(ALL):
+        assert g.stats(i) == oracle.genome_stats(fasta(n))
+    with pytest.raises(galah_amd.GalahHipError):
+        ctx.genomes_from_host([b"ACGT" * 10]).stats(0)   # only file-backed genomes carry statistics
+
+
+def test_sketch_matrix_save_load_round_trip(ctx, tmp_path):
+    rng = np.random.default_rng(12)
+    hashes, lens = random_sketches(rng, 23, 200, shared_groups=3, min_len=1)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    path = str(tmp_path / "sketches.ghipsk")
+    sk.save(path)
+    sk2 = ctx.sketches_load(path)
+    h2, l2 = sk2.to_host()
+    h1, l1 = sk.to_host()
+    assert np.array_equal(h1, h2) and np.array_equal(l1, l2) and sk2.kmer == 21 and sk2.size == 200
+    assert ctx.precluster(sk2, np.float32(0.5)).tobytes() == ctx.precluster(sk, np.float32(0.5)).tobytes()
+    with open(path, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(galah_amd.GalahHipError):
+        ctx.sketches_load(path)

@@ -38,3 +38,11 @@ def test_sketch_extremes_from_survey(golden_sketches):
     assert int(golden_sketches["set1_1mbp"][0]) == 3491212462166
     assert int(golden_sketches["set1_1mbp"][-1]) == 18302639908299747
     assert int(golden_sketches["set1_500kb"][-1]) == 38405002408362914
+
+
+def test_genome_stats_reference_goldens(golden):
+    # src/genome_stats.rs:61-86: both rows are asserted by the reference's own unit tests
+    assert oracle.genome_stats(fasta("abisko_S2D10")) == (161, 6506, 8289)
+    assert oracle.genome_stats(fasta("set1_1mbp")) == (1, 0, 1_000_000)
+    for name, want in golden["genome_stats"].items():
+        assert list(oracle.genome_stats(fasta(name))) == want
