@@ -67,7 +67,10 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     __shared__ uint32_t l_code[SEED_LDS_CAP];
     __shared__ uint16_t l_pos[SEED_LDS_CAP];
     __shared__ uint32_t l_ctot[SEED_LDS_CHUNKS];
-    __shared__ uint32_t l_n, l_base;
+    __shared__ uint32_t l_wave_n[GHIP_SKETCH_THREADS / 64], l_wave_base[GHIP_SKETCH_THREADS / 64];
+    constexpr uint32_t SEED_WAVE_CAP = SEED_LDS_CAP / (GHIP_SKETCH_THREADS / 64);
+    const uint32_t wave_base = (threadIdx.x >> 6) * SEED_WAVE_CAP;
+    uint32_t wave_n = 0;
 
     const ghip_sketch_work wk = work[blockIdx.x];
     const uint32_t g = wk.slot;
@@ -81,7 +84,6 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint32_t scap = (uint32_t)(seed_start[g + 1] - sstart);
     uint32_t *ctot = chunk_total + chunk_start[g];
     if (threadIdx.x < SEED_LDS_CHUNKS) l_ctot[threadIdx.x] = 0;
-    if (threadIdx.x == 0) l_n = 0;
     __syncthreads();
 
     {
@@ -115,31 +117,49 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 good = valid ? good + 1 : 0;
                 const uint32_t canon = min(fwd, rev);
                 const uint64_t h = mm_hash64((uint64_t)canon);
-                if (b < NB && b >= (int)K - 1 && good >= K && h < thr) {
-                    const uint32_t rel = toff + (uint32_t)(b - ((int)K - 1));  // position - blk0 (< 16384)
-                    const uint32_t li = atomicAdd(&l_n, 1u);
-                    if (li < SEED_LDS_CAP) { l_code[li] = canon; l_pos[li] = (uint16_t)rel; }
-                    else {  // LDS buffer full (never at c=125): straight to the global list
-                        const uint32_t ch = ch_first + (rem_first + rel) / chunk;
-                        uint32_t idx = atomicAdd(&seed_count[g], 1u);
-                        if (idx < scap) { seed_code[sstart + idx] = canon; seed_chunk[sstart + idx] = (uint16_t)ch; }
-                        atomicAdd(&ctot[ch], 1u);
+                const bool pass = b < NB && b >= (int)K - 1 && good >= K && h < thr;
+                // Wave-private append: rank among the passing lanes by ballot/mbcnt, wave-uniform count
+                // in a scalar -- no LDS atomic (its returned value would stall the wave ~100 cycles at
+                // 40 % of the positions).
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const uint32_t slot = wave_n + rank;
+                    if (pass) {
+                        const uint32_t rel = toff + (uint32_t)(b - ((int)K - 1));  // position - blk0 (< 16384)
+                        if (slot < SEED_WAVE_CAP) { l_code[wave_base + slot] = canon; l_pos[wave_base + slot] = (uint16_t)rel; }
+                        else {  // wave buffer full (never at c=125): straight to the global list
+                            const uint32_t ch = ch_first + (rem_first + rel) / chunk;
+                            uint32_t idx = atomicAdd(&seed_count[g], 1u);
+                            if (idx < scap) { seed_code[sstart + idx] = canon; seed_chunk[sstart + idx] = (uint16_t)ch; }
+                            atomicAdd(&ctot[ch], 1u);
+                        }
                     }
+                    wave_n += (uint32_t)__popcll(m);
                 }
             }
         }
+        if ((threadIdx.x & 63u) == 0) l_wave_n[threadIdx.x >> 6] = min(wave_n, SEED_WAVE_CAP);
     }
     __syncthreads();
-    const uint32_t nloc = min(l_n, SEED_LDS_CAP);
-    if (threadIdx.x == 0) l_base = nloc ? atomicAdd(&seed_count[g], nloc) : 0u;
+    // one global atomic per block reserves room for all waves' seeds; then every wave flushes its own
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < GHIP_SKETCH_THREADS / 64; w++) { l_wave_base[w] = tot; tot += l_wave_n[w]; }
+        const uint32_t base = tot ? atomicAdd(&seed_count[g], tot) : 0u;
+        for (uint32_t w = 0; w < GHIP_SKETCH_THREADS / 64; w++) l_wave_base[w] += base;
+    }
     __syncthreads();
-    const uint32_t base = l_base;
-    for (uint32_t i = threadIdx.x; i < nloc; i += blockDim.x) {
-        const uint32_t chrel = (rem_first + l_pos[i]) / chunk;
-        const uint32_t idx = base + i;
-        if (idx < scap) { seed_code[sstart + idx] = l_code[i]; seed_chunk[sstart + idx] = (uint16_t)(ch_first + chrel); }
-        if (chrel < SEED_LDS_CHUNKS) atomicAdd(&l_ctot[chrel], 1u);
-        else atomicAdd(&ctot[ch_first + chrel], 1u);
+    {
+        const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        const uint32_t nw = l_wave_n[w], gbase = l_wave_base[w];
+        for (uint32_t i = lane; i < nw; i += 64) {
+            const uint32_t chrel = (rem_first + l_pos[wave_base + i]) / chunk;
+            const uint32_t idx = gbase + i;
+            if (idx < scap) { seed_code[sstart + idx] = l_code[wave_base + i]; seed_chunk[sstart + idx] = (uint16_t)(ch_first + chrel); }
+            if (chrel < SEED_LDS_CHUNKS) atomicAdd(&l_ctot[chrel], 1u);
+            else atomicAdd(&ctot[ch_first + chrel], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < SEED_LDS_CHUNKS && l_ctot[threadIdx.x]) atomicAdd(&ctot[ch_first + threadIdx.x], l_ctot[threadIdx.x]);

@@ -1,0 +1,88 @@
+// Micro-benchmark: issue cost (cycles per wave64 instruction per SIMD) of the integer ops the
+// sketch / seed kernels are made of.  Each kernel runs 8 independent dependency chains per lane.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define REP 4096
+#define CHAINS 8
+
+#define KERNEL(NAME, DECL, BODY, SINK)                                                          \
+    __global__ void NAME(uint64_t *out, uint32_t seed) {                                        \
+        DECL;                                                                                    \
+        for (int i = 0; i < REP; i++) { BODY }                                                   \
+        SINK;                                                                                    \
+    }
+
+KERNEL(k_add32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mul_lo, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mul_hi, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mul_u24, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mad64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(a[c]) : "v"(seed) : "vcc");,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_lshl_add64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshl_add_u64 %0, %0, 3, %0" : "+v"(a[c]));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_lshl64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(a[c]));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_lshr64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = ~0ull - seed - c - threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(a[c]));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_alignbit, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_addc_pair, uint32_t lo[CHAINS]; uint32_t hi[CHAINS]; for (int c = 0; c < CHAINS; c++) { lo[c] = seed + c + threadIdx.x; hi[c] = c; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(lo[c]), "+v"(hi[c]) : "v"(seed) : "vcc");,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += lo[c] + hi[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_cmp64, uint64_t a[CHAINS]; uint32_t cnt = 0; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_cmp_lt_u64 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a[c]), "v"(a[(c + 1) % CHAINS]) : "vcc");,
+       out[blockIdx.x * blockDim.x + threadIdx.x] = cnt)
+KERNEL(k_perm, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_perm_b32 %0, %0, %1, %0" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+
+template <typename K>
+static void run(const char *name, K kern, uint64_t *d_out, int insts_per_iter) {
+    const int blocks = 256 * 8, threads = 256;  // 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double wave_insts = (double)blocks * (threads / 64) * REP * CHAINS * insts_per_iter;
+    const double simd_cycles = ms * 1e-3 * 2.4e9 * 1024;  // 1024 SIMDs, nominal 2.4 GHz (DVFS makes this an upper bound)
+    printf("%-14s %8.3f ms  %6.2f SIMD-cycles per wave-instruction (at 2.4 GHz)\n", name, ms, simd_cycles / wave_insts);
+}
+
+int main() {
+    uint64_t *d_out;
+    hipMalloc(&d_out, 256 * 8 * 256 * 8);
+    run("v_add_u32", k_add32, d_out, 1);
+    run("v_mul_lo_u32", k_mul_lo, d_out, 1);
+    run("v_mul_hi_u32", k_mul_hi, d_out, 1);
+    run("v_mul_u32_u24", k_mul_u24, d_out, 1);
+    run("v_mad_u64_u32", k_mad64, d_out, 1);
+    run("v_lshl_add_u64", k_lshl_add64, d_out, 1);
+    run("v_lshlrev_b64", k_lshl64, d_out, 1);
+    run("v_lshrrev_b64", k_lshr64, d_out, 1);
+    run("v_alignbit_b32", k_alignbit, d_out, 1);
+    run("add_co+addc", k_addc_pair, d_out, 2);
+    run("cmp_lt_u64+addc", k_cmp64, d_out, 2);
+    run("v_perm_b32", k_perm, d_out, 1);
+    return 0;
+}
