@@ -160,6 +160,7 @@ def main():
 
     for _ in range(args.warmup):
         job.step()
+    job.reset_stage_timers()
     ctx.profile(True)
     ctx.profile_reset()
     barrier()

@@ -18,11 +18,24 @@ namespace {
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
+// x * C mod 2^64 as three v_mad_u64_u32 (32x32+64): on gfx950 every VOP3 integer op issues in ~4.4
+// cycles per wave64, multiplies included (scripts/ubench/int_ops.hip), so instruction COUNT is what
+// matters; hipcc's default expansion is five instructions (mad64, 2x mul_lo, 2x add).
+template <uint64_t C>
+__device__ __forceinline__ uint64_t mulc(uint64_t x) {
+    constexpr uint32_t c_lo = (uint32_t)C, c_hi = (uint32_t)(C >> 32);
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint64_t r0 = (uint64_t)lo * c_lo;
+    uint64_t acc = (uint64_t)lo * c_hi + (r0 >> 32);
+    acc = (uint64_t)hi * c_lo + acc;
+    return (uint64_t)(uint32_t)r0 | (acc << 32);
+}
+
 __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
     k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdULL;
+    k = mulc<0xff51afd7ed558ccdULL>(k);
     k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ULL;
+    k = mulc<0xc4ceb9fe1a85ec53ULL>(k);
     k ^= k >> 33;
     return k;
 }
@@ -120,14 +133,14 @@ __device__ __forceinline__ void build_kmer_luts(KmerLuts &L) {
 }
 
 __device__ __forceinline__ uint64_t hash_canonical21_lut(uint64_t code_le, uint32_t seed, const KmerLuts &L) {
-    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    constexpr uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
     const uint32_t lo = (uint32_t)code_le, hi = (uint32_t)(code_le >> 32);
     uint64_t h1 = seed, h2 = seed;
     uint64_t k1 = L.c1[lo & 0xffu] + ((uint64_t)(uint32_t)L.c1[(lo >> 8) & 0xffu] << 32);    // k1 * c1
     uint64_t k2 = L.c2[(lo >> 16) & 0xffu] + ((uint64_t)(uint32_t)L.c2[lo >> 24] << 32);     // k2 * c2
-    k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    k1 = rotl64(k1, 31); k1 = mulc<c2>(k1); h1 ^= k1;
     h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-    k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    k2 = rotl64(k2, 33); k2 = mulc<c1>(k2); h2 ^= k2;
     h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
     h1 ^= L.tail[hi & 0x3ffu];
     h1 ^= 21ull; h2 ^= 21ull;
@@ -207,9 +220,9 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
             fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
             good = valid ? good + 1 : 0;
             if (b < K - 1) continue;  // compile-time: warm-up bytes only roll the state
-            // reverse complement: rc_be = ~fwd_le, rc_le = ~fwd_be (complement = 3 - code)
-            uint64_t rc_be = (~fwd_le) & mask;
-            uint64_t canon_le = (rc_be < fwd_be) ? ((~fwd_be) & mask) : fwd_le;
+            // reverse complement: rc_be = mask - fwd_le, rc_le = mask - fwd_be (complement = 3 - code), so
+            // rc_be < fwd_be  <=>  fwd_be + fwd_le > mask
+            uint64_t canon_le = (fwd_be + fwd_le > mask) ? (mask - fwd_be) : fwd_le;
             uint64_t h = (K == 21) ? hash_canonical21_lut(canon_le, seed, luts) : hash_canonical<K>(canon_le, seed);
             if (good >= (uint32_t)K && h <= thr) {  // rare: ~2.5*s survivors per genome
                 uint32_t idx = atomicAdd(&cand_count[slot], 1u);

@@ -231,6 +231,9 @@ class DereplicationJob:
         self._stage[name] = self._stage.get(name, 0.0) + (t1 - t0)
         return t1
 
+    def reset_stage_timers(self):
+        self._stage, self._steps = {}, 0
+
     def stage_ms(self) -> Dict[str, float]:
         return {k: v / max(self._steps, 1) * 1e3 for k, v in self._stage.items()}
 
