@@ -175,9 +175,11 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     const uint32_t *__restrict__ in_code, const uint16_t *__restrict__ in_chunk,
     uint32_t *__restrict__ out_code, uint16_t *__restrict__ out_chunk,
     const uint64_t *__restrict__ seed_start, const uint32_t *__restrict__ seed_count,
-    uint32_t *__restrict__ bin_start) {
+    uint32_t *__restrict__ bin_start, uint32_t *__restrict__ pos_tmp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);  // BIN_COUNT counters
+    constexpr uint32_t BIN_WINDOW = 8192;
+    static_assert(BIN_WINDOW * 6 <= BIN_COUNT * 4, "the output window reuses the histogram's LDS");
     __shared__ uint32_t wave_tot[BIN_THREADS / 64];
     const uint32_t g = blockIdx.x;
     const uint64_t s0 = seed_start[g];
@@ -212,15 +214,32 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     }
     if (threadIdx.x == BIN_THREADS - 1) bstart[BIN_COUNT] = run;  // == n
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
-        const uint32_t c = in_code[s0 + i];
-        const uint32_t pos = atomicAdd(&hist[code_bin(c)], 1u);
-        out_code[s0 + pos] = c;
-        out_chunk[s0 + pos] = in_chunk[s0 + i];
+    // destination slot of every seed (one LDS atomic each), kept in a scratch array
+    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS)
+        pos_tmp[s0 + i] = atomicAdd(&hist[code_bin(in_code[s0 + i])], 1u);
+    __syncthreads();
+    // Scatter through an LDS window and write each window out contiguously: scattering 4-byte
+    // stores straight to HBM costs a whole sector per seed (PMC: 3.3 GB written for 0.27 GB).
+    uint32_t *w_code = hist;                                               // 8192 x 4 B (the histogram is dead)
+    uint16_t *w_chunk = reinterpret_cast<uint16_t *>(hist + BIN_WINDOW);   // 8192 x 2 B
+    for (uint32_t w0 = 0; w0 < n; w0 += BIN_WINDOW) {
+        for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
+            const uint32_t p = pos_tmp[s0 + i] - w0;
+            if (p < BIN_WINDOW) { w_code[p] = in_code[s0 + i]; w_chunk[p] = in_chunk[s0 + i]; }
+        }
+        __syncthreads();
+        const uint32_t m = min(BIN_WINDOW, n - w0);
+        for (uint32_t k = threadIdx.x; k < m; k += BIN_THREADS) {
+            out_code[s0 + w0 + k] = w_code[k];
+            out_chunk[s0 + w0 + k] = w_chunk[k];
+        }
+        __syncthreads();
     }
 }
 
 constexpr uint32_t ANI_PAIR_THREADS = 512;
+constexpr uint32_t ANI_PAIR_WAVES = ANI_PAIR_THREADS / 64;
+constexpr uint32_t ANI_STAGE = 448;  // seeds of 64 consecutive bins staged per wave and genome (expected ~154)
 
 __device__ __forceinline__ void reduce_direction(const uint32_t *mc, const uint32_t *tc, uint32_t nch, uint64_t L,
                                                  uint32_t chunk, unsigned long long *red) {
@@ -244,6 +263,11 @@ __device__ __forceinline__ void reduce_direction(const uint32_t *mc, const uint3
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[0], M); atomicAdd(&red[1], T); atomicAdd(&red[2], bases); }
 }
 
+// The 64 bins a wave joins in one round are consecutive, so their seeds form ONE contiguous run
+// per genome: the wave copies both runs into its private LDS stage with coalesced loads and every
+// lane then joins its own bin out of LDS.  (Walking the bins straight from global memory chained
+// ~25 dependent L2 round trips per lane and bin.)  A round whose run exceeds the stage -- a
+// pathologically repetitive genome -- falls back to the global-memory walk for that round only.
 __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ seed_code,
     const uint16_t *__restrict__ seed_chunk, const uint64_t *__restrict__ seed_start,
@@ -251,8 +275,10 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, uint32_t chunk,
     uint64_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
     __shared__ unsigned long long red[6];
+    __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE];
+    __shared__ uint16_t st_chunk[ANI_PAIR_WAVES][2][ANI_STAGE];
+    uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
 
     // physical block b runs on XCD b % 8: give each XCD runs of 32 consecutive pairs (one precluster's
     // genomes are then re-read from that XCD's L2)
@@ -270,20 +296,65 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t *qb = bin_start + (uint64_t)q * (BIN_COUNT + 1), *rb = bin_start + (uint64_t)r * (BIN_COUNT + 1);
     const uint32_t *qc = seed_code + seed_start[q], *rc = seed_code + seed_start[r];
     const uint16_t *qk = seed_chunk + seed_start[q], *rk = seed_chunk + seed_start[r];
-    for (uint32_t b = threadIdx.x; b < BIN_COUNT; b += blockDim.x) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *sq = st_code[wave][0], *sr = st_code[wave][1];
+    uint16_t *kq = st_chunk[wave][0], *kr = st_chunk[wave][1];
+    for (uint32_t b0 = wave * 64; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * 64) {
+        const uint32_t b = b0 + lane;
         const uint32_t qs = qb[b], qe = qb[b + 1], rs = rb[b], re = rb[b + 1];
-        if (qs == qe || rs == re) continue;
-        for (uint32_t i = qs; i < qe; i++) {       // q seeds that occur in r
-            const uint32_t c = qc[i];
-            bool hit = false;
-            for (uint32_t j = rs; j < re; j++) hit |= (rc[j] == c);
-            if (hit) atomicAdd(&mcq[qk[i]], 1u);
-        }
-        for (uint32_t j = rs; j < re; j++) {       // r seeds that occur in q
-            const uint32_t c = rc[j];
-            bool hit = false;
-            for (uint32_t i = qs; i < qe; i++) hit |= (qc[i] == c);
-            if (hit) atomicAdd(&mcr[rk[j]], 1u);
+        const uint32_t q_lo = __shfl(qs, 0, 64), q_hi = __shfl(qe, 63, 64);
+        const uint32_t r_lo = __shfl(rs, 0, 64), r_hi = __shfl(re, 63, 64);
+        if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
+        const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
+        if (staged) {
+            for (uint32_t k = lane; k < q_hi - q_lo; k += 64) { sq[k] = qc[q_lo + k]; kq[k] = qk[q_lo + k]; }
+            for (uint32_t k = lane; k < r_hi - r_lo; k += 64) { sr[k] = rc[r_lo + k]; kr[k] = rk[r_lo + k]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t qa = qs - q_lo, qz = qe - q_lo, ra = rs - r_lo, rz = re - r_lo;
+            if (rz - ra <= 32) {  // one pass: per-q "any match" plus a bit mask of matched r seeds
+                uint32_t rmask = 0;
+                for (uint32_t i = qa; i < qz; i++) {
+                    const uint32_t c = sq[i];
+                    uint32_t m = 0;
+                    for (uint32_t j = ra; j < rz; j++) m |= (uint32_t)(sr[j] == c) << (j - ra);
+                    if (m) atomicAdd(&mcq[kq[i]], 1u);
+                    rmask |= m;
+                }
+                while (rmask) {
+                    const uint32_t j = ra + (uint32_t)__builtin_ctz(rmask);
+                    rmask &= rmask - 1;
+                    atomicAdd(&mcr[kr[j]], 1u);
+                }
+            } else {
+                for (uint32_t i = qa; i < qz; i++) {       // q seeds that occur in r
+                    const uint32_t c = sq[i];
+                    bool hit = false;
+                    for (uint32_t j = ra; j < rz; j++) hit |= (sr[j] == c);
+                    if (hit) atomicAdd(&mcq[kq[i]], 1u);
+                }
+                for (uint32_t j = ra; j < rz; j++) {       // r seeds that occur in q
+                    const uint32_t c = sr[j];
+                    bool hit = false;
+                    for (uint32_t i = qa; i < qz; i++) hit |= (sq[i] == c);
+                    if (hit) atomicAdd(&mcr[kr[j]], 1u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
+        } else {
+            for (uint32_t i = qs; i < qe; i++) {
+                const uint32_t c = qc[i];
+                bool hit = false;
+                for (uint32_t j = rs; j < re; j++) hit |= (rc[j] == c);
+                if (hit) atomicAdd(&mcq[qk[i]], 1u);
+            }
+            for (uint32_t j = rs; j < re; j++) {
+                const uint32_t c = rc[j];
+                bool hit = false;
+                for (uint32_t i = qs; i < qe; i++) hit |= (qc[i] == c);
+                if (hit) atomicAdd(&mcr[rk[j]], 1u);
+            }
         }
     }
     __syncthreads();
@@ -311,7 +382,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
 
 void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint16_t *in_chunk, uint32_t *out_code,
                          uint16_t *out_chunk, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
-                         uint32_t *d_bin_start) {
+                         uint32_t *d_bin_start, uint32_t *d_pos_tmp) {
     if (n == 0) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -320,7 +391,7 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
     }
     ghip_prof_begin(ctx, "ani_bin");
     hipLaunchKernelGGL(ani_bin_kernel, dim3((unsigned)n), dim3(BIN_THREADS), BIN_COUNT * sizeof(uint32_t), ctx->stream,
-                       in_code, in_chunk, out_code, out_chunk, d_seed_start, d_seed_count, d_bin_start);
+                       in_code, in_chunk, out_code, out_chunk, d_seed_start, d_seed_count, d_bin_start, d_pos_tmp);
     ghip_prof_end(ctx);
 }
 
@@ -328,11 +399,10 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
                            uint32_t max_chunks, uint64_t *d_out) {
     if (n_pairs == 0) return;
     const size_t lds = (size_t)2 * max_chunks * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr_set = true;
+    static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand (+43 KiB static stage)
+    if (lds > attr_lds) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
     }
     ghip_prof_begin(ctx, "ani_pairs");
     const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs

@@ -129,6 +129,27 @@ double finch_ani(uint64_t common, uint64_t total, uint32_t k) {
     return 1.0 - cl;
 }
 
+// strtof(sprintf("%.2f", x)) for x in [0, 100]: hundredths -> f32 from a table built with strtof itself;
+// the hundredth is found arithmetically unless x*100 is within 1e-6 of a rounding tie, where printf's exact
+// decimal rounding is consulted.
+float two_decimals_as_f32(double x) {
+    static std::vector<float> table = [] {
+        std::vector<float> t(10001);
+        char txt[32];
+        for (int k = 0; k <= 10000; k++) { snprintf(txt, sizeof txt, "%d.%02d", k / 100, k % 100); t[k] = strtof(txt, nullptr); }
+        return t;
+    }();
+    const double y = x * 100.0;
+    const double fl = std::floor(y);
+    const double frac = y - fl;
+    if (!(x >= 0.0 && x <= 100.0) || std::fabs(frac - 0.5) < 1e-6) {
+        char txt[64];
+        snprintf(txt, sizeof txt, "%.2f", x);
+        return strtof(txt, nullptr);
+    }
+    return table[(int)fl + (frac > 0.5 ? 1 : 0)];
+}
+
 struct DeviceFree {  // scratch buffers go back to the pool; ctx->mu is held by the caller
     ghip_ctx *ctx;
     std::vector<void *> ptrs;
@@ -819,17 +840,18 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
     }
     if (rc == GHIP_OK) {
         // reorder every genome's seed list by hash bin and record the bin offsets (the join index)
-        uint32_t *d_code2 = nullptr; uint16_t *d_chunk2 = nullptr;
+        uint32_t *d_code2 = nullptr, *d_pos = nullptr; uint16_t *d_chunk2 = nullptr;
         if (!(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) &&
-            !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n]))) {
+            !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n])) &&
+            !(rc = dmalloc(ctx, &d_pos, idx->seed_start[n]))) {
             ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_chunk, d_code2, d_chunk2, idx->d_seed_start,
-                                idx->d_seed_count, idx->d_bin_start);
+                                idx->d_seed_count, idx->d_bin_start, d_pos);
             std::swap(idx->d_seed_code, d_code2);
             std::swap(idx->d_seed_chunk, d_chunk2);
             if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
                 rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
         }
-        ghip_pool_free(ctx, d_code2); ghip_pool_free(ctx, d_chunk2);  // the unordered lists
+        ghip_pool_free(ctx, d_code2); ghip_pool_free(ctx, d_chunk2); ghip_pool_free(ctx, d_pos);  // the unordered lists
     }
     if (rc) { free_index_locked(idx); return rc; }
     *out = idx;
@@ -868,9 +890,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
         if (T != 0 && M != 0 && !(afq < (double)min_af && afr < (double)min_af)) {
             // skani prints ANI with two decimals and galah parses that text as f32 (src/skani.rs:770)
             double ani = 100.0 * std::pow((double)M / (double)T, 1.0 / (double)idx->k);
-            char txt[64];
-            snprintf(txt, sizeof txt, "%.2f", ani);
-            v = strtof(txt, nullptr);
+            v = two_decimals_as_f32(ani);
         }
         out_ani[p] = v;
     }

@@ -118,7 +118,7 @@ struct ghip_ani_index {
 
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
-#define GHIP_ANI_MAX_CHUNKS 19000u  // two u32 counter arrays of one pair must fit the 160 KiB LDS
+#define GHIP_ANI_MAX_CHUNKS 14000u  // two u32 counter arrays of one pair + the 43 KiB stage must fit the 160 KiB LDS
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);
 
@@ -171,7 +171,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
                            const ghip_sketch_work *d_work, size_t n_work);
 void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint16_t *in_chunk, uint32_t *out_code,
                          uint16_t *out_chunk, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
-                         uint32_t *d_bin_start);
+                         uint32_t *d_bin_start, uint32_t *d_pos_tmp);
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out /* [n_pairs][2][3] = M, T, aligned bases */);
 
