@@ -5,8 +5,8 @@
 // The device does integer work only; the host finishes pow/rounding.
 //
 //   ani_seeds : pass over the base stream; canonical 2-bit k-mer (k <= 16, fits u32) ->
-//               invertible 64-bit mix; seeds with hash < 2^64/c are appended as (code u32,
-//               chunk u16) and counted per chunk.  The mix is invertible, so "same hash" ==
+//               fmix32 (bijective); seeds with fmix32(code) < 2^32/c are appended as (code u32,
+//               chunk u16) and counted per chunk.  The mix is a bijection, so "same hash" ==
 //               "same code" and the 4-byte code is what is stored and compared.
 //   ani_bin   : per genome, counting sort of the seed list by the top 14 bits of a 32-bit
 //               multiplicative hash of the code; writes the binned list and its bin offsets
@@ -21,28 +21,15 @@
 
 namespace {
 
-// D = (a << sh) + b in one VALU op (sh <= 4).  hipcc turns the *265 and *21 steps of the mix into
-// 64-bit multiplies (3 quarter-rate ops each); spelled as shift-adds they are 5 full-rate ops.
-template <int SH>
-__device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {
-    uint64_t d;
-    asm("v_lshl_add_u64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
-    return d;
-}
-
-// minimap2 / skani invertible 64-bit mix
-__device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
-    key = ~key + (key << 21);
-    key = key ^ (key >> 24);
-    {   // key * 265 = key + (key << 3) + (key << 8)
-        const uint64_t t = lshl_add_u64<3>(key, key);
-        key = lshl_add_u64<4>(lshl_add_u64<4>(key, 0ull), t);
-    }
-    key = key ^ (key >> 14);
-    key = lshl_add_u64<4>(key, lshl_add_u64<2>(key, key));  // key * 21
-    key = key ^ (key >> 28);
-    key = key + (key << 31);
-    return key;
+// Seed-selection hash: MurmurHash3 fmix32, a bijection on the 32-bit canonical code (see
+// oracle/galah_oracle_ani.c).  8 instructions per position; every position of every genome pays it.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
 }
 
 __device__ __forceinline__ uint32_t base_code(uint32_t c) {
@@ -61,7 +48,7 @@ constexpr uint32_t SEED_LDS_CHUNKS = 64;  // per-block chunk counters
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const ghip_sketch_work *__restrict__ work, uint32_t K,
-    uint64_t thr, uint32_t chunk, uint32_t *__restrict__ seed_code, uint16_t *__restrict__ seed_chunk,
+    uint32_t thr, uint32_t chunk, uint32_t *__restrict__ seed_code, uint16_t *__restrict__ seed_chunk,
     const uint64_t *__restrict__ seed_start, uint32_t *__restrict__ seed_count,
     uint32_t *__restrict__ chunk_total, const uint64_t *__restrict__ chunk_start) {
     __shared__ uint32_t l_code[SEED_LDS_CAP];
@@ -116,8 +103,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 rev = (rev >> 2) | ((3u - code) << top);
                 good = valid ? good + 1 : 0;
                 const uint32_t canon = min(fwd, rev);
-                const uint64_t h = mm_hash64((uint64_t)canon);
-                const bool pass = b < NB && b >= (int)K - 1 && good >= K && h < thr;
+                const bool pass = b < NB && b >= (int)K - 1 && good >= K && fmix32(canon) < thr;
                 // Wave-private append: rank among the passing lanes by ballot/mbcnt, wave-uniform count
                 // in a scalar -- no LDS atomic (its returned value would stall the wave ~100 cycles at
                 // 40 % of the positions).
@@ -371,7 +357,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    const uint64_t thr = ~0ull / c;
+    const uint32_t thr = ~0u / c;
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),

@@ -10,13 +10,13 @@
  * (SURVEY.md 8c).  What follows is therefore a BUILD-DEFINED estimator in skani's style
  * (Shaw & Yu 2023: FracMinHash seeds k=15 c=125, ~20 kb query chunks, ANI from seed
  * containment^(1/k), aligned fraction gate, two-decimal TSV output) WITHOUT skani's
- * colinear chaining and learned regression.  It defines what the HIP ani_pairs kernel
+ * colinear chaining and learned regression, and with a 32-bit invertible seed hash.  It defines what the HIP ani_pairs kernel
  * must reproduce; it makes no claim to reproduce skani's floats.
  *
  * Definition (all integer until the final pow):
  *   stream G  = for each FASTA record: normalised bytes, then one 'N'          (length L)
- *   seed at p = window G[p..p+k) all ACGT; code = min(2-bit fwd, 2-bit revcomp) (A0 C1 G2 T3,
- *               first base most significant); h = mm_hash64(code); kept iff h < 2^64-1 / c
+ *   seed at p = window G[p..p+k) all ACGT (k <= 16); code = min(2-bit fwd, 2-bit revcomp) (A0 C1 G2
+ *               T3, first base most significant); kept iff fmix32(code) < (2^32-1) / c
  *   chunk(p)  = p / chunk_len
  *   q->r      : for every chunk of q: T_c = #seeds, M_c = #seeds whose h is a seed of r;
  *               chunk aligned iff T_c >= 1 and M_c * 10000 >= 510 * T_c   (0.82^15 ~ 0.0510)
@@ -45,16 +45,17 @@ struct go_ani_sketch {
     uint32_t n_chunks;
 };
 
-/* minimap2's invertible integer hash, the one skani's seeding uses [recollection]. */
-static inline uint64_t mm_hash64(uint64_t key) {
-    key = ~key + (key << 21);
-    key = key ^ (key >> 24);
-    key = (key + (key << 3)) + (key << 8);
-    key = key ^ (key >> 14);
-    key = (key + (key << 2)) + (key << 4);
-    key = key ^ (key >> 28);
-    key = key + (key << 31);
-    return key;
+/* Seed-selection hash: MurmurHash3's 32-bit finaliser (a bijection on 32 bits) over the canonical
+ * 2-bit k-mer code (k <= 16).  skani uses minimap2's invertible 64-bit mix for the same purpose; any
+ * invertible mix gives a FracMinHash, and this one is 8 integer instructions per position on the GPU
+ * instead of ~30 (the seeding pass hashes every position of every genome). */
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
 }
 
 static int cmp_u64(const void *a, const void *b) {
@@ -69,7 +70,7 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
     size_t cap = n / (c ? c : 1) + 1024;
     s->h = (uint64_t *)malloc(cap * sizeof(uint64_t));
     s->chunk_id = (uint32_t *)malloc(cap * sizeof(uint32_t));
-    const uint64_t thr = UINT64_MAX / c;
+    const uint32_t thr = UINT32_MAX / c;
     const uint64_t mask = (k < 32) ? ((1ULL << (2 * k)) - 1) : UINT64_MAX;
     uint64_t fwd = 0, rev = 0;
     size_t good = 0;
@@ -81,8 +82,8 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
         rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k - 1)));
         if (++good < k) continue;
         uint64_t code = fwd < rev ? fwd : rev;
-        uint64_t h = mm_hash64(code);
-        if (h >= thr) continue;
+        if (fmix32((uint32_t)code) >= thr) continue;
+        uint64_t h = code; /* the mix is a bijection: seeds are identified by their code */
         if (s->n == cap) {
             cap *= 2;
             s->h = (uint64_t *)realloc(s->h, cap * sizeof(uint64_t));
