@@ -65,9 +65,10 @@ def pmc_traffic(kernel: str):
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d["kernels"][kernel + "_kernel"]["hbm_bytes_per_launch"]), d.get("tag")
+        k = d["kernels"][kernel + "_kernel"]
+        return float(k["hbm_bytes_per_launch"]), d.get("tag"), k.get("valu_busy")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def cpu_baseline(args, hashes, lens, n_pairs_total, min_ani, gpu_pairs=None):
@@ -197,11 +198,12 @@ def main():
                     e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBS
                 kern[k] = e
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
-        traffic, traffic_tag = pmc_traffic(dom) if world == 1 else (None, None)
+        traffic, traffic_tag, valu_busy = pmc_traffic(dom) if world == 1 else (None, None, None)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
                     "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag,
                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "valu_busy": valu_busy,  # SQ_ACTIVE_INST_VALU*4 / (SIMDs * GRBM_GUI_ACTIVE), same PMC file
                     "note": ("sketch_kmers is integer-VALU bound (MurmurHash3 multiplies), not HBM bound; "
                              "pair_intersect_tile is the HBM-roofline kernel of the path, see 'kernels'")}
         out = {

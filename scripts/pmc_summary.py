@@ -26,6 +26,30 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, (n, v) in agg.items():
         out[k][C + "_KB_per_launch"] = v / n
         out[k]["launches_" + C] = n
+# third pass (scripts/gpu_pmc.sh): SQ counters -> VALU pipe occupancy.  GRBM_GUI_ACTIVE comes back summed
+# over the 8 XCDs, SQ_ACTIVE_INST_VALU in quad-cycles summed over all SIMDs:
+#   VALUBusy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+try:
+    sq = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    import glob
+    for fpath in glob.glob(f"{src}/SQ/*counter_collection.csv"):
+        for r in csv.DictReader(open(fpath)):
+            m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+            if not m:
+                continue
+            sq[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_WAVES":
+                cnt[m.group(1)] += 1
+    for k, d in sq.items():
+        n = max(cnt[k], 1)
+        out[k]["valu_insts_per_launch"] = d["SQ_INSTS_VALU"] / n
+        out[k]["salu_insts_per_launch"] = d["SQ_INSTS_SALU"] / n
+        out[k]["lds_insts_per_launch"] = d["SQ_INSTS_LDS"] / n
+        if d["GRBM_GUI_ACTIVE"] > 0:
+            out[k]["valu_busy"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0)
+except Exception as e:  # the SQ pass is optional
+    print("no SQ pass:", e)
 for k, d in out.items():
     f = d.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024
     w = d.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
@@ -34,4 +58,5 @@ for k, d in out.items():
 json.dump({"tag": tag, "command": "rocprofv3 --pmc <C> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
            "kernels": out}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
 for k, d in sorted(out.items(), key=lambda x: -x[1]["hbm_bytes_per_launch"]):
-    print("%-28s %.3f GB/launch" % (k, d["hbm_bytes_per_launch"] / 1e9))
+    print("%-28s %.3f GB/launch  VALUBusy %s" % (k, d["hbm_bytes_per_launch"] / 1e9,
+                                                 ("%.0f %%" % (100 * d["valu_busy"])) if "valu_busy" in d else "-"))
