@@ -18,61 +18,25 @@
 //               sum M_c, sum T_c and aligned bases per direction.  All four streams (two
 //               bin-offset arrays, two code arrays) are read front to back, coalesced.
 #include "ghip_internal.h"
+#include "seed_common.h"
 
 namespace {
 
-// Seed-selection hash: MurmurHash3 fmix32, a bijection on the 32-bit canonical code (see
-// oracle/galah_oracle_ani.c).  8 instructions per position; every position of every genome pays it.
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16;
-    h *= 0x85ebca6bu;
-    h ^= h >> 13;
-    h *= 0xc2b2ae35u;
-    h ^= h >> 16;
-    return h;
-}
+using namespace ghip_seed;
 
-__device__ __forceinline__ uint32_t base_code(uint32_t c) {
-    uint32_t d = c - 0x41u;
-    bool ok = d < 20u && ((0x80045u >> d) & 1u);
-    return ok ? (((c >> 1) ^ (c >> 2)) & 3u) : 4u;
-}
-
-constexpr uint32_t SEED_LDS_CAP = 1024;   // seeds buffered per block (expected 16384/c ~ 131)
-constexpr uint32_t SEED_LDS_CHUNKS = 64;  // per-block chunk counters
-
-// Seeds are rare (1/c of the k-mers) but with 64 lanes a wave still meets one at ~40 % of the
-// positions, so the per-seed work inside the position loop is kept to one LDS atomic and two LDS
-// stores (code, block-relative position); chunk ids, per-chunk totals and the global append are
-// done afterwards by all threads, with ONE global atomic per block on the genome's counter.
+// Standalone seeding pass (the fused form lives in sketch.hip: sketch_kmers<K, true>).
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
-    const uint64_t *__restrict__ lens, const ghip_sketch_work *__restrict__ work, uint32_t K,
-    uint32_t thr, uint32_t chunk, uint32_t *__restrict__ seed_code, uint16_t *__restrict__ seed_chunk,
-    const uint64_t *__restrict__ seed_start, uint32_t *__restrict__ seed_count,
-    uint32_t *__restrict__ chunk_total, const uint64_t *__restrict__ chunk_start) {
-    __shared__ uint32_t l_code[SEED_LDS_CAP];
-    __shared__ uint16_t l_pos[SEED_LDS_CAP];
-    __shared__ uint32_t l_ctot[SEED_LDS_CHUNKS];
-    __shared__ uint32_t l_wave_n[GHIP_SKETCH_THREADS / 64], l_wave_base[GHIP_SKETCH_THREADS / 64];
-    constexpr uint32_t SEED_WAVE_CAP = SEED_LDS_CAP / (GHIP_SKETCH_THREADS / 64);
-    const uint32_t wave_base = (threadIdx.x >> 6) * SEED_WAVE_CAP;
-    uint32_t wave_n = 0;
-
+    const uint64_t *__restrict__ lens, const ghip_sketch_work *__restrict__ work, SeedOut so) {
+    __shared__ SeedLds sl;
     const ghip_sketch_work wk = work[blockIdx.x];
     const uint32_t g = wk.slot;
     const uint64_t L = lens[g];
     const uint64_t blk0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK;
     const uint32_t toff = threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
     const uint64_t p0 = blk0 + toff;
-    const uint32_t ch_first = (uint32_t)(blk0 / chunk);
-    const uint32_t rem_first = (uint32_t)(blk0 - (uint64_t)ch_first * chunk);
-    const uint64_t sstart = seed_start[g];
-    const uint32_t scap = (uint32_t)(seed_start[g + 1] - sstart);
-    uint32_t *ctot = chunk_total + chunk_start[g];
-    if (threadIdx.x < SEED_LDS_CHUNKS) l_ctot[threadIdx.x] = 0;
-    __syncthreads();
-
+    const uint32_t K = so.k;
+    SeedBlock sb = seed_block_begin(sl, so, g, blk0);
     {
         // every base is fetched once: own 64 bytes from memory, the K-1 overlap bytes from the next
         // lane's registers (lane 63: from memory); lanes past the stream end hold 'N'
@@ -103,52 +67,12 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 rev = (rev >> 2) | ((3u - code) << top);
                 good = valid ? good + 1 : 0;
                 const uint32_t canon = min(fwd, rev);
-                const bool pass = b < NB && b >= (int)K - 1 && good >= K && fmix32(canon) < thr;
-                // Wave-private append: rank among the passing lanes by ballot/mbcnt, wave-uniform count
-                // in a scalar -- no LDS atomic (its returned value would stall the wave ~100 cycles at
-                // 40 % of the positions).
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const uint32_t slot = wave_n + rank;
-                    if (pass) {
-                        const uint32_t rel = toff + (uint32_t)(b - ((int)K - 1));  // position - blk0 (< 16384)
-                        if (slot < SEED_WAVE_CAP) { l_code[wave_base + slot] = canon; l_pos[wave_base + slot] = (uint16_t)rel; }
-                        else {  // wave buffer full (never at c=125): straight to the global list
-                            const uint32_t ch = ch_first + (rem_first + rel) / chunk;
-                            uint32_t idx = atomicAdd(&seed_count[g], 1u);
-                            if (idx < scap) { seed_code[sstart + idx] = canon; seed_chunk[sstart + idx] = (uint16_t)ch; }
-                            atomicAdd(&ctot[ch], 1u);
-                        }
-                    }
-                    wave_n += (uint32_t)__popcll(m);
-                }
+                const bool pass = b < NB && b >= (int)K - 1 && good >= K && fmix32(canon) < so.thr;
+                seed_append(sl, so, sb, pass, canon, toff + (uint32_t)(b - ((int)K - 1)));
             }
         }
-        if ((threadIdx.x & 63u) == 0) l_wave_n[threadIdx.x >> 6] = min(wave_n, SEED_WAVE_CAP);
     }
-    __syncthreads();
-    // one global atomic per block reserves room for all waves' seeds; then every wave flushes its own
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < GHIP_SKETCH_THREADS / 64; w++) { l_wave_base[w] = tot; tot += l_wave_n[w]; }
-        const uint32_t base = tot ? atomicAdd(&seed_count[g], tot) : 0u;
-        for (uint32_t w = 0; w < GHIP_SKETCH_THREADS / 64; w++) l_wave_base[w] += base;
-    }
-    __syncthreads();
-    {
-        const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-        const uint32_t nw = l_wave_n[w], gbase = l_wave_base[w];
-        for (uint32_t i = lane; i < nw; i += 64) {
-            const uint32_t chrel = (rem_first + l_pos[wave_base + i]) / chunk;
-            const uint32_t idx = gbase + i;
-            if (idx < scap) { seed_code[sstart + idx] = l_code[wave_base + i]; seed_chunk[sstart + idx] = (uint16_t)(ch_first + chrel); }
-            if (chrel < SEED_LDS_CHUNKS) atomicAdd(&l_ctot[chrel], 1u);
-            else atomicAdd(&ctot[ch_first + chrel], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < SEED_LDS_CHUNKS && l_ctot[threadIdx.x]) atomicAdd(&ctot[ch_first + threadIdx.x], l_ctot[threadIdx.x]);
+    seed_block_flush(sl, so, sb);
 }
 
 __device__ __forceinline__ uint32_t code_bin(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - GHIP_ANI_BIN_BITS); }
@@ -357,12 +281,11 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    const uint32_t thr = ~0u / c;
+    ghip_seed::SeedOut so{k, ~0u / c, chunk, d_seed_code, d_seed_chunk, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start};
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),
-                           dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, g->d_bytes, g->d_starts, g->d_lens, d_work + off, k,
-                           thr, chunk, d_seed_code, d_seed_chunk, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start);
+                           dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, g->d_bytes, g->d_starts, g->d_lens, d_work + off, so);
     ghip_prof_end(ctx);
 }
 

@@ -540,14 +540,11 @@ extern "C" int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches
 
 // finch::sketch_files replacement.  Exactness: a genome is accepted only when its candidate
 // list did not overflow and held >= s distinct hashes (or the threshold was already 2^64-1).
-extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
-                                   ghip_sketches **out) {
-    if (!ctx || !g || !out) return GHIP_EINVAL;
+static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
+                                 const ghip_seed_args *seeds, ghip_sketches **out) {
     if (k < 1 || k > 32) return ghip_set_error(ctx, GHIP_EINVAL, "kmer_length must be in 1..=32");
     if (s < 1 || s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "num_kmers must be in 1..=4096");
     if (seed > 0xffffffffull) return ghip_set_error(ctx, GHIP_EINVAL, "hash_seed must fit 32 bits (murmurhash3 seed)");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = g->n;
     ghip_sketches *sk = new ghip_sketches();
     ctx->live_handles++;
@@ -609,7 +606,7 @@ extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_
         if ((rc = h2d(ctx, d_cap, slot_cap.data(), ns))) break;
         if (hipMemsetAsync(d_count, 0, ns * sizeof(uint32_t), ctx->stream) != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed"); break; }
         ghip_launch_sketch_kmers(ctx, g->d_bytes, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
-                                 d_work, n_work, k, (uint32_t)seed, d_cand, d_count);
+                                 d_work, n_work, k, (uint32_t)seed, d_cand, d_count, first ? seeds : nullptr);
         ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, s, sk->d_hashes,
                                   sk->d_lens, d_status);
         std::vector<uint32_t> status(ns), count(ns);
@@ -633,6 +630,14 @@ extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_
     if (rc) { free_sketches_locked(sk); return rc; }
     *out = sk;
     return GHIP_OK;
+}
+
+extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
+                                   ghip_sketches **out) {
+    if (!ctx || !g || !out) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return sketch_genomes_locked(ctx, g, k, s, seed, nullptr, out);
 }
 
 extern "C" int ghip_sketch_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s,
@@ -791,12 +796,11 @@ extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
     ctx_release(ctx);
 }
 
-extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
-                                    ghip_ani_index **out) {
-    if (!ctx || !g || !out) return GHIP_EINVAL;
+// ---- ANI index construction, in steps so that the seeding pass can be the standalone ani_seeds
+// kernel or ride along with the MinHash pass (ghip_sketch_and_index)
+static int index_new(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk, ghip_ani_index **out,
+                     std::vector<uint64_t> &cap) {
     if (k < 1 || k > 16 || c < 1 || chunk < 1) return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters (k must be 1..=16)");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = g->n;
     ghip_ani_index *idx = new ghip_ani_index();
     ctx->live_handles++;
@@ -808,53 +812,133 @@ extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32
         idx->max_chunks = (uint32_t)std::max<uint64_t>(idx->max_chunks, nch);
         idx->chunk_start[i + 1] = idx->chunk_start[i] + nch;
     }
-    int rc = GHIP_OK;
-    if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");
-    std::vector<uint64_t> cap(n);
+    if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) {
+        free_index_locked(idx);
+        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");
+    }
+    cap.resize(n);
     for (size_t i = 0; i < n; i++) cap[i] = ghip_ani_seed_capacity(g->lens[i], c);
-    for (int attempt = 0; attempt < 2 && rc == GHIP_OK; attempt++) {
-        idx->seed_start.assign(n + 1, 0);
-        for (size_t i = 0; i < n; i++) idx->seed_start[i + 1] = idx->seed_start[i] + cap[i];
-        if (attempt) hipStreamSynchronize(ctx->stream);
-        free_index_arrays_locked(idx);
-        if ((rc = dmalloc(ctx, &idx->d_seed_code, idx->seed_start[n]))) break;
-        if ((rc = dmalloc(ctx, &idx->d_seed_chunk, idx->seed_start[n]))) break;
-        if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) break;
-        if ((rc = dmalloc(ctx, &idx->d_seed_count, n))) break;
-        if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) break;
-        if ((rc = dmalloc(ctx, &idx->d_chunk_start, n + 1))) break;
-        if ((rc = dmalloc(ctx, &idx->d_glen, n))) break;
-        if ((rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) break;
-        if ((rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) break;
-        if ((rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) break;
-        hipMemsetAsync(idx->d_seed_count, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), ctx->stream);
-        hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream);
-        ghip_launch_ani_seeds(ctx, g, k, c, chunk, idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start,
+    *out = idx;
+    return GHIP_OK;
+}
+
+// (re)allocates the seed arrays for the given capacities and zeroes the counters
+static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vector<uint64_t> &cap) {
+    const size_t n = idx->n;
+    int rc;
+    idx->seed_start.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) idx->seed_start[i + 1] = idx->seed_start[i] + cap[i];
+    hipStreamSynchronize(ctx->stream);
+    free_index_arrays_locked(idx);
+    if ((rc = dmalloc(ctx, &idx->d_seed_code, idx->seed_start[n]))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_seed_chunk, idx->seed_start[n]))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_seed_count, n))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_chunk_start, n + 1))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_glen, n))) return rc;
+    if ((rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) return rc;
+    if ((rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) return rc;
+    if ((rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seed_count, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream));
+    return GHIP_OK;
+}
+
+static ghip_seed_args index_seed_args(const ghip_ani_index *idx) {
+    return ghip_seed_args{idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start,
+                          idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start};
+}
+
+// reads the per-genome seed counts; *overflow = some list was too small (cap raised to the exact count)
+static int index_check_seeds(ghip_ctx *ctx, ghip_ani_index *idx, std::vector<uint64_t> &cap, bool *overflow) {
+    const size_t n = idx->n;
+    idx->seed_count.assign(n, 0);
+    int rc = d2h(ctx, idx->seed_count.data(), idx->d_seed_count, n);
+    if (rc) return rc;
+    *overflow = false;
+    for (size_t i = 0; i < n; i++) if (idx->seed_count[i] > cap[i]) { *overflow = true; cap[i] = idx->seed_count[i]; }
+    return GHIP_OK;
+}
+
+// standalone seeding with retry on overflow
+static int index_seed_standalone(ghip_ctx *ctx, const ghip_genomes *g, ghip_ani_index *idx, std::vector<uint64_t> &cap) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = index_alloc_seeds(ctx, idx, cap);
+        if (rc) return rc;
+        ghip_launch_ani_seeds(ctx, g, idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start,
                               idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
-        idx->seed_count.assign(n, 0);
-        if ((rc = d2h(ctx, idx->seed_count.data(), idx->d_seed_count, n))) break;
         bool overflow = false;
-        for (size_t i = 0; i < n; i++) if (idx->seed_count[i] > cap[i]) { overflow = true; cap[i] = idx->seed_count[i]; }
-        if (!overflow) break;
-        if (attempt == 1) rc = ghip_set_error(ctx, GHIP_EHIP, "ANI seed list overflowed twice");
+        if ((rc = index_check_seeds(ctx, idx, cap, &overflow))) return rc;
+        if (!overflow) return GHIP_OK;
     }
-    if (rc == GHIP_OK) {
-        // reorder every genome's seed list by hash bin and record the bin offsets (the join index)
-        uint32_t *d_code2 = nullptr, *d_pos = nullptr; uint16_t *d_chunk2 = nullptr;
-        if (!(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) &&
-            !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n])) &&
-            !(rc = dmalloc(ctx, &d_pos, idx->seed_start[n]))) {
-            ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_chunk, d_code2, d_chunk2, idx->d_seed_start,
-                                idx->d_seed_count, idx->d_bin_start, d_pos);
-            std::swap(idx->d_seed_code, d_code2);
-            std::swap(idx->d_seed_chunk, d_chunk2);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
-                rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
-        }
-        ghip_pool_free(ctx, d_code2); ghip_pool_free(ctx, d_chunk2); ghip_pool_free(ctx, d_pos);  // the unordered lists
+    return ghip_set_error(ctx, GHIP_EHIP, "ANI seed list overflowed twice");
+}
+
+// reorder every genome's seed list by hash bin and record the bin offsets (the join index)
+static int index_finish(ghip_ctx *ctx, ghip_ani_index *idx) {
+    const size_t n = idx->n;
+    int rc;
+    uint32_t *d_code2 = nullptr, *d_pos = nullptr; uint16_t *d_chunk2 = nullptr;
+    if (!(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) &&
+        !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n])) &&
+        !(rc = dmalloc(ctx, &d_pos, idx->seed_start[n]))) {
+        ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_chunk, d_code2, d_chunk2, idx->d_seed_start,
+                            idx->d_seed_count, idx->d_bin_start, d_pos);
+        std::swap(idx->d_seed_code, d_code2);
+        std::swap(idx->d_seed_chunk, d_chunk2);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
     }
+    ghip_pool_free(ctx, d_code2); ghip_pool_free(ctx, d_chunk2); ghip_pool_free(ctx, d_pos);  // the unordered lists
+    return rc;
+}
+
+extern "C" int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
+                                    ghip_ani_index **out) {
+    if (!ctx || !g || !out) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ghip_ani_index *idx = nullptr;
+    std::vector<uint64_t> cap;
+    int rc = index_new(ctx, g, k, c, chunk, &idx, cap);
+    if (rc) return rc;
+    if (!(rc = index_seed_standalone(ctx, g, idx, cap))) rc = index_finish(ctx, idx);
     if (rc) { free_index_locked(idx); return rc; }
     *out = idx;
+    return GHIP_OK;
+}
+
+// One pass over the bases for both sketches: the MinHash k-mer pass also emits the ANI seeds
+// (sketch.hip: sketch_kmers<21, true>).  Same results as ghip_sketch_genomes + ghip_ani_index_build.
+extern "C" int ghip_sketch_and_index(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
+                                     uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, ghip_sketches **out_sk,
+                                     ghip_ani_index **out_idx) {
+    if (!ctx || !g || !out_sk || !out_idx) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ghip_ani_index *idx = nullptr;
+    ghip_sketches *sk = nullptr;
+    std::vector<uint64_t> cap;
+    int rc = index_new(ctx, g, ani_k, ani_c, ani_chunk, &idx, cap);
+    if (rc) return rc;
+    const bool fuse = (k == 21 && ani_k <= k);  // the fused kernel exists for finch's k = 21
+    if (fuse) {
+        if (!(rc = index_alloc_seeds(ctx, idx, cap))) {
+            const ghip_seed_args sa = index_seed_args(idx);
+            rc = sketch_genomes_locked(ctx, g, k, s, seed, &sa, &sk);
+        }
+        bool overflow = false;
+        if (!rc) rc = index_check_seeds(ctx, idx, cap, &overflow);
+        if (!rc && overflow) rc = index_seed_standalone(ctx, g, idx, cap);  // exact counts now known
+    } else {
+        rc = sketch_genomes_locked(ctx, g, k, s, seed, nullptr, &sk);
+        if (!rc) rc = index_seed_standalone(ctx, g, idx, cap);
+    }
+    if (!rc) rc = index_finish(ctx, idx);
+    if (rc) { if (sk) free_sketches_locked(sk); free_index_locked(idx); return rc; }
+    *out_sk = sk;
+    *out_idx = idx;
     return GHIP_OK;
 }
 

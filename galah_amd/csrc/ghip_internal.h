@@ -138,12 +138,22 @@ void ghip_prof_end(ghip_ctx *ctx);
 void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
                        uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr);
 
+struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the ANI seeds
+    uint32_t k, c, chunk;
+    uint32_t *d_seed_code;
+    uint16_t *d_seed_chunk;
+    const uint64_t *d_seed_start;
+    uint32_t *d_seed_count;
+    uint32_t *d_chunk_total;
+    const uint64_t *d_chunk_start;
+};
+
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,
                               const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
                               const uint32_t *d_slot_cand_cap, const ghip_sketch_work *d_work,
                               size_t n_work, uint32_t k, uint32_t seed, uint64_t *d_cand,
-                              uint32_t *d_cand_count);
+                              uint32_t *d_cand_count, const ghip_seed_args *seeds /* nullable */);
 void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, size_t n_slots,
                                uint64_t *d_cand, const uint32_t *d_cand_count,
                                const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap,

@@ -12,9 +12,14 @@
 //                   genome with a wider threshold / larger list if fewer than s distinct
 //                   hashes survived or the list overflowed.
 //   synth_genomes : counter-based synthetic genomes written straight into HBM (bench input).
+#include <type_traits>
+
 #include "ghip_internal.h"
+#include "seed_common.h"
 
 namespace {
+
+using ghip_seed::base_code;
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
@@ -150,21 +155,18 @@ __device__ __forceinline__ uint64_t hash_canonical21_lut(uint64_t code_le, uint3
     return h1;
 }
 
-// A..T -> 0..3, anything else -> 4
-__device__ __forceinline__ uint32_t base_code(uint32_t c) {
-    uint32_t d = c - 0x41u;
-    bool ok = d < 20u && ((0x80045u >> d) & 1u);
-    return ok ? (((c >> 1) ^ (c >> 2)) & 3u) : 4u;
-}
-
-template <int K>
+// SEEDS = true: the same pass also emits the FracMinHash seeds of the ANI index (ani.hip), whose
+// k <= 16 rolling codes are bit fields of the K-mer codes already in registers -- one read of the
+// bases, one byte decode, for both sketches.
+template <int K, bool SEEDS>
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
     const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
     const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
     const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
-    uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count) {
+    uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count, ghip_seed::SeedOut so) {
     __shared__ KmerLuts luts;
+    __shared__ typename std::conditional<SEEDS, ghip_seed::SeedLds, char>::type sl;
     if (K == 21) {
         build_kmer_luts(luts);
         __syncthreads();
@@ -173,8 +175,17 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
     const uint32_t slot = wk.slot;
     const uint32_t g = slot_genome[slot];
     const uint64_t L = lens[g];
-    const uint64_t p0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK + (uint64_t)threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    const uint64_t blk0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK;
+    const uint32_t toff = threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
+    const uint64_t p0 = blk0 + toff;
     const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's bytes
+    ghip_seed::SeedBlock sb;
+    uint32_t amask = 0, ashift = 0;
+    if constexpr (SEEDS) {
+        sb = ghip_seed::seed_block_begin(sl, so, g, blk0);
+        amask = (so.k < 16) ? ((1u << (2 * so.k)) - 1) : ~0u;
+        ashift = 2 * (K - so.k);  // the newest so.k bases of the K-mer
+    }
     const uint64_t thr = slot_thr[slot];
     const uint64_t cstart = slot_cand_start[slot];
     const uint32_t ccap = slot_cand_cap[slot];
@@ -219,7 +230,18 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
             fwd_be = ((fwd_be << 2) | code) & mask;
             fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
             good = valid ? good + 1 : 0;
-            if (b < K - 1) continue;  // compile-time: warm-up bytes only roll the state
+            if constexpr (SEEDS) {
+                // so.k-mer ending here: forward code = low bits of fwd_be, reverse complement = complement
+                // of the top so.k bases of fwd_le (same layout as ani_seeds' rolling fwd / rev)
+                const uint32_t f15 = (uint32_t)fwd_be & amask;
+                const uint32_t r15 = ~(uint32_t)(fwd_le >> ashift) & amask;
+                const uint32_t c15 = min(f15, r15);
+                const int ak = (int)so.k;
+                const bool pass = b >= ak - 1 && b < (int)GHIP_SKETCH_POS_PER_THREAD + ak - 1 && good >= so.k &&
+                                  ghip_seed::fmix32(c15) < so.thr;
+                ghip_seed::seed_append(sl, so, sb, pass, c15, toff + (uint32_t)(b - (ak - 1)));
+            }
+            if (b < K - 1) continue;  // warm-up bytes only roll the state
             // reverse complement: rc_be = mask - fwd_le, rc_le = mask - fwd_be (complement = 3 - code), so
             // rc_be < fwd_be  <=>  fwd_be + fwd_le > mask
             uint64_t canon_le = (fwd_be + fwd_le > mask) ? (mask - fwd_be) : fwd_le;
@@ -230,6 +252,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
             }
         }
     }
+    if constexpr (SEEDS) ghip_seed::seed_block_flush(sl, so, sb);
 }
 
 // Generic-k fallback (k in [1,32], not 21): same algorithm, runtime k.
@@ -454,15 +477,23 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
                               const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
                               const uint32_t *d_slot_cand_cap, const ghip_sketch_work *d_work,
                               size_t n_work, uint32_t k, uint32_t seed, uint64_t *d_cand,
-                              uint32_t *d_cand_count) {
+                              uint32_t *d_cand_count, const ghip_seed_args *seeds) {
     if (n_work == 0) return;
+    ghip_seed::SeedOut so{};
+    if (seeds)
+        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, seeds->chunk, seeds->d_seed_code, seeds->d_seed_chunk,
+                                seeds->d_seed_start, seeds->d_seed_count, seeds->d_chunk_total, seeds->d_chunk_start};
     ghip_prof_begin(ctx, "sketch_kmers");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID) {  // one AQL dispatch holds < 2^32 work-items
         const unsigned grid = (unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID);
-        if (k == 21) {
-            hipLaunchKernelGGL(sketch_kmers_kernel<21>, dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
+        if (k == 21 && seeds) {  // fused MinHash + ANI seeding pass (first pass over all genomes only)
+            hipLaunchKernelGGL((sketch_kmers_kernel<21, true>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
                                d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
-                               d_slot_cand_cap, d_work + off, seed, d_cand, d_cand_count);
+                               d_slot_cand_cap, d_work + off, seed, d_cand, d_cand_count, so);
+        } else if (k == 21) {
+            hipLaunchKernelGGL((sketch_kmers_kernel<21, false>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
+                               d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
+                               d_slot_cand_cap, d_work + off, seed, d_cand, d_cand_count, so);
         } else {
             hipLaunchKernelGGL(sketch_kmers_kernel_rt, dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
                                d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,

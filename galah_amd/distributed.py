@@ -134,7 +134,9 @@ class HipEngine:
     def sketch_local(self, block: int):
         """-> (int64[block][s], int32[block]) device tensors, rows past the local count padded."""
         t = self.torch
-        sk = self.ctx.sketch_genomes(self.genomes, self.kmer, self.s, 0)
+        # one pass over the bases yields the MinHash sketches and the ANI seed index
+        sk, self._fused_index = self.ctx.sketch_and_index(self.genomes, self.kmer, self.s, 0, self.ani_k, self.ani_c,
+                                                          self.ani_chunk)
         hashes = t.full((block, self.s), -1, dtype=t.int64, device=self.device)  # -1 == 2^64-1
         lens = t.zeros(block, dtype=t.int32, device=self.device)
         t.cuda.current_stream().synchronize()
@@ -158,7 +160,10 @@ class HipEngine:
     def ani_build_local(self):
         """-> (meta dict of host arrays, dict of flat device tensors)."""
         t = self.torch
-        idx = self.ctx.ani_index_build(self.genomes, self.ani_k, self.ani_c, self.ani_chunk)
+        idx = getattr(self, "_fused_index", None)
+        self._fused_index = None
+        if idx is None:
+            idx = self.ctx.ani_index_build(self.genomes, self.ani_k, self.ani_c, self.ani_chunk)
         glen, cap, cnt = idx.meta()
         lay = idx.layout()
         self._local_index = idx

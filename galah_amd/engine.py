@@ -246,6 +246,13 @@ class Context:
         check(_lib.lib().ghip_ani_index_build(self._h, g._h, k, c, chunk, C.byref(h)), self._h)
         return AniIndex(self, h)
 
+    def sketch_and_index(self, g: Genomes, k: int = 21, s: int = 1000, seed: int = 0, ani_k: int = 15,
+                         ani_c: int = 125, ani_chunk: int = 20000) -> Tuple[Sketches, AniIndex]:
+        hs, hi = C.c_void_p(), C.c_void_p()
+        check(_lib.lib().ghip_sketch_and_index(self._h, g._h, k, s, seed, ani_k, ani_c, ani_chunk, C.byref(hs),
+                                               C.byref(hi)), self._h)
+        return Sketches(self, hs), AniIndex(self, hi)
+
     def ani_index_wrap_device(self, k: int, c: int, chunk: int, genome_len, seed_cap, seed_count,
                               d_seed_code: int, d_seed_chunk: int, d_bin_start: int, d_chunk_total: int) -> AniIndex:
         glen = np.ascontiguousarray(genome_len, dtype=np.uint64)

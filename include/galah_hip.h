@@ -139,6 +139,11 @@ uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
  * Build-defined estimator, skani parity unpinned: see DESIGN.md "ANI". Thread-safe. */
 int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c,
                          uint32_t chunk, ghip_ani_index **out);
+/* MinHash sketches and ANI index from ONE pass over the bases (fused kernel for k = 21; otherwise the
+ * two passes run back to back).  Results are identical to ghip_sketch_genomes + ghip_ani_index_build. */
+int ghip_sketch_and_index(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
+                          uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, ghip_sketches **out_sk,
+                          ghip_ani_index **out_idx);
 int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */,
                    size_t n, float min_aligned_fraction, float *out_ani_percent,
                    float *out_af /* nullable, [n][2] */);

@@ -247,3 +247,34 @@ def test_sketch_matrix_save_load_round_trip(ctx, tmp_path):
         f.write(b"XXXX")
     with pytest.raises(galah_amd.GalahHipError):
         ctx.sketches_load(path)
+
+
+def test_fused_sketch_and_index_equals_separate_passes(ctx):
+    """ghip_sketch_and_index (one pass over the bases) == ghip_sketch_genomes + ghip_ani_index_build,
+    on streams with N runs, short genomes and a repetitive genome (forces the sketch retry path)."""
+    streams = _streams()
+    names = [n for n in streams if n != "empty"] + ["empty"]
+    g = ctx.genomes_from_host([streams[n] for n in names])
+    sk1 = ctx.sketch_genomes(g, 21, 1000, 0)
+    idx1 = ctx.ani_index_build(g, 15, 125, 20000)
+    sk2, idx2 = ctx.sketch_and_index(g, 21, 1000, 0, 15, 125, 20000)
+    h1, l1 = sk1.to_host()
+    h2, l2 = sk2.to_host()
+    assert np.array_equal(h1, h2) and np.array_equal(l1, l2)
+    for a, b in zip(idx1.meta(), idx2.meta()):
+        assert np.array_equal(a, b)
+    n = len(names)
+    pairs = np.array([(i, j) for i in range(n) for j in range(i + 1, n)], dtype=np.uint32)
+    a1, f1 = ctx.ani_pairs(idx1, pairs, 0.0, want_af=True)
+    a2, f2 = ctx.ani_pairs(idx2, pairs, 0.0, want_af=True)
+    assert np.array_equal(a1, a2) and np.array_equal(f1, f2)
+    osk = [oracle.AniSketch.from_bytes(streams[nm]) for nm in names]
+    for x, (i, j) in enumerate(pairs):
+        assert np.float32(oracle.ani_pair(osk[i], osk[j], 0.0)[0]) == a2[x], (names[i], names[j])
+    # other k: the fused kernel only exists for k = 21, the call must still work
+    sk3, idx3 = ctx.sketch_and_index(g, 15, 200, 0, 15, 125, 20000)
+    h3, l3 = sk3.to_host()
+    for i, nm in enumerate(names):
+        o = oracle.sketch_bytes(streams[nm], 15, 200, 0)
+        assert l3[i] == len(o) and np.array_equal(h3[i, : l3[i]], o)
+    assert np.array_equal(ctx.ani_pairs(idx3, pairs, 0.0), a1)
