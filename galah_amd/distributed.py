@@ -5,9 +5,11 @@
   1. sketch the local genomes                     -> u64[B][s] + u32[B]      (no communication)
   2. ALL-GATHER the packed sketch matrix          -> u64[N][s] on every rank (N*s*8 bytes, once)
   3. pair tiles t with t % world == rank          -> local candidate list    (no communication)
-  4. build the local ANI seed index, ALL-GATHER its flat arrays; ANI for the local candidates
-  5. all-gather the (small) candidate lists, ANI for an interleaved slice per rank, gather the ANI
-     values on rank 0; greedy clustering on the host                         (src/clusterer.rs)
+  4. all-gather the (small) candidate lists; a pair is computed on the rank that owns its first
+     genome, so only the ANI seed indexes of genomes needed by a rank that does not own them are
+     exchanged (ALL-GATHER of the packed slices; ~0.33 MB per needed genome)
+  5. ANI of the local share; gather the values on rank 0; greedy clustering on the host
+                                                                             (src/clusterer.rs)
 
 With world == 1 the same code runs with the exchange steps skipped.  The compute engine is
 pluggable so the exchange logic can be exercised on CPU (gloo) in tests; the product engine is
@@ -79,6 +81,8 @@ class Exchange:
         import torch
         if self.world == 1:
             return local
+        if max(sizes) == 0:  # nothing to exchange (e.g. no candidate pair spans two ranks)
+            return local[:0]
         esz = local.element_size()
         raw = local.contiguous().view(torch.uint8)
         m = max(sizes) * esz
@@ -245,6 +249,31 @@ class DereplicationJob:
     def sketches_to_host(self):
         return self.engine.sketches_to_host(*self._full)
 
+    def _pack_genomes(self, arrs, meta, ids):
+        """Flat-array slices of the local genomes `ids` (ascending), packed back to back."""
+        import torch
+        cap = meta["cap"].astype(np.int64)
+        nch = (meta["glen"].astype(np.int64) + self._chunk() - 1) // self._chunk()
+        s0 = np.concatenate([[0], np.cumsum(cap)])
+        c0 = np.concatenate([[0], np.cumsum(nch)])
+        nb = 16385  # 2^14 + 1 bin offsets per genome (GHIP_ANI_BIN_COUNT + 1)
+
+        def cat(t, spans):
+            return torch.cat([t[a:b] for a, b in spans]) if spans else t[:0]
+
+        packed = {
+            "seed_code": cat(arrs["seed_code"], [(s0[g], s0[g + 1]) for g in ids]),
+            "seed_chunk": cat(arrs["seed_chunk"], [(s0[g], s0[g + 1]) for g in ids]),
+            "bin_start": cat(arrs["bin_start"], [(g * nb, (g + 1) * nb) for g in ids]),
+            "chunk_total": cat(arrs["chunk_total"], [(c0[g], c0[g + 1]) for g in ids]),
+        }
+        pmeta = {k: meta[k][ids] for k in ("glen", "cap", "cnt")}
+        pmeta["sizes"] = {k: int(v.shape[0]) for k, v in packed.items()}
+        return packed, pmeta
+
+    def _chunk(self) -> int:
+        return getattr(self.engine, "ani_chunk", 20000)
+
     def step(self) -> Dict:
         e, ex = self.engine, self.ex
         t = time.perf_counter()
@@ -258,40 +287,50 @@ class DereplicationJob:
         t = self._tick("pairs", t)
         idx_l, meta_l, lay = e.ani_build_local()
         t = self._tick("ani_index", t)
-        if self.world > 1:
-            arrs_l = e.ani_export(idx_l, lay)
-            metas = ex.all_gather_object({k: v for k, v in meta_l.items()} | {
-                "sizes": (int(lay.n_seed_slots), int(lay.n_bin_slots), int(lay.n_chunk_slots))})
-            meta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt")}
-            arrs = {
-                "seed_code": ex.all_gather_flat(arrs_l["seed_code"], [m["sizes"][0] for m in metas]),
-                "seed_chunk": ex.all_gather_flat(arrs_l["seed_chunk"], [m["sizes"][0] for m in metas]),
-                "bin_start": ex.all_gather_flat(arrs_l["bin_start"], [m["sizes"][1] for m in metas]),
-                "chunk_total": ex.all_gather_flat(arrs_l["chunk_total"], [m["sizes"][2] for m in metas]),
-            }
-            idx = e.ani_wrap(meta, arrs)
-            t = self._tick("allgather_ani_index", t)
+        result = {"n_pairs": 0, "n_clusters": 0, "clusters": None, "pairs": None, "pair_ani": None}
+        if self.world == 1:
+            idx, allp = idx_l, pairs
+            alla = e.ani_pairs(idx, allp, self.min_af)
+            t = self._tick("ani_pairs", t)
         else:
-            idx = idx_l
-        # candidates cluster near the diagonal, so the per-rank lists are uneven: every rank learns the
-        # whole (small) list and computes the ANI of an interleaved slice of it
-        if self.world > 1:
+            # every rank learns the whole (small) candidate list
             parts = ex.all_gather_object(pairs)
             allp = np.concatenate(parts) if parts else np.zeros(0, PAIR_DTYPE)
             allp = allp[np.argsort(allp, order=["i", "j"], kind="stable")]
             t = self._tick("allgather_pairs", t)
-        else:
-            allp = pairs
-        mine = allp[self.rank::self.world]
-        ani_mine = e.ani_pairs(idx, mine, self.min_af)
-        t = self._tick("ani_pairs", t)
-        gathered = ex.gather_object(ani_mine, 0)
-        result = {"n_pairs": 0, "n_clusters": 0, "clusters": None, "pairs": None, "pair_ani": None}
+            # A pair is computed where its first genome lives; only the genomes a rank needs but does
+            # not own are exchanged (instead of all-gathering the whole index, ~0.33 MB per genome).
+            owner_i = allp["i"] // self.block
+            owner_j = allp["j"] // self.block
+            needed = np.unique(allp["j"][owner_i != owner_j]).astype(np.int64)   # same on every rank
+            mine_mask = owner_i == self.rank
+            mine = allp[mine_mask]
+            arrs_l = e.ani_export(idx_l, lay)
+            send_ids = needed[(needed >= self.first) & (needed < self.first + self.count)] - self.first
+            packed, pmeta = self._pack_genomes(arrs_l, meta_l, send_ids)
+            metas = ex.all_gather_object(pmeta)
+            recv = {k: ex.all_gather_flat(packed[k], [m["sizes"][k] for m in metas]) for k in packed}
+            rmeta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt")}
+            # combined index = local genomes, then the received ones (in `needed` order: owners ascending)
+            cmeta = {k: np.concatenate([meta_l[k], rmeta[k]]) for k in ("glen", "cap", "cnt")}
+            import torch
+            carrs = {k: torch.cat([arrs_l[k], recv[k]]) for k in arrs_l}
+            idx = e.ani_wrap(cmeta, carrs)
+            t = self._tick("exchange_ani_index", t)
+            remap = np.full(self.n, -1, dtype=np.int64)
+            remap[self.first: self.first + self.count] = np.arange(self.count)
+            remap[needed] = np.where(remap[needed] >= 0, remap[needed], self.count + np.arange(len(needed)))
+            local_pairs = np.zeros(len(mine), dtype=PAIR_DTYPE)
+            local_pairs["i"], local_pairs["j"] = remap[mine["i"]], remap[mine["j"]]
+            ani_mine = e.ani_pairs(idx, local_pairs, self.min_af)
+            t = self._tick("ani_pairs", t)
+            gathered = ex.gather_object((np.nonzero(mine_mask)[0], ani_mine), 0)
+            if self.rank == 0:
+                alla = np.zeros(len(allp), dtype=np.float32)
+                for where, a in gathered:
+                    alla[where] = a
+                t = self._tick("gather_ani", t)
         if self.rank == 0:
-            alla = np.zeros(len(allp), dtype=np.float32)
-            for r, a in enumerate(gathered):
-                alla[r::self.world] = a
-            t = self._tick("gather_ani", t)
             clusters = e.cluster(self.n, allp, alla, self.ani_threshold)
             t = self._tick("host_cluster", t)
             result = {"n_pairs": len(allp), "n_clusters": len(clusters), "clusters": clusters, "pairs": allp,
