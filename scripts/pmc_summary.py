@@ -47,7 +47,9 @@ try:
         out[k]["salu_insts_per_launch"] = d["SQ_INSTS_SALU"] / n
         out[k]["lds_insts_per_launch"] = d["SQ_INSTS_LDS"] / n
         if d["GRBM_GUI_ACTIVE"] > 0:
-            out[k]["valu_busy"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0)
+            # can read slightly above 1: VOP2 instructions are counted as a full quad-cycle but issue faster
+            out[k]["valu_busy_raw"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0)
+            out[k]["valu_busy"] = min(1.0, out[k]["valu_busy_raw"])
 except Exception as e:  # the SQ pass is optional
     print("no SQ pass:", e)
 for k, d in out.items():
