@@ -14,8 +14,10 @@
 //               bin by bin -- no hash table, no atomics on the device-wide memory.
 //   ani_pairs : one workgroup per PAIR (both directions at once): lane b joins bin b of the
 //               two genomes (~2.4 x 2.4 seeds), counting matched seeds per 20 kb chunk of
-//               each genome in LDS; a chunk is aligned iff M_c*10000 >= 510*T_c; emits
-//               sum M_c, sum T_c and aligned bases per direction.  All four streams (two
+//               each genome in LDS; a chunk is aligned iff M_c*10000 >= 510*T_c; emits the
+//               (M_c, T_c) of the lower-median containment over the aligned chunks of both
+//               directions (rank selection, exact cross-multiplied compares), their number, and
+//               the aligned bases per direction.  All four streams (two
 //               bin-offset arrays, two code arrays) are read front to back, coalesced.
 #include "ghip_internal.h"
 #include "seed_common.h"
@@ -151,13 +153,15 @@ constexpr uint32_t ANI_PAIR_THREADS = 512;
 constexpr uint32_t ANI_PAIR_WAVES = ANI_PAIR_THREADS / 64;
 constexpr uint32_t ANI_STAGE = 448;  // seeds of 64 consecutive bins staged per wave and genome (expected ~154)
 
-__device__ __forceinline__ void reduce_direction(const uint32_t *mc, const uint32_t *tc, uint32_t nch, uint64_t L,
-                                                 uint32_t chunk, unsigned long long *red) {
-    unsigned long long M = 0, T = 0, bases = 0;
+// Appends (M_c << 32 | T_c) of every aligned chunk (M_c*10000 >= 510*T_c) to `list` and returns this
+// thread's share of the aligned bases.
+__device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *mc, const uint32_t *tc, uint32_t nch, uint64_t L,
+                                                              uint32_t chunk, unsigned long long *list, uint32_t *n_al) {
+    unsigned long long bases = 0;
     for (uint32_t c = threadIdx.x; c < nch; c += blockDim.x) {
         const unsigned long long t = tc[c], m = mc[c];
         if (t >= 1 && m * 10000ull >= 510ull * t) {
-            M += m; T += t;
+            list[atomicAdd(n_al, 1u)] = (m << 32) | t;
             const uint64_t lo = (uint64_t)c * chunk;
             uint64_t hi = lo + chunk;
             if (hi > L) hi = L;
@@ -165,12 +169,8 @@ __device__ __forceinline__ void reduce_direction(const uint32_t *mc, const uint3
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        M += __shfl_xor(M, off, 64);
-        T += __shfl_xor(T, off, 64);
-        bases += __shfl_xor(bases, off, 64);
-    }
-    if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[0], M); atomicAdd(&red[1], T); atomicAdd(&red[2], bases); }
+    for (int off = 32; off > 0; off >>= 1) bases += __shfl_xor(bases, off, 64);
+    return bases;
 }
 
 // The 64 bins a wave joins in one round are consecutive, so their seeds form ONE contiguous run
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     uint64_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned long long red[6];
+    __shared__ uint32_t n_al;
     __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE];
     __shared__ uint16_t st_chunk[ANI_PAIR_WAVES][2][ANI_STAGE];
     uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t nchq = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
     const uint32_t nchr = (uint32_t)(chunk_start[r + 1] - chunk_start[r]);
     uint32_t *mcr = mcq + nchq;
+    unsigned long long *list = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)(nchq + nchr) * 4 + 7) & ~(size_t)7));
     for (uint32_t i = threadIdx.x; i < nchq + nchr; i += blockDim.x) mcq[i] = 0;
     if (threadIdx.x < 6) red[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_al = 0;
     __syncthreads();
 
     const uint32_t *qb = bin_start + (uint64_t)q * (BIN_COUNT + 1), *rb = bin_start + (uint64_t)r * (BIN_COUNT + 1);
@@ -268,8 +271,26 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
         }
     }
     __syncthreads();
-    reduce_direction(mcq, chunk_total + chunk_start[q], nchq, glen[q], chunk, red);
-    reduce_direction(mcr, chunk_total + chunk_start[r], nchr, glen[r], chunk, red + 3);
+    // (M_c, T_c) of the aligned chunks of both directions, then the LOWER MEDIAN containment M_c/T_c
+    // by rank selection (exact: fractions compared by cross-multiplication)
+    const unsigned long long bq = collect_aligned(mcq, chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
+    const unsigned long long br = collect_aligned(mcr, chunk_total + chunk_start[r], nchr, glen[r], chunk, list, &n_al);
+    if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[2], bq); atomicAdd(&red[5], br); }
+    __syncthreads();
+    const uint32_t n = n_al;
+    if (threadIdx.x == 0) red[3] = n;
+    const uint32_t target = n ? (n - 1) / 2 : 0;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const unsigned long long me = list[e];
+        const unsigned long long mm = me >> 32, mt = me & 0xffffffffull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const unsigned long long o = list[j];
+            const unsigned long long l = (o >> 32) * mt, rr = mm * (o & 0xffffffffull);  // o < me  <=>  om*mt < mm*ot
+            rank += (l < rr || (l == rr && j < e)) ? 1u : 0u;
+        }
+        if (rank == target) { red[0] = mm; red[1] = mt; }
+    }
     __syncthreads();
     if (threadIdx.x < 6) out[(uint64_t)pair * 6 + threadIdx.x] = red[threadIdx.x];
 }
@@ -307,7 +328,7 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out) {
     if (n_pairs == 0) return;
-    const size_t lds = (size_t)2 * max_chunks * sizeof(uint32_t);
+    const size_t lds = (size_t)2 * max_chunks * (sizeof(uint32_t) + sizeof(uint64_t)) + 16;  // counters + aligned-chunk list
     static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand (+43 KiB static stage)
     if (lds > attr_lds) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

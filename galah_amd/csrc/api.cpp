@@ -965,13 +965,14 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
     for (size_t p = 0; p < n; p++) {
-        const uint64_t M = res[6 * p] + res[6 * p + 3], T = res[6 * p + 1] + res[6 * p + 4];
+        // res: [0] M and [1] T of the median-containment chunk, [2] aligned bases of q, [3] #aligned chunks, [5] bases of r
+        const uint64_t M = res[6 * p], T = res[6 * p + 1], n_aligned = res[6 * p + 3];
         const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1];
         const double afq = idx->glen[q] ? (double)res[6 * p + 2] / (double)idx->glen[q] : 0.0;
         const double afr = idx->glen[r] ? (double)res[6 * p + 5] / (double)idx->glen[r] : 0.0;
         if (out_af) { out_af[2 * p] = (float)afq; out_af[2 * p + 1] = (float)afr; }
         float v = 0.0f;
-        if (T != 0 && M != 0 && !(afq < (double)min_af && afr < (double)min_af)) {
+        if (n_aligned != 0 && T != 0 && !(afq < (double)min_af && afr < (double)min_af)) {
             // skani prints ANI with two decimals and galah parses that text as f32 (src/skani.rs:770)
             double ani = 100.0 * std::pow((double)M / (double)T, 1.0 / (double)idx->k);
             v = two_decimals_as_f32(ani);

@@ -118,7 +118,7 @@ struct ghip_ani_index {
 
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
-#define GHIP_ANI_MAX_CHUNKS 14000u  // two u32 counter arrays of one pair + the 43 KiB stage must fit the 160 KiB LDS
+#define GHIP_ANI_MAX_CHUNKS 4800u  // per genome: counters (4 B) + aligned-chunk list (8 B) of both genomes + the 43 KiB stage fit the 160 KiB LDS
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);
 

@@ -20,9 +20,12 @@
  *   chunk(p)  = p / chunk_len
  *   q->r      : for every chunk of q: T_c = #seeds, M_c = #seeds whose h is a seed of r;
  *               chunk aligned iff T_c >= 1 and M_c * 10000 >= 510 * T_c   (0.82^15 ~ 0.0510)
- *   M,T       = sums of M_c,T_c over aligned chunks of BOTH directions
+ *   M,T       = the (M_c, T_c) of the LOWER MEDIAN containment M_c/T_c over the aligned chunks of BOTH
+ *               directions (exact order by cross-multiplication; skani likewise reports a robust
+ *               per-chunk statistic rather than a pooled count, and with this choice the reference's
+ *               own membership tests src/clusterer.rs:631-690 are reproduced, see tests)
  *   AF_x      = (bases in aligned chunks of x) / L_x
- *   ANI%      = 100 * (M/T)^(1/k); 0 if T==0 or (AF_q < min_af and AF_r < min_af)
+ *   ANI%      = 100 * (M/T)^(1/k); 0 if no chunk aligned or (AF_q < min_af and AF_r < min_af)
  *   returned  = strtof(sprintf("%.2f", ANI%))   -- skani prints two decimals, galah parses f32
  */
 #define _GNU_SOURCE
@@ -152,8 +155,17 @@ static int contains_sorted(const uint64_t *a, size_t n, uint64_t x) {
     return lo < n && a[lo] == x;
 }
 
-/* one direction: adds aligned M,T and aligned bases of q */
-static void ani_direction(const go_ani_sketch *q, const go_ani_sketch *r, uint64_t *M, uint64_t *T, uint64_t *aligned_bases) {
+typedef struct { uint64_t m, t; } chunk_frac;
+
+/* exact order of the fractions m/t (t >= 1): cross-multiplication, no floating point */
+static int cmp_frac(const void *pa, const void *pb) {
+    const chunk_frac *a = (const chunk_frac *)pa, *b = (const chunk_frac *)pb;
+    uint64_t l = a->m * b->t, r = b->m * a->t;
+    return (l > r) - (l < r);
+}
+
+/* one direction: appends (M_c, T_c) of every aligned chunk of q and adds its aligned bases */
+static void ani_direction(const go_ani_sketch *q, const go_ani_sketch *r, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
     size_t i = 0;
     while (i < q->n) {
         uint32_t c = q->chunk_id[i];
@@ -164,7 +176,7 @@ static void ani_direction(const go_ani_sketch *q, const go_ani_sketch *r, uint64
             i++;
         }
         if (tc >= 1 && mc * 10000 >= 510 * tc) {
-            *M += mc; *T += tc;
+            out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++;
             uint64_t lo = (uint64_t)c * q->chunk, hi = lo + q->chunk;
             if (hi > q->length) hi = q->length;
             *aligned_bases += hi - lo;
@@ -173,16 +185,22 @@ static void ani_direction(const go_ani_sketch *q, const go_ani_sketch *r, uint64
 }
 
 float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r) {
-    uint64_t M = 0, T = 0, bq = 0, br = 0;
-    ani_direction(q, r, &M, &T, &bq);
-    ani_direction(r, q, &M, &T, &br);
+    uint64_t bq = 0, br = 0;
+    size_t n = 0;
+    chunk_frac *fr = (chunk_frac *)malloc(((size_t)q->n_chunks + r->n_chunks + 1) * sizeof(chunk_frac));
+    ani_direction(q, r, fr, &n, &bq);
+    ani_direction(r, q, fr, &n, &br);
     double afq = q->length ? (double)bq / (double)q->length : 0.0;
     double afr = r->length ? (double)br / (double)r->length : 0.0;
     if (af_q) *af_q = (float)afq;
     if (af_r) *af_r = (float)afr;
-    if (T == 0 || M == 0) return 0.0f;
+    if (n == 0) { free(fr); return 0.0f; }
+    /* lower median of the per-chunk containments over the aligned chunks of both directions */
+    qsort(fr, n, sizeof(chunk_frac), cmp_frac);
+    const chunk_frac med = fr[(n - 1) / 2];
+    free(fr);
     if (afq < (double)min_af_fraction && afr < (double)min_af_fraction) return 0.0f;
-    double ani = 100.0 * pow((double)M / (double)T, 1.0 / (double)q->k);
+    double ani = 100.0 * pow((double)med.m / (double)med.t, 1.0 / (double)q->k);
     char txt[64];
     snprintf(txt, sizeof txt, "%.2f", ani);
     return strtof(txt, NULL);

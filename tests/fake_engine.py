@@ -109,18 +109,20 @@ class FakeEngine:
         M = np.bincount(qc, weights=hit, minlength=len(qt)).astype(np.uint64)
         al = (T >= 1) & (M * 10000 >= 510 * T)
         bases = sum(min((c + 1) * self.ani_chunk, ql) - c * self.ani_chunk for c in np.nonzero(al)[0])
-        return int(M[al].sum()), int(T[al].sum()), int(bases)
+        return [(int(m), int(t)) for m, t in zip(M[al], T[al])], int(bases)
 
     def ani_pairs(self, idx, pairs, min_af):
+        from fractions import Fraction
         out = np.zeros(len(pairs), np.float32)
         for x, p in enumerate(pairs):
             q, r = self._genome(idx, int(p["i"])), self._genome(idx, int(p["j"]))
-            m1, t1, b1 = self._direction(q, r)
-            m2, t2, b2 = self._direction(r, q)
-            M, T = m1 + m2, t1 + t2
+            f1, b1 = self._direction(q, r)
+            f2, b2 = self._direction(r, q)
+            fr = sorted(f1 + f2, key=lambda mt: Fraction(mt[0], mt[1]))
             afq, afr = b1 / q[2], b2 / r[2]
-            if T and M and not (afq < min_af and afr < min_af):
-                out[x] = np.float32(float("%.2f" % (100.0 * (M / T) ** (1.0 / self.ani_k))))
+            if fr and not (afq < min_af and afr < min_af):
+                m, t = fr[(len(fr) - 1) // 2]
+                out[x] = np.float32(float("%.2f" % (100.0 * (m / t) ** (1.0 / self.ani_k))))
         return out
 
     def cluster(self, n, pairs, pair_ani, ani_threshold):

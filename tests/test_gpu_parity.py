@@ -278,3 +278,15 @@ def test_fused_sketch_and_index_equals_separate_passes(ctx):
         o = oracle.sketch_bytes(streams[nm], 15, 200, 0)
         assert l3[i] == len(o) and np.array_equal(h3[i, : l3[i]], o)
     assert np.array_equal(ctx.ani_pairs(idx3, pairs, 0.0), a1)
+
+
+def test_reference_membership_tests_through_hip(ctx):
+    """The reference's finch+skani cluster tests (src/clusterer.rs:631-690) through the GPU path:
+    cluster(genomes, FinchPreclusterer{0.9,1000,21}, clusterer{threshold, 0.2}) -> [[0,1,2,3]] @95, [[0,1,3],[2]] @99."""
+    names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13"]
+    paths = [fasta(n) for n in names]
+    for thr, want in ((95.0, [[0, 1, 2, 3]]), (99.0, [[0, 1, 3], [2]])):
+        pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=4)
+        cl = galah_amd.HipAniClusterer(thr, 0.2, ctx=ctx, io_threads=4)
+        got = galah_amd.cluster(paths, pre, cl)
+        assert sorted(got) == want   # the reference sorts before comparing (clusterer.rs:562-564)

@@ -46,3 +46,19 @@ def test_genome_stats_reference_goldens(golden):
     assert oracle.genome_stats(fasta("set1_1mbp")) == (1, 0, 1_000_000)
     for name, want in golden["genome_stats"].items():
         assert list(oracle.genome_stats(fasta(name))) == want
+
+
+def test_reference_membership_tests_finch_plus_skani():
+    """src/clusterer.rs:631-690 (test_minhash_skani_hello_world / _two_clusters_same_ani): the four abisko
+    genomes, finch precluster at 0.9, skani clusterer with min_aligned_threshold 0.2 ->
+    [[0,1,2,3]] at 95 and [[0,1,3],[2]] at 99.  The reference needs the skani binary for these; the
+    build-defined ANI estimator (median per-chunk containment) reproduces both memberships."""
+    names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13"]  # order of the reference test
+    paths = [fasta(n) for n in names]
+    pairs = oracle.distances(paths, np.float32(0.9))
+    assert len(pairs) == 6  # every pair clears the 0.9 precluster threshold
+    sks = [oracle.AniSketch.from_file(p) for p in paths]
+    ani = lambda a, b: oracle.ani_pair(sks[a], sks[b], 0.2)[0]
+    cache = oracle.Cache.from_pairs(pairs)
+    assert sorted(oracle.cluster(4, cache, 95.0, ani)) == [[0, 1, 2, 3]]
+    assert sorted(oracle.cluster(4, cache, 99.0, ani)) == [[0, 1, 3], [2]]
