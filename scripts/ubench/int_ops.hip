@@ -51,6 +51,61 @@ KERNEL(k_perm, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed 
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_perm_b32 %0, %0, %1, %0" : "+v"(a[c]) : "v"(seed));,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
 
+KERNEL(k_add32_e64, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_xor_e32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_xor_e64, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_xor_lit, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_xor_b32_e32 %0, 0x12345678, %0" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_lshr_e32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshrrev_b32_e32 %0, 1, %0" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_and_e32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_cndmask, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(seed) : "vcc");,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_bfe, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_bfe_u32 %0, %0, 3, 17" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_lshl_or, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_and_or, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_and_or_b32 %0, %0, %1, %0" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_add3, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_add3_u32 %0, %0, %1, %0" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_bitop3, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0x48" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_sdwa, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_or_sdwa, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_cmp32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1\n v_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(a[c]) : "v"(seed) : "vcc");,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_sub_e32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_sub_u32_e32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_min, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mov, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+
 template <typename K>
 static void run(const char *name, K kern, uint64_t *d_out, int insts_per_iter) {
     const int blocks = 256 * 8, threads = 256;  // 8 waves per SIMD
@@ -84,5 +139,23 @@ int main() {
     run("add_co+addc", k_addc_pair, d_out, 2);
     run("cmp_lt_u64+addc", k_cmp64, d_out, 2);
     run("v_perm_b32", k_perm, d_out, 1);
+    run("v_add_u32_e64", k_add32_e64, d_out, 1);
+    run("v_xor_b32_e32", k_xor_e32, d_out, 1);
+    run("v_xor_b32_e64", k_xor_e64, d_out, 1);
+    run("v_xor_b32 literal", k_xor_lit, d_out, 1);
+    run("v_lshrrev_b32_e32", k_lshr_e32, d_out, 1);
+    run("v_and_b32_e32", k_and_e32, d_out, 1);
+    run("v_cndmask_b32_e32", k_cndmask, d_out, 1);
+    run("v_bfe_u32", k_bfe, d_out, 1);
+    run("v_lshl_or_b32", k_lshl_or, d_out, 1);
+    run("v_and_or_b32", k_and_or, d_out, 1);
+    run("v_add3_u32", k_add3, d_out, 1);
+    run("v_bitop3_b32", k_bitop3, d_out, 1);
+    run("v_lshlrev_b32_sdwa", k_sdwa, d_out, 1);
+    run("v_or_b32_sdwa", k_or_sdwa, d_out, 1);
+    run("cmp_lt_u32+addc", k_cmp32, d_out, 2);
+    run("v_sub_u32_e32", k_sub_e32, d_out, 1);
+    run("v_min_u32_e32", k_min, d_out, 1);
+    run("v_mov_b32_e32", k_mov, d_out, 1);
     return 0;
 }

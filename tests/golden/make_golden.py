@@ -38,11 +38,13 @@ GENOMES = {
     "antonio_MAG189": "antonio_mags/BE_RX_R3_MAG189.fna",
     "clash_500kb": "set1_name_clash/500kb.fna",
     "abisko_S2D10": "abisko4/73.20110600_S2D.10.fna",   # src/genome_stats.rs:61-73 golden
+    "abisko_S1D21": "abisko4/73.20120800_S1D.21.fna",   # tests/test_cmdline.rs:12-61,304-352 (quality order)
+    "abisko_S2M16": "abisko4/73.20110800_S2M.16.fna",
 }
 PAIRS = [("set1_1mbp", "set1_500kb"), ("abisko_S1X13", "abisko_S2D19"), ("abisko_S1X13", "abisko_S3X12"),
          ("abisko_S1X13", "abisko_S2D13"), ("abisko_S2D19", "abisko_S3X12"), ("abisko_S2D19", "abisko_S2D13"),
          ("abisko_S3X12", "abisko_S2D13"), ("antonio_MAG52", "antonio_MAG189"), ("set2_1mbp", "set2_half"),
-         ("set1_500kb", "clash_500kb"), ("abisko_S1X13", "antonio_MAG52")]
+         ("set1_500kb", "clash_500kb"), ("abisko_S1X13", "antonio_MAG52"), ("abisko_S1D21", "abisko_S2M16")]
 
 
 def main():

@@ -9,7 +9,7 @@ from conftest import fasta, random_sketches
 pytestmark = pytest.mark.gpu
 
 ALL = ["set1_1mbp", "set1_500kb", "set2_1mbp", "set2_half", "abisko_S1X13", "abisko_S2D19", "abisko_S3X12",
-       "abisko_S2D13", "antonio_MAG52", "antonio_MAG189", "clash_500kb"]
+       "abisko_S2D13", "antonio_MAG52", "antonio_MAG189", "clash_500kb", "abisko_S1D21", "abisko_S2M16"]
 
 
 def test_reference_golden_through_hip(ctx):
@@ -290,3 +290,25 @@ def test_reference_membership_tests_through_hip(ctx):
         cl = galah_amd.HipAniClusterer(thr, 0.2, ctx=ctx, io_threads=4)
         got = galah_amd.cluster(paths, pre, cl)
         assert sorted(got) == want   # the reference sorts before comparing (clusterer.rs:562-564)
+
+
+def test_reference_cli_expectations_through_hip(ctx):
+    """tests/test_cmdline.rs through the GPU path: :36-61 + :304-352 (Parks2020_reduced order from the ingest's
+    own genome statistics, then finch + ANI -> one cluster, representative S2M.16) and :262-302
+    (--min-aligned-fraction 0.2 -> one representative, 0.6 -> two)."""
+    names = ["abisko_S1D21", "abisko_S2M16"]
+    checkm = {"abisko_S1D21": (95.21, 0.00), "abisko_S2M16": (95.92, 0.65)}   # test_cmdline.rs:14-16
+    g = ctx.genomes_from_files([fasta(n) for n in names], io_threads=2)
+    st = [g.stats(i) for i in range(2)]
+    comp = np.array([checkm[n][0] for n in names], np.float32) / np.float32(100)
+    cont = np.array([checkm[n][1] for n in names], np.float32) / np.float32(100)
+    order = galah_amd.quality_order_parks2020_reduced(comp, cont, [s[0] for s in st], [s[1] for s in st])
+    assert list(order) == [1, 0]
+    paths = [fasta(names[i]) for i in order]
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=2)
+    got = galah_amd.cluster(paths, pre, galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=2))
+    assert got == [[0, 1]]
+    paths = [fasta("set2_1mbp"), fasta("set2_half")]
+    for min_af, want in ((0.2, [[0, 1]]), (0.6, [[0], [1]])):
+        cl = galah_amd.HipAniClusterer(95.0, min_af, ctx=ctx, io_threads=2)
+        assert sorted(galah_amd.cluster(paths, pre, cl)) == want

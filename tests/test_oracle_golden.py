@@ -62,3 +62,40 @@ def test_reference_membership_tests_finch_plus_skani():
     cache = oracle.Cache.from_pairs(pairs)
     assert sorted(oracle.cluster(4, cache, 95.0, ani)) == [[0, 1, 2, 3]]
     assert sorted(oracle.cluster(4, cache, 99.0, ani)) == [[0, 1, 3], [2]]
+
+
+# CheckM rows the reference's CLI tests use (tests/data/abisko4/abisko4.csv via tests/test_cmdline.rs:12-61;
+# the values are quoted in the comment at test_cmdline.rs:14-16): completeness %, contamination %.
+CHECKM = {"abisko_S1D21": (95.21, 0.00), "abisko_S2M16": (95.92, 0.65)}
+
+
+def test_reference_cli_quality_order_and_skani_cluster():
+    """tests/test_cmdline.rs:36-61 (Parks2020_reduced picks S2M.16 over S1D.21) and :304-352 (finch precluster +
+    skani clusterer put both in one cluster whose representative is S2M.16)."""
+    import galah_amd.quality as q
+    names = ["abisko_S1D21", "abisko_S2M16"]          # order of the CLI's --genome-fasta-files
+    st = [oracle.genome_stats(fasta(n)) for n in names]
+    comp = np.array([CHECKM[n][0] for n in names], np.float32) / np.float32(100)
+    cont = np.array([CHECKM[n][1] for n in names], np.float32) / np.float32(100)
+    order = q.quality_order_parks2020_reduced(comp, cont, [s[0] for s in st], [s[1] for s in st])
+    assert list(order) == [1, 0]
+    # completeness-4contamination (test_cmdline.rs:12-34) prefers S1D.21 instead
+    assert np.argmax(comp - np.float32(4) * cont) == 0
+    paths = [fasta(names[i]) for i in order]
+    pairs = oracle.distances(paths, np.float32(0.9))
+    assert len(pairs) == 1
+    sks = [oracle.AniSketch.from_file(p) for p in paths]
+    ani = lambda a, b: oracle.ani_pair(sks[a], sks[b], 0.15)[0]   # CLI default --min-aligned-fraction 15
+    assert oracle.cluster(2, oracle.Cache.from_pairs(pairs), 95.0, ani) == [[0, 1]]   # rep = S2M.16
+
+
+def test_reference_cli_min_aligned_fraction():
+    """tests/test_cmdline.rs:262-302: 1mbp.fna vs 1mbp.half_aligned.fna, finch precluster, ANI 95:
+    --min-aligned-fraction 0.2 -> one representative (1mbp.fna); 0.6 -> two."""
+    paths = [fasta("set2_1mbp"), fasta("set2_half")]
+    pairs = oracle.distances(paths, np.float32(0.9))
+    assert len(pairs) == 1
+    sks = [oracle.AniSketch.from_file(p) for p in paths]
+    for min_af, want in ((0.2, [[0, 1]]), (0.6, [[0], [1]])):
+        ani = lambda a, b: oracle.ani_pair(sks[a], sks[b], min_af)[0]
+        assert sorted(oracle.cluster(2, oracle.Cache.from_pairs(pairs), 95.0, ani)) == want
