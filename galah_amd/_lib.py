@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgalah_hip.so")
+LIB_PATH = os.environ.get("GHIP_LIB_OVERRIDE") or os.path.join(_HERE, "libgalah_hip.so")  # override: timing experiments only
 
 PAIR_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("common", "<u4"), ("total", "<u4"), ("ani", "<f4")])
 

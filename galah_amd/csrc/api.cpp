@@ -333,6 +333,8 @@ extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const
             hipError_t e = hipMemcpyAsync(g->d_bytes + g->starts[i], bytes + offsets[i], lens[i], hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
         }
+    // caller-supplied bytes are arbitrary: anything but A,C,G,T becomes 'N' (the k-mer kernels' alphabet invariant)
+    if (rc == GHIP_OK) ghip_launch_sanitize(ctx, g->d_bytes, g->total_alloc / 16 * 16);
     if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
     if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
     *out = g;

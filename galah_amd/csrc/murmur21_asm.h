@@ -1,0 +1,75 @@
+// MurmurHash3_x64_128 of a 21-byte key whose first-stage multiplies come from tables (sketch.hip), in
+// hand-written gfx950 ISA.  Shared by sketch.hip and scripts/ubench/int_ops.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+// x * C mod 2^64: result in v[R0:R1], v[E0:E1] is scratch (gfx950 wants even-aligned 64-bit tuples, so
+// the cross terms are accumulated in their own pair and added to the high word): 3 mads + 1 add.
+#define GHIP_MULC(R0, R1, E0, E1, X0, X1, CLO, CHI)                                     \
+    "v_mad_u64_u32 v[" #E0 ":" #E1 "], vcc, " X1 ", " CLO ", 0\n"                      \
+    "v_mad_u64_u32 v[" #E0 ":" #E1 "], vcc, " X0 ", " CHI ", v[" #E0 ":" #E1 "]\n"     \
+    "v_mad_u64_u32 v[" #R0 ":" #R1 "], vcc, " X0 ", " CLO ", 0\n"                      \
+    "v_add_u32 v" #R1 ", v" #R1 ", v" #E0 "\n"
+#define GHIP_XORSHIFT33(LO, HI) "v_lshrrev_b32 v52, 1, " HI "\n v_xor_b32 " LO ", " LO ", v52\n"
+
+// MurmurHash3_x64_128(canonical 21-mer, seed).h1 from the table terms A = k1*c1, B = k2*c2,
+// T = rotl(tail*c1,31)*c2 ^ 21.  S1/S2/S3 are the three instructions a non-zero seed adds.
+#define GHIP_MURMUR21_BODY(S1, S2, S3)                                                   \
+    "v_alignbit_b32 v48, %[a0], %[a1], 1\n"                                             \
+    "v_alignbit_b32 v49, %[a1], %[a0], 1\n" /* rotl(A,31) */                            \
+    GHIP_MULC(40, 41, 42, 43, "v48", "v49", "%[c2lo]", "%[c2hi]")                       \
+    S1                                       /* h1 = seed ^ k1 */                       \
+    "v_alignbit_b32 v48, v40, v41, 5\n"                                                 \
+    "v_alignbit_b32 v49, v41, v40, 5\n"     /* rotl(h1,27) */                           \
+    S2                                       /* h1 += h2 (= seed) */                    \
+    "v_lshl_add_u64 v[48:49], v[48:49], 2, v[48:49]\n"                                  \
+    "v_lshl_add_u64 v[48:49], v[48:49], 0, %[k52]\n"                                    \
+    "v_alignbit_b32 v50, %[b1], %[b0], 31\n"                                            \
+    "v_alignbit_b32 v51, %[b0], %[b1], 31\n" /* rotl(B,33) */                           \
+    GHIP_MULC(44, 45, 46, 47, "v50", "v51", "%[c1lo]", "%[c1hi]")                       \
+    S3                                       /* h2 = seed ^ k2 */                       \
+    "v_alignbit_b32 v50, v44, v45, 1\n"                                                 \
+    "v_alignbit_b32 v51, v45, v44, 1\n"     /* rotl(h2,31) */                           \
+    "v_lshl_add_u64 v[50:51], v[50:51], 0, v[48:49]\n"                                  \
+    "v_lshl_add_u64 v[50:51], v[50:51], 2, v[50:51]\n"                                  \
+    "v_lshl_add_u64 v[50:51], v[50:51], 0, %[k38]\n"                                    \
+    "v_xor_b32 v48, v48, %[t0]\n"                                                       \
+    "v_xor_b32 v49, v49, %[t1]\n"           /* h1 ^= tail ^ 21 */                       \
+    "v_xor_b32 v50, 21, v50\n"              /* h2 ^= 21 */                              \
+    "v_lshl_add_u64 v[48:49], v[48:49], 0, v[50:51]\n"                                  \
+    "v_lshl_add_u64 v[50:51], v[50:51], 0, v[48:49]\n"                                  \
+    GHIP_XORSHIFT33("v48", "v49")                                                       \
+    GHIP_MULC(40, 41, 42, 43, "v48", "v49", "%[f1lo]", "%[f1hi]")                       \
+    GHIP_XORSHIFT33("v40", "v41")                                                       \
+    GHIP_MULC(44, 45, 46, 47, "v40", "v41", "%[f2lo]", "%[f2hi]")                       \
+    GHIP_XORSHIFT33("v44", "v45")           /* fmix64(h1) = v[44:45] */                 \
+    GHIP_XORSHIFT33("v50", "v51")                                                       \
+    GHIP_MULC(40, 41, 42, 43, "v50", "v51", "%[f1lo]", "%[f1hi]")                       \
+    GHIP_XORSHIFT33("v40", "v41")                                                       \
+    GHIP_MULC(48, 49, 46, 47, "v40", "v41", "%[f2lo]", "%[f2hi]")                       \
+    GHIP_XORSHIFT33("v48", "v49")           /* fmix64(h2) = v[48:49] */                 \
+    "v_lshl_add_u64 %[h], v[48:49], 0, v[44:45]\n"
+
+template <bool SEED0>
+__device__ __forceinline__ uint64_t murmur21_core(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t t0,
+                                                   uint32_t t1, uint32_t seed) {
+    uint64_t h;
+    const uint64_t k52 = 0x52dce729ull, k38 = 0x38495ab5ull, seed64 = seed;
+#define GHIP_MURMUR21_OPERANDS                                                                                       \
+    [h] "=v"(h) : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [t0] "v"(t0), [t1] "v"(t1),                \
+        [c1lo] "s"(0x114253d5u), [c1hi] "s"(0x87c37b91u), [c2lo] "s"(0x2745937fu), [c2hi] "s"(0x4cf5ad43u),          \
+        [f1lo] "s"(0xed558ccdu), [f1hi] "s"(0xff51afd7u), [f2lo] "s"(0x1a85ec53u), [f2hi] "s"(0xc4ceb9feu),          \
+        [k52] "s"(k52), [k38] "s"(k38), [seed] "s"(seed), [seed64] "s"(seed64)                                       \
+        : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "vcc"
+    if constexpr (SEED0) {
+        asm volatile(GHIP_MURMUR21_BODY("", "", "") : GHIP_MURMUR21_OPERANDS);
+    } else {
+        asm volatile(GHIP_MURMUR21_BODY("v_xor_b32 v40, %[seed], v40\n", "v_lshl_add_u64 v[48:49], v[48:49], 0, %[seed64]\n",
+                               "v_xor_b32 v44, %[seed], v44\n")
+            : GHIP_MURMUR21_OPERANDS);
+    }
+#undef GHIP_MURMUR21_OPERANDS
+    return h;
+}
+

@@ -16,6 +16,7 @@
 
 #include "ghip_internal.h"
 #include "seed_common.h"
+#include "murmur21_asm.h"
 
 namespace {
 
@@ -105,16 +106,28 @@ __device__ __forceinline__ uint64_t hash_canonical(uint64_t code_le, uint32_t se
     return murmur3_h1<K>(w, seed);
 }
 
-// ---- K = 21 fast path: the first-stage multiplies of MurmurHash3 by table look-up ----------
-// k1 = bytes 0..7, k2 = bytes 8..15, tail = bytes 16..20 of the canonical k-mer.  A 64-bit
-// multiply is linear mod 2^64:  k1*c1 = A4(x0)*c1 + ((A4(x1)*c1) << 32)  with A4(x) the 4 ASCII
-// bytes of the 8-bit 2-bit-code x.  So 256-entry LDS tables of A4(x)*c1 and A4(x)*c2 replace the
-// 2-bit->ASCII expansion and the two first multiplies, and a 1024-entry table holds the whole
-// tail term rotl(tail*c1,31)*c2.  12 KiB of LDS, built once per block; bit-identical results.
+// ---- K = 21 fast path ---------------------------------------------------------------------------
+// Cost model (scripts/ubench/int_ops.hip, cycles per wave64 instruction per SIMD): add/sub/and/or/xor/
+// 32-bit shifts/v_bitop3/v_mov ~2.4; everything else (all multiplies, v_mad_u64_u32 ~5, 64-bit shifts,
+// v_alignbit, v_lshl_add_u64, SDWA forms, compares) ~4.4.  The kernel is VALU-issue bound, so the loop
+// is written to that model:
+//  * first-stage multiplies of MurmurHash3 by table look-up.  k1 = bytes 0..7, k2 = bytes 8..15,
+//    tail = bytes 16..20 of the canonical k-mer.  A 64-bit multiply is linear mod 2^64:
+//    k1*c1 = A4(x0)*c1 + ((A4(x1)*c1) << 32) with A4(x) the 4 ASCII bytes of the 8-bit 2-bit-code x.
+//    256-entry LDS tables of A4(x)*c1 and A4(x)*c2 replace the 2-bit->ASCII expansion and the two first
+//    multiplies; a 1024-entry table holds the whole tail term rotl(tail*c1,31)*c2 ^ 21.  12 KiB of LDS.
+//  * the rest of the hash (55 instructions) in hand-written ISA: x*C mod 2^64 is three v_mad_u64_u32 and
+//    an add (hipcc emits six instructions), rotations are v_alignbit pairs, x*5+c is two v_lshl_add_u64.
+//  * rolling state = the little-endian 2-bit codes of the forward strand and of the reverse complement;
+//    the canonical k-mer (needletail: the lexicographically smaller strand) is the numerically smaller
+//    of the two: rc_be < fwd_be  <=>  mask - fwd_le < mask - rc_le  <=>  rc_le < fwd_le.
+//  * validity (no non-ACGT byte in the window) is only evaluated for the ~1/2000 hashes under the
+//    threshold: per lane the position of the last bad byte, refreshed per 4-byte word under a
+//    wave-uniform branch.  Device base streams hold A,C,G,T or bytes with bit 3 set ('N', '-').
 struct KmerLuts {
     uint64_t c1[256];    // A4(x) * c1
     uint64_t c2[256];    // A4(x) * c2
-    uint64_t tail[1024]; // rotl64(A5(x) * c1, 31) * c2
+    uint64_t tail[1024]; // rotl64(A5(x) * c1, 31) * c2 ^ 21   (the length xor of h1 folded in)
 };
 
 __device__ __forceinline__ uint32_t ascii4(uint32_t x8) {
@@ -133,44 +146,35 @@ __device__ __forceinline__ void build_kmer_luts(KmerLuts &L) {
     }
     for (uint32_t x = threadIdx.x; x < 1024; x += blockDim.x) {
         const uint64_t a = (uint64_t)ascii4(x & 0xffu) | ((uint64_t)((0x54474341u >> (8 * (x >> 8))) & 0xffu) << 32);
-        L.tail[x] = rotl64(a * c1, 31) * c2;
+        L.tail[x] = (rotl64(a * c1, 31) * c2) ^ 21ull;
     }
 }
 
-__device__ __forceinline__ uint64_t hash_canonical21_lut(uint64_t code_le, uint32_t seed, const KmerLuts &L) {
-    constexpr uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
-    const uint32_t lo = (uint32_t)code_le, hi = (uint32_t)(code_le >> 32);
-    uint64_t h1 = seed, h2 = seed;
-    uint64_t k1 = L.c1[lo & 0xffu] + ((uint64_t)(uint32_t)L.c1[(lo >> 8) & 0xffu] << 32);    // k1 * c1
-    uint64_t k2 = L.c2[(lo >> 16) & 0xffu] + ((uint64_t)(uint32_t)L.c2[lo >> 24] << 32);     // k2 * c2
-    k1 = rotl64(k1, 31); k1 = mulc<c2>(k1); h1 ^= k1;
-    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-    k2 = rotl64(k2, 33); k2 = mulc<c1>(k2); h2 ^= k2;
-    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-    h1 ^= L.tail[hi & 0x3ffu];
-    h1 ^= 21ull; h2 ^= 21ull;
-    h1 += h2; h2 += h1;
-    h1 = fmix64(h1); h2 = fmix64(h2);
-    h1 += h2;
-    return h1;
-}
+struct Roll21 {  // per-lane rolling state of the 21-mer window
+    uint64_t fl;      // forward strand, little-endian 2-bit codes (first base in bits 1:0)
+    uint64_t rc;      // reverse complement, little-endian (= mask - forward big-endian)
+    int32_t lastbad;  // byte index (lane-relative) of the last non-ACGT byte in the words before the current one
+};
 
 // SEEDS = true: the same pass also emits the FracMinHash seeds of the ANI index (ani.hip), whose
-// k <= 16 rolling codes are bit fields of the K-mer codes already in registers -- one read of the
-// bases, one byte decode, for both sketches.
-template <int K, bool SEEDS>
-__global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
+// k <= 16 rolling codes are bit fields of the 21-mer codes already in registers -- one read of the
+// bases, one byte decode, for both sketches.  A lane owns the 21-mers STARTING at its 64 bytes, i.e.
+// ending at bytes 20..83; in the fused pass it owns the seeds ending at the same bytes (starts
+// 21-k .. 84-k of its range), and the first lane of a genome adds the seeds ending at bytes k-1..19.
+template <bool SEEDS, bool SEED0>
+__global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
     const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
     const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
     uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count, ghip_seed::SeedOut so) {
+    constexpr int K = 21;
+    constexpr uint64_t mask = (1ull << (2 * K)) - 1;
     __shared__ KmerLuts luts;
-    __shared__ typename std::conditional<SEEDS, ghip_seed::SeedLds, char>::type sl;
-    if (K == 21) {
-        build_kmer_luts(luts);
-        __syncthreads();
-    }
+    __shared__ __attribute__((aligned(16))) unsigned char sl_raw[SEEDS ? sizeof(ghip_seed::SeedLds) : 16];
+    ghip_seed::SeedLds &sl = *reinterpret_cast<ghip_seed::SeedLds *>(sl_raw);  // only touched when SEEDS
+    build_kmer_luts(luts);
+    __syncthreads();
     const ghip_sketch_work wk = work[blockIdx.x];
     const uint32_t slot = wk.slot;
     const uint32_t g = slot_genome[slot];
@@ -181,77 +185,158 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel(
     const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's bytes
     ghip_seed::SeedBlock sb;
     uint32_t amask = 0, ashift = 0;
+    int ak = 1;
     if constexpr (SEEDS) {
         sb = ghip_seed::seed_block_begin(sl, so, g, blk0);
         amask = (so.k < 16) ? ((1u << (2 * so.k)) - 1) : ~0u;
-        ashift = 2 * (K - so.k);  // the newest so.k bases of the K-mer
+        ashift = 2 * (K - so.k);  // the newest so.k bases of the 21-mer
+        ak = (int)so.k;
     }
     const uint64_t thr = slot_thr[slot];
     const uint64_t cstart = slot_cand_start[slot];
     const uint32_t ccap = slot_cand_cap[slot];
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);  // 16-B aligned
 
-    constexpr uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
-    uint64_t fwd_be = 0, fwd_le = 0;
-    uint32_t good = 0;
-    // bytes b = 0 .. 63+K-1; the k-mer ending at byte b starts at b-K+1 and is ours iff that
-    // start is in [0, 64) -- i.e. b >= K-1.
-    constexpr int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
-    constexpr int NV = (NB + 15) / 16;
-    static_assert(NV <= 6, "the 6-entry byte queue covers 64 + 31 bytes");
-    // Every base is fetched from HBM once: a lane loads only its own 64 bytes; the K-1 bytes that
-    // run into the next lane's range come from that lane's registers (wave shuffle), and only
-    // lane 63 reads them from memory.  Lanes past the stream end hold 'N'.
+    // Every base is fetched from HBM once: a lane loads only its own 64 bytes; the 20 bytes that run
+    // into the next lane's range come from that lane's registers (wave shuffle), and only lane 63
+    // reads them from memory.  Lanes past the stream end hold 'N'.
     const uint4 NNNN = make_uint4(0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu);
-    uint4 q0 = live ? src[0] : NNNN, q1 = live ? src[1] : NNNN, q2 = live ? src[2] : NNNN, q3 = live ? src[3] : NNNN;
-    uint4 q4, q5;
+    uint4 q0 = NNNN, q1 = NNNN, q2 = NNNN, q3 = NNNN;
+    if (live) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
+    uint4 q4;
     q4.x = __shfl_down(q0.x, 1, 64); q4.y = __shfl_down(q0.y, 1, 64); q4.z = __shfl_down(q0.z, 1, 64); q4.w = __shfl_down(q0.w, 1, 64);
-    q5.x = __shfl_down(q1.x, 1, 64); q5.y = __shfl_down(q1.y, 1, 64); q5.z = __shfl_down(q1.z, 1, 64); q5.w = __shfl_down(q1.w, 1, 64);
+    uint32_t q5x = __shfl_down(q1.x, 1, 64);
     if ((threadIdx.x & 63u) == 63u) {  // next wave's bytes (or the 'N' tail padding of the genome)
-        q4 = live ? src[4] : NNNN;
-        q5 = live ? src[5] : NNNN;
+        q4 = NNNN; q5x = NNNN.x;
+        if (live) { q4 = src[4]; q5x = src[5].x; }
     }
-#pragma unroll 1
-    for (int v = 0; v < NV; v++) {
-        const uint4 cur = q0;
-        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5;
-        uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int b = v * 16 + j;
-            if (b >= NB) break;
-            uint32_t c = (words[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            uint32_t code = base_code(c);
-            // branch-free state update; an invalid byte enters as 'A' and resets the run length,
-            // so its bits have left both registers before `good` reaches K again.  Bytes past
-            // the stream end are 'N' padding (ghip_genomes layout), hence no bounds test.
-            const bool valid = code <= 3u;
-            code &= 3u;
-            fwd_be = ((fwd_be << 2) | code) & mask;
-            fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
-            good = valid ? good + 1 : 0;
-            if constexpr (SEEDS) {
-                // so.k-mer ending here: forward code = low bits of fwd_be, reverse complement = complement
-                // of the top so.k bases of fwd_le (same layout as ani_seeds' rolling fwd / rev)
-                const uint32_t f15 = (uint32_t)fwd_be & amask;
-                const uint32_t r15 = ~(uint32_t)(fwd_le >> ashift) & amask;
-                const uint32_t c15 = min(f15, r15);
-                const int ak = (int)so.k;
-                const bool pass = b >= ak - 1 && b < (int)GHIP_SKETCH_POS_PER_THREAD + ak - 1 && good >= so.k &&
-                                  ghip_seed::fmix32(c15) < so.thr;
-                ghip_seed::seed_append(sl, so, sb, pass, c15, toff + (uint32_t)(b - (ak - 1)));
+
+    constexpr uint32_t CAND_WAVE_CAP = 64;  // expected 64*64*2.5*s/L ~ 2 per wave at the default threshold
+    __shared__ uint64_t cand_lds[GHIP_SKETCH_THREADS / 64][CAND_WAVE_CAP];
+    __shared__ uint32_t cand_wave_n[GHIP_SKETCH_THREADS / 64], cand_base;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t cand_n = 0;  // wave-uniform
+    Roll21 st{0, 0, -1};
+    struct Pend { uint64_t A, B, T; uint32_t ax, bx; } pend{};  // table terms of the position whose hash is pending
+    // hash one position from its table terms and append it to the genome's candidate list if it is under the
+    // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word)
+    auto finish = [&](const Pend &p, const int b, const uint32_t inword) {
+        const uint32_t a1 = (uint32_t)(p.A >> 32) + p.ax, b1 = (uint32_t)(p.B >> 32) + p.bx;
+#ifdef GHIP_DBG_NOHASH  // timing experiment only: wrong results
+        const uint64_t h = ((p.A ^ p.B ^ p.T) + (((uint64_t)a1 << 32) | b1)) * 0x9e3779b97f4a7c15ull;
+#else
+        const uint64_t h = murmur21_core<SEED0>((uint32_t)p.A, a1, (uint32_t)p.B, b1, (uint32_t)p.T, (uint32_t)(p.T >> 32), seed);
+#endif
+        // rare (~2.5*s survivors per genome): wave-private LDS buffer, one global atomic per block at the end --
+        // the ~300 concurrent blocks of a genome would otherwise serialise on its counter inside the hot loop
+        bool hit = h <= thr;
+        if (__ballot(hit)) {
+            hit = hit && (b - st.lastbad >= K) && inword == 0;
+            const unsigned long long m = __ballot(hit);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (hit) {
+                const uint32_t at = cand_n + rank;
+                if (at < CAND_WAVE_CAP) cand_lds[wave][at] = h;
+                else {  // wave buffer full (thresholds far above the default): straight to the global list
+                    uint32_t idx = atomicAdd(&cand_count[slot], 1u);
+                    if (idx < ccap) cand[cstart + idx] = h;
+                }
             }
-            if (b < K - 1) continue;  // warm-up bytes only roll the state
-            // reverse complement: rc_be = mask - fwd_le, rc_le = mask - fwd_be (complement = 3 - code), so
-            // rc_be < fwd_be  <=>  fwd_be + fwd_le > mask
-            uint64_t canon_le = (fwd_be + fwd_le > mask) ? (mask - fwd_be) : fwd_le;
-            uint64_t h = (K == 21) ? hash_canonical21_lut(canon_le, seed, luts) : hash_canonical<K>(canon_le, seed);
-            if (good >= (uint32_t)K && h <= thr) {  // rare: ~2.5*s survivors per genome
-                uint32_t idx = atomicAdd(&cand_count[slot], 1u);
-                if (idx < ccap) cand[cstart + idx] = h;
+            cand_n += (uint32_t)__popcll(m);
+        }
+    };
+    // after the position loop, by every thread of the block (contains __syncthreads)
+    auto flush_candidates = [&]() {
+        if ((threadIdx.x & 63u) == 0) cand_wave_n[wave] = min(cand_n, CAND_WAVE_CAP);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < GHIP_SKETCH_THREADS / 64; w++) { const uint32_t c = cand_wave_n[w]; cand_wave_n[w] = tot; tot += c; }
+            cand_base = tot ? atomicAdd(&cand_count[slot], tot) : 0u;
+        }
+        __syncthreads();
+        const uint32_t mine = min(cand_n, CAND_WAVE_CAP), base = cand_base + cand_wave_n[wave];
+        for (uint32_t i = threadIdx.x & 63u; i < mine; i += 64)
+            if (base + i < ccap) cand[cstart + base + i] = cand_lds[wave][i];
+    };
+    // one 4-byte word: decode once (SWAR), then per byte roll both strands; HASH: hash the 21-mer ending there
+    auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, const bool seed_gate, const bool have_pend) {
+        constexpr bool HASH = decltype(hash_tag)::value;
+        constexpr bool SEED_HERE = SEEDS && decltype(seed_tag)::value;
+        const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;   // A0 C1 G2 T3 per byte
+        const uint32_t tc = t ^ 0x03030303u;                       // complement
+        const uint32_t bad4 = w & 0x08080808u;                     // bit 3: not one of A,C,G,T
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t code = (t >> (8 * j)) & 3u, ccode = (tc >> (8 * j)) & 3u;
+            st.fl = (st.fl >> 2) | ((uint64_t)code << (2 * (K - 1)));
+            st.rc = ((st.rc << 2) | ccode) & mask;
+            const int b = b0 + j;
+            [[maybe_unused]] const uint32_t inword = bad4 & (0xffffffffu >> (8 * (3 - j)));  // bad bytes 0..j of this word
+            if constexpr (SEED_HERE) {
+                // so.k-mer ending here: forward big-endian code = complement of rc's low bits; reverse
+                // complement = complement of the top so.k bases of the forward little-endian code
+                const uint32_t f15 = ~(uint32_t)st.rc & amask;
+                const uint32_t r15 = ~(uint32_t)(st.fl >> ashift) & amask;
+                const uint32_t c15 = min(f15, r15);
+                bool pass = seed_gate && ghip_seed::fmix32(c15) < so.thr;
+                if (__ballot(pass)) {  // validity only where some lane passed
+                    pass = pass && (b - st.lastbad >= ak) && inword == 0;
+                    ghip_seed::seed_append(sl, so, sb, pass, c15, toff + (uint32_t)(b - (ak - 1)));
+                }
+            }
+            if constexpr (HASH) {
+                // software pipeline: issue this position's five table reads, then hash the PREVIOUS position
+                // (its reads were issued one step ago), so LDS latency hides behind ~240 cycles of hashing
+                const uint64_t canon = st.rc < st.fl ? st.rc : st.fl;
+                const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+                Pend cur;
+#ifdef GHIP_DBG_NOLDS  // timing experiment only (scripts/sketch_variants.sh): wrong results
+                cur.A = canon ^ 0x1234u; cur.B = canon + 77u; cur.T = canon >> 3; cur.ax = lo; cur.bx = hi;
+#else
+                cur.A = luts.c1[lo & 0xffu]; cur.B = luts.c2[(lo >> 16) & 0xffu]; cur.T = luts.tail[hi];
+                cur.ax = reinterpret_cast<const uint32_t *>(luts.c1)[2 * ((lo >> 8) & 0xffu)];  // low words only
+                cur.bx = reinterpret_cast<const uint32_t *>(luts.c2)[2 * (lo >> 24)];
+#endif
+                // the previous position is byte j-1 of this word, or byte 3 of the word before (whose bad
+                // bytes are already folded into lastbad)
+                if (j > 0 || have_pend) finish(pend, b - 1, j > 0 ? (bad4 & (0xffffffffu >> (8 * (4 - j)))) : 0u);
+                pend = cur;
             }
         }
+        if (__ballot(bad4 != 0)) {  // wave-uniform: rare
+            if (bad4) st.lastbad = b0 + 3 - (int)(__builtin_clz(bad4) >> 3);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // warm-up: bytes 0..19 only roll the state -- except in the first wave of a genome, whose lane 0
+    // owns the seeds that end before byte 20
+    const uint32_t warm[5] = {q0.x, q0.y, q0.z, q0.w, q1.x};
+    if (SEEDS && wk.chunk == 0 && threadIdx.x < 64) {
+        const bool first = threadIdx.x == 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            // bytes b < ak-1 cannot end a seed: the validity window b - lastbad >= ak with lastbad = -1 says so
+            word(warm[i], 4 * i, F_{}, T_{}, first, false);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; i++) word(warm[i], 4 * i, F_{}, F_{}, false, false);
     }
+    uint32_t w0 = q1.y, w1 = q1.z, w2 = q1.w, w3 = q2.x;
+#pragma unroll 1
+    for (int v = 0; v < 4; v++) {
+        const int b0 = 20 + 16 * v;
+        word(w0, b0, T_{}, std::integral_constant<bool, SEEDS>{}, true, v > 0);
+        word(w1, b0 + 4, T_{}, std::integral_constant<bool, SEEDS>{}, true, true);
+        word(w2, b0 + 8, T_{}, std::integral_constant<bool, SEEDS>{}, true, true);
+        word(w3, b0 + 12, T_{}, std::integral_constant<bool, SEEDS>{}, true, true);
+        w0 = q2.y; w1 = q2.z; w2 = q2.w; w3 = q3.x;
+        q2 = q3; q3 = q4; q4.x = q5x;
+    }
+    finish(pend, 83, 0u);  // the last position (ends at byte 83)
+    flush_candidates();
     if constexpr (SEEDS) ghip_seed::seed_block_flush(sl, so, sb);
 }
 
@@ -461,6 +546,27 @@ __global__ __launch_bounds__(256) void synth_genomes_kernel(uint8_t *__restrict_
     *reinterpret_cast<uint4 *>(bytes + starts[g] + p0) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// Device base streams hold A,C,G,T or a byte with bit 3 set (what sketch_kmers21 tests): caller-supplied
+// streams (ghip_genomes_from_host) are rewritten in place, every other byte becomes 'N'.  16 bytes per thread.
+__global__ __launch_bounds__(256) void sanitize_bases_kernel(uint4 *__restrict__ bytes, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 v = bytes[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t c = (w[k] >> (8 * j)) & 0xffu;
+                const bool ok = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+                out |= (ok ? c : (uint32_t)'N') << (8 * j);
+            }
+            w[k] = out;
+        }
+        bytes[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 }  // namespace
 
 void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
@@ -470,6 +576,13 @@ void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts
     ghip_prof_begin(ctx, "synth_genomes");
     hipLaunchKernelGGL(synth_genomes_kernel, grid, dim3(256), 0, ctx->stream, d_bytes, d_starts, length, first, members, seed, sub_thr);
     ghip_prof_end(ctx);
+}
+
+void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes /* multiple of 16 */) {
+    const uint64_t n16 = n_bytes / 16;
+    if (n16 == 0) return;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(sanitize_bases_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(d_bytes), n16);
 }
 
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
@@ -486,14 +599,16 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
     ghip_prof_begin(ctx, "sketch_kmers");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID) {  // one AQL dispatch holds < 2^32 work-items
         const unsigned grid = (unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID);
-        if (k == 21 && seeds) {  // fused MinHash + ANI seeding pass (first pass over all genomes only)
-            hipLaunchKernelGGL((sketch_kmers_kernel<21, true>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                               d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
-                               d_slot_cand_cap, d_work + off, seed, d_cand, d_cand_count, so);
-        } else if (k == 21) {
-            hipLaunchKernelGGL((sketch_kmers_kernel<21, false>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                               d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
-                               d_slot_cand_cap, d_work + off, seed, d_cand, d_cand_count, so);
+        if (k == 21) {  // seeds != nullptr: fused MinHash + ANI seeding pass (first pass over all genomes only)
+#define GHIP_LAUNCH21(SEEDS, SEED0)                                                                                  \
+    hipLaunchKernelGGL((sketch_kmers21_kernel<SEEDS, SEED0>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, \
+                       d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start, d_slot_cand_cap,     \
+                       d_work + off, seed, d_cand, d_cand_count, so)
+            if (seeds && seed == 0) GHIP_LAUNCH21(true, true);
+            else if (seeds) GHIP_LAUNCH21(true, false);
+            else if (seed == 0) GHIP_LAUNCH21(false, true);
+            else GHIP_LAUNCH21(false, false);
+#undef GHIP_LAUNCH21
         } else {
             hipLaunchKernelGGL(sketch_kmers_kernel_rt, dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
                                d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,

@@ -75,7 +75,8 @@ int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *launches, dou
  * Any byte other than A,C,G,T breaks k-mers. */
 int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
                             ghip_genomes **out);
-/* Host streams already in device format: genome g = bytes[offsets[g] .. offsets[g+1]). */
+/* Host streams already in device format: genome g = bytes[offsets[g] .. offsets[g+1]).  Every byte other
+ * than A,C,G,T is stored as 'N' (so ghip_genomes_to_host returns the sanitised stream). */
 int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, size_t n,
                            ghip_genomes **out);
 /* Counter-based synthetic genomes generated directly in HBM (bench/test input):

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include "../../galah_amd/csrc/murmur21_asm.h"
 #define REP 4096
 #define CHAINS 8
 
@@ -124,6 +125,76 @@ static void run(const char *name, K kern, uint64_t *d_out, int insts_per_iter) {
     printf("%-14s %8.3f ms  %6.2f SIMD-cycles per wave-instruction (at 2.4 GHz)\n", name, ms, simd_cycles / wave_insts);
 }
 
+
+// --- composite blocks of the sketch kernel -------------------------------------------------
+#define REPB 1024
+__global__ void k_hash_block(uint64_t *out, uint32_t seed) {   // the 55-instruction asm hash, dependent chain per lane
+    uint32_t a0 = seed + threadIdx.x, a1 = seed * 3 + threadIdx.x, b0 = a0 ^ 0x1234567, b1 = a1 + 99, t0 = a0 * 7, t1 = a1 * 11;
+    uint64_t acc = 0;
+    for (int i = 0; i < REPB; i++) {
+        uint64_t h = murmur21_core<true>(a0, a1, b0, b1, t0, t1, 0);
+        acc += h; a0 = (uint32_t)h; a1 ^= (uint32_t)(h >> 32);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void k_cmp_cnd(uint64_t *out, uint32_t seed) {      // v_cmp_lt_u64 + 2 v_cndmask (canonical select)
+    uint64_t a = seed + threadIdx.x, b = seed * 77ull + threadIdx.x * 3, acc = 0;
+    for (int i = 0; i < REPB * 8; i++) {
+        uint32_t m, alo = (uint32_t)a, blo = (uint32_t)b;
+        asm volatile("v_cmp_lt_u64 vcc, %1, %2\n s_nop 1\n v_cndmask_b32 %0, %3, %4, vcc\n" : "=v"(m) : "v"(a), "v"(b), "v"(alo), "v"(blo) : "vcc");
+        acc += m; a += acc; b ^= a;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void k_select_c(uint64_t *out, uint32_t seed) {     // what hipcc makes of min(a,b) on u64
+    uint64_t a = seed + threadIdx.x, b = seed * 77ull + threadIdx.x * 3, acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < REPB * 8; i++) {
+        uint64_t m = a < b ? a : b;
+        acc += m; a += acc * 3; b ^= a >> 7;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void k_select_base(uint64_t *out, uint32_t seed) {  // same loop without the select
+    uint64_t a = seed + threadIdx.x, b = seed * 77ull + threadIdx.x * 3, acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < REPB * 8; i++) {
+        uint64_t m = a ^ b;
+        acc += m; a += acc * 3; b ^= a >> 7;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void k_lds_lut(uint64_t *out, uint32_t seed) {      // 3 ds_read_b64 + 2 ds_read_b32 at hashed indices per iteration
+    __shared__ uint64_t lut[1536];
+    for (uint32_t i = threadIdx.x; i < 1536; i += blockDim.x) lut[i] = i * 0x9e3779b97f4a7c15ull;
+    __syncthreads();
+    uint32_t x = seed + threadIdx.x * 2654435761u; uint64_t acc = 0;
+#pragma unroll 4
+    for (int i = 0; i < REPB * 4; i++) {
+        uint64_t A = lut[x & 0xff], B = lut[256 + ((x >> 16) & 0xff)], T = lut[512 + ((x >> 9) & 0x3ff)];
+        uint32_t a1 = (uint32_t)lut[(x >> 8) & 0xff], b1 = (uint32_t)lut[256 + (x >> 24)];
+        acc += A ^ B ^ T ^ a1 ^ ((uint64_t)b1 << 32);
+        x = x * 1664525u + 1013904223u + (uint32_t)acc;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+template <typename K>
+static void run_block(const char *name, K kern, uint64_t *d_out, double iters) {
+    const int blocks = 256 * 8, threads = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double wave_iters = (double)blocks * (threads / 64) * iters;
+    printf("%-14s %8.3f ms  %7.1f SIMD-cycles per wave-iteration (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 * 1024 / wave_iters);
+}
+
 int main() {
     uint64_t *d_out;
     hipMalloc(&d_out, 256 * 8 * 256 * 8);
@@ -157,5 +228,10 @@ int main() {
     run("v_sub_u32_e32", k_sub_e32, d_out, 1);
     run("v_min_u32_e32", k_min, d_out, 1);
     run("v_mov_b32_e32", k_mov, d_out, 1);
+    run_block("hash_block", k_hash_block, d_out, REPB);
+    run_block("cmp64+cndmask", k_cmp_cnd, d_out, REPB * 8);
+    run_block("select_c", k_select_c, d_out, REPB * 8);
+    run_block("select_base", k_select_base, d_out, REPB * 8);
+    run_block("lds_lut5", k_lds_lut, d_out, REPB * 4);
     return 0;
 }
