@@ -48,6 +48,7 @@ struct ghip_ctx {
     // device-memory pool: hipMalloc/hipFree synchronise the device, so blocks are recycled
     std::vector<ghip_pool_block> pool;
     ghip_cmin_cache cmin;
+    uint64_t *d_kmer_luts = nullptr;  // MurmurHash3 first-stage tables of sketch_kmers21 (12 KiB, built once; pool-owned)
     int live_handles = 0;   // genomes / sketches / ani indexes still alive
     bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };

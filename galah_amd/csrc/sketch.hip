@@ -137,17 +137,25 @@ __device__ __forceinline__ uint32_t ascii4(uint32_t x8) {
     return __builtin_amdgcn_perm(lut, lut, v);
 }
 
-__device__ __forceinline__ void build_kmer_luts(KmerLuts &L) {
+// the tables do not depend on the input: built once per context into global memory, copied to LDS per block
+__global__ __launch_bounds__(256) void build_kmer_luts_kernel(KmerLuts *L) {
     const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
     for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {
         const uint64_t a = ascii4(x);
-        L.c1[x] = a * c1;
-        L.c2[x] = a * c2;
+        L->c1[x] = a * c1;
+        L->c2[x] = a * c2;
     }
     for (uint32_t x = threadIdx.x; x < 1024; x += blockDim.x) {
         const uint64_t a = (uint64_t)ascii4(x & 0xffu) | ((uint64_t)((0x54474341u >> (8 * (x >> 8))) & 0xffu) << 32);
-        L.tail[x] = (rotl64(a * c1, 31) * c2) ^ 21ull;
+        L->tail[x] = (rotl64(a * c1, 31) * c2) ^ 21ull;
     }
+}
+
+__device__ __forceinline__ void load_kmer_luts(KmerLuts &L, const KmerLuts *__restrict__ g) {
+    static_assert(sizeof(KmerLuts) % 16 == 0, "copied in 16-byte pieces");
+    const uint4 *src = reinterpret_cast<const uint4 *>(g);
+    uint4 *dst = reinterpret_cast<uint4 *>(&L);
+    for (uint32_t i = threadIdx.x; i < sizeof(KmerLuts) / 16; i += blockDim.x) dst[i] = src[i];
 }
 
 struct Roll21 {  // per-lane rolling state of the 21-mer window
@@ -167,13 +175,14 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
     const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
     const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
-    uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count, ghip_seed::SeedOut so) {
+    uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count, ghip_seed::SeedOut so,
+    const KmerLuts *__restrict__ g_luts) {
     constexpr int K = 21;
     constexpr uint64_t mask = (1ull << (2 * K)) - 1;
-    __shared__ KmerLuts luts;
+    __shared__ __attribute__((aligned(16))) KmerLuts luts;
     __shared__ __attribute__((aligned(16))) unsigned char sl_raw[SEEDS ? sizeof(ghip_seed::SeedLds) : 16];
     ghip_seed::SeedLds &sl = *reinterpret_cast<ghip_seed::SeedLds *>(sl_raw);  // only touched when SEEDS
-    build_kmer_luts(luts);
+    load_kmer_luts(luts, g_luts);
     __syncthreads();
     const ghip_sketch_work wk = work[blockIdx.x];
     const uint32_t slot = wk.slot;
@@ -596,6 +605,15 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
     if (seeds)
         so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, seeds->chunk, seeds->d_seed_code, seeds->d_seed_chunk,
                                 seeds->d_seed_start, seeds->d_seed_count, seeds->d_chunk_total, seeds->d_chunk_start};
+    const KmerLuts *luts = nullptr;
+    if (k == 21) {
+        if (!ctx->d_kmer_luts) {
+            ctx->d_kmer_luts = (uint64_t *)ghip_pool_alloc(ctx, sizeof(KmerLuts));
+            if (!ctx->d_kmer_luts) return;  // ctx->err is set; the caller's next HIP check reports it
+            hipLaunchKernelGGL(build_kmer_luts_kernel, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<KmerLuts *>(ctx->d_kmer_luts));
+        }
+        luts = reinterpret_cast<const KmerLuts *>(ctx->d_kmer_luts);
+    }
     ghip_prof_begin(ctx, "sketch_kmers");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID) {  // one AQL dispatch holds < 2^32 work-items
         const unsigned grid = (unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID);
@@ -603,7 +621,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
 #define GHIP_LAUNCH21(SEEDS, SEED0)                                                                                  \
     hipLaunchKernelGGL((sketch_kmers21_kernel<SEEDS, SEED0>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, \
                        d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start, d_slot_cand_cap,     \
-                       d_work + off, seed, d_cand, d_cand_count, so)
+                       d_work + off, seed, d_cand, d_cand_count, so, luts)
             if (seeds && seed == 0) GHIP_LAUNCH21(true, true);
             else if (seeds) GHIP_LAUNCH21(true, false);
             else if (seed == 0) GHIP_LAUNCH21(false, true);

@@ -312,3 +312,70 @@ def test_reference_cli_expectations_through_hip(ctx):
     for min_af, want in ((0.2, [[0, 1]]), (0.6, [[0], [1]])):
         cl = galah_amd.HipAniClusterer(95.0, min_af, ctx=ctx, io_threads=2)
         assert sorted(galah_amd.cluster(paths, pre, cl)) == want
+
+
+def _dirty_streams(seed=5, n=6, length=20_000):
+    """Streams where ~8 % of the bytes break k-mers (N, '-', lower case, arbitrary bytes), so that fewer than
+    4096 valid 21-mers remain: with s = 4096 the sketch is the full k-mer set and every window is checked."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    junk = np.frombuffer(b"NN-nacgtRYx\x00\xff*", dtype=np.uint8)
+    out = []
+    for i in range(n):
+        L = length + int(rng.integers(0, 700))
+        s = rng.choice(acgt, size=L)
+        bad = rng.random(L) < 0.08
+        s[bad] = rng.choice(junk, size=int(bad.sum()))
+        for edge in (64, 128, 16384, 16384 + 64):      # bad bytes right at lane / block boundaries, all alignments
+            for d in range(-3, 4):
+                if rng.random() < 0.5 and 0 <= edge + d < L:
+                    s[edge + d] = ord("N")
+        out.append(s)
+    return out
+
+
+def _clean(stream):
+    ok = np.isin(stream, np.frombuffer(b"ACGT", dtype=np.uint8))
+    return np.where(ok, stream, np.uint8(ord("N")))
+
+
+def test_every_window_of_dirty_streams_minhash(ctx):
+    streams = _dirty_streams()
+    g = ctx.genomes_from_host(streams)
+    for i, st in enumerate(streams):
+        assert np.array_equal(g.to_host(i), _clean(st))          # caller bytes are sanitised on upload
+    for seed in (0, 7):
+        hashes, lens = ctx.sketch_genomes(g, 21, 4096, seed).to_host()
+        sk2, _ = ctx.sketch_and_index(g, 21, 4096, seed)
+        h2, l2 = sk2.to_host()
+        assert np.array_equal(hashes, h2) and np.array_equal(lens, l2)
+        for i, st in enumerate(streams):
+            want = oracle.sketch_bytes(st, 21, 4096, seed)
+            assert 1000 < len(want) < 4096                       # the whole k-mer set, nothing truncated
+            assert lens[i] == len(want) and np.array_equal(hashes[i, : lens[i]], want), i
+
+
+@pytest.mark.parametrize("c", [1, 3, 125])
+def test_every_seed_of_dirty_streams(ctx, c):
+    """Seed sets (code, chunk) of the fused and the standalone seeding pass against the oracle, dense (c = 1 keeps
+    every valid 15-mer and overflows the per-block LDS buffers) to sparse."""
+    import torch
+    streams = _dirty_streams(seed=6, n=4)
+    g = ctx.genomes_from_host(streams)
+    osk = [oracle.AniSketch.from_bytes(_clean(s), 15, c, 5000) for s in streams]
+    for idx in (ctx.ani_index_build(g, 15, c, 5000), ctx.sketch_and_index(g, 21, 1000, 0, 15, c, 5000)[1]):
+        lay = idx.layout()
+        glen, cap, cnt = idx.meta()
+        code = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device="cuda")
+        chunk = torch.empty(int(lay.n_seed_slots), dtype=torch.int16, device="cuda")
+        ctx.memcpy_d2d(code.data_ptr(), lay.d_seed_code, code.numel() * 4)
+        ctx.memcpy_d2d(chunk.data_ptr(), lay.d_seed_chunk, chunk.numel() * 2)
+        ctx.synchronize()
+        code, chunk = code.cpu().numpy().view(np.uint32), chunk.cpu().numpy().view(np.uint16)
+        start = 0
+        for i, o in enumerate(osk):
+            assert cnt[i] == len(o.seeds()), (c, i, cnt[i], len(o.seeds()))
+            got = sorted(zip(code[start:start + cnt[i]].tolist(), chunk[start:start + cnt[i]].tolist()))
+            want = sorted(zip(o.seeds().astype(np.uint32).tolist(), o.chunks().astype(np.uint16).tolist()))
+            assert got == want, (c, i)
+            start += int(cap[i])
