@@ -202,6 +202,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         ak = (int)so.k;
     }
     const uint64_t thr = slot_thr[slot];
+    const uint32_t thr_bound = murmur21_filter_bound(thr);
     const uint64_t cstart = slot_cand_start[slot];
     const uint32_t ccap = slot_cand_cap[slot];
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);  // 16-B aligned
@@ -231,16 +232,19 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word)
     auto finish = [&](const Pend &p, const int b, const uint32_t inword) {
         const uint32_t a1 = (uint32_t)(p.A >> 32) + p.ax, b1 = (uint32_t)(p.B >> 32) + p.bx;
+        uint64_t F1, F2;
 #ifdef GHIP_DBG_NOHASH  // timing experiment only: wrong results
-        const uint64_t h = ((p.A ^ p.B ^ p.T) + (((uint64_t)a1 << 32) | b1)) * 0x9e3779b97f4a7c15ull;
+        F1 = ((p.A ^ p.B ^ p.T) + (((uint64_t)a1 << 32) | b1)) * 0x9e3779b97f4a7c15ull; F2 = 0;
+        const uint32_t s1 = (uint32_t)(F1 >> 32) + 1u;
 #else
-        const uint64_t h = murmur21_core<SEED0>((uint32_t)p.A, a1, (uint32_t)p.B, b1, (uint32_t)p.T, (uint32_t)(p.T >> 32), seed);
+        const uint32_t s1 = murmur21_filter<SEED0>((uint32_t)p.A, a1, (uint32_t)p.B, b1, (uint32_t)p.T, (uint32_t)(p.T >> 32), seed, F1, F2);
 #endif
         // rare (~2.5*s survivors per genome): wave-private LDS buffer, one global atomic per block at the end --
         // the ~300 concurrent blocks of a genome would otherwise serialise on its counter inside the hot loop
-        bool hit = h <= thr;
+        bool hit = s1 <= thr_bound;  // necessary for h <= thr (murmur21_asm.h)
         if (__ballot(hit)) {
-            hit = hit && (b - st.lastbad >= K) && inword == 0;
+            const uint64_t h = murmur21_finish(F1, F2);
+            hit = hit && h <= thr && (b - st.lastbad >= K) && inword == 0;
             const unsigned long long m = __ballot(hit);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (hit) {

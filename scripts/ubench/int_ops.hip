@@ -178,6 +178,26 @@ __global__ void k_lds_lut(uint64_t *out, uint32_t seed) {      // 3 ds_read_b64 
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// same, with the number of resident waves per SIMD limited by a dynamic LDS allocation
+template <typename K>
+static void run_block_occ(const char *name, K kern, uint64_t *d_out, double iters, int waves_per_simd) {
+    const int threads = 256, blocks = 256 * waves_per_simd * 4;  // 4 rounds of fully occupied CUs
+    const size_t lds = (160 * 1024 / waves_per_simd) & ~(size_t)255;  // one 4-wave block per SIMD-wave slot
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, d_out, 12345u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, d_out, 12345u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double wave_iters = (double)blocks * (threads / 64) * iters;
+    printf("%-14s waves/SIMD %d  %8.3f ms  %7.1f SIMD-cycles per wave-iteration (at 2.4 GHz)\n", name, waves_per_simd, ms, ms * 1e-3 * 2.4e9 * 1024 / wave_iters);
+}
+
 template <typename K>
 static void run_block(const char *name, K kern, uint64_t *d_out, double iters) {
     const int blocks = 256 * 8, threads = 256;
@@ -197,7 +217,7 @@ static void run_block(const char *name, K kern, uint64_t *d_out, double iters) {
 
 int main() {
     uint64_t *d_out;
-    hipMalloc(&d_out, 256 * 8 * 256 * 8);
+    hipMalloc(&d_out, (size_t)256 * 8 * 4 * 256 * 8);
     run("v_add_u32", k_add32, d_out, 1);
     run("v_mul_lo_u32", k_mul_lo, d_out, 1);
     run("v_mul_hi_u32", k_mul_hi, d_out, 1);
@@ -229,6 +249,7 @@ int main() {
     run("v_min_u32_e32", k_min, d_out, 1);
     run("v_mov_b32_e32", k_mov, d_out, 1);
     run_block("hash_block", k_hash_block, d_out, REPB);
+    for (int w : {1, 2, 3, 4, 5, 6, 8}) run_block_occ("hash_block", k_hash_block, d_out, REPB, w);
     run_block("cmp64+cndmask", k_cmp_cnd, d_out, REPB * 8);
     run_block("select_c", k_select_c, d_out, REPB * 8);
     run_block("select_base", k_select_base, d_out, REPB * 8);
