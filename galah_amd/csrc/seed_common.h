@@ -23,10 +23,9 @@ __device__ __forceinline__ uint32_t base_code(uint32_t c) {
     return ok ? (((c >> 1) ^ (c >> 2)) & 3u) : 4u;
 }
 
-constexpr uint32_t SEED_LDS_CAP = 1024;   // seeds buffered per block (expected 16384/c ~ 131)
-constexpr uint32_t SEED_LDS_CHUNKS = 64;  // per-block chunk counters
+constexpr uint32_t SEED_LANE_CAP = 4;      // seeds buffered per lane (expected 64/c ~ 0.5 at c = 125)
+constexpr uint32_t SEED_LDS_CHUNKS = 64;   // per-block chunk counters
 constexpr uint32_t SEED_WAVES = GHIP_SKETCH_THREADS / 64;
-constexpr uint32_t SEED_WAVE_CAP = SEED_LDS_CAP / SEED_WAVES;
 
 struct SeedOut {  // where a block's seeds go (kernel argument, by value)
     uint32_t k, thr, chunk;
@@ -38,15 +37,15 @@ struct SeedOut {  // where a block's seeds go (kernel argument, by value)
     const uint64_t *chunk_start;
 };
 
-struct SeedLds {  // per-block LDS state; declare as `__shared__ ghip_seed::SeedLds`
-    uint32_t code[SEED_LDS_CAP];
-    uint16_t pos[SEED_LDS_CAP];
+struct SeedLds {  // per-block LDS state; slot-major so that the 64 lanes of a wave write consecutive words
+    uint32_t code[SEED_LANE_CAP][GHIP_SKETCH_THREADS];
+    uint16_t pos[SEED_LANE_CAP][GHIP_SKETCH_THREADS];
     uint32_t ctot[SEED_LDS_CHUNKS];
     uint32_t wave_n[SEED_WAVES], wave_base[SEED_WAVES];
 };
 
 struct SeedBlock {  // per-thread view of one block's seeding state
-    uint32_t g, ch_first, rem_first, scap, wave_base, wave_n;
+    uint32_t g, ch_first, rem_first, scap, n_lane;
     uint64_t sstart;
     uint32_t *ctot;
 };
@@ -60,55 +59,53 @@ __device__ __forceinline__ SeedBlock seed_block_begin(SeedLds &sl, const SeedOut
     sb.sstart = so.seed_start[g];
     sb.scap = (uint32_t)(so.seed_start[g + 1] - sb.sstart);
     sb.ctot = so.chunk_total + so.chunk_start[g];
-    sb.wave_base = (threadIdx.x >> 6) * SEED_WAVE_CAP;
-    sb.wave_n = 0;
+    sb.n_lane = 0;
     if (threadIdx.x < SEED_LDS_CHUNKS) sl.ctot[threadIdx.x] = 0;
     __syncthreads();
     return sb;
 }
 
-// Wave-private append: rank among the passing lanes by ballot/mbcnt, wave-uniform count in a scalar --
-// no LDS atomic in the position loop.  Must be reached by all 64 lanes.  rel = position - block start.
+// Lane-private append: no cross-lane ranking in the position loop (a ballot/mbcnt rank cost ~10 instructions
+// on the 40 % of positions where some lane of the wave holds a seed).  rel = position - block start.
 __device__ __forceinline__ void seed_append(SeedLds &sl, const SeedOut &so, SeedBlock &sb, bool pass, uint32_t canon, uint32_t rel) {
-    const unsigned long long m = __ballot(pass);
-    if (m) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const uint32_t slot = sb.wave_n + rank;
-        if (pass) {
-            if (slot < SEED_WAVE_CAP) { sl.code[sb.wave_base + slot] = canon; sl.pos[sb.wave_base + slot] = (uint16_t)rel; }
-            else {  // wave buffer full (never at c=125): straight to the global list
-                const uint32_t ch = sb.ch_first + (sb.rem_first + rel) / so.chunk;
-                uint32_t idx = atomicAdd(&so.seed_count[sb.g], 1u);
-                if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_chunk[sb.sstart + idx] = (uint16_t)ch; }
-                atomicAdd(&sb.ctot[ch], 1u);
-            }
+    if (pass) {
+        if (sb.n_lane < SEED_LANE_CAP) { sl.code[sb.n_lane][threadIdx.x] = canon; sl.pos[sb.n_lane][threadIdx.x] = (uint16_t)rel; }
+        else {  // lane buffer full (P ~ 1e-4 per lane at c = 125; always at c = 1): straight to the global list
+            const uint32_t ch = sb.ch_first + (sb.rem_first + rel) / so.chunk;
+            uint32_t idx = atomicAdd(&so.seed_count[sb.g], 1u);
+            if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_chunk[sb.sstart + idx] = (uint16_t)ch; }
+            atomicAdd(&sb.ctot[ch], 1u);
         }
-        sb.wave_n += (uint32_t)__popcll(m);
+        sb.n_lane++;
     }
 }
 
 // call after the position loop by every thread of the block (contains __syncthreads)
 __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so, SeedBlock &sb) {
-    if ((threadIdx.x & 63u) == 0) sl.wave_n[threadIdx.x >> 6] = min(sb.wave_n, SEED_WAVE_CAP);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t mine = min(sb.n_lane, SEED_LANE_CAP);
+    uint32_t incl = mine;  // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += v;
+    }
+    if (lane == 63) sl.wave_n[w] = incl;
     __syncthreads();
-    // one global atomic per block reserves room for all waves' seeds; then every wave flushes its own
+    // one global atomic per block reserves room for all waves' seeds
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (uint32_t w = 0; w < SEED_WAVES; w++) { sl.wave_base[w] = tot; tot += sl.wave_n[w]; }
+        for (uint32_t i = 0; i < SEED_WAVES; i++) { sl.wave_base[i] = tot; tot += sl.wave_n[i]; }
         const uint32_t base = tot ? atomicAdd(&so.seed_count[sb.g], tot) : 0u;
-        for (uint32_t w = 0; w < SEED_WAVES; w++) sl.wave_base[w] += base;
+        for (uint32_t i = 0; i < SEED_WAVES; i++) sl.wave_base[i] += base;
     }
     __syncthreads();
-    {
-        const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-        const uint32_t nw = sl.wave_n[w], gbase = sl.wave_base[w];
-        for (uint32_t i = lane; i < nw; i += 64) {
-            const uint32_t chrel = (sb.rem_first + sl.pos[sb.wave_base + i]) / so.chunk;
-            const uint32_t idx = gbase + i;
-            if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = sl.code[sb.wave_base + i]; so.seed_chunk[sb.sstart + idx] = (uint16_t)(sb.ch_first + chrel); }
-            if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
-            else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
-        }
+    uint32_t idx = sl.wave_base[w] + incl - mine;
+    for (uint32_t i = 0; i < mine; i++, idx++) {
+        const uint32_t chrel = (sb.rem_first + sl.pos[i][threadIdx.x]) / so.chunk;
+        if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = sl.code[i][threadIdx.x]; so.seed_chunk[sb.sstart + idx] = (uint16_t)(sb.ch_first + chrel); }
+        if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
+        else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
     }
     __syncthreads();
     if (threadIdx.x < SEED_LDS_CHUNKS && sl.ctot[threadIdx.x]) atomicAdd(&sb.ctot[sb.ch_first + threadIdx.x], sl.ctot[threadIdx.x]);
