@@ -7,9 +7,13 @@ ANI on the surviving pairs -> host greedy clustering at 95 %.  value = genome pa
 (all N(N-1)/2 pairs of the workload divided by the whole-step wall time, max over ranks).
 
 Default workload = BASELINE.json configs[1]: 1 000 synthetic ~5 Mb genomes (100 species x 10
-members at ~95 % pairwise identity), sketch size 1000, one MI355X.  With --gpus N the SAME
-workload is sharded over N ranks (strong scaling): genomes are sketched where they live,
-sketches and ANI seed indexes are all-gathered over RCCL, pair tiles are dealt block-cyclically.
+members at ~95 % pairwise identity), sketch size 1000, one MI355X.  With --gpus N every rank brings
+ITS OWN 1 000 genomes (weak scaling: N x 1 000 genomes in total, the shape of configs[2] = 10 000 genomes
+on 8 GPUs): genomes are sketched where they live, the sketch matrix is all-gathered over RCCL, the
+(N x 1 000)^2 / 2 pair tiles are dealt block-cyclically, ANI runs where a pair's first genome lives.
+The metric counts ALL pairs of the workload, which grow quadratically with the genome count, so
+`value` grows faster than N under weak scaling; `genomes_per_s` in the same line is the linear figure.
+--strong keeps the total at --species x --members genomes and shards them instead.
 
 Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline leg.
 """
@@ -34,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--species", type=int, default=100)
+    ap.add_argument("--species", type=int, default=100, help="species per GPU (total with --strong)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --species is the total, sharded over the ranks")
     ap.add_argument("--members", type=int, default=10)
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--sub-rate", type=float, default=0.0253)
@@ -66,7 +71,7 @@ def pmc_traffic(kernel: str):
         with open(path) as f:
             d = json.load(f)
         k = d["kernels"][kernel + "_kernel"]
-        return float(k["hbm_bytes_per_launch"]), d.get("tag"), k.get("valu_busy")
+        return float(k["hbm_bytes_per_launch"]), d.get("tag"), {x: k.get(x) for x in ("simd_cycles_per_valu_inst", "valu_insts_per_launch")}
     except Exception:
         return None, None, None
 
@@ -143,6 +148,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = galah_amd.Context(local_rank)
 
+    if not args.strong:
+        args.species *= world   # weak scaling: every rank brings --species species of its own
     n = args.species * args.members
     n_pairs_total = n * (n - 1) // 2
     min_ani = parse_percentage(args.precluster_ani)           # fraction (finch.rs:5-6)
@@ -198,24 +205,26 @@ def main():
                     e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBS
                 kern[k] = e
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
-        traffic, traffic_tag, valu_busy = pmc_traffic(dom) if world == 1 else (None, None, None)
+        traffic, traffic_tag, valu = pmc_traffic(dom) if world == 1 else (None, None, None)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
                     "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag,
                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
-                    "valu_busy": valu_busy,  # SQ_ACTIVE_INST_VALU*4 / (SIMDs * GRBM_GUI_ACTIVE), same PMC file
-                    "note": ("sketch_kmers is integer-VALU bound (MurmurHash3 multiplies), not HBM bound; "
-                             "pair_intersect_tile is the HBM-roofline kernel of the path, see 'kernels'")}
+                    "valu": valu,  # SQ_INSTS_VALU per launch and SIMD-cycles per VALU instruction, same PMC file
+                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 55 of its ~95 "
+                             "VALU instructions per base (DESIGN.md); the HBM fraction is reported because the tier "
+                             "asks for it.  pair_intersect_tile is the HBM-roofline kernel of the path, see 'kernels'")}
         out = {
             "metric": "genome-pairs/sec (MinHash+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{n} synthetic genomes x {args.length} bp ({args.species} species x {args.members} "
                                    f"members, ~95% ANI), finch precluster s={args.sketch_size} k={args.kmer} at "
                                    f"{args.precluster_ani}% + ANI at {args.ani}%, greedy clustering",
-                       "genomes": n, "genome_length": args.length, "pairs": n_pairs_total,
+                       "genomes": n, "genomes_per_gpu": n // world, "genome_length": args.length, "pairs": n_pairs_total,
                        "parallelism": f"pair-tiles x{world}" if world > 1 else "single"},
+            "genomes_per_s": n * args.steps / elapsed,
             "roofline": roofline,
             "kernels": kern,
             "stage_ms_per_step": stage_ms,

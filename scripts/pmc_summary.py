@@ -15,20 +15,28 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/pmc_{tag}"
 WIDE = {"sketch_kmers_kernel", "ani_seeds_kernel", "synth_genomes_kernel"}  # 16 B/lane global loads
 out = collections.defaultdict(dict)
+
+
+def kname(k):  # the profiling label of the k = 21 sketch kernel is "sketch_kmers" (ghip_prof_begin)
+    return "sketch_kmers_kernel" if k == "sketch_kmers21_kernel" else k
+
+
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f"{src}/{C}/{C}_counter_collection.csv")):
         m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
         if not m:
             continue
-        agg[m.group(1)][0] += 1
-        agg[m.group(1)][1] += float(r["Counter_Value"])
+        agg[kname(m.group(1))][0] += 1
+        agg[kname(m.group(1))][1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         out[k][C + "_KB_per_launch"] = v / n
         out[k]["launches_" + C] = n
-# third pass (scripts/gpu_pmc.sh): SQ counters -> VALU pipe occupancy.  GRBM_GUI_ACTIVE comes back summed
-# over the 8 XCDs, SQ_ACTIVE_INST_VALU in quad-cycles summed over all SIMDs:
-#   VALUBusy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+# third pass (scripts/gpu_pmc.sh): SQ counters -> VALU issue rate.  GRBM_GUI_ACTIVE comes back summed over the
+# 8 XCDs; on gfx950 SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU (a count, not cycles), so the figure reported is
+#   simd_cycles_per_valu_inst = (1024 SIMDs * GRBM_GUI_ACTIVE / 8) / SQ_INSTS_VALU
+# to be read against the per-instruction issue costs measured by scripts/ubench/int_ops.hip (2.4 cycles for
+# add/logic/32-bit shifts, 4.3-5.0 for multiplies, 64-bit shifts/adds, alignbit, SDWA forms and compares).
 try:
     sq = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
@@ -38,18 +46,17 @@ try:
             m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
             if not m:
                 continue
-            sq[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
+            sq[kname(m.group(1))][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == "SQ_WAVES":
-                cnt[m.group(1)] += 1
+                cnt[kname(m.group(1))] += 1
     for k, d in sq.items():
         n = max(cnt[k], 1)
         out[k]["valu_insts_per_launch"] = d["SQ_INSTS_VALU"] / n
         out[k]["salu_insts_per_launch"] = d["SQ_INSTS_SALU"] / n
         out[k]["lds_insts_per_launch"] = d["SQ_INSTS_LDS"] / n
-        if d["GRBM_GUI_ACTIVE"] > 0:
-            # can read slightly above 1: VOP2 instructions are counted as a full quad-cycle but issue faster
-            out[k]["valu_busy_raw"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0)
-            out[k]["valu_busy"] = min(1.0, out[k]["valu_busy_raw"])
+        if d["GRBM_GUI_ACTIVE"] > 0 and d["SQ_INSTS_VALU"] > 0:
+            out[k]["simd_cycles_per_valu_inst"] = 1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0 / d["SQ_INSTS_VALU"]
+            out[k]["waves_per_launch"] = d["SQ_WAVES"] / n
 except Exception as e:  # the SQ pass is optional
     print("no SQ pass:", e)
 for k, d in out.items():
@@ -60,5 +67,5 @@ for k, d in out.items():
 json.dump({"tag": tag, "command": "rocprofv3 --pmc <C> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
            "kernels": out}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
 for k, d in sorted(out.items(), key=lambda x: -x[1]["hbm_bytes_per_launch"]):
-    print("%-28s %.3f GB/launch  VALUBusy %s" % (k, d["hbm_bytes_per_launch"] / 1e9,
-                                                 ("%.0f %%" % (100 * d["valu_busy"])) if "valu_busy" in d else "-"))
+    print("%-28s %.3f GB/launch  SIMD-cycles per VALU instruction %s" % (
+        k, d["hbm_bytes_per_launch"] / 1e9, ("%.2f" % d["simd_cycles_per_valu_inst"]) if "simd_cycles_per_valu_inst" in d else "-"))
