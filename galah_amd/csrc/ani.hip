@@ -278,19 +278,48 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[2], bq); atomicAdd(&red[5], br); }
     __syncthreads();
     const uint32_t n = n_al;
-    if (threadIdx.x == 0) red[3] = n;
+    if (threadIdx.x == 0) { red[3] = n; red[4] = ~0ull; }
     const uint32_t target = n ? (n - 1) / 2 : 0;
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        const unsigned long long me = list[e];
-        const unsigned long long mm = me >> 32, mt = me & 0xffffffffull;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; j++) {
-            const unsigned long long o = list[j];
-            const unsigned long long l = (o >> 32) * mt, rr = mm * (o & 0xffffffffull);  // o < me  <=>  om*mt < mm*ot
-            rank += (l < rr || (l == rr && j < e)) ? 1u : 0u;
+    // Exact order of the fractions M_c/T_c through f64 keys: the quotient is correctly rounded, hence monotone, and
+    // two different fractions with T < 2^26 differ by more than an ulp, so key order == cross-multiplied order and
+    // equal keys <=> equal fractions.  The keys live in the (now idle) seed stage; longer lists compare by
+    // cross-multiplication.  Every member of the median's tie group holds the same fraction: the smallest
+    // (m, t) of the group is reported.
+    constexpr uint32_t KEY_CAP = sizeof(st_code) / sizeof(double);
+    if (n <= KEY_CAP) {
+        double *keys = reinterpret_cast<double *>(&st_code[0][0][0]);
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const unsigned long long me = list[e];
+            keys[e] = (double)(uint32_t)(me >> 32) / (double)(uint32_t)me;
         }
-        if (rank == target) { red[0] = mm; red[1] = mt; }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const double me = keys[e];
+            uint32_t lt = 0, le = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const double o = keys[j];
+                lt += o < me ? 1u : 0u;
+                le += o <= me ? 1u : 0u;
+            }
+            if (lt <= target && target < le) atomicMin(&red[4], list[e]);
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const unsigned long long me = list[e];
+            const unsigned long long mm = me >> 32, mt = me & 0xffffffffull;
+            uint32_t lt = 0, le = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const unsigned long long o = list[j];
+                const unsigned long long l = (o >> 32) * mt, rr = mm * (o & 0xffffffffull);  // o < me  <=>  om*mt < mm*ot
+                lt += l < rr ? 1u : 0u;
+                le += l <= rr ? 1u : 0u;
+            }
+            if (lt <= target && target < le) atomicMin(&red[4], me);
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && n) { red[0] = red[4] >> 32; red[1] = red[4] & 0xffffffffull; }
+    if (threadIdx.x == 0) red[4] = 0;
     __syncthreads();
     if (threadIdx.x < 6) out[(uint64_t)pair * 6 + threadIdx.x] = red[threadIdx.x];
 }

@@ -802,7 +802,8 @@ extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
 // kernel or ride along with the MinHash pass (ghip_sketch_and_index)
 static int index_new(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk, ghip_ani_index **out,
                      std::vector<uint64_t> &cap) {
-    if (k < 1 || k > 16 || c < 1 || chunk < 1) return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters (k must be 1..=16)");
+    if (k < 1 || k > 16 || c < 1 || chunk < 1 || chunk > (1u << 24))
+        return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters (k must be 1..=16, chunk 1..=2^24)");
     const size_t n = g->n;
     ghip_ani_index *idx = new ghip_ani_index();
     ctx->live_handles++;
@@ -1009,7 +1010,7 @@ extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, u
                                           const uint64_t *genome_len, const uint64_t *seed_cap,
                                           const uint32_t *seed_count, void *d_seed_code, void *d_seed_chunk,
                                           void *d_bin_start, void *d_chunk_total, ghip_ani_index **out) {
-    if (!ctx || !out || chunk == 0 || (n && (!genome_len || !seed_cap || !seed_count))) return GHIP_EINVAL;
+    if (!ctx || !out || chunk == 0 || chunk > (1u << 24) || (n && (!genome_len || !seed_cap || !seed_count))) return GHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ghip_ani_index *idx = new ghip_ani_index();

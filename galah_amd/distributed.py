@@ -296,7 +296,9 @@ class DereplicationJob:
             # every rank learns the whole (small) candidate list
             parts = ex.all_gather_object(pairs)
             allp = np.concatenate(parts) if parts else np.zeros(0, PAIR_DTYPE)
-            allp = allp[np.argsort(allp, order=["i", "j"], kind="stable")]
+            # (i, j) order through one u64 key: numpy's structured-field sort is ~5x slower at 10^4..10^5 pairs
+            key = (allp["i"].astype(np.uint64) << np.uint64(32)) | allp["j"].astype(np.uint64)
+            allp = allp[np.argsort(key, kind="stable")]
             t = self._tick("allgather_pairs", t)
             # A pair is computed where its first genome lives; only the genomes a rank needs but does
             # not own are exchanged (instead of all-gathering the whole index, ~0.33 MB per genome).
@@ -305,17 +307,22 @@ class DereplicationJob:
             needed = np.unique(allp["j"][owner_i != owner_j]).astype(np.int64)   # same on every rank
             mine_mask = owner_i == self.rank
             mine = allp[mine_mask]
-            arrs_l = e.ani_export(idx_l, lay)
-            send_ids = needed[(needed >= self.first) & (needed < self.first + self.count)] - self.first
-            packed, pmeta = self._pack_genomes(arrs_l, meta_l, send_ids)
-            metas = ex.all_gather_object(pmeta)
-            recv = {k: ex.all_gather_flat(packed[k], [m["sizes"][k] for m in metas]) for k in packed}
-            rmeta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt")}
-            # combined index = local genomes, then the received ones (in `needed` order: owners ascending)
-            cmeta = {k: np.concatenate([meta_l[k], rmeta[k]]) for k in ("glen", "cap", "cnt")}
-            import torch
-            carrs = {k: torch.cat([arrs_l[k], recv[k]]) for k in arrs_l}
-            idx = e.ani_wrap(cmeta, carrs)
+            if len(needed) == 0:
+                # no candidate pair spans two ranks (families do not straddle block boundaries): the local
+                # index serves as it is -- no export, no collective (`needed` is identical on every rank)
+                idx = idx_l
+            else:
+                arrs_l = e.ani_export(idx_l, lay)
+                send_ids = needed[(needed >= self.first) & (needed < self.first + self.count)] - self.first
+                packed, pmeta = self._pack_genomes(arrs_l, meta_l, send_ids)
+                metas = ex.all_gather_object(pmeta)
+                recv = {k: ex.all_gather_flat(packed[k], [m["sizes"][k] for m in metas]) for k in packed}
+                rmeta = {k: np.concatenate([m[k] for m in metas]) for k in ("glen", "cap", "cnt")}
+                # combined index = local genomes, then the received ones (in `needed` order: owners ascending)
+                cmeta = {k: np.concatenate([meta_l[k], rmeta[k]]) for k in ("glen", "cap", "cnt")}
+                import torch
+                carrs = {k: torch.cat([arrs_l[k], recv[k]]) for k in arrs_l}
+                idx = e.ani_wrap(cmeta, carrs)
             t = self._tick("exchange_ani_index", t)
             remap = np.full(self.n, -1, dtype=np.int64)
             remap[self.first: self.first + self.count] = np.arange(self.count)
@@ -337,7 +344,7 @@ class DereplicationJob:
                       "pair_ani": alla}
         if hasattr(idx, "free"):
             idx.free()
-        if self.world > 1 and hasattr(idx_l, "free"):
+        if self.world > 1 and idx is not idx_l and hasattr(idx_l, "free"):
             idx_l.free()
         self._steps += 1
         return result
