@@ -189,6 +189,8 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     __shared__ uint32_t n_al;
     __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE];
     __shared__ uint16_t st_chunk[ANI_PAIR_WAVES][2][ANI_STAGE];
+    __shared__ uint8_t st_flag[ANI_PAIR_WAVES][ANI_STAGE];  // r seed of the stage matched by some q seed
+    __shared__ uint16_t st_roff[ANI_PAIR_WAVES][66];         // stage offsets of the 64 bins' r runs
     uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
 
     // physical block b runs on XCD b % 8: give each XCD runs of 32 consecutive pairs (one precluster's
@@ -212,6 +214,9 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t *sq = st_code[wave][0], *sr = st_code[wave][1];
     uint16_t *kq = st_chunk[wave][0], *kr = st_chunk[wave][1];
+    uint8_t *rf = st_flag[wave];
+    uint16_t *ro = st_roff[wave];
+    for (uint32_t k = lane; k < ANI_STAGE; k += 64) rf[k] = 0;
     for (uint32_t b0 = wave * 64; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * 64) {
         const uint32_t b = b0 + lane;
         const uint32_t qs = qb[b], qe = qb[b + 1], rs = rb[b], re = rb[b + 1];
@@ -224,35 +229,27 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             for (uint32_t k = lane; k < r_hi - r_lo; k += 64) { sr[k] = rc[r_lo + k]; kr[k] = rk[r_lo + k]; }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t qa = qs - q_lo, qz = qe - q_lo, ra = rs - r_lo, rz = re - r_lo;
-            if (rz - ra <= 32) {  // one pass: per-q "any match" plus a bit mask of matched r seeds
-                uint32_t rmask = 0;
-                for (uint32_t i = qa; i < qz; i++) {
-                    const uint32_t c = sq[i];
-                    uint32_t m = 0;
-                    for (uint32_t j = ra; j < rz; j++) m |= (uint32_t)(sr[j] == c) << (j - ra);
-                    if (m) atomicAdd(&mcq[kq[i]], 1u);
-                    rmask |= m;
-                }
-                while (rmask) {
-                    const uint32_t j = ra + (uint32_t)__builtin_ctz(rmask);
-                    rmask &= rmask - 1;
-                    atomicAdd(&mcr[kr[j]], 1u);
-                }
-            } else {
-                for (uint32_t i = qa; i < qz; i++) {       // q seeds that occur in r
-                    const uint32_t c = sq[i];
-                    bool hit = false;
-                    for (uint32_t j = ra; j < rz; j++) hit |= (sr[j] == c);
-                    if (hit) atomicAdd(&mcq[kq[i]], 1u);
-                }
-                for (uint32_t j = ra; j < rz; j++) {       // r seeds that occur in q
-                    const uint32_t c = sr[j];
-                    bool hit = false;
-                    for (uint32_t i = qa; i < qz; i++) hit |= (sq[i] == c);
-                    if (hit) atomicAdd(&mcr[kr[j]], 1u);
-                }
+            // Flattened join: q seeds are dealt to the lanes one each (not one BIN per lane, whose cost is the
+            // largest bin of the wave squared); a seed's bin, hence its short r range, follows from its code.
+            // Matched r seeds are flagged and counted in a second balanced pass.
+            const uint32_t nq = q_hi - q_lo, nr = r_hi - r_lo;
+            ro[lane] = (uint16_t)(rs - r_lo);            // r range of bin b0 + x = [ro[x], ro[x + 1])
+            if (lane == 63) ro[64] = (uint16_t)nr;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < nq; i += 64) {
+                const uint32_t c = sq[i];
+                const uint32_t x = code_bin(c) - b0;
+                const uint32_t jz = ro[x + 1];
+                bool hit = false;
+                for (uint32_t j = ro[x]; j < jz; j++)
+                    if (sr[j] == c) { hit = true; rf[j] = 1; }
+                if (hit) atomicAdd(&mcq[kq[i]], 1u);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < nr; j += 64)
+                if (rf[j]) { rf[j] = 0; atomicAdd(&mcr[kr[j]], 1u); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
         } else {
