@@ -242,7 +242,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         // rare (~2.5*s survivors per genome): wave-private LDS buffer, one global atomic per block at the end --
         // the ~300 concurrent blocks of a genome would otherwise serialise on its counter inside the hot loop
         bool hit = s1 <= thr_bound;  // necessary for h <= thr (murmur21_asm.h)
-        if (__ballot(hit)) {
+        if (__builtin_amdgcn_ballot_w64(hit)) {
             const uint64_t h = murmur21_finish(F1, F2);
             hit = hit && h <= thr && (b - st.lastbad >= K) && inword == 0;
             const unsigned long long m = __ballot(hit);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 const uint32_t r15 = ~(uint32_t)(st.fl >> ashift) & amask;
                 const uint32_t c15 = min(f15, r15);
                 bool pass = seed_gate && ghip_seed::fmix32(c15) < so.thr;
-                if (__ballot(pass)) {  // validity only where some lane passed
+                if (__builtin_amdgcn_ballot_w64(pass)) {  // validity only where some lane passed
                     pass = pass && (b - st.lastbad >= ak) && inword == 0;
                     ghip_seed::seed_append(sl, so, sb, pass, c15, toff + (uint32_t)(b - (ak - 1)));
                 }
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 pend = cur;
             }
         }
-        if (__ballot(bad4 != 0)) {  // wave-uniform: rare
+        if (__builtin_amdgcn_ballot_w64(bad4 != 0)) {  // wave-uniform: rare
+            asm volatile("" ::: "memory");  // keep this a branch: if-converted it costs 9 instructions per word
             if (bad4) st.lastbad = b0 + 3 - (int)(__builtin_clz(bad4) >> 3);
         }
     };
