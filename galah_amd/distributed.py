@@ -105,9 +105,11 @@ class Exchange:
     def gather_object(self, obj, dst: int = 0):
         if self.world == 1:
             return [obj]
-        out = [None] * self.world if self.rank == dst else None
-        self.dist.gather_object(obj, out, dst=dst)
-        return out
+        # all_gather_object is implemented for every backend (gather_object is not for all NCCL builds);
+        # the payloads are a few KB of candidate indices and ANI values
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out if self.rank == dst else None
 
 
 class HipEngine:
