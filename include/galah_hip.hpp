@@ -1,0 +1,304 @@
+// galah_hip.hpp -- C++ host side above the C ABI (include/galah_hip.h): the reference's plug-in interface for
+// the finch-precluster + ANI path, restated with the same names, argument meaning and error behaviour.
+//
+// galah is compiled Rust; this image has no Rust toolchain, so the host mirror is C++ (header-only, C++17) and the
+// Rust shim a maintainer adds is in INTEGRATION.md.  Rust `panic!` / `expect` become std::runtime_error carrying the
+// reference's message.
+//
+//   reference                                             here
+//   ---------------------------------------------------   -----------------------------------------------
+//   SortedPairGenomeDistanceCache                          galah::SortedPairGenomeDistanceCache
+//     (src/sorted_pair_genome_distance_cache.rs:5-59)
+//   trait PreclusterDistanceFinder (src/lib.rs:29-45)      galah::PreclusterDistanceFinder
+//   trait ClusterDistanceFinder    (src/lib.rs:47-55)      galah::ClusterDistanceFinder
+//   FinchPreclusterer (src/finch.rs:4-46), finch::         galah::FinchPreclusterer, galah::finch::distances
+//     distances (src/finch.rs:48-97)
+//   SkaniClusterer (src/skani.rs:689-716)                  galah::HipAniClusterer ("hipani": build-defined ANI)
+//   clusterer::cluster (src/clusterer.rs:14-152)           galah::cluster
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "galah_hip.h"
+
+namespace galah {
+
+// ---------------------------------------------------------------------------------------------------------------
+class SortedPairGenomeDistanceCache {  // src/sorted_pair_genome_distance_cache.rs
+public:
+    using Key = std::pair<size_t, size_t>;
+    std::map<Key, std::optional<float>> internal;  // BTreeMap<(usize, usize), Option<f32>>
+
+    void insert(Key pair, std::optional<float> distance) { internal[sorted(pair)] = distance; }          // :22-29
+    // Some(&Option<f32>) / None: outer optional = key present
+    std::optional<std::optional<float>> get(Key pair) const {                                              // :31-37
+        auto it = internal.find(sorted(pair));
+        if (it == internal.end()) return std::nullopt;
+        return it->second;
+    }
+    bool contains_key(Key pair) const { return internal.count(sorted(pair)) != 0; }                        // :39-45
+    // keep pairs whose both members are in `ids`, renumbered by their position in `ids`                   // :47-58
+    SortedPairGenomeDistanceCache transform_ids(const std::vector<size_t> &ids) const {
+        SortedPairGenomeDistanceCache out;
+        for (size_t i = 0; i < ids.size(); i++)
+            for (size_t j = i + 1; j < ids.size(); j++) {
+                auto v = get({ids[i], ids[j]});
+                if (v) out.insert({i, j}, *v);
+            }
+        return out;
+    }
+    size_t len() const { return internal.size(); }
+    bool operator==(const SortedPairGenomeDistanceCache &o) const { return internal == o.internal; }
+
+private:
+    static Key sorted(Key p) { return p.first < p.second ? p : Key{p.second, p.first}; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+struct PreclusterDistanceFinder {  // src/lib.rs:29-45
+    virtual ~PreclusterDistanceFinder() = default;
+    virtual SortedPairGenomeDistanceCache distances(const std::vector<std::string> &genome_fasta_paths) = 0;
+    virtual SortedPairGenomeDistanceCache distances_contigs(const std::vector<std::string> &genome_fasta_paths,
+                                                            const std::vector<std::string> &contig_names) = 0;
+    virtual SortedPairGenomeDistanceCache distances_with_references(const std::vector<std::string> &genome_fasta_paths,
+                                                                    const std::vector<std::string> &reference_genomes) = 0;
+    virtual std::string method_name() const = 0;
+};
+
+struct ClusterDistanceFinder {  // src/lib.rs:47-55
+    virtual ~ClusterDistanceFinder() = default;
+    virtual void initialise() const = 0;
+    virtual std::string method_name() const = 0;
+    virtual float get_ani_threshold() const = 0;
+    virtual std::optional<float> calculate_ani(const std::string &fasta1, const std::string &fasta2) = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// One HIP context shared by the back-ends of a run (ghip_init / ghip_destroy).
+class HipContext {
+public:
+    explicit HipContext(int device = 0) {
+        if (ghip_init(device, &ctx_) != GHIP_OK)
+            throw std::runtime_error(std::string("Failed to initialise the HIP back-end: ") + ghip_last_error(nullptr));
+    }
+    ~HipContext() { ghip_destroy(ctx_); }
+    HipContext(const HipContext &) = delete;
+    HipContext &operator=(const HipContext &) = delete;
+    ghip_ctx *get() const { return ctx_; }
+    std::string last_error() const { return ghip_last_error(ctx_); }
+
+private:
+    ghip_ctx *ctx_ = nullptr;
+};
+
+namespace detail {
+inline std::vector<const char *> c_paths(const std::vector<std::string> &paths) {
+    std::vector<const char *> out;
+    out.reserve(paths.size());
+    for (auto &p : paths) out.push_back(p.c_str());
+    return out;
+}
+}  // namespace detail
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace finch {
+// finch::distances (src/finch.rs:48-97): sketch every file (k-mers never span records, seed 0, no filtering,
+// no_strict), then every pair i<j whose Mash ANI >= min_ani (compared in f64) enters the cache as `ANI as f32`.
+// `edges` (optional) receives the same entries as the sorted edge list ghip_cluster consumes.
+inline SortedPairGenomeDistanceCache distances(HipContext &hip, const std::vector<std::string> &genome_fasta_paths,
+                                               float min_ani, size_t num_kmers, uint8_t kmer_length, int threads = 1,
+                                               std::vector<ghip_pair> *edges = nullptr) {
+    auto paths = detail::c_paths(genome_fasta_paths);
+    ghip_sketches *sk = nullptr;
+    if (ghip_sketch_files(hip.get(), paths.data(), paths.size(), kmer_length, (uint32_t)num_kmers, 0, threads, &sk) != GHIP_OK)
+        throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());        // finch.rs:72
+    ghip_pair *pairs = nullptr;
+    size_t n = 0;
+    const int rc = ghip_precluster(hip.get(), sk, min_ani, &pairs, &n);
+    ghip_sketches_free(sk);
+    if (rc != GHIP_OK) throw std::runtime_error("Failed to compare finch sketches: " + hip.last_error());  // finch.rs:80-85
+    SortedPairGenomeDistanceCache cache;
+    for (size_t x = 0; x < n; x++) cache.insert({pairs[x].i, pairs[x].j}, pairs[x].ani);              // finch.rs:91-93
+    if (edges) edges->assign(pairs, pairs + n);
+    ghip_free(pairs);
+    return cache;
+}
+}  // namespace finch
+
+class FinchPreclusterer : public PreclusterDistanceFinder {  // src/finch.rs:4-46
+public:
+    float min_ani;         // a fraction, not a percentage (finch.rs:5-6)
+    size_t num_kmers;      // 1000 (src/cluster_argument_parsing.rs:1301)
+    uint8_t kmer_length;   // 21   (src/cluster_argument_parsing.rs:1302)
+    bool low_memory;
+    int threads;
+
+    FinchPreclusterer(std::shared_ptr<HipContext> hip, float min_ani, size_t num_kmers, uint8_t kmer_length,
+                      bool low_memory = false, int threads = 1)
+        : min_ani(min_ani), num_kmers(num_kmers), kmer_length(kmer_length), low_memory(low_memory), threads(threads),
+          hip_(std::move(hip)) {}
+
+    SortedPairGenomeDistanceCache distances(const std::vector<std::string> &genome_fasta_paths) override {
+        if (low_memory)                                                                                 // finch.rs:14-15
+            throw std::runtime_error("Low-memory clustering currently only supported with skani preclusterer");
+        return finch::distances(*hip_, genome_fasta_paths, min_ani, num_kmers, kmer_length, threads, &last_edges);
+    }
+    SortedPairGenomeDistanceCache distances_contigs(const std::vector<std::string> &,
+                                                    const std::vector<std::string> &) override {
+        return SortedPairGenomeDistanceCache();                                                         // finch.rs:26-33
+    }
+    SortedPairGenomeDistanceCache distances_with_references(const std::vector<std::string> &,
+                                                            const std::vector<std::string> &) override {
+        throw std::runtime_error("Reference genome clustering currently only supported with skani preclusterer");  // :40
+    }
+    std::string method_name() const override { return "finch"; }  // the string matters: src/clusterer.rs:33,39
+
+    std::vector<ghip_pair> last_edges;  // the last distances() result as a sorted edge list
+
+private:
+    std::shared_ptr<HipContext> hip_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The clusterer-stage ANI back-end (replaces SkaniClusterer, src/skani.rs:689-716): device-resident FracMinHash index
+// built once per genome list; calculate_ani answers from it.  Build-defined estimator.
+class HipAniClusterer : public ClusterDistanceFinder {
+public:
+    float threshold;              // percent, like SkaniClusterer::threshold
+    float min_aligned_threshold;  // fraction
+    bool small_genomes;
+    int threads;
+
+    HipAniClusterer(std::shared_ptr<HipContext> hip, float threshold, float min_aligned_threshold,
+                    bool small_genomes = false, int threads = 1)
+        : threshold(threshold), min_aligned_threshold(min_aligned_threshold), small_genomes(small_genomes),
+          threads(threads), hip_(std::move(hip)) {}
+    ~HipAniClusterer() override { ghip_ani_index_free(index_); }
+
+    void initialise() const override {                                                                  // skani.rs:696-698
+        if (!(threshold > 1.0f)) throw std::runtime_error("assertion failed: self.threshold > 1.0");
+    }
+    std::string method_name() const override { return "hipani"; }
+    float get_ani_threshold() const override { return threshold; }
+
+    // index the genome list once (what a per-pair `skani dist` subprocess re-does for both genomes every call)
+    void prepare(const std::vector<std::string> &genomes) {
+        ghip_ani_index_free(index_);
+        index_ = nullptr;
+        path_index_.clear();
+        auto paths = detail::c_paths(genomes);
+        ghip_genomes *g = nullptr;
+        if (ghip_genomes_from_files(hip_->get(), paths.data(), paths.size(), threads, &g) != GHIP_OK)
+            throw std::runtime_error("Failed to read genomes for ANI: " + hip_->last_error());
+        const int rc = ghip_ani_index_build(hip_->get(), g, 15, small_genomes ? 30 : 125, 20000, &index_);
+        ghip_genomes_free(g);
+        if (rc != GHIP_OK) throw std::runtime_error("Failed to build the ANI index: " + hip_->last_error());
+        for (size_t i = 0; i < genomes.size(); i++) path_index_.emplace(genomes[i], (uint32_t)i);
+    }
+    bool prepared_for(const std::vector<std::string> &genomes) const { return index_ && path_index_.size() == genomes.size(); }
+
+    std::optional<float> calculate_ani(const std::string &fasta1, const std::string &fasta2) override {
+        auto a = path_index_.find(fasta1), b = path_index_.find(fasta2);
+        if (a == path_index_.end() || b == path_index_.end()) prepare_missing(fasta1, fasta2);
+        const uint32_t pair[2] = {path_index_.at(fasta1), path_index_.at(fasta2)};
+        float ani = 0.0f;
+        if (ghip_ani_pairs(hip_->get(), index_, pair, 1, min_aligned_threshold, &ani, nullptr) != GHIP_OK)
+            throw std::runtime_error("ANI failed: " + hip_->last_error());
+        return ani;                                                  // always Some(..): src/skani.rs:709
+    }
+    // the batch form galah::cluster uses: pairs = flat (a, b) genome indices of the prepared list
+    std::vector<float> calculate_ani_indices(const std::vector<uint32_t> &pairs) {
+        std::vector<float> out(pairs.size() / 2);
+        if (!out.empty() && ghip_ani_pairs(hip_->get(), index_, pairs.data(), out.size(), min_aligned_threshold,
+                                           out.data(), nullptr) != GHIP_OK)
+            throw std::runtime_error("ANI failed: " + hip_->last_error());
+        return out;
+    }
+
+private:
+    void prepare_missing(const std::string &f1, const std::string &f2) {  // calculate_ani on an un-prepared pair
+        std::vector<std::string> g;
+        for (auto &kv : path_index_) g.push_back(kv.first);
+        if (!path_index_.count(f1)) g.push_back(f1);
+        if (!path_index_.count(f2) && f2 != f1) g.push_back(f2);
+        prepare(g);
+    }
+    std::shared_ptr<HipContext> hip_;
+    ghip_ani_index *index_ = nullptr;
+    std::unordered_map<std::string, uint32_t> path_index_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// clusterer::cluster (src/clusterer.rs:14-152).  Returns Vec<Vec<usize>>, the representative first in each cluster.
+// The O(N^2) host loops (partition_sketches, transform_ids) run on the sorted edge list inside ghip_cluster; a
+// HipAniClusterer is asked for the ANI of every precluster pair in one batch, any other ClusterDistanceFinder through
+// calculate_ani -- the clusters are the same because calculate_ani is a pure function of the pair.
+inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &genomes,
+                                                PreclusterDistanceFinder &preclusterer, ClusterDistanceFinder &clusterer,
+                                                bool cluster_contigs = false,
+                                                const std::vector<std::string> *contig_names = nullptr,
+                                                const std::vector<std::string> *reference_genomes = nullptr) {
+    clusterer.initialise();
+    const std::string preclusterer_name = preclusterer.method_name(), clusterer_name = clusterer.method_name();
+    bool skip_clusterer = false;
+    if (clusterer_name == preclusterer_name) skip_clusterer = true;                          // clusterer.rs:32-36
+    if (cluster_contigs) {                                                                    // clusterer.rs:38-44
+        if (preclusterer_name == "finch") throw std::runtime_error(preclusterer_name + " does not support contig comparisons.");
+        skip_clusterer = true;
+    }
+    SortedPairGenomeDistanceCache cache =                                                     // clusterer.rs:47-54
+        reference_genomes ? preclusterer.distances_with_references(genomes, *reference_genomes)
+        : cluster_contigs ? preclusterer.distances_contigs(genomes, *contig_names)
+                          : preclusterer.distances(genomes);
+    const size_t n = cluster_contigs ? contig_names->size() : genomes.size();
+
+    std::vector<ghip_pair> edges;
+    edges.reserve(cache.len());
+    for (auto &kv : cache.internal) {
+        if (!kv.second) throw std::runtime_error("precluster cache holds None: not produced by a precluster back-end");
+        edges.push_back(ghip_pair{(uint32_t)kv.first.first, (uint32_t)kv.first.second, 0, 0, *kv.second});
+    }
+    std::vector<float> pair_ani;
+    struct CbState { ClusterDistanceFinder *c; const std::vector<std::string> *g; } st{&clusterer, &genomes};
+    ghip_ani_callback cb = nullptr;
+    if (!skip_clusterer) {
+        if (auto *hipani = dynamic_cast<HipAniClusterer *>(&clusterer)) {
+            if (!hipani->prepared_for(genomes)) hipani->prepare(genomes);
+            std::vector<uint32_t> idx;
+            idx.reserve(2 * edges.size());
+            for (auto &e : edges) { idx.push_back(e.i); idx.push_back(e.j); }
+            pair_ani = hipani->calculate_ani_indices(idx);
+        } else {
+            cb = [](void *user, uint32_t a, uint32_t b, float *out) -> int {
+                auto *s = static_cast<CbState *>(user);
+                auto v = s->c->calculate_ani((*s->g)[a], (*s->g)[b]);
+                if (!v) return 0;
+                *out = *v;
+                return 1;
+            };
+        }
+    }
+    uint32_t *members = nullptr;
+    uint64_t *offsets = nullptr;
+    size_t n_clusters = 0;
+    const int rc = ghip_cluster(n, edges.data(), edges.size(), pair_ani.empty() ? nullptr : pair_ani.data(),
+                                skip_clusterer ? 1 : 0, clusterer.get_ani_threshold(), cb, &st, &members, &offsets,
+                                &n_clusters);
+    if (rc != GHIP_OK)  // best_rep.unwrap() on None (src/clusterer.rs:444)
+        throw std::runtime_error("called `Option::unwrap()` on a `None` value: a genome has no representative");
+    std::vector<std::vector<size_t>> out(n_clusters);
+    for (size_t c = 0; c < n_clusters; c++) out[c].assign(members + offsets[c], members + offsets[c + 1]);
+    ghip_free(members);
+    ghip_free(offsets);
+    return out;
+}
+
+}  // namespace galah

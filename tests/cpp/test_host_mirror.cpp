@@ -1,0 +1,114 @@
+// The reference's own unit tests for this path, restated against the C++ host mirror (include/galah_hip.hpp) and run
+// on the GPU through the C ABI.  Usage: test_host_mirror <tests/golden/fasta dir>.  Exit code 0 = all passed.
+//   src/finch.rs:111-128                       test_finch_hello_world, test_finch_no_pairs
+//   src/sorted_pair_genome_distance_cache.rs   insert / get / contains_key / transform_ids semantics
+//   src/clusterer.rs:631-690                   test_minhash_skani_hello_world, .._two_clusters_same_ani
+//                                              (the reference needs the skani binary; the build-defined ANI reproduces both)
+//   tests/test_cmdline.rs:262-302              --min-aligned-fraction 0.2 -> one representative, 0.6 -> two
+//   src/finch.rs:14-15,40, src/clusterer.rs:38-44   refusals (panics -> std::runtime_error with the same text)
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "galah_hip.hpp"
+
+static int failures = 0;
+#define CHECK(cond)                                                                      \
+    do {                                                                                 \
+        if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); failures++; } \
+    } while (0)
+
+template <typename F>
+static bool panics_with(F &&f, const char *needle) {
+    try { f(); } catch (const std::runtime_error &e) { return std::strstr(e.what(), needle) != nullptr; }
+    return false;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { std::printf("usage: %s <fasta dir>\n", argv[0]); return 2; }
+    const std::string d = std::string(argv[1]) + "/";
+    auto fa = [&](const char *name) { return d + name + ".fna.gz"; };
+    auto hip = std::make_shared<galah::HipContext>(0);
+
+    {   // src/finch.rs:111-119 test_finch_hello_world
+        galah::SortedPairGenomeDistanceCache expected;
+        expected.insert({0, 1}, 0.9808188f);
+        auto got = galah::finch::distances(*hip, {fa("set1_1mbp"), fa("set1_500kb")}, 0.9f, 1000, 21);
+        CHECK(got == expected);
+    }
+    {   // src/finch.rs:121-128: nothing at 0.99
+        auto got = galah::finch::distances(*hip, {fa("set1_1mbp"), fa("set1_500kb")}, 0.99f, 1000, 21);
+        CHECK(got == galah::SortedPairGenomeDistanceCache());
+    }
+    {   // cache semantics
+        galah::SortedPairGenomeDistanceCache c;
+        c.insert({3, 1}, 0.5f);
+        c.insert({2, 5}, std::nullopt);
+        CHECK(c.contains_key({1, 3}) && c.contains_key({3, 1}) && !c.contains_key({1, 2}));
+        CHECK(c.get({1, 3}).has_value() && **c.get({1, 3}) == 0.5f);
+        CHECK(c.get({5, 2}).has_value() && !c.get({5, 2})->has_value());   // present, None
+        CHECK(!c.get({0, 9}).has_value());
+        auto t = c.transform_ids({5, 1, 3});                               // (1,3) -> positions (1,2)
+        CHECK(t.len() == 1 && t.contains_key({1, 2}) && **t.get({2, 1}) == 0.5f);
+    }
+    const std::vector<std::string> abisko = {fa("abisko_S1X13"), fa("abisko_S2D19"), fa("abisko_S3X12"), fa("abisko_S2D13")};
+    auto sorted = [](std::vector<std::vector<size_t>> c) { std::sort(c.begin(), c.end()); return c; };
+    {   // src/clusterer.rs:631-659: finch 0.9 + skani-equivalent at 95, min aligned fraction 0.2 -> [[0,1,2,3]]
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        galah::HipAniClusterer cl(hip, 95.0f, 0.2f);
+        auto clusters = sorted(galah::cluster(abisko, pre, cl));
+        CHECK((clusters == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
+        CHECK(pre.last_edges.size() == 6);
+    }
+    {   // src/clusterer.rs:661-690: at 99 -> [[0,1,3],[2]]
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        galah::HipAniClusterer cl(hip, 99.0f, 0.2f);
+        auto clusters = sorted(galah::cluster(abisko, pre, cl));
+        CHECK((clusters == std::vector<std::vector<size_t>>{{0, 1, 3}, {2}}));
+        // calculate_ani through the trait object, one pair at a time, gives the batch's values
+        galah::ClusterDistanceFinder &tr = cl;
+        auto a01 = tr.calculate_ani(abisko[0], abisko[1]);
+        CHECK(a01.has_value() && *a01 >= 99.0f && *tr.calculate_ani(abisko[0], abisko[2]) < 99.0f);
+    }
+    {   // skip_clusterer: preclusterer and clusterer of the same name reuse the precluster ANI (src/clusterer.rs:32-36)
+        struct SameName : galah::ClusterDistanceFinder {
+            void initialise() const override {}
+            std::string method_name() const override { return "finch"; }
+            float get_ani_threshold() const override { return 0.95f; }   // finch ANI is a fraction
+            std::optional<float> calculate_ani(const std::string &, const std::string &) override {
+                throw std::runtime_error("must not be called");
+            }
+        } same;
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        auto clusters = sorted(galah::cluster(abisko, pre, same));
+        // finch ANIs: (0,1) .9894 (0,2) .9793 (0,3) .9973 (1,2) .9847 (1,3) .9893 (2,3) .9791 -> one cluster at 0.95
+        CHECK((clusters == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
+    }
+    {   // tests/test_cmdline.rs:262-302
+        const std::vector<std::string> g = {fa("set2_1mbp"), fa("set2_half")};
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        galah::HipAniClusterer lo(hip, 95.0f, 0.2f), hi(hip, 95.0f, 0.6f);
+        CHECK((sorted(galah::cluster(g, pre, lo)) == std::vector<std::vector<size_t>>{{0, 1}}));
+        CHECK((sorted(galah::cluster(g, pre, hi)) == std::vector<std::vector<size_t>>{{0}, {1}}));
+    }
+    {   // refusals
+        galah::FinchPreclusterer lowmem(hip, 0.9f, 1000, 21, true);
+        CHECK(panics_with([&] { lowmem.distances(abisko); }, "Low-memory clustering currently only supported with skani preclusterer"));
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        CHECK(panics_with([&] { pre.distances_with_references(abisko, abisko); },
+                          "Reference genome clustering currently only supported with skani preclusterer"));
+        CHECK(pre.distances_contigs(abisko, abisko).len() == 0);
+        galah::HipAniClusterer cl(hip, 95.0f, 0.2f);
+        std::vector<std::string> names = {"a"};
+        CHECK(panics_with([&] { galah::cluster(abisko, pre, cl, true, &names); }, "finch does not support contig comparisons."));
+        galah::HipAniClusterer bad(hip, 0.95f, 0.2f);   // threshold given as a fraction: skani.rs:696-698 asserts > 1
+        CHECK(panics_with([&] { bad.initialise(); }, "self.threshold > 1.0"));
+        CHECK(panics_with([&] { galah::finch::distances(*hip, {d + "does_not_exist.fna"}, 0.9f, 1000, 21); },
+                          "Failed to sketch genomes with finch"));
+    }
+    std::printf(failures ? "%d check(s) failed\n" : "host mirror: all reference tests passed\n", failures);
+    return failures ? 1 : 0;
+}
