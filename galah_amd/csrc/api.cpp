@@ -708,16 +708,19 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, 
         if ((rc = dmalloc(ctx, &ctx->cmin.d_cmin, cmin.size()))) return rc;
         if ((rc = h2d(ctx, ctx->cmin.d_cmin, cmin.data(), cmin.size()))) return rc;
         ctx->cmin.ani_bits = ani_bits; ctx->cmin.s = s; ctx->cmin.k = k; ctx->cmin.valid = true;
+        ctx->cmin.floor = ghip_cmin_floor(cmin);
     }
     uint16_t *d_cmin = ctx->cmin.d_cmin;
 
-    // s <= 1024: hash-probe form (pairs_probe.hip); otherwise, or if a sketch holds 2^64-1 / a cuckoo
-    // insertion failed, the 64-way merge-path kernel (pairs.hip).  GHIP_PAIR_KERNEL=merge forces the latter.
-    bool use_probe = s <= 1024 && !(getenv("GHIP_PAIR_KERNEL") && !strcmp(getenv("GHIP_PAIR_KERNEL"), "merge"));
-    if (use_probe) {
-        if ((rc = prepare_probe(ctx, sk))) return rc;
-        use_probe = sk->probe_flags == 0;
-    }
+    // Three forms of the pair stage, identical results (tests/test_gpu_parity.py runs all three against the oracle):
+    //   join  (pairs_join.hip)   inverted index over all N*s hashes; N >= GHIP_JOIN_MIN_N, declines dense inputs
+    //   probe (pairs_probe.hip)  dense, cuckoo sets in LDS; s <= 1024
+    //   merge (pairs.hip)        dense, 64-way merge path; s > 1024, or a sketch holds 2^64-1 / a cuckoo insertion failed
+    // GHIP_PAIR_KERNEL=join|probe|merge forces a form (join still declines what it cannot do).
+    const char *force = getenv("GHIP_PAIR_KERNEL");
+    const bool want_join = force ? !strcmp(force, "join") : n >= GHIP_JOIN_MIN_N;
+    bool use_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
+    bool probe_checked = false;
 
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     uint64_t cap = std::min<uint64_t>(P, std::max<uint64_t>(1u << 20, 64ull * n));
@@ -731,7 +734,16 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, 
         DeviceFree t2(ctx); t2.add(d_out);
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         uint64_t compared = 0;
-        if (use_probe) {
+        bool joined = false;
+        if (want_join && (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor, rank, world,
+                                               d_out, d_count, cap, &compared, &joined))) return rc;
+        if (!joined && use_probe && !probe_checked) {
+            if ((rc = prepare_probe(ctx, sk))) return rc;
+            use_probe = sk->probe_flags == 0;
+            probe_checked = true;
+        }
+        if (joined) {
+        } else if (use_probe) {
             ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, n, s, sk->probe_cb, sk->d_row_start,
                                     (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, rank, world, d_out, d_count, cap);
             compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, rank, world);

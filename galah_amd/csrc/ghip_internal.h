@@ -31,6 +31,7 @@ struct ghip_pool_block {
 struct ghip_cmin_cache {  // device filter table of ghip_precluster, keyed by (min_ani bits, s, k)
     uint32_t ani_bits = 0, s = 0, k = 0;
     uint16_t *d_cmin = nullptr;
+    uint32_t floor = 0;  // smallest common that passes the filter for any total >= 1 (0: min_ani <= 0)
     bool valid = false;
 };
 
@@ -166,6 +167,12 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
                        uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world,
                        ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
                        uint64_t *pairs_compared);
+
+constexpr size_t GHIP_JOIN_MIN_N = 2000;  // the inverted-index form of the pair stage takes over from here
+uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin);
+int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used);
 
 size_t ghip_probe_table_slots(uint32_t s);
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,

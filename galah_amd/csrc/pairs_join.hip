@@ -1,0 +1,426 @@
+// Pair stage, join form (large N): the same result as the dense all-vs-all kernels (pairs_probe.hip, pairs.hip) from
+// an inverted index instead of N^2/2 sketch-pair probes.
+//
+// raw_distance (reference src/finch.rs:79 -> finch::distance::raw_distance) needs |A n B| and two ranks per pair, and a
+// pair can only reach the precluster threshold if it shares hashes (common >= cmin[total] >= 1 for every total >= 1
+// whenever min_ani > 0).  So instead of probing 5x10^7 sketch pairs at N = 10 000 (5x10^10 set probes), all N*s
+// (hash, genome) elements are partitioned by 16 bits of the hash (two MSD passes of 8 bits: LDS histograms, one
+// global atomic per digit and block, unordered scatter -- grouping is all that is needed, not order), equal hashes
+// inside a bucket (~150 elements) yield one record (i, j) per sharing genome pair, the records are partitioned the same
+// way by a hash of (i, j), and a per-bucket LDS table counts them: that count IS common.  Ranks i = #{a <= m},
+// j = #{b <= m} come from binary searches in the sorted rows, the integer filter common >= cmin[total] and the host's
+// exact f64 recheck are those of the dense path.  Work ~ N*s + #records instead of N^2*s.
+//
+// The join form declines (the caller then runs a dense kernel) when it would not pay or cannot be exact in its
+// fixed-size buffers: min_ani <= 0 (pairs without a common hash qualify), two or more empty sketches (ANI of
+// empty vs empty is 1.0 by the reference's NaN semantics), a hash bucket or a record bucket beyond its LDS capacity
+// (large families: many genomes share each hash), more records than a dense pass would cost, N*s >= 2^32.
+#include <algorithm>
+
+#include "ghip_internal.h"
+
+namespace {
+
+constexpr uint32_t J_THREADS = 256, J_PER = 16, J_TILE = J_THREADS * J_PER;  // elements per partition block
+constexpr uint32_t J_BUCKETS = 65536;
+constexpr uint32_t J_ELEM_CAP = 1024;   // elements of one hash bucket staged per wave (expected N*s/65536)
+constexpr uint32_t J_TAB = 256;         // distinct genome pairs counted per record bucket
+constexpr uint32_t J_WAVES = J_THREADS / 64;
+constexpr uint64_t J_EMPTY = ~0ull;
+
+struct ElemSrc {  // the packed sketch matrix as (hash, genome) elements; padded slots are skipped
+    const uint64_t *hashes;
+    const uint32_t *lens;
+    uint32_t s;
+    uint32_t total;  // n * s < 2^32
+    __device__ bool get(uint32_t t, uint64_t &key, uint32_t &val) const {
+        if (t >= total) return false;
+        const uint32_t g = t / s, r = t - g * s;
+        if (r >= lens[g]) return false;
+        key = hashes[t];
+        val = g;
+        return true;
+    }
+    __device__ static uint32_t mix(uint64_t key) { return (uint32_t)key & 0xffffu; }  // MurmurHash3 low bits: uniform
+};
+
+struct RecSrc {  // genome-pair records (i << 32 | j), i < j
+    const uint64_t *rec;
+    uint32_t total;
+    __device__ bool get(uint32_t t, uint64_t &key, uint32_t &val) const {
+        if (t >= total) return false;
+        key = rec[t];
+        val = 0;
+        return true;
+    }
+    __device__ static uint32_t mix(uint64_t key) {
+        return (((uint32_t)(key >> 32) * 0x9E3779B1u) ^ ((uint32_t)key * 0x85EBCA77u)) >> 16;
+    }
+};
+
+// ---- MSD pass 1: digit = mix bits 15..8 -------------------------------------------------------------------------
+template <typename Src>
+__global__ __launch_bounds__(J_THREADS) void join_hist1_kernel(Src src, uint32_t *__restrict__ hist1) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * J_TILE;
+#pragma unroll 4
+    for (uint32_t u = 0; u < J_PER; u++) {
+        uint64_t key; uint32_t val;
+        if (src.get(base + u * J_THREADS + threadIdx.x, key, val)) atomicAdd(&h[(Src::mix(key) >> 8) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], h[threadIdx.x]);
+}
+
+// exclusive scan of 256 counters -> start[257]
+__global__ __launch_bounds__(256) void join_scan256_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ start) {
+    __shared__ uint32_t v[256];
+    v[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) { const uint32_t c = v[i]; start[i] = run; run += c; }
+        start[256] = run;
+    }
+}
+
+template <typename Src>
+__global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const uint32_t *__restrict__ start1,
+                                                                  uint32_t *__restrict__ cursor1,
+                                                                  uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
+    __shared__ uint32_t h[256], base[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t t0 = blockIdx.x * J_TILE;
+    uint64_t keys[J_PER];
+    uint32_t vals[J_PER];
+    uint32_t okmask = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < J_PER; u++) {
+        if (src.get(t0 + u * J_THREADS + threadIdx.x, keys[u], vals[u])) {
+            okmask |= 1u << u;
+            atomicAdd(&h[(Src::mix(keys[u]) >> 8) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    {   // one global atomic per digit and block reserves the block's range in that bucket
+        const uint32_t c = h[threadIdx.x];
+        base[threadIdx.x] = c ? start1[threadIdx.x] + atomicAdd(&cursor1[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    h[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < J_PER; u++) {
+        if (okmask & (1u << u)) {
+            const uint32_t d = (Src::mix(keys[u]) >> 8) & 255u;
+            const uint32_t pos = base[d] + atomicAdd(&h[d], 1u);
+            out_keys[pos] = keys[u];
+            if (out_vals) out_vals[pos] = vals[u];
+        }
+    }
+}
+
+// ---- MSD pass 2: inside first-level bucket blockIdx.y, digit = mix bits 7..0 -------------------------------------
+template <typename Src>
+__global__ __launch_bounds__(J_THREADS) void join_hist2_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ start1,
+                                                               uint32_t *__restrict__ hist2) {
+    const uint32_t d1 = blockIdx.y;
+    const uint32_t lo = start1[d1] + blockIdx.x * J_TILE, end = start1[d1 + 1];
+    if (lo >= end) return;
+    const uint32_t hi = min(end, lo + J_TILE);
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) atomicAdd(&h[Src::mix(keys[t]) & 255u], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist2[d1 * 256u + threadIdx.x], h[threadIdx.x]);
+}
+
+// exclusive scan of 65536 counters -> start[65537]; also the largest counter
+__global__ __launch_bounds__(1024) void join_scan64k_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ start,
+                                                            uint32_t *__restrict__ max_out) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t mx[1024];
+    constexpr uint32_t PER = J_BUCKETS / 1024;
+    uint32_t sum = 0, m = 0;
+    for (uint32_t i = 0; i < PER; i++) { const uint32_t c = hist[threadIdx.x * PER + i]; sum += c; m = max(m, c); }
+    part[threadIdx.x] = sum;
+    mx[threadIdx.x] = m;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        const uint32_t w = threadIdx.x >= off ? mx[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        mx[threadIdx.x] = max(mx[threadIdx.x], w);
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = 0; i < PER; i++) { start[threadIdx.x * PER + i] = run; run += hist[threadIdx.x * PER + i]; }
+    if (threadIdx.x == 1023) { start[J_BUCKETS] = part[1023]; if (max_out) *max_out = mx[1023]; }
+    // NOTE: 32-bit offsets; the host bounds the inputs (n*s < 2^32 elements, per-bucket record counts checked below)
+}
+
+template <typename Src>
+__global__ __launch_bounds__(J_THREADS) void join_scatter2_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                                  const uint32_t *__restrict__ start1,
+                                                                  const uint32_t *__restrict__ start2, uint32_t *__restrict__ cursor2,
+                                                                  uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
+    const uint32_t d1 = blockIdx.y;
+    const uint32_t lo = start1[d1] + blockIdx.x * J_TILE, end = start1[d1 + 1];
+    if (lo >= end) return;
+    const uint32_t hi = min(end, lo + J_TILE);
+    __shared__ uint32_t h[256], base[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) atomicAdd(&h[Src::mix(keys[t]) & 255u], 1u);
+    __syncthreads();
+    {
+        const uint32_t c = h[threadIdx.x], b = d1 * 256u + threadIdx.x;
+        base[threadIdx.x] = c ? start2[b] + atomicAdd(&cursor2[b], c) : 0u;
+    }
+    __syncthreads();
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) {
+        const uint64_t k = keys[t];
+        const uint32_t d = Src::mix(k) & 255u;
+        const uint32_t pos = base[d] + atomicAdd(&h[d], 1u);
+        out_keys[pos] = k;
+        if (out_vals) out_vals[pos] = vals[t];
+    }
+}
+
+// ---- equal hashes inside a bucket -> one record per sharing genome pair ------------------------------------------
+// One wavefront per bucket.  EMIT = false counts the records of the bucket, EMIT = true writes them at rec_start[bucket].
+// flags bit 0: a bucket exceeds the LDS stage.
+template <bool EMIT>
+__global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                                    const uint32_t *__restrict__ start2,
+                                                                    uint32_t *__restrict__ rec_count, const uint32_t *__restrict__ rec_start,
+                                                                    uint64_t *__restrict__ rec, uint32_t *__restrict__ flags,
+                                                                    unsigned long long *__restrict__ rec_total) {
+    __shared__ uint64_t lk[J_WAVES][J_ELEM_CAP];
+    __shared__ uint32_t lv[J_WAVES][J_ELEM_CAP];
+    __shared__ uint32_t lcnt[J_WAVES];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t bucket = blockIdx.x * J_WAVES + wave;
+    const uint32_t lo = start2[bucket], cnt = start2[bucket + 1] - lo;
+    if (cnt > J_ELEM_CAP) {
+        if (lane == 0) { atomicOr(flags, 1u); if (!EMIT) rec_count[bucket] = 0; }
+        return;
+    }
+    for (uint32_t e = lane; e < cnt; e += 64) { lk[wave][e] = keys[lo + e]; lv[wave][e] = vals[lo + e]; }
+    if (lane == 0) lcnt[wave] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t out0 = EMIT ? rec_start[bucket] : 0u;
+    uint32_t found = 0;
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        const uint64_t ka = lk[wave][a];
+        const uint32_t ga = lv[wave][a];
+        for (uint32_t b = a + 1; b < cnt; b++) {
+            if (lk[wave][b] != ka) continue;
+            const uint32_t gb = lv[wave][b];
+            if (gb == ga) continue;  // a sketch row is distinct; guards caller-supplied matrices
+            const uint32_t i = min(ga, gb), j = max(ga, gb);
+            if (EMIT) rec[out0 + atomicAdd(&lcnt[wave], 1u)] = ((uint64_t)i << 32) | j;
+            else found++;
+        }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) found += __shfl_xor(found, off, 64);
+        if (lane == 0) { rec_count[bucket] = found; if (found) atomicAdd(rec_total, (unsigned long long)found); }  // 64-bit: the 32-bit offsets may wrap
+    }
+}
+
+// ---- records of one bucket -> common per genome pair -> ranks, integer filter, candidate list --------------------
+// flags bit 1: more distinct genome pairs in a record bucket than the LDS table holds.
+__global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *__restrict__ rec, const uint32_t *__restrict__ start2,
+                                                                const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
+                                                                uint32_t s, const uint16_t *__restrict__ cmin, uint32_t cmin_floor,
+                                                                uint32_t rank, uint32_t world, ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count,
+                                                                uint64_t cap, uint32_t *__restrict__ flags) {
+    __shared__ unsigned long long tk[J_WAVES][J_TAB];
+    __shared__ uint32_t tc[J_WAVES][J_TAB];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t bucket = blockIdx.x * J_WAVES + wave;
+    const uint32_t lo = start2[bucket], hi = start2[bucket + 1];
+    if (lo == hi) return;
+    for (uint32_t e = lane; e < J_TAB; e += 64) { tk[wave][e] = J_EMPTY; tc[wave][e] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lo + lane; t < hi; t += 64) {
+        const unsigned long long key = rec[t];
+        uint32_t slot = ((uint32_t)(key >> 32) * 0x632BE5ABu + (uint32_t)key * 0x2545F491u) >> 24;  // 8 bits; independent of the bucket hash
+        bool done = false;
+        for (uint32_t it = 0; it < J_TAB && !done; it++) {
+            const unsigned long long prev = atomicCAS(&tk[wave][slot], (unsigned long long)J_EMPTY, key);
+            if (prev == J_EMPTY || prev == key) { atomicAdd(&tc[wave][slot], 1u); done = true; }
+            else slot = (slot + 1) & (J_TAB - 1);
+        }
+        if (!done) atomicOr(flags, 2u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < J_TAB; e += 64) {
+        const unsigned long long key = tk[wave][e];
+        const uint32_t common = tc[wave][e];
+        if (key == J_EMPTY || common < cmin_floor) continue;
+        const uint32_t gi = (uint32_t)(key >> 32), gj = (uint32_t)key;
+        // Multi-GPU: every rank runs the whole (cheap) join, so all ranks take the same accept/decline decisions, and
+        // reports the pairs with (i + j) mod world == rank.
+        if (world > 1 && (gi + gj) % world != rank) continue;
+        const uint32_t na = lens[gi], nb = lens[gj];  // both > 0: they share a hash
+        const uint64_t *ra = hashes + (uint64_t)gi * s, *rb = hashes + (uint64_t)gj * s;
+        const uint64_t maxa = ra[na - 1], maxb = rb[nb - 1];
+        // i = #{a <= m}, j = #{b <= m}, m = min(max A, max B)  (closed form of the reference's merge loop)
+        uint32_t icnt = na, jcnt = nb;
+        if (maxa > maxb) {  // upper bound of maxb in row A
+            uint32_t l = 0, h = na;
+            while (l < h) { const uint32_t mid = (l + h) >> 1; if (ra[mid] <= maxb) l = mid + 1; else h = mid; }
+            icnt = l;
+        } else if (maxb > maxa) {
+            uint32_t l = 0, h = nb;
+            while (l < h) { const uint32_t mid = (l + h) >> 1; if (rb[mid] <= maxa) l = mid + 1; else h = mid; }
+            jcnt = l;
+        }
+        const uint32_t total = icnt + jcnt - common;
+        if (common >= (uint32_t)cmin[total]) {
+            const unsigned long long idx = atomicAdd(out_count, 1ull);
+            if (idx < cap) {
+                ghip_pair r;
+                r.i = gi; r.j = gj; r.common = common; r.total = total; r.ani = 0.0f;
+                out[idx] = r;
+            }
+        }
+    }
+}
+
+template <typename T>
+T *jalloc(ghip_ctx *ctx, std::vector<void *> &owned, size_t count) {
+    T *p = (T *)ghip_pool_alloc(ctx, std::max<size_t>(count, 1) * sizeof(T));
+    if (p) owned.push_back(p);
+    return p;
+}
+
+// Partition `src` (total_t candidate slots, n_valid unknown to the host) into 65536 buckets.
+// On return keys_out/vals_out hold the elements bucket by bucket and d_start2[65537] the bucket offsets.
+template <typename Src>
+int partition16(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_t total_t, uint32_t n_valid_bound,
+                bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */) {
+    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256);          // hist1 | start1 | cursor1
+    uint32_t *d_hist2 = jalloc<uint32_t>(ctx, owned, 2 * (size_t)J_BUCKETS);     // hist2 | cursor2
+    uint32_t *d_start2 = jalloc<uint32_t>(ctx, owned, J_BUCKETS + 1);
+    uint64_t *k1 = jalloc<uint64_t>(ctx, owned, n_valid_bound), *k2 = jalloc<uint64_t>(ctx, owned, n_valid_bound);
+    uint32_t *v1 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
+    uint32_t *v2 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
+    if (!d_hist1 || !d_hist2 || !d_start2 || !k1 || !k2 || (with_vals && (!v1 || !v2))) return GHIP_EHIP;
+    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_cursor2 = d_hist2 + J_BUCKETS;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (256 + 257 + 256) * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist2, 0, 2 * (size_t)J_BUCKETS * sizeof(uint32_t), ctx->stream));
+    const unsigned tiles = (total_t + J_TILE - 1) / J_TILE;
+    if (tiles) hipLaunchKernelGGL((join_hist1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, d_hist1);
+    hipLaunchKernelGGL(join_scan256_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist1, d_start1);
+    if (tiles) hipLaunchKernelGGL((join_scatter1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, d_start1, d_cursor1, k1, v1);
+    // the second pass runs per first-level bucket: its grid needs the largest bucket
+    uint32_t hist1[256];
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(hist1, d_hist1, sizeof(hist1), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t big = *std::max_element(hist1, hist1 + 256);
+    const unsigned tiles2 = (big + J_TILE - 1) / J_TILE;
+    if (tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, d_start1, d_hist2);
+    hipLaunchKernelGGL(join_scan64k_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_hist2, d_start2, d_max);
+    if (tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, d_start1,
+                                   d_start2, d_cursor2, k2, v2);
+    *keys_out = k2;
+    if (vals_out) *vals_out = v2;
+    *d_start2_out = d_start2;
+    return GHIP_OK;
+}
+
+}  // namespace
+
+// Smallest common that can pass the integer filter for any total >= 1 (0xffff entries = impossible totals).
+uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin) {
+    uint32_t f = 0xffffu;
+    for (size_t t = 1; t < cmin.size(); t++) f = std::min<uint32_t>(f, cmin[t]);
+    return f;
+}
+
+// *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
+int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used) {
+    *used = false;
+    if (cmin_floor == 0 || cmin_floor == 0xffffu || n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
+    std::vector<uint32_t> lens(n);
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(lens.data(), d_lens, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t n_elem = 0;
+    size_t n_empty = 0;
+    for (uint32_t l : lens) { n_elem += l; n_empty += (l == 0); }
+    if (n_empty >= 2) return GHIP_OK;  // empty vs empty: ANI 1.0 by the reference's NaN-dropping max/min
+    struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
+    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 4);  // [0] flags, [1] largest element bucket, [2..3] u64 record total
+    if (!d_flags) return GHIP_EHIP;
+    unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_flags + 2);
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(uint32_t), ctx->stream));
+
+    ghip_prof_begin(ctx, "pair_join");
+    // 1. elements -> 65536 hash buckets
+    uint64_t *ek = nullptr; uint32_t *ev = nullptr, *d_estart = nullptr;
+    ElemSrc es{d_hashes, d_lens, s, (uint32_t)(n * s)};
+    int rc = partition16(ctx, own.p, es, es.total, (uint32_t)n_elem, true, &ek, &ev, &d_estart, d_flags + 1);
+    if (rc) { ghip_prof_end(ctx); return rc; }
+    // 2. records per bucket, their offsets, their number
+    uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, J_BUCKETS), *d_rstart = jalloc<uint32_t>(ctx, own.p, J_BUCKETS + 1);
+    if (!d_rcount || !d_rstart) { ghip_prof_end(ctx); return GHIP_EHIP; }
+    hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(J_BUCKETS / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
+                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total);
+    hipLaunchKernelGGL(join_scan64k_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_rcount, d_rstart, (uint32_t *)nullptr);
+    uint32_t flags[2];
+    unsigned long long total_rec = 0;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&total_rec, d_total, sizeof(total_rec), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t P = (uint64_t)n * (n - 1) / 2;
+    // a dense pass costs ~1 ns per pair, a record ~0.3 ns: beyond 4 records per pair the dense kernel is the better tool
+    if ((flags[0] & 1u) || total_rec > 4 * P + (1u << 20) || total_rec >= (1ull << 31)) { ghip_prof_end(ctx); return GHIP_OK; }
+    const uint32_t n_rec = (uint32_t)total_rec;
+    uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
+    if (!d_rec) { ghip_prof_end(ctx); return GHIP_EHIP; }
+    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(J_BUCKETS / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total);
+    // 3. records -> 65536 pair buckets -> common per pair -> candidates
+    uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
+    RecSrc rs{d_rec, n_rec};
+    rc = partition16(ctx, own.p, rs, n_rec, n_rec, false, &rk, nullptr, &d_pstart, nullptr);
+    if (rc) { ghip_prof_end(ctx); return rc; }
+    hipLaunchKernelGGL(join_reduce_kernel, dim3(J_BUCKETS / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, d_pstart, d_hashes, d_lens, s,
+                       d_cmin, cmin_floor, rank, world, d_out, d_count, cap, d_flags);
+    ghip_prof_end(ctx);
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags[0] & 2u) {  // a record bucket overflowed its table: discard what was written, let a dense kernel run
+        GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+        return GHIP_OK;
+    }
+    if (pairs_compared) {  // pairs this rank is responsible for: (i + j) mod world == rank
+        if (world == 1) *pairs_compared = P;
+        else {
+            uint64_t c = 0;
+            for (uint64_t i = 0; i + 1 < n; i++) {  // j in (i, n) with (i + j) % world == rank
+                const uint64_t first = i + 1 + ((rank + 2 * (uint64_t)world - (2 * i + 1) % world) % world);
+                if (first < n) c += (n - 1 - first) / world + 1;
+            }
+            *pairs_compared = c;
+        }
+    }
+    *used = true;
+    return GHIP_OK;
+}

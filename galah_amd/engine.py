@@ -12,8 +12,8 @@ import numpy as np
 from . import _lib
 from ._lib import PAIR_DTYPE, GalahHipError, check
 
-KERNELS = ("sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_tile", "ani_seeds", "ani_bin", "ani_pairs",
-           "synth_genomes")
+KERNELS = ("sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_tile", "pair_join", "ani_seeds", "ani_bin",
+           "ani_pairs", "synth_genomes")
 
 
 def device_count() -> int:

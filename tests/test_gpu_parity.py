@@ -379,3 +379,48 @@ def test_every_seed_of_dirty_streams(ctx, c):
             want = sorted(zip(o.seeds().astype(np.uint32).tolist(), o.chunks().astype(np.uint16).tolist()))
             assert got == want, (c, i)
             start += int(cap[i])
+
+
+def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
+    """The inverted-index form (pairs_join.hip; automatic from N >= 2000) forced on small inputs: same bytes as
+    the oracle's pair loop, whole and sharded; and the inputs it must decline (threshold 0, empty sketches)
+    still give the dense kernels' answer."""
+    monkeypatch.setenv("GHIP_PAIR_KERNEL", "join")
+    ctx.profile(True)
+    for n, s, min_len, thr, groups in ((37, 1000, None, 0.9, 5), (130, 256, 1, 0.8, 5), (300, 1000, 700, 0.9, 40),
+                                       (64, 1000, 1, 0.0, 5), (2, 1000, None, 0.9, 1)):
+        rng = np.random.default_rng(n * 11 + s)
+        hashes, lens = random_sketches(rng, n, s, shared_groups=groups, min_len=min_len)
+        sk = ctx.sketches_from_host(hashes, lens, 21)
+        ctx.profile_reset()
+        got = ctx.precluster(sk, np.float32(thr))
+        want = oracle.distances_from_sketches(hashes, lens, np.float32(thr))
+        assert got.tobytes() == want.tobytes(), (n, s, thr)
+        assert ctx.last_pairs_compared == n * (n - 1) // 2
+        st = ctx.kernel_stats()
+        used_join = st["pair_join"][0] > 0 and st["pair_intersect_tile"][0] == 0
+        assert used_join == (thr > 0.0), (n, thr, st)  # threshold 0 must be declined
+        if thr > 0.0:
+            for world in (2, 3):
+                parts, compared = [], 0
+                for r in range(world):
+                    parts.append(ctx.precluster(sk, np.float32(thr), r, world))
+                    compared += ctx.last_pairs_compared
+                assert compared == n * (n - 1) // 2
+                merged = np.sort(np.concatenate(parts), order=["i", "j"])
+                assert merged.tobytes() == want.tobytes()
+    ctx.profile(False)
+    # two empty sketches: (empty, empty) has ANI 1.0 -- only the dense forms can report it
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    hashes = np.full((5, 8), M, dtype=np.uint64)
+    lens = np.array([0, 0, 3, 8, 8], dtype=np.uint32)
+    hashes[2, :3] = [5, 9, 11]
+    hashes[3] = [1, 5, 9, 11, 20, 30, 40, 50]
+    hashes[4] = [5, 9, 11, 12, 13, 14, 15, 2**64 - 2]
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    assert ctx.precluster(sk, np.float32(0.5)).tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.5)).tobytes()
+    # one big family (every genome shares most hashes with every other): records outnumber pairs -> declined
+    rng = np.random.default_rng(5)
+    hashes, lens = random_sketches(rng, 200, 1000, shared_groups=1)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    assert ctx.precluster(sk, np.float32(0.9)).tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9)).tobytes()
