@@ -4,9 +4,10 @@
 // raw_distance (reference src/finch.rs:79 -> finch::distance::raw_distance) needs |A n B| and two ranks per pair, and a
 // pair can only reach the precluster threshold if it shares hashes (common >= cmin[total] >= 1 for every total >= 1
 // whenever min_ani > 0).  So instead of probing 5x10^7 sketch pairs at N = 10 000 (5x10^10 set probes), all N*s
-// (hash, genome) elements are partitioned by 16 bits of the hash (two MSD passes of 8 bits: LDS histograms, one
+// (hash, genome) elements are partitioned by 16-20 bits of the hash (two MSD passes, 8 + 8..12 bits, the bucket count
+// sized to ~256 elements per bucket: LDS histograms, one
 // global atomic per digit and block, unordered scatter -- grouping is all that is needed, not order), equal hashes
-// inside a bucket (~150 elements) yield one record (i, j) per sharing genome pair, the records are partitioned the same
+// inside a bucket yield one record (i, j) per sharing genome pair, the records are partitioned the same
 // way by a hash of (i, j), and a per-bucket LDS table counts them: that count IS common.  Ranks i = #{a <= m},
 // j = #{b <= m} come from binary searches in the sorted rows, the integer filter common >= cmin[total] and the host's
 // exact f64 recheck are those of the dense path.  Work ~ N*s + #records instead of N^2*s.
@@ -22,7 +23,8 @@
 namespace {
 
 constexpr uint32_t J_THREADS = 256, J_PER = 16, J_TILE = J_THREADS * J_PER;  // elements per partition block
-constexpr uint32_t J_BUCKETS = 65536;
+constexpr uint32_t J_BITS2_MIN = 8, J_BITS2_MAX = 12;   // buckets = 256 << bits2: 65 536 .. 1 048 576, sized to the input
+constexpr uint32_t J_D2_MAX = 1u << J_BITS2_MAX;
 constexpr uint32_t J_ELEM_CAP = 1024;   // elements of one hash bucket staged per wave (expected N*s/65536)
 constexpr uint32_t J_TAB = 256;         // distinct genome pairs counted per record bucket
 constexpr uint32_t J_WAVES = J_THREADS / 64;
@@ -41,7 +43,7 @@ struct ElemSrc {  // the packed sketch matrix as (hash, genome) elements; padded
         val = g;
         return true;
     }
-    __device__ static uint32_t mix(uint64_t key) { return (uint32_t)key & 0xffffu; }  // MurmurHash3 low bits: uniform
+    __device__ static uint32_t mix(uint64_t key) { return (uint32_t)key & 0xfffffu; }  // 20 MurmurHash3 low bits: uniform
 };
 
 struct RecSrc {  // genome-pair records (i << 32 | j), i < j
@@ -54,11 +56,15 @@ struct RecSrc {  // genome-pair records (i << 32 | j), i < j
         return true;
     }
     __device__ static uint32_t mix(uint64_t key) {
-        return (((uint32_t)(key >> 32) * 0x9E3779B1u) ^ ((uint32_t)key * 0x85EBCA77u)) >> 16;
+        return (((uint32_t)(key >> 32) * 0x9E3779B1u) ^ ((uint32_t)key * 0x85EBCA77u)) >> 12;  // 20 bits
     }
 };
 
-// ---- MSD pass 1: digit = mix bits 15..8 -------------------------------------------------------------------------
+// mix() yields 20 bits: the first-level digit is bits 19..12, the second-level digit the next bits2 bits below.
+__device__ __forceinline__ uint32_t digit1(uint32_t m) { return m >> 12; }
+__device__ __forceinline__ uint32_t digit2(uint32_t m, uint32_t bits2) { return (m >> (12 - bits2)) & ((1u << bits2) - 1); }
+
+// ---- MSD pass 1 -------------------------------------------------------------------------------------------------
 template <typename Src>
 __global__ __launch_bounds__(J_THREADS) void join_hist1_kernel(Src src, uint32_t *__restrict__ hist1) {
     __shared__ uint32_t h[256];
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(J_THREADS) void join_hist1_kernel(Src src, uint32_t
 #pragma unroll 4
     for (uint32_t u = 0; u < J_PER; u++) {
         uint64_t key; uint32_t val;
-        if (src.get(base + u * J_THREADS + threadIdx.x, key, val)) atomicAdd(&h[(Src::mix(key) >> 8) & 255u], 1u);
+        if (src.get(base + u * J_THREADS + threadIdx.x, key, val)) atomicAdd(&h[digit1(Src::mix(key))], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], h[threadIdx.x]);
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const
     for (uint32_t u = 0; u < J_PER; u++) {
         if (src.get(t0 + u * J_THREADS + threadIdx.x, keys[u], vals[u])) {
             okmask |= 1u << u;
-            atomicAdd(&h[(Src::mix(keys[u]) >> 8) & 255u], 1u);
+            atomicAdd(&h[digit1(Src::mix(keys[u]))], 1u);
         }
     }
     __syncthreads();
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const
 #pragma unroll
     for (uint32_t u = 0; u < J_PER; u++) {
         if (okmask & (1u << u)) {
-            const uint32_t d = (Src::mix(keys[u]) >> 8) & 255u;
+            const uint32_t d = digit1(Src::mix(keys[u]));
             const uint32_t pos = base[d] + atomicAdd(&h[d], 1u);
             out_keys[pos] = keys[u];
             if (out_vals) out_vals[pos] = vals[u];
@@ -123,30 +129,30 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const
     }
 }
 
-// ---- MSD pass 2: inside first-level bucket blockIdx.y, digit = mix bits 7..0 -------------------------------------
+// ---- MSD pass 2: inside first-level bucket blockIdx.y, digit = the next bits2 bits --------------------------------
 template <typename Src>
 __global__ __launch_bounds__(J_THREADS) void join_hist2_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ start1,
-                                                               uint32_t *__restrict__ hist2) {
-    const uint32_t d1 = blockIdx.y;
+                                                               uint32_t bits2, uint32_t *__restrict__ hist2) {
+    const uint32_t d1 = blockIdx.y, nd2 = 1u << bits2;
     const uint32_t lo = start1[d1] + blockIdx.x * J_TILE, end = start1[d1 + 1];
     if (lo >= end) return;
     const uint32_t hi = min(end, lo + J_TILE);
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[J_D2_MAX];
+    for (uint32_t d = threadIdx.x; d < nd2; d += J_THREADS) h[d] = 0;
     __syncthreads();
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) atomicAdd(&h[Src::mix(keys[t]) & 255u], 1u);
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) atomicAdd(&h[digit2(Src::mix(keys[t]), bits2)], 1u);
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist2[d1 * 256u + threadIdx.x], h[threadIdx.x]);
+    for (uint32_t d = threadIdx.x; d < nd2; d += J_THREADS)
+        if (h[d]) atomicAdd(&hist2[(d1 << bits2) + d], h[d]);
 }
 
-// exclusive scan of 65536 counters -> start[65537]; also the largest counter
-__global__ __launch_bounds__(1024) void join_scan64k_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ start,
-                                                            uint32_t *__restrict__ max_out) {
+// exclusive scan of nb = 1024 * per counters -> start[nb + 1]; also the largest counter
+__global__ __launch_bounds__(1024) void join_scan_kernel(const uint32_t *__restrict__ hist, uint32_t per, uint32_t *__restrict__ start,
+                                                         uint32_t *__restrict__ max_out) {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t mx[1024];
-    constexpr uint32_t PER = J_BUCKETS / 1024;
     uint32_t sum = 0, m = 0;
-    for (uint32_t i = 0; i < PER; i++) { const uint32_t c = hist[threadIdx.x * PER + i]; sum += c; m = max(m, c); }
+    for (uint32_t i = 0; i < per; i++) { const uint32_t c = hist[threadIdx.x * per + i]; sum += c; m = max(m, c); }
     part[threadIdx.x] = sum;
     mx[threadIdx.x] = m;
     __syncthreads();
@@ -159,35 +165,35 @@ __global__ __launch_bounds__(1024) void join_scan64k_kernel(const uint32_t *__re
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = 0; i < PER; i++) { start[threadIdx.x * PER + i] = run; run += hist[threadIdx.x * PER + i]; }
-    if (threadIdx.x == 1023) { start[J_BUCKETS] = part[1023]; if (max_out) *max_out = mx[1023]; }
-    // NOTE: 32-bit offsets; the host bounds the inputs (n*s < 2^32 elements, per-bucket record counts checked below)
+    for (uint32_t i = 0; i < per; i++) { start[threadIdx.x * per + i] = run; run += hist[threadIdx.x * per + i]; }
+    if (threadIdx.x == 1023) { start[1024 * per] = part[1023]; if (max_out) *max_out = mx[1023]; }
+    // 32-bit offsets: the host bounds the inputs (n*s < 2^32 elements, < 2^31 records from a 64-bit total)
 }
 
 template <typename Src>
 __global__ __launch_bounds__(J_THREADS) void join_scatter2_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                                  const uint32_t *__restrict__ start1,
+                                                                  const uint32_t *__restrict__ start1, uint32_t bits2,
                                                                   const uint32_t *__restrict__ start2, uint32_t *__restrict__ cursor2,
                                                                   uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
-    const uint32_t d1 = blockIdx.y;
+    const uint32_t d1 = blockIdx.y, nd2 = 1u << bits2;
     const uint32_t lo = start1[d1] + blockIdx.x * J_TILE, end = start1[d1 + 1];
     if (lo >= end) return;
     const uint32_t hi = min(end, lo + J_TILE);
-    __shared__ uint32_t h[256], base[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[J_D2_MAX], base[J_D2_MAX];
+    for (uint32_t d = threadIdx.x; d < nd2; d += J_THREADS) h[d] = 0;
     __syncthreads();
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) atomicAdd(&h[Src::mix(keys[t]) & 255u], 1u);
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) atomicAdd(&h[digit2(Src::mix(keys[t]), bits2)], 1u);
     __syncthreads();
-    {
-        const uint32_t c = h[threadIdx.x], b = d1 * 256u + threadIdx.x;
-        base[threadIdx.x] = c ? start2[b] + atomicAdd(&cursor2[b], c) : 0u;
+    for (uint32_t d = threadIdx.x; d < nd2; d += J_THREADS) {
+        const uint32_t c = h[d], b = (d1 << bits2) + d;
+        base[d] = c ? start2[b] + atomicAdd(&cursor2[b], c) : 0u;
     }
     __syncthreads();
-    h[threadIdx.x] = 0;
+    for (uint32_t d = threadIdx.x; d < nd2; d += J_THREADS) h[d] = 0;
     __syncthreads();
     for (uint32_t t = lo + threadIdx.x; t < hi; t += J_THREADS) {
         const uint64_t k = keys[t];
-        const uint32_t d = Src::mix(k) & 255u;
+        const uint32_t d = digit2(Src::mix(k), bits2);
         const uint32_t pos = base[d] + atomicAdd(&h[d], 1u);
         out_keys[pos] = k;
         if (out_vals) out_vals[pos] = vals[t];
@@ -308,21 +314,22 @@ T *jalloc(ghip_ctx *ctx, std::vector<void *> &owned, size_t count) {
     return p;
 }
 
-// Partition `src` (total_t candidate slots, n_valid unknown to the host) into 65536 buckets.
-// On return keys_out/vals_out hold the elements bucket by bucket and d_start2[65537] the bucket offsets.
+// Partition `src` (total_t candidate slots, at most n_valid_bound of them valid) into nb = 256 << bits2 buckets.
+// On return keys_out/vals_out hold the elements bucket by bucket and d_start2[nb + 1] the bucket offsets.
 template <typename Src>
-int partition16(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_t total_t, uint32_t n_valid_bound,
-                bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */) {
-    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256);          // hist1 | start1 | cursor1
-    uint32_t *d_hist2 = jalloc<uint32_t>(ctx, owned, 2 * (size_t)J_BUCKETS);     // hist2 | cursor2
-    uint32_t *d_start2 = jalloc<uint32_t>(ctx, owned, J_BUCKETS + 1);
+int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_t total_t, uint32_t n_valid_bound, uint32_t bits2,
+              bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */) {
+    const uint32_t nb = 256u << bits2;
+    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256);   // hist1 | start1 | cursor1
+    uint32_t *d_hist2 = jalloc<uint32_t>(ctx, owned, 2 * (size_t)nb);     // hist2 | cursor2
+    uint32_t *d_start2 = jalloc<uint32_t>(ctx, owned, nb + 1);
     uint64_t *k1 = jalloc<uint64_t>(ctx, owned, n_valid_bound), *k2 = jalloc<uint64_t>(ctx, owned, n_valid_bound);
     uint32_t *v1 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
     uint32_t *v2 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
     if (!d_hist1 || !d_hist2 || !d_start2 || !k1 || !k2 || (with_vals && (!v1 || !v2))) return GHIP_EHIP;
-    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_cursor2 = d_hist2 + J_BUCKETS;
+    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_cursor2 = d_hist2 + nb;
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (256 + 257 + 256) * sizeof(uint32_t), ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist2, 0, 2 * (size_t)J_BUCKETS * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist2, 0, 2 * (size_t)nb * sizeof(uint32_t), ctx->stream));
     const unsigned tiles = (total_t + J_TILE - 1) / J_TILE;
     if (tiles) hipLaunchKernelGGL((join_hist1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, d_hist1);
     hipLaunchKernelGGL(join_scan256_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist1, d_start1);
@@ -333,14 +340,21 @@ int partition16(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint3
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t big = *std::max_element(hist1, hist1 + 256);
     const unsigned tiles2 = (big + J_TILE - 1) / J_TILE;
-    if (tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, d_start1, d_hist2);
-    hipLaunchKernelGGL(join_scan64k_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_hist2, d_start2, d_max);
-    if (tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, d_start1,
+    if (tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, d_start1, bits2, d_hist2);
+    hipLaunchKernelGGL(join_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_hist2, nb / 1024, d_start2, d_max);
+    if (tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, d_start1, bits2,
                                    d_start2, d_cursor2, k2, v2);
     *keys_out = k2;
     if (vals_out) *vals_out = v2;
     *d_start2_out = d_start2;
     return GHIP_OK;
+}
+
+// buckets sized so that the average bucket holds <= 256 items
+uint32_t bits2_for(uint64_t items) {
+    uint32_t b = J_BITS2_MIN;
+    while (b < J_BITS2_MAX && (items >> (8 + b)) > 256) b++;
+    return b;
 }
 
 }  // namespace
@@ -375,14 +389,15 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     // 1. elements -> 65536 hash buckets
     uint64_t *ek = nullptr; uint32_t *ev = nullptr, *d_estart = nullptr;
     ElemSrc es{d_hashes, d_lens, s, (uint32_t)(n * s)};
-    int rc = partition16(ctx, own.p, es, es.total, (uint32_t)n_elem, true, &ek, &ev, &d_estart, d_flags + 1);
+    const uint32_t ebits = bits2_for(n_elem), enb = 256u << ebits;
+    int rc = partition(ctx, own.p, es, es.total, (uint32_t)n_elem, ebits, true, &ek, &ev, &d_estart, d_flags + 1);
     if (rc) { ghip_prof_end(ctx); return rc; }
     // 2. records per bucket, their offsets, their number
-    uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, J_BUCKETS), *d_rstart = jalloc<uint32_t>(ctx, own.p, J_BUCKETS + 1);
+    uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
     if (!d_rcount || !d_rstart) { ghip_prof_end(ctx); return GHIP_EHIP; }
-    hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(J_BUCKETS / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
+    hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
                        d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total);
-    hipLaunchKernelGGL(join_scan64k_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_rcount, d_rstart, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(join_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_rcount, enb / 1024, d_rstart, (uint32_t *)nullptr);
     uint32_t flags[2];
     unsigned long long total_rec = 0;
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
@@ -394,14 +409,15 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     const uint32_t n_rec = (uint32_t)total_rec;
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) { ghip_prof_end(ctx); return GHIP_EHIP; }
-    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(J_BUCKETS / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
+    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
                        (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total);
     // 3. records -> 65536 pair buckets -> common per pair -> candidates
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
-    rc = partition16(ctx, own.p, rs, n_rec, n_rec, false, &rk, nullptr, &d_pstart, nullptr);
+    const uint32_t rbits = bits2_for(n_rec), rnb = 256u << rbits;  // ~350 records per sharing pair: few distinct pairs per bucket
+    rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr);
     if (rc) { ghip_prof_end(ctx); return rc; }
-    hipLaunchKernelGGL(join_reduce_kernel, dim3(J_BUCKETS / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, d_pstart, d_hashes, d_lens, s,
+    hipLaunchKernelGGL(join_reduce_kernel, dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, d_pstart, d_hashes, d_lens, s,
                        d_cmin, cmin_floor, rank, world, d_out, d_count, cap, d_flags);
     ghip_prof_end(ctx);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -25,6 +25,8 @@ ctx.profile(True); ctx.profile_reset()
 for _ in range(5):
     p = ctx.precluster(sk, np.float32(0.9))
 ctx.profile(False)
-nl, ms = ctx.kernel_stats()["pair_intersect_tile"]
+st = ctx.kernel_stats()
+nl, ms = st["pair_join"] if st["pair_join"][0] and not st["pair_intersect_tile"][0] else st["pair_intersect_tile"]
+nl = max(nl, 1)
 pairs = n * (n - 1) // 2
-print(f"mode={os.environ.get('GHIP_PAIR_DEBUG','0')} n={n} s={s} hits={len(p)} avg {ms/nl:.3f} ms  {pairs/(ms/nl*1e-3):.3e} pairs/s  {pairs*16*s/(ms/nl*1e-3)/1e9:.0f} GB/s alg")
+print(f"form={os.environ.get('GHIP_PAIR_KERNEL','auto')} n={n} s={s} hits={len(p)} avg {ms/nl:.3f} ms  {pairs/(ms/nl*1e-3):.3e} pairs/s  {pairs*16*s/(ms/nl*1e-3)/1e9:.0f} GB/s alg")
