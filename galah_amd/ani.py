@@ -63,6 +63,13 @@ class HipAniClusterer:
         self._index = ctx.ani_index_build(genomes, ANI_K, self.seed_compression, ANI_CHUNK)
         self._path_index = {p: i for i, p in enumerate(names)} if names is not None else {}
 
+    def adopt_index(self, index: AniIndex, genomes, genome_fasta_paths: Sequence[str]) -> None:
+        """Take an index built elsewhere (the fused sketch + index pass of galah_amd.clusterer.cluster)."""
+        if self._index is not None:
+            self._index.free()
+        self._genomes, self._index = genomes, index
+        self._path_index = {p: i for i, p in enumerate(genome_fasta_paths)}
+
     def calculate_ani_indices(self, pairs: np.ndarray) -> np.ndarray:
         assert self._index is not None, "call prepare() first"
         return self._context().ani_pairs(self._index, pairs, float(self.min_aligned_threshold))

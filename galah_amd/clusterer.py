@@ -31,6 +31,36 @@ def _pairs_of(cache) -> np.ndarray:
     return out
 
 
+def _one_ingest(preclusterer, clusterer) -> bool:
+    from .ani import HipAniClusterer
+    from .finch import FinchPreclusterer
+    if not (isinstance(preclusterer, FinchPreclusterer) and isinstance(clusterer, HipAniClusterer)):
+        return False
+    if preclusterer.low_memory:
+        return False  # distances() raises the reference's refusal
+    return clusterer._ctx is None or clusterer._ctx is preclusterer._context()
+
+
+def _distances_and_index(genomes, preclusterer, clusterer):
+    from .ani import ANI_CHUNK, ANI_K
+    from .cache import SortedPairGenomeDistanceCache
+    ctx = preclusterer._context()
+    clusterer._ctx = ctx
+    try:
+        g = ctx.genomes_from_files(list(genomes), max(preclusterer.io_threads, clusterer.io_threads))
+    except Exception as e:  # finch.rs:72
+        raise RuntimeError(f"Failed to sketch genomes with finch: {e}") from e
+    sk, idx = ctx.sketch_and_index(g, preclusterer.kmer_length, preclusterer.num_kmers, 0, ANI_K,
+                                   clusterer.seed_compression, ANI_CHUNK)
+    pairs = ctx.precluster(sk, np.float32(preclusterer.min_ani))
+    sk.free()
+    clusterer.adopt_index(idx, g, genomes)
+    cache = SortedPairGenomeDistanceCache.from_pairs(pairs)
+    cache._pairs = pairs
+    preclusterer.last_pairs = pairs
+    return cache
+
+
 def cluster(genomes: Sequence[str], preclusterer, clusterer, cluster_contigs: bool = False,
             contig_names: Optional[Sequence[str]] = None,
             reference_genomes: Optional[Sequence[str]] = None) -> List[List[int]]:
@@ -52,6 +82,10 @@ def cluster(genomes: Sequence[str], preclusterer, clusterer, cluster_contigs: bo
         cache = preclusterer.distances_with_references(genomes, reference_genomes)
     elif cluster_contigs:
         cache = preclusterer.distances_contigs(genomes, contig_names)
+    elif not skip_clusterer and _one_ingest(preclusterer, clusterer):
+        # both back-ends are HIP: read every FASTA once and take the MinHash sketches AND the ANI index from one
+        # pass over the bases (the reference reads each genome for finch, then twice per ANI pair for skani)
+        cache = _distances_and_index(genomes, preclusterer, clusterer)
     else:
         cache = preclusterer.distances(genomes)
 

@@ -6,7 +6,9 @@
 // followed by a single 'N' so that no k-mer spans two records.
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -49,40 +51,60 @@ bool slurp(const char *path, std::vector<uint8_t> &buf) {
 
 }  // namespace
 
-// Returns 0 ok, GHIP_EIO on unreadable / non-FASTA input.  The same pass yields the assembly
-// statistics galah computes in a second read of every file (reference src/genome_stats.rs:11-51):
-// records, raw 'N'/'n' count, N50 over record lengths (bases, line ends excluded).
-int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, ghip_genome_stats &st, std::string &err) {
+// Parses a whole FASTA file image into the device-format stream: per record the normalised bytes, then one 'N'.
+// Writes at most `cap` bytes to `out`; *out_len is the full stream length even when it exceeds cap (the caller
+// then re-parses with room).  The same pass yields the assembly statistics galah computes in a second read of
+// every file (reference src/genome_stats.rs:11-51): records, raw 'N'/'n' count, N50 over record lengths (bases,
+// line ends excluded).  Line-oriented: memchr finds the line ends, the table maps a line's bytes in a tight loop.
+int ghip_parse_fasta(const uint8_t *buf, size_t n, const char *path, uint8_t *out, size_t cap, size_t *out_len,
+                     ghip_genome_stats &st, std::string &err) {
     st = ghip_genome_stats();
+    *out_len = 0;
     std::vector<uint64_t> contig_lengths;
-    std::vector<uint8_t> buf;
-    if (!slurp(path, buf)) { err = std::string("Failed to open fasta file ") + path; return GHIP_EIO; }
-    const size_t n = buf.size();
-    out.clear();
-    out.reserve(n + 16);
-    size_t p = 0;
+    size_t p = 0, m = 0;
     while (p < n && (buf[p] == '\n' || buf[p] == '\r')) p++;
     if (p == n) return GHIP_OK;  // empty file: empty stream, empty sketch
     if (buf[p] != '>') { err = std::string("Not a FASTA file (no '>' header): ") + path; return GHIP_EIO; }
+    uint64_t amb = 0;
     while (p < n) {
-        while (p < n && buf[p] != '\n') p++;  // header line
-        if (p < n) p++;
-        bool line_start = true;
+        const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', n - p);  // header line
+        p = nl ? (size_t)(nl - buf) + 1 : n;
         uint64_t bases = 0;
-        while (p < n) {
-            const uint8_t c = buf[p];
-            if (line_start && c == '>') break;
-            line_start = (c == '\n');
-            if (c != '\n' && c != '\r') bases++;
-            if (c == 'N' || c == 'n') st.num_ambiguous_bases++;
-            const uint8_t o = kNorm.t[c];
-            if (o) out.push_back(o);
-            p++;
+        while (p < n && buf[p] != '>') {  // sequence lines up to the next line that starts with '>'
+            nl = (const uint8_t *)memchr(buf + p, '\n', n - p);
+            const size_t e = nl ? (size_t)(nl - buf) : n;
+            size_t len = e - p;
+            uint64_t cr = 0;
+            if (m + len <= cap) {
+                uint8_t *o = out + m;
+                size_t w = 0;
+                for (size_t q = p; q < e; q++) {
+                    const uint8_t c = buf[q];
+                    const uint8_t t = kNorm.t[c];
+                    o[w] = t;
+                    w += (t != 0);
+                    amb += (c == 'N') | (c == 'n');
+                    cr += (c == '\r');
+                }
+                m += w;
+            } else {  // over capacity: only count
+                for (size_t q = p; q < e; q++) {
+                    const uint8_t c = buf[q];
+                    m += (kNorm.t[c] != 0);
+                    amb += (c == 'N') | (c == 'n');
+                    cr += (c == '\r');
+                }
+            }
+            bases += len - cr;
+            p = nl ? e + 1 : n;
         }
-        out.push_back('N');
+        if (m < cap) out[m] = 'N';
+        m++;
         st.num_contigs++;
         contig_lengths.push_back(bases);
     }
+    st.num_ambiguous_bases = amb;
+    *out_len = m;
     // genome_stats.rs:33-45: ascending lengths, first running sum >= total/2
     std::sort(contig_lengths.begin(), contig_lengths.end());
     uint64_t total = 0, run = 0;
@@ -91,6 +113,40 @@ int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, ghip_gen
         run += l;
         if (run >= total / 2) { st.n50 = l; break; }
     }
+    return GHIP_OK;
+}
+
+// Reads a whole file (plain or gzip) into `buf`.
+bool ghip_slurp(const char *path, std::vector<uint8_t> &buf) { return slurp(path, buf); }
+
+// Upper bound of the stream length of a file without reading it: every header line ('>' ... '\n', >= 2 bytes)
+// is replaced by one 'N', so a plain file's stream is no longer than the file; for a single-member gzip the
+// trailer holds the uncompressed size (mod 2^32).  0 = unknown (unreadable; the parse reports the error).
+uint64_t ghip_stream_capacity_hint(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 0;
+    unsigned char magic[2] = {0, 0};
+    size_t got = fread(magic, 1, 2, f);
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    uint64_t cap = size > 0 ? (uint64_t)size : 0;
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && size >= 4) {
+        unsigned char t[4];
+        fseek(f, -4, SEEK_END);
+        if (fread(t, 1, 4, f) == 4) cap = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+    }
+    fclose(f);
+    return cap + 1;  // a file without a final newline still gets its trailing 'N'
+}
+
+int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, ghip_genome_stats &st, std::string &err) {
+    std::vector<uint8_t> buf;
+    if (!slurp(path, buf)) { err = std::string("Failed to open fasta file ") + path; return GHIP_EIO; }
+    out.resize(buf.size() + 16);
+    size_t len = 0;
+    int rc = ghip_parse_fasta(buf.data(), buf.size(), path, out.data(), out.size(), &len, st, err);
+    if (rc != GHIP_OK) return rc;
+    out.resize(len);  // len <= file size + 1 always fits
     return GHIP_OK;
 }
 

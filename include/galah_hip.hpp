@@ -16,6 +16,7 @@
 //   SkaniClusterer (src/skani.rs:689-716)                  galah::HipAniClusterer ("hipani": build-defined ANI)
 //   clusterer::cluster (src/clusterer.rs:14-152)           galah::cluster
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -162,6 +163,7 @@ public:
     std::string method_name() const override { return "finch"; }  // the string matters: src/clusterer.rs:33,39
 
     std::vector<ghip_pair> last_edges;  // the last distances() result as a sorted edge list
+    const std::shared_ptr<HipContext> &context() const { return hip_; }
 
 private:
     std::shared_ptr<HipContext> hip_;
@@ -204,6 +206,15 @@ public:
         for (size_t i = 0; i < genomes.size(); i++) path_index_.emplace(genomes[i], (uint32_t)i);
     }
     bool prepared_for(const std::vector<std::string> &genomes) const { return index_ && path_index_.size() == genomes.size(); }
+    // take an index built elsewhere (galah::cluster builds sketches and index from one pass over the bases)
+    void adopt_index(ghip_ani_index *index, const std::vector<std::string> &genomes) {
+        ghip_ani_index_free(index_);
+        index_ = index;
+        path_index_.clear();
+        for (size_t i = 0; i < genomes.size(); i++) path_index_.emplace(genomes[i], (uint32_t)i);
+    }
+    uint32_t seed_compression() const { return small_genomes ? 30 : 125; }
+    const std::shared_ptr<HipContext> &context() const { return hip_; }
 
     std::optional<float> calculate_ani(const std::string &fasta1, const std::string &fasta2) override {
         auto a = path_index_.find(fasta1), b = path_index_.find(fasta2);
@@ -254,10 +265,34 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
         if (preclusterer_name == "finch") throw std::runtime_error(preclusterer_name + " does not support contig comparisons.");
         skip_clusterer = true;
     }
-    SortedPairGenomeDistanceCache cache =                                                     // clusterer.rs:47-54
-        reference_genomes ? preclusterer.distances_with_references(genomes, *reference_genomes)
-        : cluster_contigs ? preclusterer.distances_contigs(genomes, *contig_names)
-                          : preclusterer.distances(genomes);
+    SortedPairGenomeDistanceCache cache;                                                      // clusterer.rs:47-54
+    auto *hip_finch = dynamic_cast<FinchPreclusterer *>(&preclusterer);
+    auto *hip_ani = dynamic_cast<HipAniClusterer *>(&clusterer);
+    if (reference_genomes) cache = preclusterer.distances_with_references(genomes, *reference_genomes);
+    else if (cluster_contigs) cache = preclusterer.distances_contigs(genomes, *contig_names);
+    else if (!skip_clusterer && hip_finch && hip_ani && !hip_finch->low_memory && hip_finch->context() == hip_ani->context()) {
+        // both back-ends are HIP: read every FASTA once, MinHash sketches AND ANI index from one pass over the bases
+        HipContext &hip = *hip_finch->context();
+        auto paths = detail::c_paths(genomes);
+        ghip_genomes *g = nullptr;
+        if (ghip_genomes_from_files(hip.get(), paths.data(), paths.size(), std::max(hip_finch->threads, hip_ani->threads), &g) != GHIP_OK)
+            throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());       // finch.rs:72
+        ghip_sketches *sk = nullptr;
+        ghip_ani_index *idx = nullptr;
+        int rc = ghip_sketch_and_index(hip.get(), g, hip_finch->kmer_length, (uint32_t)hip_finch->num_kmers, 0, 15,
+                                       hip_ani->seed_compression(), 20000, &sk, &idx);
+        ghip_genomes_free(g);
+        if (rc != GHIP_OK) throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());
+        ghip_pair *pairs = nullptr;
+        size_t np = 0;
+        rc = ghip_precluster(hip.get(), sk, hip_finch->min_ani, &pairs, &np);
+        ghip_sketches_free(sk);
+        if (rc != GHIP_OK) { ghip_ani_index_free(idx); throw std::runtime_error("Failed to compare finch sketches: " + hip.last_error()); }
+        for (size_t x = 0; x < np; x++) cache.insert({pairs[x].i, pairs[x].j}, pairs[x].ani);
+        hip_finch->last_edges.assign(pairs, pairs + np);
+        ghip_free(pairs);
+        hip_ani->adopt_index(idx, genomes);
+    } else cache = preclusterer.distances(genomes);
     const size_t n = cluster_contigs ? contig_names->size() : genomes.size();
 
     std::vector<ghip_pair> edges;
