@@ -14,6 +14,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build what the tests load -- the C-ABI library,
+    # the C++ host-mirror test program and the oracle -- exactly as __graft_entry__.build() does
+    import subprocess
+    need = [os.path.join(ROOT, "galah_amd", "libgalah_hip.so"), os.path.join(ROOT, "galah_amd", "csrc", "build", "test_host_mirror"),
+            os.path.join(ROOT, "oracle", "libgalah_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "galah_amd", "csrc"), "-j8"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
 def fasta(name: str) -> str:
