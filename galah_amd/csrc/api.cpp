@@ -661,15 +661,16 @@ static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t 
     if (!rc) rc = dmalloc(ctx, &sk->d_lens, n);
     if (rc) { free_sketches_locked(sk); return rc; }
 
-    // pending slots: initially every genome, with threshold ~ 2.5*s expected survivors
+    // pending slots: initially every genome, with a threshold that lets ~1.5*s hashes survive (for s = 1000:
+    // 1500 +- 39, so fewer than s survive only on repetitive or tiny genomes, which the retry loop widens)
     std::vector<uint32_t> slot_genome(n);
     std::vector<uint64_t> slot_thr(n);
     std::vector<uint32_t> slot_cap(n);
-    const uint32_t cap0 = next_pow2(4ull * s);
+    const uint32_t cap0 = next_pow2(2ull * s + 64);
     for (size_t i = 0; i < n; i++) {
         slot_genome[i] = (uint32_t)i;
         uint64_t nk = g->lens[i] >= k ? g->lens[i] - k + 1 : 1;
-        unsigned __int128 want = ((unsigned __int128)(5ull * s / 2 + 1)) << 64;
+        unsigned __int128 want = ((unsigned __int128)(3ull * s / 2 + 8)) << 64;
         unsigned __int128 t = want / nk;
         slot_thr[i] = (t >> 64) ? ~0ull : (uint64_t)t;
         slot_cap[i] = cap0;
