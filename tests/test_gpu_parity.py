@@ -424,3 +424,34 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
     hashes, lens = random_sketches(rng, 200, 1000, shared_groups=1)
     sk = ctx.sketches_from_host(hashes, lens, 21)
     assert ctx.precluster(sk, np.float32(0.9)).tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9)).tobytes()
+
+
+def test_join_form_takes_over_at_scale_with_awkward_families(ctx):
+    """N = 2500 (the automatic switch to the join form): identical genomes, subset sketches, short sketches,
+    one family of 120 -- every pair result equal to the oracle's (parallel) pair loop."""
+    rng = np.random.default_rng(77)
+    n, s = 2500, 1000
+    hashes, lens = random_sketches(rng, n, s, shared_groups=300, min_len=400)
+    # 40 identical copies of one sketch, and 30 strict prefixes of another (smaller genome of the same species)
+    for i in range(100, 140):
+        hashes[i], lens[i] = hashes[100], lens[100]
+    base, base_len = hashes[200].copy(), int(lens[200])
+    for x, i in enumerate(range(200, 230)):
+        keep = base_len - 10 * x
+        hashes[i] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        hashes[i, :keep] = base[:keep]
+        lens[i] = keep
+    # a family of 120 genomes sharing most hashes (records >> pairs inside the family, still sparse overall)
+    pool = np.unique(rng.integers(0, 2**62, size=1300, dtype=np.uint64))
+    for i in range(300, 420):
+        pick = np.sort(rng.choice(pool, size=1000, replace=False))
+        hashes[i], lens[i] = pick, 1000
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    ctx.profile(True); ctx.profile_reset()
+    got = ctx.precluster(sk, np.float32(0.9))
+    st = ctx.kernel_stats()
+    ctx.profile(False)
+    assert st["pair_join"][0] > 0 and st["pair_intersect_tile"][0] == 0      # the join form ran and did not decline
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32)
+    assert got.tobytes() == want.tobytes()
+    assert len(got) > 120 * 119 // 2 + 40 * 39 // 2
