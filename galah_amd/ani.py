@@ -20,10 +20,11 @@ ANI_CHUNK = 20000
 
 class HipAniClusterer:
     def __init__(self, threshold: float, min_aligned_threshold: float = 0.15, small_genomes: bool = False,
-                 ctx: Optional[Context] = None, io_threads: int = 1):
+                 ctx: Optional[Context] = None, io_threads: int = 1, seed_compression: Optional[int] = None):
         self.threshold = np.float32(threshold)                       # percent (skani.rs:203-209)
         self.min_aligned_threshold = np.float32(min_aligned_threshold)  # fraction (skani.rs:734: * 100 for the CLI)
         self.small_genomes = small_genomes
+        self._seed_compression = seed_compression  # override of the FracMinHash density (1 = every 15-mer is a seed)
         self._ctx = ctx
         self.io_threads = io_threads
         self._index: Optional[AniIndex] = None
@@ -32,6 +33,8 @@ class HipAniClusterer:
 
     @property
     def seed_compression(self) -> int:
+        if self._seed_compression is not None:
+            return int(self._seed_compression)
         return 30 if self.small_genomes else 125  # skani --small-genomes ~ -c 30
 
     def _context(self) -> Context:

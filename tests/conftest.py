@@ -68,3 +68,21 @@ def random_sketches(rng, n, s, shared_groups=0, min_len=None):
         hashes[i, : len(u)] = u
         lens[i] = len(u)
     return hashes, lens
+
+
+def fasta_records(name: str):
+    """(names, upper-cased sequences as uint8 arrays) of a multi-record fixture."""
+    import gzip
+    names, seqs, cur = [], [], []
+    with gzip.open(fasta(name), "rt") as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(">"):
+                if names:
+                    seqs.append("".join(cur))
+                names.append(line[1:].split()[0])
+                cur = []
+            elif line:
+                cur.append(line)
+    seqs.append("".join(cur))
+    return names, [np.frombuffer(s.upper().encode(), dtype=np.uint8) for s in seqs]

@@ -41,6 +41,8 @@ GENOMES = {
     "abisko_S1D21": "abisko4/73.20120800_S1D.21.fna",   # tests/test_cmdline.rs:12-61,304-352 (quality order)
     "abisko_S2M16": "abisko4/73.20110800_S2M.16.fna",
 }
+# multi-record files whose RECORDS the reference clusters (--cluster-contigs); copied as data, not sketched here
+CONTIG_FILES = {"contigs_specific": "contigs/contigs_specific.fna"}   # tests/test_cmdline.rs:482-505
 PAIRS = [("set1_1mbp", "set1_500kb"), ("abisko_S1X13", "abisko_S2D19"), ("abisko_S1X13", "abisko_S3X12"),
          ("abisko_S1X13", "abisko_S2D13"), ("abisko_S2D19", "abisko_S3X12"), ("abisko_S2D19", "abisko_S2D13"),
          ("abisko_S3X12", "abisko_S2D13"), ("antonio_MAG52", "antonio_MAG189"), ("set2_1mbp", "set2_half"),
@@ -61,6 +63,9 @@ def main():
         assert np.array_equal(sk_plain, sk_gz), name
         sketches[name] = sk_plain
     np.savez_compressed(os.path.join(HERE, "sketches.npz"), **sketches)
+    for name, rel in CONTIG_FILES.items():
+        with open(os.path.join(REF, rel), "rb") as f, gzip.GzipFile(os.path.join(fasta_dir, name + ".fna.gz"), "wb", compresslevel=9, mtime=0) as g:
+            shutil.copyfileobj(f, g)
     rows = []
     for a, b in PAIRS:
         common, total = oracle.raw_distance(sketches[a], sketches[b])

@@ -455,3 +455,20 @@ def test_join_form_takes_over_at_scale_with_awkward_families(ctx):
     want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32)
     assert got.tobytes() == want.tobytes()
     assert len(got) > 120 * 119 // 2 + 40 * 39 // 2
+
+
+def test_reference_contig_expectation_through_hip(ctx):
+    """tests/test_cmdline.rs:482-505 (expected clusters of the records of contigs_specific.fna at 95 %) with every record
+    a genome: finch precluster on the GPU, ANI with dense seeds (c = 1; at c = 30 a 1 kb contig keeps ~30 seeds, see
+    tests/test_oracle_golden.py), host clusterer -- and every ANI equal to the oracle's."""
+    from conftest import fasta_records
+    names, seqs = fasta_records("contigs_specific")
+    g = ctx.genomes_from_host(seqs)
+    sk, idx = ctx.sketch_and_index(g, 21, 1000, 0, 15, 1, 20000)
+    pairs = ctx.precluster(sk, np.float32(0.9))
+    pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32)
+    ani = ctx.ani_pairs(idx, pi, 0.15)
+    osk = [oracle.AniSketch.from_bytes(s, 15, 1, 20000) for s in seqs]
+    for x, (a, b) in enumerate(pi):
+        assert np.float32(oracle.ani_pair(osk[a], osk[b], 0.15)[0]) == ani[x], (names[a], names[b])
+    assert galah_amd.cluster_pairs(len(seqs), pairs, np.float32(95.0), ani) == [[0, 1, 2, 3, 4, 5], [6], [7], [8]]

@@ -99,3 +99,32 @@ def test_reference_cli_min_aligned_fraction():
     for min_af, want in ((0.2, [[0, 1]]), (0.6, [[0], [1]])):
         ani = lambda a, b: oracle.ani_pair(sks[a], sks[b], min_af)[0]
         assert sorted(oracle.cluster(2, oracle.Cache.from_pairs(pairs), 95.0, ani)) == want
+
+
+# tests/test_cmdline.rs:482-505 (test_contig_cluster_specific): the reference's expected clusters of the nine records of
+# contigs_specific.fna at 95 % -- the ~1 kb contig, its four 100 %-identity variants and the 96 % variant together; the
+# 94 % variant and the two unrelated contigs alone.
+CONTIG_CLUSTERS = [[0, 1, 2, 3, 4, 5], [6], [7], [8]]
+
+
+def test_reference_contig_expectation_needs_dense_seeds():
+    """On 1 kb contigs the FracMinHash ANI keeps ~30 seeds at c = 30 (skani's --small-genomes density): the estimate's
+    standard error (~1.5 ANI points) does not separate 96 % from 94 % at the 95 % threshold.  With every 15-mer as a seed
+    (c = 1) the build-defined estimator reproduces the reference's expected contig clusters."""
+    from conftest import fasta_records
+    names, seqs = fasta_records("contigs_specific")
+    assert names[5].startswith("96ANI") and names[6].startswith("94ANI") and len(names) == 9
+    sk = [oracle.sketch_bytes(s, 21, 1000, 0) for s in seqs]
+    n = len(seqs)
+    cache = oracle.Cache()
+    for i in range(n):
+        for j in range(i + 1, n):
+            c, t = oracle.raw_distance(sk[i], sk[j])
+            ani = oracle.mash_ani(c, t, 21)
+            if ani >= float(np.float32(0.9)):
+                cache.insert((i, j), np.float32(ani))
+    dense = [oracle.AniSketch.from_bytes(s, 15, 1, 20000) for s in seqs]
+    got = oracle.cluster(n, cache, 95.0, lambda a, b: oracle.ani_pair(dense[a], dense[b], 0.15)[0])
+    assert got == CONTIG_CLUSTERS
+    sparse = [oracle.AniSketch.from_bytes(s, 15, 30, 20000) for s in seqs]
+    assert oracle.ani_pair(sparse[0], sparse[5], 0.15)[0] < 95.0 <= oracle.ani_pair(dense[0], dense[5], 0.15)[0]
