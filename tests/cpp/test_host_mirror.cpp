@@ -5,6 +5,7 @@
 //   src/clusterer.rs:631-690                   test_minhash_skani_hello_world, .._two_clusters_same_ani
 //                                              (the reference needs the skani binary; the build-defined ANI reproduces both)
 //   tests/test_cmdline.rs:262-302              --min-aligned-fraction 0.2 -> one representative, 0.6 -> two
+//   tests/test_cmdline.rs:161-181, 417-440     representative list order; github issue 7
 //   src/finch.rs:14-15,40, src/clusterer.rs:38-44   refusals (panics -> std::runtime_error with the same text)
 #include <algorithm>
 #include <cstdio>
@@ -93,6 +94,12 @@ int main(int argc, char **argv) {
         galah::HipAniClusterer lo(hip, 95.0f, 0.2f), hi(hip, 95.0f, 0.6f);
         CHECK((sorted(galah::cluster(g, pre, lo)) == std::vector<std::vector<size_t>>{{0, 1}}));
         CHECK((sorted(galah::cluster(g, pre, hi)) == std::vector<std::vector<size_t>>{{0}, {1}}));
+    }
+    {   // tests/test_cmdline.rs:161-181 (representative list) and :417-440 (github issue 7, --min-aligned-fraction 60)
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        galah::HipAniClusterer a(hip, 95.0f, 0.15f), b(hip, 95.0f, 0.6f);
+        CHECK((galah::cluster({fa("clash_500kb"), fa("set1_500kb"), fa("set1_1mbp")}, pre, a) == std::vector<std::vector<size_t>>{{1, 2}, {0}}));
+        CHECK((galah::cluster({fa("antonio_MAG52"), fa("antonio_MAG189")}, pre, b) == std::vector<std::vector<size_t>>{{0, 1}}));
     }
     {   // refusals
         galah::FinchPreclusterer lowmem(hip, 0.9f, 1000, 21, true);

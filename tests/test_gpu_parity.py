@@ -472,3 +472,14 @@ def test_reference_contig_expectation_through_hip(ctx):
     for x, (a, b) in enumerate(pi):
         assert np.float32(oracle.ani_pair(osk[a], osk[b], 0.15)[0]) == ani[x], (names[a], names[b])
     assert galah_amd.cluster_pairs(len(seqs), pairs, np.float32(95.0), ani) == [[0, 1, 2, 3, 4, 5], [6], [7], [8]]
+
+
+def test_reference_cli_representative_list_and_github7_through_hip(ctx):
+    """tests/test_cmdline.rs:161-181 and :417-440 through the GPU path (see tests/test_oracle_golden.py)."""
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=2)
+    got = galah_amd.cluster([fasta(n) for n in ("clash_500kb", "set1_500kb", "set1_1mbp")], pre,
+                            galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=2))
+    assert got == [[1, 2], [0]]
+    got = galah_amd.cluster([fasta(n) for n in ("antonio_MAG52", "antonio_MAG189")], pre,
+                            galah_amd.HipAniClusterer(95.0, 0.6, ctx=ctx, io_threads=2))
+    assert got == [[0, 1]]

@@ -128,3 +128,18 @@ def test_reference_contig_expectation_needs_dense_seeds():
     assert got == CONTIG_CLUSTERS
     sparse = [oracle.AniSketch.from_bytes(s, 15, 30, 20000) for s in seqs]
     assert oracle.ani_pair(sparse[0], sparse[5], 0.15)[0] < 95.0 <= oracle.ani_pair(dense[0], dense[5], 0.15)[0]
+
+
+def _finch_plus_ani(names, thr, min_af):
+    paths = [fasta(n) for n in names]
+    sks = [oracle.AniSketch.from_file(p) for p in paths]
+    pairs = oracle.distances(paths, np.float32(0.9))
+    return oracle.cluster(len(names), oracle.Cache.from_pairs(pairs), thr, lambda a, b: oracle.ani_pair(sks[a], sks[b], min_af)[0])
+
+
+def test_reference_cli_representative_list_and_github7():
+    """tests/test_cmdline.rs:161-181: [name_clash/500kb, set1/500kb, set1/1mbp] -> representatives set1/500kb, then
+    name_clash/500kb (the bigger precluster first; 1mbp joins 500kb).  :417-440 (github issue 7): the two antonio MAGs at
+    --min-aligned-fraction 60 -> one cluster, representative MAG52."""
+    assert _finch_plus_ani(["clash_500kb", "set1_500kb", "set1_1mbp"], 95.0, 0.15) == [[1, 2], [0]]
+    assert _finch_plus_ani(["antonio_MAG52", "antonio_MAG189"], 95.0, 0.6) == [[0, 1]]
