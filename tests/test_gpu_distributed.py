@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N=N, LENGTH=LENGTH):
     import torch
 
     import galah_amd
@@ -42,6 +42,34 @@ def _worker(rank, world, port, q):
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
+
+
+def test_three_ranks_join_form_equals_single_rank(ctx):
+    """N = 2100 short genomes on three ranks (ragged shards): the pair stage switches to the join form, which every
+    rank runs in full and reports by (i + j) mod world; families straddle the shard boundaries, so the ANI index
+    slices are exchanged too."""
+    import oracle
+    from galah_amd.distributed import DereplicationJob
+    n, length = 2100, 30_000
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 3, port, q, n, length)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    job = DereplicationJob(ctx, 0, 1, n_genomes=n, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
+    job.load_synthetic(SEED, MEMBERS, length, RATE)
+    want = job.step()
+    hashes, lens = job.sketches_to_host()
+    assert got["hashes"] == hashes.tobytes() and got["lens"] == lens.tobytes()
+    assert got["pairs"] == want["pairs"].tobytes()
+    assert got["ani"] == want["pair_ani"].tobytes()
+    assert got["clusters"] == want["clusters"]
+    assert want["pairs"].tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32).tobytes()
 
 
 def test_two_ranks_one_gpu_equals_single_rank(ctx):
