@@ -46,15 +46,15 @@ def _distances_and_index(genomes, preclusterer, clusterer):
     from .cache import SortedPairGenomeDistanceCache
     ctx = preclusterer._context()
     clusterer._ctx = ctx
-    try:
-        g = ctx.genomes_from_files(list(genomes), max(preclusterer.io_threads, clusterer.io_threads))
+    try:  # batched inside the library: inputs larger than HBM work
+        sk, idx, _stats = ctx.sketch_and_index_files(list(genomes), preclusterer.kmer_length, preclusterer.num_kmers, 0, ANI_K,
+                                                     clusterer.seed_compression, ANI_CHUNK,
+                                                     max(preclusterer.io_threads, clusterer.io_threads))
     except Exception as e:  # finch.rs:72
         raise RuntimeError(f"Failed to sketch genomes with finch: {e}") from e
-    sk, idx = ctx.sketch_and_index(g, preclusterer.kmer_length, preclusterer.num_kmers, 0, ANI_K,
-                                   clusterer.seed_compression, ANI_CHUNK)
     pairs = ctx.precluster(sk, np.float32(preclusterer.min_ani))
     sk.free()
-    clusterer.adopt_index(idx, g, genomes)
+    clusterer.adopt_index(idx, None, genomes)
     cache = SortedPairGenomeDistanceCache.from_pairs(pairs)
     cache._pairs = pairs
     preclusterer.last_pairs = pairs

@@ -749,14 +749,14 @@ extern "C" int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_
     return sketch_genomes_locked(ctx, g, k, s, seed, nullptr, out);
 }
 
+extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s, uint64_t seed,
+                                           uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, int io_threads, uint64_t batch_bytes,
+                                           ghip_sketches **out_sk, ghip_ani_index **out_idx, uint64_t *out_stats);
+
+// finch::sketch_files for a file list (src/finch.rs:55-69); inputs larger than HBM are sketched in batches
 extern "C" int ghip_sketch_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s,
                                  uint64_t seed, int io_threads, ghip_sketches **out) {
-    ghip_genomes *g = nullptr;
-    int rc = ghip_genomes_from_files(ctx, paths, n, io_threads, &g);
-    if (rc) return rc;
-    rc = ghip_sketch_genomes(ctx, g, k, s, seed, out);
-    ghip_genomes_free(g);
-    return rc;
+    return ghip_sketch_and_index_files(ctx, paths, n, k, s, seed, 0, 0, 0, io_threads, 0, out, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------ precluster
@@ -1061,6 +1061,116 @@ extern "C" int ghip_sketch_and_index(ghip_ctx *ctx, const ghip_genomes *g, uint3
     if (rc) { if (sk) free_sketches_locked(sk); free_index_locked(idx); return rc; }
     *out_sk = sk;
     *out_idx = idx;
+    return GHIP_OK;
+}
+
+// Files in -> MinHash sketches (+ ANI index, + assembly statistics), with at most `batch_bytes` of bases resident in
+// HBM at a time: the files are ingested, sketched and seeded batch by batch and the per-batch results -- packed
+// sketch rows and the flat, genome-relative index arrays -- are concatenated on the device.  One batch (the common
+// case) returns its handles as they are.
+extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s, uint64_t seed,
+                                           uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, int io_threads, uint64_t batch_bytes,
+                                           ghip_sketches **out_sk, ghip_ani_index **out_idx, uint64_t *out_stats) {
+    if (!ctx || !out_sk || (n && !paths)) return GHIP_EINVAL;
+    if (batch_bytes == 0) batch_bytes = 96ull << 30;  // a third of the 288 GB of an MI355X
+    *out_sk = nullptr;
+    if (out_idx) *out_idx = nullptr;
+    std::vector<ghip_sketches *> sks;
+    std::vector<ghip_ani_index *> idxs;
+    auto drop = [&]() {
+        for (auto *x : sks) ghip_sketches_free(x);
+        for (auto *x : idxs) ghip_ani_index_free(x);
+    };
+    size_t first = 0;
+    do {  // at least one (possibly empty) batch, so that n == 0 yields empty handles
+        size_t last = first;
+        uint64_t bytes = 0;
+        while (last < n) {
+            const uint64_t c = ghip_stream_capacity_hint(paths[last]) + GHIP_TAIL_PAD + 16;
+            if (last > first && bytes + c > batch_bytes) break;
+            bytes += c;
+            last++;
+        }
+        ghip_genomes *g = nullptr;
+        int rc = ghip_genomes_from_files(ctx, paths + first, last - first, io_threads, &g);
+        ghip_sketches *sk = nullptr;
+        ghip_ani_index *idx = nullptr;
+        if (!rc) rc = out_idx ? ghip_sketch_and_index(ctx, g, k, s, seed, ani_k, ani_c, ani_chunk, &sk, &idx)
+                              : ghip_sketch_genomes(ctx, g, k, s, seed, &sk);
+        if (!rc && out_stats)
+            for (size_t i = first; i < last; i++) {
+                const ghip_genome_stats &st = g->stats[i - first];
+                out_stats[3 * i] = st.num_contigs; out_stats[3 * i + 1] = st.num_ambiguous_bases; out_stats[3 * i + 2] = st.n50;
+            }
+        if (g) ghip_genomes_free(g);
+        if (rc) { if (sk) ghip_sketches_free(sk); if (idx) ghip_ani_index_free(idx); drop(); return rc; }
+        sks.push_back(sk);
+        if (out_idx) idxs.push_back(idx);
+        first = last;
+    } while (first < n);
+    if (sks.size() == 1) {
+        *out_sk = sks[0];
+        if (out_idx) *out_idx = idxs[0];
+        return GHIP_OK;
+    }
+    // ---- concatenate the batches on the device
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = GHIP_OK;
+    ghip_sketches *sk = new ghip_sketches();
+    ctx->live_handles++;
+    sk->ctx = ctx; sk->n = n; sk->s = s; sk->k = k;
+    if (!(rc = dmalloc(ctx, &sk->d_hashes, n * (size_t)s)) && !(rc = dmalloc(ctx, &sk->d_lens, n))) {
+        size_t at = 0;
+        for (auto *b : sks) {
+            if (b->n && (hipMemcpyAsync(sk->d_hashes + at * s, b->d_hashes, b->n * (size_t)s * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                         hipMemcpyAsync(sk->d_lens + at, b->d_lens, b->n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
+                rc = ghip_set_error(ctx, GHIP_EHIP, "sketch concatenation failed");
+            at += b->n;
+        }
+    }
+    ghip_ani_index *idx = nullptr;
+    if (!rc && out_idx) {
+        idx = new ghip_ani_index();
+        ctx->live_handles++;
+        idx->ctx = ctx; idx->n = n; idx->k = ani_k; idx->c = ani_c; idx->chunk = ani_chunk;
+        idx->seed_start.assign(1, 0); idx->chunk_start.assign(1, 0);
+        for (auto *b : idxs) {
+            idx->max_chunks = std::max(idx->max_chunks, b->max_chunks);
+            idx->glen.insert(idx->glen.end(), b->glen.begin(), b->glen.end());
+            idx->seed_count.insert(idx->seed_count.end(), b->seed_count.begin(), b->seed_count.end());
+            for (size_t i = 0; i < b->n; i++) {
+                idx->seed_start.push_back(idx->seed_start.back() + (b->seed_start[i + 1] - b->seed_start[i]));
+                idx->chunk_start.push_back(idx->chunk_start.back() + (b->chunk_start[i + 1] - b->chunk_start[i]));
+            }
+        }
+        const uint64_t n_seed = idx->seed_start[n], n_chunk = idx->chunk_start[n];
+        if (!(rc = dmalloc(ctx, &idx->d_seed_code, n_seed)) && !(rc = dmalloc(ctx, &idx->d_seed_chunk, n_seed)) &&
+            !(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) && !(rc = dmalloc(ctx, &idx->d_chunk_total, n_chunk)) &&
+            !(rc = dmalloc(ctx, &idx->d_seed_start, n + 1)) && !(rc = dmalloc(ctx, &idx->d_seed_count, n)) &&
+            !(rc = dmalloc(ctx, &idx->d_chunk_start, n + 1)) && !(rc = dmalloc(ctx, &idx->d_glen, n)) &&
+            !(rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1)) && !(rc = h2d(ctx, idx->d_seed_count, idx->seed_count.data(), n)) &&
+            !(rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1)) && !(rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) {
+            uint64_t at_seed = 0, at_chunk = 0;
+            size_t at_g = 0;
+            for (auto *b : idxs) {
+                const uint64_t ns = b->seed_start[b->n], nc = b->chunk_start[b->n];
+                hipError_t e = hipSuccess;
+                if (ns) e = hipMemcpyAsync(idx->d_seed_code + at_seed, b->d_seed_code, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
+                if (ns && e == hipSuccess) e = hipMemcpyAsync(idx->d_seed_chunk + at_seed, b->d_seed_chunk, ns * sizeof(uint16_t), hipMemcpyDeviceToDevice, ctx->stream);
+                if (b->n && e == hipSuccess) e = hipMemcpyAsync(idx->d_bin_start + at_g * (GHIP_ANI_BIN_COUNT + 1), b->d_bin_start, b->n * (size_t)(GHIP_ANI_BIN_COUNT + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
+                if (nc && e == hipSuccess) e = hipMemcpyAsync(idx->d_chunk_total + at_chunk, b->d_chunk_total, nc * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
+                if (e != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index concatenation failed"); break; }
+                at_seed += ns; at_chunk += nc; at_g += b->n;
+            }
+        }
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "concatenation failed");
+    for (auto *b : sks) free_sketches_locked(b);
+    for (auto *b : idxs) free_index_locked(b);
+    if (rc) { free_sketches_locked(sk); if (idx) free_index_locked(idx); return rc; }
+    *out_sk = sk;
+    if (out_idx) *out_idx = idx;
     return GHIP_OK;
 }
 

@@ -253,6 +253,19 @@ class Context:
                                                C.byref(hi)), self._h)
         return Sketches(self, hs), AniIndex(self, hi)
 
+    def sketch_and_index_files(self, paths: Sequence[str], k: int = 21, s: int = 1000, seed: int = 0, ani_k: int = 15,
+                               ani_c: int = 125, ani_chunk: int = 20000, io_threads: int = 1, batch_bytes: int = 0,
+                               want_index: bool = True):
+        """Files in -> (Sketches, AniIndex or None, stats u64[n][3] = contigs, ambiguous bases, N50): one read of every
+        file, at most `batch_bytes` of bases in HBM at a time (0 = the library default)."""
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        hs, hi = C.c_void_p(), C.c_void_p()
+        stats = np.zeros((len(paths), 3), dtype=np.uint64)
+        check(_lib.lib().ghip_sketch_and_index_files(self._h, arr, len(paths), k, s, seed, ani_k, ani_c, ani_chunk, io_threads,
+                                                     batch_bytes, C.byref(hs), C.byref(hi) if want_index else None,
+                                                     stats.ctypes.data), self._h)
+        return Sketches(self, hs), (AniIndex(self, hi) if want_index else None), stats
+
     def ani_index_wrap_device(self, k: int, c: int, chunk: int, genome_len, seed_cap, seed_count,
                               d_seed_code: int, d_seed_chunk: int, d_bin_start: int, d_chunk_total: int) -> AniIndex:
         glen = np.ascontiguousarray(genome_len, dtype=np.uint64)

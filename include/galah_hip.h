@@ -145,6 +145,15 @@ int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint3
 int ghip_sketch_and_index(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
                           uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, ghip_sketches **out_sk,
                           ghip_ani_index **out_idx);
+/* Files in -> sketches + ANI index (+ statistics) in one call: ONE read of every FASTA file serves both back-ends
+ * (the reference reads each genome for finch and again, twice per pair, for skani: src/finch.rs:69,
+ * src/skani.rs:725-726), and at most batch_bytes of bases are resident at a time (0 = default 96 GiB), so inputs
+ * larger than HBM work.  out_idx NULL: sketches only (then ani_* are ignored).  out_stats NULL or u64[n][3] =
+ * contigs, ambiguous bases, N50 (src/genome_stats.rs:11-51). */
+int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s,
+                                uint64_t seed, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, int io_threads,
+                                uint64_t batch_bytes, ghip_sketches **out_sk, ghip_ani_index **out_idx,
+                                uint64_t *out_stats);
 int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */,
                    size_t n, float min_aligned_fraction, float *out_ani_percent,
                    float *out_af /* nullable, [n][2] */);

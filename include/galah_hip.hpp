@@ -274,15 +274,12 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
         // both back-ends are HIP: read every FASTA once, MinHash sketches AND ANI index from one pass over the bases
         HipContext &hip = *hip_finch->context();
         auto paths = detail::c_paths(genomes);
-        ghip_genomes *g = nullptr;
-        if (ghip_genomes_from_files(hip.get(), paths.data(), paths.size(), std::max(hip_finch->threads, hip_ani->threads), &g) != GHIP_OK)
-            throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());       // finch.rs:72
         ghip_sketches *sk = nullptr;
         ghip_ani_index *idx = nullptr;
-        int rc = ghip_sketch_and_index(hip.get(), g, hip_finch->kmer_length, (uint32_t)hip_finch->num_kmers, 0, 15,
-                                       hip_ani->seed_compression(), 20000, &sk, &idx);
-        ghip_genomes_free(g);
-        if (rc != GHIP_OK) throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());
+        int rc = ghip_sketch_and_index_files(hip.get(), paths.data(), paths.size(), hip_finch->kmer_length, (uint32_t)hip_finch->num_kmers,
+                                             0, 15, hip_ani->seed_compression(), 20000, std::max(hip_finch->threads, hip_ani->threads),
+                                             0, &sk, &idx, nullptr);
+        if (rc != GHIP_OK) throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());   // finch.rs:72
         ghip_pair *pairs = nullptr;
         size_t np = 0;
         rc = ghip_precluster(hip.get(), sk, hip_finch->min_ani, &pairs, &np);

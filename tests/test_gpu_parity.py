@@ -483,3 +483,31 @@ def test_reference_cli_representative_list_and_github7_through_hip(ctx):
     got = galah_amd.cluster([fasta(n) for n in ("antonio_MAG52", "antonio_MAG189")], pre,
                             galah_amd.HipAniClusterer(95.0, 0.6, ctx=ctx, io_threads=2))
     assert got == [[0, 1]]
+
+
+def test_batched_files_entry_point_equals_one_batch(ctx):
+    """ghip_sketch_and_index_files with a tiny batch size (several batches, concatenated on the device) ==
+    one batch == the separate calls; statistics as the oracle's; sketches-only form for ghip_sketch_files."""
+    names = ALL + ["abisko_S2D10"]
+    paths = [fasta(n) for n in names]
+    sk1, idx1, st1 = ctx.sketch_and_index_files(paths, io_threads=4)                          # one batch
+    sk2, idx2, st2 = ctx.sketch_and_index_files(paths, io_threads=4, batch_bytes=3_000_000)   # ~6 batches
+    h1, l1 = sk1.to_host()
+    h2, l2 = sk2.to_host()
+    assert np.array_equal(h1, h2) and np.array_equal(l1, l2) and np.array_equal(st1, st2)
+    for a, b in zip(idx1.meta(), idx2.meta()):
+        assert np.array_equal(a, b)
+    for i, n in enumerate(names):
+        assert tuple(int(x) for x in st2[i]) == oracle.genome_stats(fasta(n))
+    n = len(names)
+    pairs = np.array([(i, j) for i in range(n) for j in range(i + 1, n)], dtype=np.uint32)
+    a1 = ctx.ani_pairs(idx1, pairs, 0.15)
+    a2 = ctx.ani_pairs(idx2, pairs, 0.15)
+    assert np.array_equal(a1, a2) and (a1 > 0).sum() >= 8
+    g = ctx.genomes_from_files(paths, 4)
+    assert np.array_equal(ctx.ani_pairs(ctx.ani_index_build(g), pairs, 0.15), a1)
+    sk3, none, _ = ctx.sketch_and_index_files(paths, io_threads=2, batch_bytes=1, want_index=False)  # one file per batch
+    h3, l3 = sk3.to_host()
+    assert none is None and np.array_equal(h3, h1) and np.array_equal(l3, l1)
+    h4, l4 = ctx.sketch_files(paths, 21, 1000, 0, io_threads=2).to_host()
+    assert np.array_equal(h4, h1) and np.array_equal(l4, l1)
