@@ -240,10 +240,20 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             for (uint32_t i = lane; i < nq; i += 64) {
                 const uint32_t c = sq[i];
                 const uint32_t x = code_bin(c) - b0;
-                const uint32_t jz = ro[x + 1];
-                bool hit = false;
-                for (uint32_t j = ro[x]; j < jz; j++)
+                const uint32_t j0 = ro[x], jz = ro[x + 1];
+                // the first 8 seeds of the bin branch-free (a bin holds ~2.4 seeds, more than 8 with P ~ 5e-4): an
+                // exec-masked loop over the bin costs ~6 scalar instructions per iteration and the kernel is as much
+                // scalar- as vector-issue bound; reads past the bin stay inside the stage and are masked off
+                uint32_t mm = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) mm |= (uint32_t)((j0 + u < jz) & (sr[min(j0 + u, ANI_STAGE - 1)] == c)) << u;
+                bool hit = mm != 0;
+                for (uint32_t j = j0 + 8; j < jz; j++)
                     if (sr[j] == c) { hit = true; rf[j] = 1; }
+                while (mm) {
+                    rf[j0 + (uint32_t)__builtin_ctz(mm)] = 1;
+                    mm &= mm - 1;
+                }
                 if (hit) atomicAdd(&mcq[kq[i]], 1u);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
