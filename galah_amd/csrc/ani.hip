@@ -225,8 +225,17 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
         if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
         const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
         if (staged) {
-            for (uint32_t k = lane; k < q_hi - q_lo; k += 64) { sq[k] = qc[q_lo + k]; kq[k] = qk[q_lo + k]; }
-            for (uint32_t k = lane; k < r_hi - r_lo; k += 64) { sr[k] = rc[r_lo + k]; kr[k] = rk[r_lo + k]; }
+            {   // both runs in one loop: the four loads of an iteration are in flight together
+                const uint32_t nqs = q_hi - q_lo, nrs = r_hi - r_lo;
+                for (uint32_t k = lane; k < max(nqs, nrs); k += 64) {
+                    uint32_t c1 = 0, c2 = 0;
+                    uint16_t h1 = 0, h2 = 0;
+                    if (k < nqs) { c1 = qc[q_lo + k]; h1 = qk[q_lo + k]; }
+                    if (k < nrs) { c2 = rc[r_lo + k]; h2 = rk[r_lo + k]; }
+                    if (k < nqs) { sq[k] = c1; kq[k] = h1; }
+                    if (k < nrs) { sr[k] = c2; kr[k] = h2; }
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // Flattened join: q seeds are dealt to the lanes one each (not one BIN per lane, whose cost is the
