@@ -217,9 +217,14 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     uint8_t *rf = st_flag[wave];
     uint16_t *ro = st_roff[wave];
     for (uint32_t k = lane; k < ANI_STAGE; k += 64) rf[k] = 0;
+    // the bin bounds of the next round are fetched while this round is joined
+    uint32_t nqs_ = qb[wave * 64 + lane], nqe_ = qb[wave * 64 + lane + 1], nrs_ = rb[wave * 64 + lane], nre_ = rb[wave * 64 + lane + 1];
     for (uint32_t b0 = wave * 64; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * 64) {
-        const uint32_t b = b0 + lane;
-        const uint32_t qs = qb[b], qe = qb[b + 1], rs = rb[b], re = rb[b + 1];
+        const uint32_t qs = nqs_, qe = nqe_, rs = nrs_, re = nre_;
+        if (b0 + ANI_PAIR_WAVES * 64 < BIN_COUNT) {
+            const uint32_t nb = b0 + ANI_PAIR_WAVES * 64 + lane;
+            nqs_ = qb[nb]; nqe_ = qb[nb + 1]; nrs_ = rb[nb]; nre_ = rb[nb + 1];
+        }
         const uint32_t q_lo = __shfl(qs, 0, 64), q_hi = __shfl(qe, 63, 64);
         const uint32_t r_lo = __shfl(rs, 0, 64), r_hi = __shfl(re, 63, 64);
         if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
