@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     uint32_t *__restrict__ bin_start, uint32_t *__restrict__ pos_tmp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);  // BIN_COUNT counters
-    constexpr uint32_t BIN_WINDOW = 8192;
+    constexpr uint32_t BIN_WINDOW = 10880;  // 64 KiB / 6 B per seed, rounded down to a multiple of 64
     static_assert(BIN_WINDOW * 6 <= BIN_COUNT * 4, "the output window reuses the histogram's LDS");
     __shared__ uint32_t wave_tot[BIN_THREADS / 64];
     const uint32_t g = blockIdx.x;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     __syncthreads();
     // Scatter through an LDS window and write each window out contiguously: scattering 4-byte
     // stores straight to HBM costs a whole sector per seed (PMC: 3.3 GB written for 0.27 GB).
-    uint32_t *w_code = hist;                                               // 8192 x 4 B (the histogram is dead)
-    uint16_t *w_chunk = reinterpret_cast<uint16_t *>(hist + BIN_WINDOW);   // 8192 x 2 B
+    uint32_t *w_code = hist;                                               // BIN_WINDOW x 4 B (the histogram is dead)
+    uint16_t *w_chunk = reinterpret_cast<uint16_t *>(hist + BIN_WINDOW);   // BIN_WINDOW x 2 B
     for (uint32_t w0 = 0; w0 < n; w0 += BIN_WINDOW) {
         for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
             const uint32_t p = pos_tmp[s0 + i] - w0;
