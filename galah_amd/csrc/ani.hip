@@ -126,9 +126,14 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     }
     if (threadIdx.x == BIN_THREADS - 1) bstart[BIN_COUNT] = run;  // == n
     __syncthreads();
-    // destination slot of every seed (one LDS atomic each), kept in a scratch array
-    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS)
-        pos_tmp[s0 + i] = atomicAdd(&hist[code_bin(in_code[s0 + i])], 1u);
+    // destination slot of every seed (one LDS atomic each), kept in a scratch array -- as 16-bit values when the
+    // genome has fewer than 65 536 seeds (it is re-read once per window)
+    const bool narrow = n <= 0xffffu;
+    uint16_t *pos16 = reinterpret_cast<uint16_t *>(pos_tmp + s0);
+    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
+        const uint32_t p = atomicAdd(&hist[code_bin(in_code[s0 + i])], 1u);
+        if (narrow) pos16[i] = (uint16_t)p; else pos_tmp[s0 + i] = p;
+    }
     __syncthreads();
     // Scatter through an LDS window and write each window out contiguously: scattering 4-byte
     // stores straight to HBM costs a whole sector per seed (PMC: 3.3 GB written for 0.27 GB).
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     uint16_t *w_chunk = reinterpret_cast<uint16_t *>(hist + BIN_WINDOW);   // BIN_WINDOW x 2 B
     for (uint32_t w0 = 0; w0 < n; w0 += BIN_WINDOW) {
         for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
-            const uint32_t p = pos_tmp[s0 + i] - w0;
+            const uint32_t p = (narrow ? (uint32_t)pos16[i] : pos_tmp[s0 + i]) - w0;
             if (p < BIN_WINDOW) { w_code[p] = in_code[s0 + i]; w_chunk[p] = in_chunk[s0 + i]; }
         }
         __syncthreads();
