@@ -1,12 +1,11 @@
 // MinHash sketching on gfx950: replaces finch::sketch_files (reference src/finch.rs:55-69).
 //
-//   sketch_kmers  : one pass over the normalised base stream.  Each lane rolls two 2-bit
-//                   encodings of its run of k-mers (forward big-endian for the canonical
-//                   compare, forward little-endian for the hash input; the reverse complement
-//                   is the bitwise complement of the other one), expands the canonical k-mer
-//                   to its ASCII bytes with v_perm_b32, hashes with MurmurHash3_x64_128
-//                   (seed, first u64) and keeps hashes <= a per-genome threshold in a
-//                   candidate list.  VALU-integer bound (~150 ops per base), not HBM bound.
+//   sketch_kmers  : one pass over the normalised base stream (k = 21: sketch_kmers21_kernel, below; any other k:
+//                   sketch_kmers_kernel_rt).  Each lane owns 64 consecutive k-mer starts, rolls the 2-bit
+//                   codes of both strands, hashes the canonical k-mer with MurmurHash3_x64_128 (seed, first
+//                   u64) and keeps hashes <= a per-genome threshold as candidates; with SEEDS the same pass
+//                   emits the FracMinHash seeds of the ANI index.  VALU-issue bound (~98 instructions per
+//                   base in the fused form), not HBM bound.
 //   sketch_select : per genome, sort the candidates (bitonic, LDS), drop duplicates, write the
 //                   s smallest into the packed u64[n][s] matrix.  Exact: the host re-runs a
 //                   genome with a wider threshold / larger list if fewer than s distinct
@@ -46,37 +45,6 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
     return k;
 }
 
-// MurmurHash3_x64_128(key, len=K, seed).h1 where the key is given as little-endian u64 words
-// w[0..3] (bytes beyond K are zero).  K <= 32.
-template <int K>
-__device__ __forceinline__ uint64_t murmur3_h1(const uint64_t (&w)[4], uint32_t seed) {
-    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
-    uint64_t h1 = seed, h2 = seed;
-    constexpr int nblocks = K / 16;
-#pragma unroll
-    for (int b = 0; b < nblocks; b++) {
-        uint64_t k1 = w[2 * b], k2 = w[2 * b + 1];
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-    }
-    constexpr int tail = K & 15;
-    if (tail > 8) {
-        uint64_t k2 = w[2 * nblocks + 1];
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-    }
-    if (tail > 0) {
-        uint64_t k1 = w[2 * nblocks];
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-    }
-    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
-    h1 += h2; h2 += h1;
-    h1 = fmix64(h1); h2 = fmix64(h2);
-    h1 += h2;
-    return h1;
-}
-
 // 8 bases (2 bits each, base j at bits [2j+1:2j]) -> 8 ASCII bytes, base j in byte j.
 __device__ __forceinline__ uint64_t expand8(uint32_t f16) {
     const uint32_t lut = 0x54474341u;  // 'A','C','G','T' in bytes 0..3
@@ -88,22 +56,6 @@ __device__ __forceinline__ uint64_t expand8(uint32_t f16) {
     uint32_t alo = __builtin_amdgcn_perm(lut, lut, lo);
     uint32_t ahi = __builtin_amdgcn_perm(lut, lut, hi);
     return ((uint64_t)ahi << 32) | alo;
-}
-
-template <int K>
-__device__ __forceinline__ uint64_t hash_canonical(uint64_t code_le, uint32_t seed) {
-    uint64_t w[4] = {0, 0, 0, 0};
-    constexpr int nw = (K + 7) / 8;
-#pragma unroll
-    for (int i = 0; i < nw; i++) {
-        uint64_t x = expand8((uint32_t)(code_le >> (16 * i)) & 0xffffu);
-        constexpr int dummy = 0;
-        (void)dummy;
-        int nb = K - 8 * i;  // bases in this word
-        if (nb < 8) x &= (nb <= 0) ? 0ull : ((1ull << (8 * nb)) - 1);
-        w[i] = x;
-    }
-    return murmur3_h1<K>(w, seed);
 }
 
 // ---- K = 21 fast path ---------------------------------------------------------------------------
