@@ -511,3 +511,52 @@ def test_batched_files_entry_point_equals_one_batch(ctx):
     assert none is None and np.array_equal(h3, h1) and np.array_equal(l3, l1)
     h4, l4 = ctx.sketch_files(paths, 21, 1000, 0, io_threads=2).to_host()
     assert np.array_equal(h4, h1) and np.array_equal(l4, l1)
+
+
+def test_ingest_forms_agree(ctx, tmp_path, monkeypatch):
+    """Plain, gzip and multi-member gzip files (whose trailer under-reports the stream, forcing the two-phase
+    ingest), CRLF line ends, no final newline, an empty file, lower case and IUPAC codes: same sketches and
+    statistics as the oracle, in the pipelined and in the two-phase form."""
+    import gzip
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGTacgtNRYn-", dtype=np.uint8)
+    recs = [rng.choice(acgt, size=int(L), p=[.22, .22, .22, .22, .02, .02, .02, .02, .01, .01, .005, .005, .01]).tobytes().decode()
+            for L in (70_000, 31, 0, 12_345)]
+    def fasta_text(eol, final_newline=True):
+        out = []
+        for i, r in enumerate(recs):
+            out.append(f">rec{i} some description")
+            out += [r[j:j + 60] for j in range(0, len(r), 60)]
+        t = eol.join(out)
+        return (t + eol if final_newline else t).encode()
+    files = {}
+    files["plain.fna"] = fasta_text("\n")
+    files["crlf.fna"] = fasta_text("\r\n")
+    files["nofinal.fna"] = fasta_text("\n", final_newline=False)
+    files["one.fna.gz"] = gzip.compress(fasta_text("\n"))
+    half = fasta_text("\n")
+    cut = half.index(b">rec2")
+    files["multi.fna.gz"] = gzip.compress(half[:cut]) + gzip.compress(half[cut:])   # two members
+    files["empty.fna"] = b""
+    paths = []
+    for name, data in files.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(str(p))
+    want_sk = [oracle.sketch_file(p) for p in paths]
+    want_st = [oracle.genome_stats(p) for p in paths]
+    for p in paths[1:5]:
+        assert np.array_equal(oracle.sketch_file(p), want_sk[0])   # all forms hold the same records
+    for form in ("pipelined", "two-phase"):
+        monkeypatch.setenv("GHIP_INGEST", form)
+        g = ctx.genomes_from_files(paths, 3)
+        hashes, lens = ctx.sketch_genomes(g, 21, 1000, 0).to_host()
+        for i, p in enumerate(paths):
+            assert lens[i] == len(want_sk[i]) and np.array_equal(hashes[i, : lens[i]], want_sk[i]), (form, p)
+            assert g.stats(i) == want_st[i], (form, p)
+    with pytest.raises(galah_amd.GalahHipError):
+        ctx.genomes_from_files([str(tmp_path / "missing.fna")], 1)
+    bad = tmp_path / "notfasta.fna"
+    bad.write_bytes(b"ACGT\n")
+    with pytest.raises(galah_amd.GalahHipError):
+        ctx.genomes_from_files([str(bad)], 1)
