@@ -150,11 +150,19 @@ def main():
     import galah_amd
     from galah_amd import distributed as gd
 
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU over RCCL ("nccl").  GHIP_BENCH_BACKEND=gloo lets several ranks share the GPUs of a smaller box
+    # (device = local_rank mod #GPUs, tensors staged through the host): a functional check of this script's N > 1
+    # path, not a measurement.
+    backend = os.environ.get("GHIP_BENCH_BACKEND", "nccl")
+    device = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = galah_amd.Context(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    ctx = galah_amd.Context(device)
 
     if not args.strong:
         args.species *= world   # weak scaling: every rank brings --species species of its own
@@ -188,7 +196,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = ctx.kernel_stats()
@@ -216,7 +224,8 @@ def main():
         traffic, traffic_tag, valu = pmc_traffic(dom) if world == 1 else (None, None, None)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
-                    "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag,
+                    "traffic_unit": ("bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag
+                                     if traffic is not None else "PMC passes are collected for the 1-GPU run only"),
                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "valu": valu,  # SQ_INSTS_VALU per launch and SIMD-cycles per VALU instruction, same PMC file
                     "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 55 of its ~95 "
