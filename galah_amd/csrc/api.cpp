@@ -873,10 +873,20 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, 
         if (ani >= thr) { host[i].ani = (float)ani; host[m++] = host[i]; }
     }
     host.resize(m);
-    std::sort(host.begin(), host.end(), [](const ghip_pair &a, const ghip_pair &b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
+    // (i, j) order: counting sort by i straight into the result (O(m + n)), then the few entries of each i by j --
+    // a comparison sort of the whole list costs 0.24 ms at 4 500 hits and 3.8 ms at 45 000
     ghip_pair *res = (ghip_pair *)malloc(std::max<size_t>(m, 1) * sizeof(ghip_pair));
     if (!res) return ghip_set_error(ctx, GHIP_ENOMEM, "out of host memory");
-    memcpy(res, host.data(), m * sizeof(ghip_pair));
+    {
+        std::vector<size_t> at(n + 1, 0);
+        for (size_t x = 0; x < m; x++) at[host[x].i + 1]++;
+        for (size_t g = 0; g < n; g++) at[g + 1] += at[g];
+        std::vector<size_t> fill(at.begin(), at.end() - 1);
+        for (size_t x = 0; x < m; x++) res[fill[host[x].i]++] = host[x];
+        for (size_t g = 0; g < n; g++)
+            if (at[g + 1] - at[g] > 1)
+                std::sort(res + at[g], res + at[g + 1], [](const ghip_pair &a, const ghip_pair &b) { return a.j < b.j; });
+    }
     *out_pairs = res; *out_n = m;
     return GHIP_OK;
 }
