@@ -110,6 +110,25 @@ int h2d(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
     return GHIP_OK;
 }
 
+// Batched form: several small copies, ONE synchronisation (each costs ~15 us of host time).  The host buffers must
+// stay alive until stream_sync().
+template <typename T>
+int h2d_nosync(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
+    if (count == 0) return GHIP_OK;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return GHIP_OK;
+}
+template <typename T>
+int d2h_nosync(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
+    if (count == 0) return GHIP_OK;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return GHIP_OK;
+}
+static int stream_sync(ghip_ctx *ctx) {
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GHIP_OK;
+}
+
 template <typename T>
 int d2h(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
     if (count == 0) return GHIP_OK;
@@ -710,17 +729,19 @@ static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t 
             if ((rc = h2d(ctx, d_slot_genome, slot_genome.data(), ns))) break;
             if ((rc = h2d(ctx, d_work, work.data(), n_work))) break;
         }
-        if ((rc = h2d(ctx, d_thr, slot_thr.data(), ns))) break;
-        if ((rc = h2d(ctx, d_cstart, cand_start.data(), ns))) break;
-        if ((rc = h2d(ctx, d_cap, slot_cap.data(), ns))) break;
+        if ((rc = h2d_nosync(ctx, d_thr, slot_thr.data(), ns))) break;
+        if ((rc = h2d_nosync(ctx, d_cstart, cand_start.data(), ns))) break;
+        if ((rc = h2d_nosync(ctx, d_cap, slot_cap.data(), ns))) break;
         if (hipMemsetAsync(d_count, 0, ns * sizeof(uint32_t), ctx->stream) != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed"); break; }
+        if ((rc = stream_sync(ctx))) break;  // the three host vectors are rebuilt below
         ghip_launch_sketch_kmers(ctx, g->d_bytes, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
                                  d_work, n_work, k, (uint32_t)seed, d_cand, d_count, first ? seeds : nullptr);
         ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, s, sk->d_hashes,
                                   sk->d_lens, d_status);
         std::vector<uint32_t> status(ns), count(ns);
-        if ((rc = d2h(ctx, status.data(), d_status, ns))) break;
-        if ((rc = d2h(ctx, count.data(), d_count, ns))) break;
+        if ((rc = d2h_nosync(ctx, status.data(), d_status, ns))) break;
+        if ((rc = d2h_nosync(ctx, count.data(), d_count, ns))) break;
+        if ((rc = stream_sync(ctx))) break;
         { hipError_t e = hipGetLastError(); if (e != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, std::string("sketch kernels: ") + hipGetErrorString(e)); break; } }
         std::vector<uint32_t> ng; std::vector<uint64_t> nthr; std::vector<uint32_t> ncap;
         for (size_t i = 0; i < ns; i++) {
@@ -969,12 +990,12 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
     if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_chunk_start, n + 1))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_glen, n))) return rc;
-    if ((rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) return rc;
-    if ((rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) return rc;
-    if ((rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
+    if ((rc = h2d_nosync(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) return rc;
+    if ((rc = h2d_nosync(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) return rc;
+    if ((rc = h2d_nosync(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seed_count, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), ctx->stream));
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream));
-    return GHIP_OK;
+    return stream_sync(ctx);  // the index's host vectors may be rewritten by a retry
 }
 
 static ghip_seed_args index_seed_args(const ghip_ani_index *idx) {
