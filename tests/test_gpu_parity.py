@@ -560,3 +560,16 @@ def test_ingest_forms_agree(ctx, tmp_path, monkeypatch):
     bad.write_bytes(b"ACGT\n")
     with pytest.raises(galah_amd.GalahHipError):
         ctx.genomes_from_files([str(bad)], 1)
+
+
+def test_empty_and_single_inputs(ctx):
+    """No genome, one genome: every entry point returns empty results instead of failing."""
+    sk, idx, st = ctx.sketch_and_index_files([], io_threads=4)
+    assert len(sk) == 0 and idx.layout().n == 0 and st.shape == (0, 3)
+    assert len(ctx.precluster(sk, np.float32(0.9))) == 0
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=0)     # io_threads <= 0 means 1
+    cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx)
+    assert galah_amd.cluster([], pre, cl) == []
+    assert galah_amd.cluster([fasta("set1_500kb")], pre, cl) == [[0]]
+    assert len(pre.distances([fasta("set1_500kb")])) == 0
+    assert ctx.ani_pairs(idx, np.zeros((0, 2), np.uint32), 0.15).shape == (0,)
