@@ -100,3 +100,58 @@ def test_two_ranks_one_gpu_equals_single_rank(ctx):
     sks = [oracle.AniSketch.from_bytes(s) for s in streams]
     oc = oracle.cluster(N, oracle.Cache.from_pairs(opairs), 95.0, lambda a, b: oracle.ani_pair(sks[a], sks[b], 0.15)[0])
     assert want["clusters"] == oc
+
+
+def _nccl_single_rank(port, q):
+    """The collectives of galah_amd.distributed.Exchange issued on a ONE-rank RCCL group: RCCL refuses two ranks on
+    one device, so this is as far as the `nccl` backend can be exercised on a one-GPU box -- dtypes, device
+    tensors, object collectives and the bench's timing reduction all go through the real RCCL entry points."""
+    import torch
+
+    import galah_amd
+    from galah_amd.distributed import DereplicationJob, Exchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ex = Exchange(0, 1)
+    ex.world, ex.dist = 2, dist          # force the collective code paths; with one rank "all" = this rank
+    assert not ex.stage_on_host
+    h = torch.arange(6 * 8, dtype=torch.int64, device="cuda").reshape(6, 8) - 3
+    out = torch.empty((6, 8), dtype=torch.int64, device="cuda")
+    dist.all_gather_into_tensor(out, h.contiguous())                       # what _gather does per rank
+    assert torch.equal(out, h)
+    lens = torch.arange(6, dtype=torch.int32, device="cuda")
+    out32 = torch.empty(6, dtype=torch.int32, device="cuda")
+    dist.all_gather_into_tensor(out32, lens)
+    assert torch.equal(out32, lens)
+    raw = torch.arange(50, dtype=torch.int16, device="cuda").view(torch.uint8)  # all_gather_flat moves raw bytes
+    pad = torch.zeros(112, dtype=torch.uint8, device="cuda"); pad[: raw.numel()] = raw
+    got = torch.empty(112, dtype=torch.uint8, device="cuda")
+    dist.all_gather_into_tensor(got, pad)
+    assert torch.equal(got[:100].view(torch.int16), torch.arange(50, dtype=torch.int16, device="cuda"))
+    pairs = np.zeros(3, dtype=galah_amd.PAIR_DTYPE); pairs["i"] = [1, 2, 3]
+    objs = [None]
+    dist.all_gather_object(objs, pairs)
+    assert objs[0].tobytes() == pairs.tobytes()
+    t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    # and a whole job on the one-rank group (world 1 short-circuits the exchange, the group is live underneath)
+    ctx = galah_amd.Context(0)
+    job = DereplicationJob(ctx, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
+    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
+    res = job.step()
+    q.put({"ok": float(t.item()) == 1.25, "clusters": len(res["clusters"])})
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_rccl_entry_points_on_one_rank():
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_nccl_single_rank, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and got["ok"] and got["clusters"] > 0
