@@ -70,6 +70,7 @@ SIGNATURES = {
     "ghip_last_pairs_compared": (_u64, [_vp]),
     "ghip_ani_index_build": (_int, [_vp, _vp, _u32, _u32, _u32, _pp]),
     "ghip_sketch_and_index": (_int, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _pp, _pp]),
+    "ghip_fasta_stream": (_int, [C.c_char_p, _pp, C.POINTER(_sz), _vp]),
     "ghip_sketch_and_index_files": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _u32, _u32, _u32, _int, _u64, _pp, _vp, _vp]),
     "ghip_ani_pairs": (_int, [_vp, _vp, _vp, _sz, _f32, _vp, _vp]),
     "ghip_ani_index_free": (None, [_vp]),

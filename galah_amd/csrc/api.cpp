@@ -368,6 +368,24 @@ extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const
     return GHIP_OK;
 }
 
+int ghip_read_fasta_stream(const char *path, std::vector<uint8_t> &out, ghip_genome_stats &st, std::string &err);
+
+extern "C" int ghip_fasta_stream(const char *path, uint8_t **out_stream, size_t *out_len, uint64_t out_stats[3]) {
+    if (!path || !out_stream || !out_len) return GHIP_EINVAL;
+    std::vector<uint8_t> v;
+    ghip_genome_stats st;
+    std::string err;
+    const int rc = ghip_read_fasta_stream(path, v, st, err);
+    if (rc != GHIP_OK) return ghip_set_error(nullptr, rc, err);
+    uint8_t *p = (uint8_t *)malloc(std::max<size_t>(v.size(), 1));
+    if (!p) return GHIP_ENOMEM;
+    memcpy(p, v.data(), v.size());
+    *out_stream = p;
+    *out_len = v.size();
+    if (out_stats) { out_stats[0] = st.num_contigs; out_stats[1] = st.num_ambiguous_bases; out_stats[2] = st.n50; }
+    return GHIP_OK;
+}
+
 // Two-phase form: parse every file into host vectors, then lay out by the exact lengths and copy.  Used when a
 // stream outgrows its capacity hint (multi-member gzip) and as the reference point of the pipelined form below.
 static int genomes_from_files_two_phase(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads, ghip_genomes **out) {

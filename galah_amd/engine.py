@@ -16,6 +16,16 @@ KERNELS = ("sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_
            "ani_pairs", "synth_genomes")
 
 
+def fasta_stream(path: str) -> Tuple[np.ndarray, Tuple[int, int, int]]:
+    """Host-only: (device-format stream of one FASTA file, (contigs, ambiguous bases, N50))."""
+    p, n = C.c_void_p(), C.c_size_t(0)
+    stats = (C.c_uint64 * 3)()
+    check(_lib.lib().ghip_fasta_stream(path.encode(), C.byref(p), C.byref(n), stats))
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value].copy()
+    _lib.lib().ghip_free(p)
+    return out, (int(stats[0]), int(stats[1]), int(stats[2]))
+
+
 def device_count() -> int:
     return int(_lib.lib().ghip_device_count())
 

@@ -75,6 +75,10 @@ int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *launches, dou
  * Any byte other than A,C,G,T breaks k-mers. */
 int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
                             ghip_genomes **out);
+/* Host-only (no GPU, no context): the device-format stream of one FASTA file and its assembly statistics
+ * {contigs, ambiguous bases, N50} (src/genome_stats.rs:11-51) -- the parser ghip_genomes_from_files runs per file.
+ * *out_stream is malloc'd (free with ghip_free).  Returns GHIP_EIO for unreadable / non-FASTA input. */
+int ghip_fasta_stream(const char *path, uint8_t **out_stream, size_t *out_len, uint64_t out_stats[3]);
 /* Host streams already in device format: genome g = bytes[offsets[g] .. offsets[g+1]).  Every byte other
  * than A,C,G,T is stored as 'N' (so ghip_genomes_to_host returns the sanitised stream). */
 int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, size_t n,

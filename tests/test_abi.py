@@ -92,3 +92,31 @@ def test_cluster_mirror_refuses_like_reference():
         galah_amd.cluster(["a"], pre, cl, cluster_contigs=True, contig_names=["c"])  # clusterer.rs:38-41
     with pytest.raises(AssertionError):
         galah_amd.HipAniClusterer(0.95).initialise()        # skani.rs:696-698 (threshold is percent)
+
+
+def test_host_fasta_parser_matches_the_oracle(tmp_path):
+    """ghip_fasta_stream (host-only; the parser of ghip_genomes_from_files): on every fixture and on hand-made files
+    (CRLF, no final newline, lower case, IUPAC, gaps, empty records, gzip, two gzip members) the MinHash sketch of the
+    stream equals the oracle's sketch of the file, and the assembly statistics equal the oracle's."""
+    import glob
+    import gzip
+    paths = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fasta", "*.fna.gz")))
+    assert len(paths) >= 14
+    text = b">a desc\nACGTNNacgtnRYKM-.~\nTTTT\n>b\n\n>c\r\nGGGGCCCCAAAATTTTGGGGCCCCAAAAT\r\nACGT"
+    (tmp_path / "odd.fna").write_bytes(text)
+    (tmp_path / "odd.fna.gz").write_bytes(gzip.compress(text))
+    (tmp_path / "two.fna.gz").write_bytes(gzip.compress(text[:30]) + gzip.compress(text[30:]))
+    (tmp_path / "empty.fna").write_bytes(b"")
+    paths += [str(tmp_path / n) for n in ("odd.fna", "odd.fna.gz", "two.fna.gz", "empty.fna")]
+    for p in paths:
+        stream, stats = galah_amd.fasta_stream(p)
+        assert stats == oracle.genome_stats(p), p
+        assert np.array_equal(oracle.sketch_bytes(stream, 21, 1000, 0), oracle.sketch_file(p)), p
+        assert np.array_equal(oracle.sketch_bytes(stream, 5, 50, 0), oracle.sketch_file(p, 5, 50)), p
+    stream, stats = galah_amd.fasta_stream(str(tmp_path / "odd.fna"))
+    assert stream.tobytes() == b"ACGTNNACGTNNNNN---TTTTNNGGGGCCCCAAAATTTTGGGGCCCCAAAATACGTN" and stats[0] == 3
+    with pytest.raises(galah_amd.GalahHipError):
+        galah_amd.fasta_stream(str(tmp_path / "missing.fna"))
+    (tmp_path / "bad.fna").write_bytes(b"ACGT\n")
+    with pytest.raises(galah_amd.GalahHipError):
+        galah_amd.fasta_stream(str(tmp_path / "bad.fna"))
