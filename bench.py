@@ -219,6 +219,10 @@ def main():
                 if k in alg:
                     e["achieved_GBps"] = alg[k] / (avg * 1e-3) / 1e9
                     e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBS
+                if world == 1:  # HBM bytes per launch of every kernel from the committed PMC passes (same workload)
+                    t, _tag, _v = pmc_traffic("pair_probe_tile" if k == "pair_intersect_tile" else k)
+                    if t is not None:
+                        e["pmc_hbm_bytes_per_launch"] = t
                 kern[k] = e
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
         traffic, traffic_tag, valu = pmc_traffic(dom) if world == 1 else (None, None, None)
