@@ -188,14 +188,13 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint16_t *__restrict__ seed_chunk, const uint64_t *__restrict__ seed_start,
     const uint32_t *__restrict__ bin_start, const uint32_t *__restrict__ chunk_total,
     const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, uint32_t chunk,
-    uint64_t *__restrict__ out) {
+    uint32_t ro_cap, uint64_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned long long red[6];
     __shared__ uint32_t n_al;
     __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE];
     __shared__ uint16_t st_chunk[ANI_PAIR_WAVES][2][ANI_STAGE];
     __shared__ uint8_t st_flag[ANI_PAIR_WAVES][ANI_STAGE];  // r seed of the stage matched by some q seed
-    __shared__ uint16_t st_roff[ANI_PAIR_WAVES][66];         // stage offsets of the 64 bins' r runs
     uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
 
     // physical block b runs on XCD b % 8: give each XCD runs of 32 consecutive pairs (one precluster's
@@ -220,18 +219,26 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     uint32_t *sq = st_code[wave][0], *sr = st_code[wave][1];
     uint16_t *kq = st_chunk[wave][0], *kr = st_chunk[wave][1];
     uint8_t *rf = st_flag[wave];
-    uint16_t *ro = st_roff[wave];
+    // stage offsets of the round's r bins: dynamic LDS behind the aligned-chunk list, ro_cap entries per wave
+    uint16_t *ro = reinterpret_cast<uint16_t *>(list + (nchq + nchr)) + (size_t)wave * ro_cap;
     for (uint32_t k = lane; k < ANI_STAGE; k += 64) rf[k] = 0;
-    // the bin bounds of the next round are fetched while this round is joined
-    uint32_t nqs_ = qb[wave * 64 + lane], nqe_ = qb[wave * 64 + lane + 1], nrs_ = rb[wave * 64 + lane], nre_ = rb[wave * 64 + lane + 1];
-    for (uint32_t b0 = wave * 64; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * 64) {
-        const uint32_t qs = nqs_, qe = nqe_, rs = nrs_, re = nre_;
-        if (b0 + ANI_PAIR_WAVES * 64 < BIN_COUNT) {
-            const uint32_t nb = b0 + ANI_PAIR_WAVES * 64 + lane;
-            nqs_ = qb[nb]; nqe_ = qb[nb + 1]; nrs_ = rb[nb]; nre_ = rb[nb + 1];
+    // Bins joined per wave and round: 64 for bacterial-size genomes (~154 seeds per run at c = 125); small genomes
+    // and contigs take 256 or 1024 bins per round so that a run still holds ~190 seeds and the fixed cost of a round
+    // (bounds, barriers, three short loops) is paid 8 or 2 times per wave instead of 32.
+    uint32_t rbins = 64;
+    {
+        const uint32_t tmax = max(qb[BIN_COUNT], rb[BIN_COUNT]);  // total seeds of the larger genome
+        if (ro_cap > 1024) rbins = tmax <= 3000 ? 1024u : (tmax <= 12000 ? 256u : 64u);
+    }
+    // the bounds of the next round are fetched while this round is joined
+    uint32_t n_rs = rb[wave * rbins + lane], n_qlo = qb[wave * rbins], n_qhi = qb[wave * rbins + rbins], n_rhi = rb[wave * rbins + rbins];
+    for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * rbins) {
+        const uint32_t rs = n_rs, q_lo = n_qlo, q_hi = n_qhi, r_hi = n_rhi;
+        const uint32_t r_lo = __shfl(rs, 0, 64);
+        if (b0 + ANI_PAIR_WAVES * rbins < BIN_COUNT) {
+            const uint32_t f = b0 + ANI_PAIR_WAVES * rbins;
+            n_rs = rb[f + lane]; n_qlo = qb[f]; n_qhi = qb[f + rbins]; n_rhi = rb[f + rbins];
         }
-        const uint32_t q_lo = __shfl(qs, 0, 64), q_hi = __shfl(qe, 63, 64);
-        const uint32_t r_lo = __shfl(rs, 0, 64), r_hi = __shfl(re, 63, 64);
         if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
         const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
         if (staged) {
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             // Matched r seeds are flagged and counted in a second balanced pass.
             const uint32_t nq = q_hi - q_lo, nr = r_hi - r_lo;
             ro[lane] = (uint16_t)(rs - r_lo);            // r range of bin b0 + x = [ro[x], ro[x + 1])
-            if (lane == 63) ro[64] = (uint16_t)nr;
+            for (uint32_t u = 64 + lane; u < rbins; u += 64) ro[u] = (uint16_t)(rb[b0 + u] - r_lo);
+            if (lane == 63) ro[rbins] = (uint16_t)nr;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (uint32_t i = lane; i < nq; i += 64) {
@@ -281,18 +289,21 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                 if (rf[j]) { rf[j] = 0; atomicAdd(&mcr[kr[j]], 1u); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
-        } else {
-            for (uint32_t i = qs; i < qe; i++) {
-                const uint32_t c = qc[i];
-                bool hit = false;
-                for (uint32_t j = rs; j < re; j++) hit |= (rc[j] == c);
-                if (hit) atomicAdd(&mcq[qk[i]], 1u);
-            }
-            for (uint32_t j = rs; j < re; j++) {
-                const uint32_t c = rc[j];
-                bool hit = false;
-                for (uint32_t i = qs; i < qe; i++) hit |= (qc[i] == c);
-                if (hit) atomicAdd(&mcr[rk[j]], 1u);
+        } else {  // a run longer than the stage (a pathologically repetitive genome): lane-per-bin walk in global memory
+            for (uint32_t u = lane; u < rbins; u += 64) {
+                const uint32_t qs = qb[b0 + u], qe = qb[b0 + u + 1], rs_ = rb[b0 + u], re = rb[b0 + u + 1];
+                for (uint32_t i = qs; i < qe; i++) {
+                    const uint32_t c = qc[i];
+                    bool hit = false;
+                    for (uint32_t j = rs_; j < re; j++) hit |= (rc[j] == c);
+                    if (hit) atomicAdd(&mcq[qk[i]], 1u);
+                }
+                for (uint32_t j = rs_; j < re; j++) {
+                    const uint32_t c = rc[j];
+                    bool hit = false;
+                    for (uint32_t i = qs; i < qe; i++) hit |= (qc[i] == c);
+                    if (hit) atomicAdd(&mcr[rk[j]], 1u);
+                }
             }
         }
     }
@@ -383,7 +394,13 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out) {
     if (n_pairs == 0) return;
-    const size_t lds = (size_t)2 * max_chunks * (sizeof(uint32_t) + sizeof(uint64_t)) + 16;  // counters + aligned-chunk list
+    // wide rounds (256 / 1024 bins) only exist when some genome is small enough to use them: their offset table
+    // costs 16 KiB of LDS per workgroup, which large-genome runs keep for a third resident workgroup per CU
+    uint32_t ro_cap = 66;
+    for (uint32_t c : idx->seed_count) if (c <= 12000) { ro_cap = 1026; break; }
+    if ((size_t)2 * max_chunks * 12 + 16 + (size_t)ANI_PAIR_WAVES * 1026 * 2 > 160 * 1024 - 46 * 1024) ro_cap = 66;  // 46 KiB static
+    const size_t lds = (size_t)2 * max_chunks * (sizeof(uint32_t) + sizeof(uint64_t)) + 16   // counters + aligned-chunk list
+                       + (size_t)ANI_PAIR_WAVES * ro_cap * sizeof(uint16_t);                  // r-bin offsets of a round
     static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand (+43 KiB static stage)
     if (lds > attr_lds) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -393,6 +410,6 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
     const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
     hipLaunchKernelGGL(ani_pairs_kernel, dim3(grid), dim3(ANI_PAIR_THREADS), lds, ctx->stream, d_pairs, (uint32_t)n_pairs,
                        idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
-                       idx->d_chunk_start, idx->d_glen, idx->chunk, d_out);
+                       idx->d_chunk_start, idx->d_glen, idx->chunk, ro_cap, d_out);
     ghip_prof_end(ctx);
 }
