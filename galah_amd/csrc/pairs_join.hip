@@ -13,8 +13,8 @@
 // exact f64 recheck are those of the dense path.  Work ~ N*s + #records instead of N^2*s.
 //
 // The join form declines (the caller then runs a dense kernel) when it would not pay or cannot be exact in its
-// fixed-size buffers: min_ani <= 0 (pairs without a common hash qualify), two or more empty sketches (ANI of
-// empty vs empty is 1.0 by the reference's NaN semantics), a hash bucket or a record bucket beyond its LDS capacity
+// fixed-size buffers: min_ani <= 0 (pairs without a common hash qualify), an empty sketch (by the reference's NaN
+// semantics its ANI with every other sketch is 1.0), a hash bucket or a record bucket beyond its LDS capacity
 // (large families: many genomes share each hash), more records than a dense pass would cost, N*s >= 2^32.
 #include <algorithm>
 
@@ -378,7 +378,10 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     uint64_t n_elem = 0;
     size_t n_empty = 0;
     for (uint32_t l : lens) { n_elem += l; n_empty += (l == 0); }
-    if (n_empty >= 2) return GHIP_OK;  // empty vs empty: ANI 1.0 by the reference's NaN-dropping max/min
+    // An empty sketch ends the reference's merge loop at once: common = total = 0, Jaccard 0/0 = NaN, and Rust's
+    // NaN-dropping f64::max/min turn that into ANI 1.0 -- it pairs with EVERY other sketch without sharing a hash.
+    // Only the dense forms enumerate those pairs.
+    if (n_empty >= 1) return GHIP_OK;
     struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
     uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 4);  // [0] flags, [1] largest element bucket, [2..3] u64 record total
     if (!d_flags) return GHIP_EHIP;

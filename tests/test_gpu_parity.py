@@ -419,6 +419,11 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
     hashes[4] = [5, 9, 11, 12, 13, 14, 15, 2**64 - 2]
     sk = ctx.sketches_from_host(hashes, lens, 21)
     assert ctx.precluster(sk, np.float32(0.5)).tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.5)).tobytes()
+    # ONE empty sketch is enough: the reference's NaN semantics pair it with every other sketch at ANI 1.0
+    lens1 = lens.copy(); lens1[1] = 2; hashes1 = hashes.copy(); hashes1[1, :2] = [7, 9]
+    sk = ctx.sketches_from_host(hashes1, lens1, 21)
+    want = oracle.distances_from_sketches(hashes1, lens1, np.float32(0.5))
+    assert ctx.precluster(sk, np.float32(0.5)).tobytes() == want.tobytes() and (want["total"] == 0).sum() == 4
     # one big family (every genome shares most hashes with every other): records outnumber pairs -> declined
     rng = np.random.default_rng(5)
     hashes, lens = random_sketches(rng, 200, 1000, shared_groups=1)
