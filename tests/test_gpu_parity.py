@@ -1,4 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 
@@ -578,3 +580,14 @@ def test_empty_and_single_inputs(ctx):
     assert galah_amd.cluster([fasta("set1_500kb")], pre, cl) == [[0]]
     assert len(pre.distances([fasta("set1_500kb")])) == 0
     assert ctx.ani_pairs(idx, np.zeros((0, 2), np.uint32), 0.15).shape == (0,)
+
+
+def test_randomised_differential_runs():
+    """A short run of the two fuzzers (tests/fuzz_sketch.py, tests/fuzz_pairs.py; seed 4 of the latter is the run that
+    found the empty-sketch case of the join form)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for script, args in (("fuzz_pairs.py", ["45", "4"]), ("fuzz_sketch.py", ["12", "21"])):
+        r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
