@@ -416,17 +416,21 @@ static int genomes_from_files_two_phase(ghip_ctx *ctx, const char *const *paths,
 
 // Pipelined ingest: the device layout is fixed up front from per-file capacity hints (a stream is never longer
 // than its plain file; a gzip trailer holds the uncompressed size), so every worker thread parses a file and ships
-// it straight to its final place in HBM while the other threads are still parsing -- parsing (~1.6 GB/s per
-// thread) and PCIe (~55 GB/s) overlap instead of adding up.  Gaps between capacity and actual length stay 'N'
+// it straight to its final place in HBM while the other threads are still parsing -- parsing (~12 GB/s per
+// thread on clean lines) and PCIe (~55 GB/s) overlap instead of adding up.  Gaps between capacity and actual length stay 'N'
 // (the buffer is 'N'-filled).
 extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
                                        ghip_genomes **out) {
     if (!ctx || !out || (n && !paths)) return GHIP_EINVAL;
     if (getenv("GHIP_INGEST") && !strcmp(getenv("GHIP_INGEST"), "two-phase"))
         return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);
+    const bool dbg = getenv("GHIP_INGEST_DEBUG") != nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<uint64_t> cap(n);
     uint64_t max_cap = 0;
     for (size_t i = 0; i < n; i++) { cap[i] = ghip_stream_capacity_hint(paths[i]); max_cap = std::max(max_cap, cap[i]); }
+    const double w_hint = since(w0);
     bool overflow = false;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -445,6 +449,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         if (rc == GHIP_OK && hipMemsetAsync(g->d_bytes, 'N', g->total_alloc, ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed");
         if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
         if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
+        const double w_alloc = since(w0) - w_hint;
 
         int threads = std::max(1, io_threads);
         threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n, 1));
@@ -464,9 +469,11 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         // Measured on the MI355X host (scripts/ubench/host_costs.cpp): a pageable H2D copy runs at 52-56 GB/s, the same
         // as a pinned one, while hipStreamCreate costs 3.4 ms and hipHostMalloc 0.16 ms/MB -- so the workers keep plain
         // heap buffers and issue blocking copies; no per-thread stream, no pinned staging.
+        // (Re-measured with the AVX2 line parser, A/B on one box: a pool of 16 pinned stream buffers is no faster than
+        // heap buffers -- workers 0.16 s vs 0.135 s for 5 GB.)
         auto worker = [&]() {
             if (hipSetDevice(ctx->device) != hipSuccess) { fail(GHIP_EHIP, "hipSetDevice failed in an ingest thread"); return; }
-            std::vector<uint8_t> raw, stream_buf((size_t)max_cap + 64);
+            std::vector<uint8_t> raw, heap_buf((size_t)max_cap + 64);
             for (;;) {
                 if (status.load() != GHIP_OK || over.load()) break;
                 const size_t i = next.fetch_add(1);
@@ -476,17 +483,22 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 const auto t1 = std::chrono::steady_clock::now();
                 size_t len = 0;
                 std::string e;
-                const int r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf.data(), (size_t)cap[i], &len, g->stats[i], e);
+                uint8_t *stream_buf = heap_buf.data();
+                const int r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf, (size_t)cap[i], &len, g->stats[i], e);
                 const auto t2 = std::chrono::steady_clock::now();
                 t_read += std::chrono::duration<double>(t1 - t0).count();
                 t_parse += std::chrono::duration<double>(t2 - t1).count();
-                if (r != GHIP_OK) { fail(r, e); break; }
-                if (len > cap[i]) { over = true; break; }  // capacity hint too small (multi-member gzip): two-phase form
-                g->lens[i] = len;
-                if (len && hipMemcpy(g->d_bytes + g->starts[i], stream_buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) {
-                    fail(GHIP_EHIP, "ingest copy failed");
-                    break;
+                bool stop = false;
+                if (r != GHIP_OK) { fail(r, e); stop = true; }
+                else if (len > cap[i]) { over = true; stop = true; }  // capacity hint too small (multi-member gzip): two-phase form
+                else {
+                    g->lens[i] = len;
+                    if (len && hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice) != hipSuccess) {
+                        fail(GHIP_EHIP, "ingest copy failed");
+                        stop = true;
+                    }
                 }
+                if (stop) break;
                 t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
             }
         };
@@ -494,8 +506,9 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         for (int t = 1; t < threads; t++) pool.emplace_back(worker);
         worker();
         for (auto &th : pool) th.join();
-        if (getenv("GHIP_INGEST_DEBUG"))
-            fprintf(stderr, "[ingest] %d threads, thread-seconds: read %.3f parse %.3f copy %.3f\n", threads, t_read.load(), t_parse.load(), t_alloc.load());
+        if (dbg)
+            fprintf(stderr, "[ingest] %d threads, thread-seconds: read %.3f parse %.3f copy %.3f; wall: hints %.3f alloc+fill %.3f workers %.3f\n",
+                    threads, t_read.load(), t_parse.load(), t_alloc.load(), w_hint, w_alloc, since(w0) - w_hint - w_alloc);
         overflow = over.load();
         rc = status.load();
         if (rc != GHIP_OK) ghip_set_error(ctx, rc, err);

@@ -2,6 +2,7 @@
 without a GPU, and its host clusterer (ghip_cluster, no GPU involved) matches the oracle."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -120,3 +121,74 @@ def test_host_fasta_parser_matches_the_oracle(tmp_path):
     (tmp_path / "bad.fna").write_bytes(b"ACGT\n")
     with pytest.raises(galah_amd.GalahHipError):
         galah_amd.fasta_stream(str(tmp_path / "bad.fna"))
+
+
+def test_host_fasta_parser_fast_path_random_lines(tmp_path):
+    """The 32-byte fast path of the line loop (pure ACGTacgt lines, overlapping last block) against the rule applied
+    byte by byte: random line widths around the block size, random case, and dirty bytes at random places."""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    dirty = np.frombuffer(b"NnRYkmUu-.~ \t*X", dtype=np.uint8)
+    for trial in range(40):
+        lines, want = [], bytearray()
+        for rec in range(int(rng.integers(1, 4))):
+            lines.append(b">r%d some text ACGT" % rec)
+            for _ in range(int(rng.integers(0, 30))):
+                w = int(rng.choice([1, 15, 16, 31, 32, 33, 47, 48, 60, 63, 64, 65, 70, 80, 96, 97, 130]))
+                line = rng.choice(alpha, size=w)
+                if rng.random() < 0.3:
+                    line[rng.integers(0, w, size=int(rng.integers(1, 4)))] = rng.choice(dirty, size=1)
+                lines.append(line.tobytes())
+                want += oracle.normalize(line.tobytes())
+            want += b"N"
+        eol = b"\r\n" if trial % 3 == 0 else b"\n"
+        body = eol.join(lines) + (eol if trial % 2 else b"")
+        p = tmp_path / f"r{trial}.fna"
+        p.write_bytes(body)
+        stream, stats = galah_amd.fasta_stream(str(p))
+        assert stream.tobytes() == bytes(want), trial
+        assert stats == oracle.genome_stats(str(p)), trial
+
+
+def test_gunzip_paths_agree(tmp_path):
+    """gzip input goes through libdeflate when the host has it and through zlib otherwise: both must give the same
+    stream -- or the same refusal -- for one member, several members, a damaged trailer, trailing garbage, a cut file
+    and a member far more compressible than the first size guess."""
+    import glob
+    import gzip
+    import subprocess
+    import zlib
+    rng = np.random.default_rng(3)
+    seq = rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), size=300_000).tobytes()
+    body = b">x\n" + b"\n".join(seq[i:i + 70] for i in range(0, len(seq), 70)) + b"\n"
+    whole = gzip.compress(body, 1)
+    files = {
+        "one.fna.gz": whole,
+        "two.fna.gz": gzip.compress(body[:100_001], 6) + gzip.compress(body[100_001:], 1),
+        "cut.fna.gz": whole[:-5000],
+        "junk.fna.gz": whole + b"garbagegarbage",
+        "trailer.fna.gz": whole[:-4] + b"\xff\xff\xff\x7f",
+        "crc.fna.gz": whole[:-8] + b"\0\0\0\0" + whole[-4:],
+        "dense.fna.gz": gzip.compress(b">z\n" + b"A" * 3_000_000 + b"\n", 9),
+    }
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    paths = [str(tmp_path / n) for n in files] + sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fasta", "*.fna.gz")))[:3]
+    code = ("import sys, zlib, galah_amd\n"
+            "for p in sys.argv[1:]:\n"
+            "    try:\n"
+            "        s, st = galah_amd.fasta_stream(p); print(len(s), zlib.crc32(s.tobytes()), st)\n"
+            "    except galah_amd.GalahHipError as e:\n"
+            "        print('error', str(e).split(':')[0])\n")
+    outs = []
+    for off in ("0", "1"):
+        env = dict(os.environ, GHIP_NO_LIBDEFLATE=off, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code] + paths, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.splitlines())
+    assert outs[0] == outs[1]
+    got = dict(zip(files, outs[0]))
+    want = oracle.normalize(seq) + b"N"
+    assert got["one.fna.gz"] == got["two.fna.gz"] == f"{len(want)} {zlib.crc32(want)} (1, {seq.count(b'N')}, {len(seq)})"
+    assert got["cut.fna.gz"].startswith("error") and got["junk.fna.gz"].startswith("error") and got["crc.fna.gz"].startswith("error")
+    assert got["dense.fna.gz"].startswith("3000001 ")
