@@ -8,6 +8,7 @@ The estimator is build-defined; skani parity is unpinned (DESIGN.md "ANI").
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -30,6 +31,7 @@ class HipAniClusterer:
         self._index: Optional[AniIndex] = None
         self._genomes = None
         self._path_index: Dict[str, int] = {}
+        self._lock = threading.Lock()  # calculate_ani may be called from many threads (clusterer.rs:14 `C: Sync`)
 
     @property
     def seed_compression(self) -> int:
@@ -79,7 +81,10 @@ class HipAniClusterer:
 
     # ---- the trait method
     def calculate_ani(self, fasta1: str, fasta2: str) -> Optional[np.float32]:
-        if fasta1 not in self._path_index or fasta2 not in self._path_index:
-            self.prepare(list(dict.fromkeys(list(self._path_index) + [fasta1, fasta2])))
-        pair = np.array([[self._path_index[fasta1], self._path_index[fasta2]]], dtype=np.uint32)
-        return np.float32(self.calculate_ani_indices(pair)[0])  # always Some(..) (skani.rs:709)
+        # The reference calls this from rayon workers (clusterer.rs:267-270,283-293,375-399).  One lock for the whole
+        # call: re-indexing frees the index other callers would be reading, and the context runs one call at a time anyway.
+        with self._lock:
+            if fasta1 not in self._path_index or fasta2 not in self._path_index:
+                self.prepare(list(dict.fromkeys(list(self._path_index) + [fasta1, fasta2])))
+            pair = np.array([[self._path_index[fasta1], self._path_index[fasta2]]], dtype=np.uint32)
+            return np.float32(self.calculate_ani_indices(pair)[0])  # always Some(..) (skani.rs:709)

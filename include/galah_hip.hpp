@@ -21,7 +21,9 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -216,9 +218,18 @@ public:
     uint32_t seed_compression() const { return small_genomes ? 30 : 125; }
     const std::shared_ptr<HipContext> &context() const { return hip_; }
 
+    // Called concurrently by the reference's rayon workers (src/clusterer.rs:267-270,283-293,375-399; the `C: Sync`
+    // bound of clusterer.rs:14): lookups share the index, only indexing a genome not seen before is exclusive.
     std::optional<float> calculate_ani(const std::string &fasta1, const std::string &fasta2) override {
-        auto a = path_index_.find(fasta1), b = path_index_.find(fasta2);
-        if (a == path_index_.end() || b == path_index_.end()) prepare_missing(fasta1, fasta2);
+        std::shared_lock<std::shared_mutex> shared(mu_);
+        while (!path_index_.count(fasta1) || !path_index_.count(fasta2)) {
+            shared.unlock();
+            {
+                std::unique_lock<std::shared_mutex> exclusive(mu_);
+                if (!path_index_.count(fasta1) || !path_index_.count(fasta2)) prepare_missing(fasta1, fasta2);
+            }
+            shared.lock();
+        }
         const uint32_t pair[2] = {path_index_.at(fasta1), path_index_.at(fasta2)};
         float ani = 0.0f;
         if (ghip_ani_pairs(hip_->get(), index_, pair, 1, min_aligned_threshold, &ani, nullptr) != GHIP_OK)
@@ -245,6 +256,7 @@ private:
     std::shared_ptr<HipContext> hip_;
     ghip_ani_index *index_ = nullptr;
     std::unordered_map<std::string, uint32_t> path_index_;
+    std::shared_mutex mu_;  // calculate_ani: shared for lookups, exclusive while (re)indexing
 };
 
 // ---------------------------------------------------------------------------------------------------------------

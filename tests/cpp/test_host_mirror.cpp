@@ -6,12 +6,14 @@
 //                                              (the reference needs the skani binary; the build-defined ANI reproduces both)
 //   tests/test_cmdline.rs:262-302              --min-aligned-fraction 0.2 -> one representative, 0.6 -> two
 //   tests/test_cmdline.rs:161-181, 417-440     representative list order; github issue 7
+//   src/clusterer.rs:14,267-296,375-399        `C: Sync`: calculate_ani called from many threads at once
 //   src/finch.rs:14-15,40, src/clusterer.rs:38-44   refusals (panics -> std::runtime_error with the same text)
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "galah_hip.hpp"
@@ -115,6 +117,32 @@ int main(int argc, char **argv) {
         CHECK(panics_with([&] { bad.initialise(); }, "self.threshold > 1.0"));
         CHECK(panics_with([&] { galah::finch::distances(*hip, {d + "does_not_exist.fna"}, 0.9f, 1000, 21); },
                           "Failed to sketch genomes with finch"));
+    }
+    {   // calculate_ani is called from rayon workers (src/clusterer.rs:267-270,283-293,375-399): 8 threads ask for every
+        // ordered pair of six genomes at once -- two of them not indexed yet, so some calls re-index while others
+        // look up -- and must all get the values of a quiet, sequential pass
+        std::vector<std::string> six = abisko;
+        six.push_back(fa("set1_1mbp"));
+        six.push_back(fa("set1_500kb"));
+        galah::HipAniClusterer quiet(hip, 95.0f, 0.15f), busy(hip, 95.0f, 0.15f);
+        quiet.prepare(six);
+        busy.prepare(abisko);
+        std::vector<float> want(36), got(36 * 8, -1.0f);
+        for (int x = 0; x < 36; x++) want[x] = *quiet.calculate_ani(six[x / 6], six[x % 6]);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < 8; t++)
+            pool.emplace_back([&, t] {
+                for (int y = 0; y < 36; y++) {
+                    const int x = (y * 7 + t * 5) % 36;   // every thread its own order
+                    got[t * 36 + x] = *busy.calculate_ani(six[x / 6], six[x % 6]);
+                }
+            });
+        for (auto &th : pool) th.join();
+        bool same = true;
+        for (int t = 0; t < 8; t++)
+            for (int x = 0; x < 36; x++) same = same && got[t * 36 + x] == want[x];
+        CHECK(same);
+        CHECK(want[0 * 6 + 1] > 95.0f && want[4 * 6 + 5] > 95.0f && want[0 * 6 + 4] == 0.0f);
     }
     std::printf(failures ? "%d check(s) failed\n" : "host mirror: all reference tests passed\n", failures);
     return failures ? 1 : 0;

@@ -177,6 +177,24 @@ def test_ani_on_fixture_files_vs_oracle(ctx):
             assert got == np.float32(oracle.ani_pair(osk[a], osk[b], 0.15)[0]), (names[a], names[b])
 
 
+def test_calculate_ani_from_many_threads(ctx):
+    """The reference calls calculate_ani from rayon workers (src/clusterer.rs:267-270,283-293,375-399; `C: Sync`,
+    clusterer.rs:14).  Eight threads ask for every ordered pair at once, two of the genomes not indexed yet (so some
+    calls re-index while others look up): every answer equals the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "set1_1mbp", "set1_500kb"]
+    paths = [fasta(n) for n in names]
+    cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=4)
+    cl.prepare(paths[:4])
+    osk = [oracle.AniSketch.from_file(p) for p in paths]
+    want = {(a, b): np.float32(oracle.ani_pair(osk[a], osk[b], 0.15)[0]) for a in range(6) for b in range(6) if a != b}
+    jobs = [(a, b) for t in range(8) for (a, b) in sorted(want, key=lambda ab: (ab[0] * 7 + ab[1] * 5 + t * 3) % 11)]
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(lambda ab: cl.calculate_ani(paths[ab[0]], paths[ab[1]]), jobs))
+    assert all(g == want[ab] for g, ab in zip(got, jobs))
+    assert want[(0, 1)] > 95 and want[(4, 5)] > 95 and want[(0, 4)] == 0
+
+
 def test_cluster_end_to_end_vs_oracle(ctx):
     names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52", "antonio_MAG189",
              "set1_1mbp", "set1_500kb"]
