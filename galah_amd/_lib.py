@@ -67,6 +67,7 @@ SIGNATURES = {
     "ghip_sketches_free": (None, [_vp]),
     "ghip_precluster": (_int, [_vp, _vp, _f32, _pp, C.POINTER(_sz)]),
     "ghip_precluster_shard": (_int, [_vp, _vp, _f32, _u32, _u32, _pp, C.POINTER(_sz)]),
+    "ghip_precluster_ranks": (_int, [_vp, _vp, _f32, _u32, _u32, _pp, C.POINTER(_sz), C.POINTER(C.c_int)]),
     "ghip_last_pairs_compared": (_u64, [_vp]),
     "ghip_ani_index_build": (_int, [_vp, _vp, _u32, _u32, _u32, _pp]),
     "ghip_sketch_and_index": (_int, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _pp, _pp]),

@@ -833,9 +833,12 @@ static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
     return GHIP_OK;
 }
 
-extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_ani, uint32_t rank,
-                                     uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
+// replicate_join: a multi-rank caller that prefers the whole list on every rank whenever the join form runs (its
+// cost, one pass over all N*s hashes, does not shard) to a share it then has to exchange.
+static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_ani, uint32_t rank, uint32_t world,
+                           bool replicate_join, ghip_pair **out_pairs, size_t *out_n, int *out_replicated) {
     ghip_sketches *sk = const_cast<ghip_sketches *>(sk_in);  // lazily caches the probe-form tables
+    if (out_replicated) *out_replicated = 0;
     if (!ctx || !sk || !out_pairs || !out_n || world == 0 || rank >= world) return GHIP_EINVAL;
     if (sk->s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "sketch size above 4096 is not supported");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -894,8 +897,13 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, 
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         uint64_t compared = 0;
         bool joined = false;
-        if (want_join && (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor, rank, world,
+        if (want_join && (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
+                                               replicate_join ? 0 : rank, replicate_join ? 1 : world,
                                                d_out, d_count, cap, &compared, &joined))) return rc;
+        if (joined && replicate_join) {  // every rank holds every pair; book an equal share of the comparisons
+            compared = P / world + (rank < P % world ? 1 : 0);
+            if (out_replicated) *out_replicated = 1;
+        }
         if (!joined && use_probe && !probe_checked) {
             if ((rc = prepare_probe(ctx, sk))) return rc;
             use_probe = sk->probe_flags == 0;
@@ -943,8 +951,19 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk_in, 
     return GHIP_OK;
 }
 
+extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
+                                     uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
+    return precluster_impl(ctx, sk, min_ani, rank, world, false, out_pairs, out_n, nullptr);
+}
+
+extern "C" int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
+                                     uint32_t world, ghip_pair **out_pairs, size_t *out_n, int *out_replicated) {
+    if (!out_replicated) return GHIP_EINVAL;
+    return precluster_impl(ctx, sk, min_ani, rank, world, world > 1, out_pairs, out_n, out_replicated);
+}
+
 extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, ghip_pair **out_pairs, size_t *out_n) {
-    return ghip_precluster_shard(ctx, sk, min_ani, 0, 1, out_pairs, out_n);
+    return precluster_impl(ctx, sk, min_ani, 0, 1, false, out_pairs, out_n, nullptr);
 }
 
 // ------------------------------------------------------------------------------------ ANI

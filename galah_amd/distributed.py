@@ -48,15 +48,27 @@ def tile_pairs_of_rank(n: int, pt: int, rank: int, world: int) -> List[Tuple[int
 class Exchange:
     """torch.distributed plumbing; tensors live wherever the engine puts them (HBM or host)."""
 
-    def __init__(self, rank: int, world: int):
+    def __init__(self, rank: int, world: int, force: bool = False):
+        self.force = force
         self.rank, self.world = rank, world
         self.stage_on_host = False
-        if world > 1:
+        # force=True (tests): issue the collectives even on a one-rank group instead of short-circuiting them
+        if world > 1 or force:
             import torch.distributed as dist
             self.dist = dist
             # gloo (CPU tests, or two test ranks sharing one GPU) moves device tensors through the host;
             # nccl (= RCCL over xGMI, the production path) gathers straight out of HBM.
             self.stage_on_host = dist.get_backend() == "gloo"
+
+    def all_gather_host_array(self, arr: np.ndarray, sizes: List[int]) -> np.ndarray:
+        """Host arrays of per-rank length sizes[r] (known to every rank) -> their concatenation, one collective."""
+        import torch
+        if self.world == 1 and not self.force:
+            return arr
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if not self.stage_on_host:  # nccl moves device tensors only
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        return self.all_gather_flat(t, sizes).cpu().numpy()
 
     def _gather(self, out, inp):
         if self.stage_on_host and inp.is_cuda:
@@ -69,7 +81,7 @@ class Exchange:
     def all_gather_blocks(self, local, n_total: int):
         """local: [block, ...] tensor (same block on every rank) -> [n_total, ...]."""
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local[:n_total]
         out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         self._gather(out, local)
@@ -79,7 +91,7 @@ class Exchange:
         """1-D tensors of per-rank length sizes[r] -> their concatenation on every rank.
         Moved as raw bytes (u8), so any element type works with any backend."""
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local
         if max(sizes) == 0:  # nothing to exchange (e.g. no candidate pair spans two ranks)
             return local[:0]
@@ -96,20 +108,11 @@ class Exchange:
         return torch.cat([out[r * m: r * m + sizes[r] * esz] for r in range(self.world)]).view(local.dtype)
 
     def all_gather_object(self, obj):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return [obj]
         out = [None] * self.world
         self.dist.all_gather_object(out, obj)
         return out
-
-    def gather_object(self, obj, dst: int = 0):
-        if self.world == 1:
-            return [obj]
-        # all_gather_object is implemented for every backend (gather_object is not for all NCCL builds);
-        # the payloads are a few KB of candidate indices and ANI values
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out if self.rank == dst else None
 
 
 class HipEngine:
@@ -151,13 +154,15 @@ class HipEngine:
         sk.free()
         return hashes, lens
 
-    def precluster(self, hashes, lens, n: int, min_ani, rank: int, world: int) -> np.ndarray:
+    def precluster(self, hashes, lens, n: int, min_ani, rank: int, world: int):
+        """-> (pairs sorted by (i, j), replicated).  replicated: every rank holds the whole list (the join form ran on
+        the full matrix everywhere), nothing to exchange; otherwise `pairs` is this rank's share."""
         self.torch.cuda.current_stream().synchronize()
         sk = self.ctx.sketches_wrap_device(hashes.data_ptr(), lens.data_ptr(), n, self.s, self.kmer)
-        pairs = self.ctx.precluster(sk, min_ani, rank, world)
+        pairs, replicated = self.ctx.precluster_ranks(sk, min_ani, rank, world)
         self.last_pairs_compared = self.ctx.last_pairs_compared
         sk.free()
-        return pairs
+        return pairs, replicated
 
     def sketches_to_host(self, hashes, lens):
         return hashes.cpu().numpy().view(np.uint64), lens.cpu().numpy().view(np.uint32)
@@ -285,7 +290,7 @@ class DereplicationJob:
         lens = ex.all_gather_blocks(lens_l, self.n)
         self._full = (hashes, lens)
         t = self._tick("allgather_sketches", t)
-        pairs = e.precluster(hashes, lens, self.n, self.min_ani, self.rank, self.world)
+        pairs, replicated = e.precluster(hashes, lens, self.n, self.min_ani, self.rank, self.world)
         t = self._tick("pairs", t)
         idx_l, meta_l, lay = e.ani_build_local()
         t = self._tick("ani_index", t)
@@ -295,12 +300,17 @@ class DereplicationJob:
             alla = e.ani_pairs(idx, allp, self.min_af)
             t = self._tick("ani_pairs", t)
         else:
-            # every rank learns the whole (small) candidate list
-            parts = ex.all_gather_object(pairs)
-            allp = np.concatenate(parts) if parts else np.zeros(0, PAIR_DTYPE)
-            # (i, j) order through one u64 key: numpy's structured-field sort is ~5x slower at 10^4..10^5 pairs
-            key = (allp["i"].astype(np.uint64) << np.uint64(32)) | allp["j"].astype(np.uint64)
-            allp = allp[np.argsort(key, kind="stable")]
+            if replicated:
+                # the join form ran on the full matrix on every rank: each already holds the whole sorted list
+                # (the branch is a function of the sketches alone, so all ranks take it together)
+                allp = pairs
+            else:
+                # every rank learns the whole (small) candidate list
+                parts = ex.all_gather_object(pairs)
+                allp = np.concatenate(parts) if parts else np.zeros(0, PAIR_DTYPE)
+                # (i, j) order through one u64 key: numpy's structured-field sort is ~5x slower at 10^4..10^5 pairs
+                key = (allp["i"].astype(np.uint64) << np.uint64(32)) | allp["j"].astype(np.uint64)
+                allp = allp[np.argsort(key, kind="stable")]
             t = self._tick("allgather_pairs", t)
             # A pair is computed where its first genome lives; only the genomes a rank needs but does
             # not own are exchanged (instead of all-gathering the whole index, ~0.33 MB per genome).
@@ -333,12 +343,13 @@ class DereplicationJob:
             local_pairs["i"], local_pairs["j"] = remap[mine["i"]], remap[mine["j"]]
             ani_mine = e.ani_pairs(idx, local_pairs, self.min_af)
             t = self._tick("ani_pairs", t)
-            gathered = ex.gather_object((np.nonzero(mine_mask)[0], ani_mine), 0)
-            if self.rank == 0:
-                alla = np.zeros(len(allp), dtype=np.float32)
-                for where, a in gathered:
-                    alla[where] = a
-                t = self._tick("gather_ani", t)
+            # allp is sorted by i and a pair is computed where genome i lives, so the ranks' results are consecutive
+            # runs of the list in rank order, of lengths every rank can count: one collective, nothing to scatter
+            alla = ex.all_gather_host_array(ani_mine.astype(np.float32, copy=False),
+                                            np.bincount(owner_i, minlength=self.world).tolist())
+            if len(allp) == 0:
+                alla = np.zeros(0, dtype=np.float32)
+            t = self._tick("gather_ani", t)
         if self.rank == 0:
             clusters = e.cluster(self.n, allp, alla, self.ani_threshold)
             t = self._tick("host_cluster", t)

@@ -234,10 +234,8 @@ class Context:
         check(_lib.lib().ghip_sketches_copy_into(self._h, sk._h, C.c_void_p(d_hashes), C.c_void_p(d_lens)), self._h)
 
     # ---- precluster
-    def precluster(self, sk: Sketches, min_ani: float, rank: int = 0, world: int = 1) -> np.ndarray:
-        p = C.c_void_p()
-        n = C.c_size_t(0)
-        check(_lib.lib().ghip_precluster_shard(self._h, sk._h, np.float32(min_ani), rank, world, C.byref(p), C.byref(n)), self._h)
+    @staticmethod
+    def _take_pairs(p, n) -> np.ndarray:
         try:
             if n.value == 0:
                 return np.empty(0, dtype=PAIR_DTYPE)
@@ -245,6 +243,21 @@ class Context:
             return np.frombuffer(buf, dtype=PAIR_DTYPE).copy()
         finally:
             _lib.lib().ghip_free(p)
+
+    def precluster(self, sk: Sketches, min_ani: float, rank: int = 0, world: int = 1) -> np.ndarray:
+        p = C.c_void_p()
+        n = C.c_size_t(0)
+        check(_lib.lib().ghip_precluster_shard(self._h, sk._h, np.float32(min_ani), rank, world, C.byref(p), C.byref(n)), self._h)
+        return self._take_pairs(p, n)
+
+    def precluster_ranks(self, sk: Sketches, min_ani: float, rank: int, world: int) -> Tuple[np.ndarray, bool]:
+        """-> (pairs, replicated): the whole list on every rank when the join form ran, else this rank's share."""
+        p = C.c_void_p()
+        n = C.c_size_t(0)
+        rep = C.c_int(0)
+        check(_lib.lib().ghip_precluster_ranks(self._h, sk._h, np.float32(min_ani), rank, world, C.byref(p), C.byref(n),
+                                               C.byref(rep)), self._h)
+        return self._take_pairs(p, n), bool(rep.value)
 
     @property
     def last_pairs_compared(self) -> int:

@@ -135,7 +135,15 @@ int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fracti
 /* Multi-GPU share: only the upper-triangle tiles t with t % world == rank (block-cyclic). */
 int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
                           uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n);
-/* Number of genome pairs the last ghip_precluster[_shard] call on this ctx compared. */
+/* What a multi-rank job calls on every rank with the SAME full sketch matrix.  When the inverted-index form of the
+ * pair stage runs (its cost is one pass over all N*s hashes and does not shard), every rank computes and returns the
+ * WHOLE list and *out_replicated = 1: no exchange of candidate lists is needed.  Otherwise the rank's share as
+ * ghip_precluster_shard and *out_replicated = 0.  The choice depends only on the sketches and the parameters, so
+ * all ranks take the same branch. */
+int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
+                          uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n,
+                          int *out_replicated);
+/* Number of genome pairs the last ghip_precluster[_shard|_ranks] call on this ctx compared. */
 uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
 
 /* ---------------------------------------------------------------- ANI on candidate pairs

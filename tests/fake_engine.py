@@ -40,9 +40,12 @@ class FakeEngine:
         return hashes.numpy().view(np.uint64), lens.numpy().view(np.uint32)
 
     def precluster(self, hashes, lens, n, min_ani, rank, world):
+        """-> (pairs, replicated) like HipEngine.precluster; `replicate` mimics the join form (whole list everywhere)."""
         h, l = self.sketches_to_host(hashes, lens)
         rows, compared = [], 0
-        for ti, tj in tile_pairs_of_rank(n, PT, rank, world):
+        replicated = bool(getattr(self, "replicate", False)) and world > 1
+        share_rank, share_world = (0, 1) if replicated else (rank, world)
+        for ti, tj in tile_pairs_of_rank(n, PT, share_rank, share_world):
             for i in range(ti * PT, min((ti + 1) * PT, n)):
                 for j in range(tj * PT, min((tj + 1) * PT, n)):
                     if i >= j:
@@ -52,9 +55,11 @@ class FakeEngine:
                     ani = oracle.mash_ani(c, t, self.kmer)
                     if ani >= float(np.float32(min_ani)):
                         rows.append((i, j, c, t, np.float32(ani)))
+        if replicated:
+            compared = compared // world + (1 if rank < compared % world else 0)
         self.last_pairs_compared = compared
         out = np.array(rows, dtype=PAIR_DTYPE) if rows else np.zeros(0, dtype=PAIR_DTYPE)
-        return np.sort(out, order=["i", "j"])
+        return np.sort(out, order=["i", "j"]), replicated
 
     def ani_build_local(self):
         caps, cnts, glens, sh, sc, ct = [], [], [], [], [], []

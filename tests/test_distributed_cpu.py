@@ -23,13 +23,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, replicate=False):
     from fake_engine import FakeEngine
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    engine = FakeEngine()
+    engine.replicate = replicate   # True: the pair stage hands every rank the whole list (what the join form does)
     job = DereplicationJob(None, rank, world, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0),
-                           min_af=0.15, engine=FakeEngine())
+                           min_af=0.15, engine=engine)
     job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
     res = job.step()
     compared = torch.tensor([job.last_pairs_compared], dtype=torch.int64)
@@ -49,12 +51,12 @@ def _single():
     return job.step()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_job_equals_single_process(world):
+@pytest.mark.parametrize("world,replicate", [(2, False), (3, False), (2, True)])
+def test_sharded_job_equals_single_process(world, replicate):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, replicate)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)

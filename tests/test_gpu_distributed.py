@@ -46,7 +46,7 @@ def _worker(rank, world, port, q, N=N, LENGTH=LENGTH):
 
 def test_three_ranks_join_form_equals_single_rank(ctx):
     """N = 2100 short genomes on three ranks (ragged shards): the pair stage switches to the join form, which every
-    rank runs in full and reports by (i + j) mod world; families straddle the shard boundaries, so the ANI index
+    rank runs in full and keeps whole (ghip_precluster_ranks: no exchange of candidate lists); families straddle the shard boundaries, so the ANI index
     slices are exchanged too."""
     import oracle
     from galah_amd.distributed import DereplicationJob
@@ -114,26 +114,19 @@ def _nccl_single_rank(port, q):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    ex = Exchange(0, 1)
-    ex.world, ex.dist = 2, dist          # force the collective code paths; with one rank "all" = this rank
+    ex = Exchange(0, 1, force=True)      # issue the collectives on the one-rank group instead of short-circuiting
     assert not ex.stage_on_host
     h = torch.arange(6 * 8, dtype=torch.int64, device="cuda").reshape(6, 8) - 3
-    out = torch.empty((6, 8), dtype=torch.int64, device="cuda")
-    dist.all_gather_into_tensor(out, h.contiguous())                       # what _gather does per rank
-    assert torch.equal(out, h)
+    assert torch.equal(ex.all_gather_blocks(h, 5), h[:5])                  # sketch rows (i64 view of u64 hashes)
     lens = torch.arange(6, dtype=torch.int32, device="cuda")
-    out32 = torch.empty(6, dtype=torch.int32, device="cuda")
-    dist.all_gather_into_tensor(out32, lens)
-    assert torch.equal(out32, lens)
-    raw = torch.arange(50, dtype=torch.int16, device="cuda").view(torch.uint8)  # all_gather_flat moves raw bytes
-    pad = torch.zeros(112, dtype=torch.uint8, device="cuda"); pad[: raw.numel()] = raw
-    got = torch.empty(112, dtype=torch.uint8, device="cuda")
-    dist.all_gather_into_tensor(got, pad)
-    assert torch.equal(got[:100].view(torch.int16), torch.arange(50, dtype=torch.int16, device="cuda"))
+    assert torch.equal(ex.all_gather_blocks(lens, 6), lens)
+    codes = torch.arange(50, dtype=torch.int16, device="cuda")             # ANI index slices travel as raw bytes
+    assert torch.equal(ex.all_gather_flat(codes, [50]), codes)
+    assert ex.all_gather_flat(codes[:0], [0]).numel() == 0
+    ani = np.linspace(90, 100, 37).astype(np.float32)                      # ANI results: host array, one collective
+    assert ex.all_gather_host_array(ani, [37]).tobytes() == ani.tobytes()
     pairs = np.zeros(3, dtype=galah_amd.PAIR_DTYPE); pairs["i"] = [1, 2, 3]
-    objs = [None]
-    dist.all_gather_object(objs, pairs)
-    assert objs[0].tobytes() == pairs.tobytes()
+    assert ex.all_gather_object(pairs)[0].tobytes() == pairs.tobytes()     # the share of a dense pair stage
     t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()

@@ -429,6 +429,20 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
                 assert compared == n * (n - 1) // 2
                 merged = np.sort(np.concatenate(parts), order=["i", "j"])
                 assert merged.tobytes() == want.tobytes()
+                # the multi-rank entry point: the join form hands every rank the whole list, nothing to exchange
+                compared = 0
+                for r in range(world):
+                    whole, replicated = ctx.precluster_ranks(sk, np.float32(thr), r, world)
+                    compared += ctx.last_pairs_compared
+                    assert replicated and whole.tobytes() == want.tobytes()
+                assert compared == n * (n - 1) // 2
+        else:  # declined: the dense forms give each rank its share
+            parts = []
+            for r in range(3):
+                part, replicated = ctx.precluster_ranks(sk, np.float32(thr), r, 3)
+                assert not replicated
+                parts.append(part)
+            assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
     ctx.profile(False)
     # two empty sketches: (empty, empty) has ANI 1.0 -- only the dense forms can report it
     M = np.uint64(0xFFFFFFFFFFFFFFFF)
