@@ -1290,7 +1290,12 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
         float v = 0.0f;
         if (n_aligned != 0 && T != 0 && !(afq < (double)min_af && afr < (double)min_af)) {
             // skani prints ANI with two decimals and galah parses that text as f32 (src/skani.rs:770)
-            double ani = 100.0 * std::pow((double)M / (double)T, 1.0 / (double)idx->k);
+            // chance matches of mutated seeds against the whole other genome: observed = c + (1 - c) p0 (oracle header)
+            const double c_obs = (double)M / (double)T;
+            const double p0 = idx->k <= 31 ? (double)(idx->glen[q] + idx->glen[r]) / (double)(1ull << (2 * idx->k)) : 0.0;
+            double c = p0 < 1.0 ? (c_obs - p0) / (1.0 - p0) : 0.0;
+            if (c < 0.0) c = 0.0;
+            double ani = 100.0 * std::pow(c, 1.0 / (double)idx->k);
             v = two_decimals_as_f32(ani);
         }
         out_ani[p] = v;

@@ -25,7 +25,9 @@
  *               per-chunk statistic rather than a pooled count, and with this choice the reference's
  *               own membership tests src/clusterer.rs:631-690 are reproduced, see tests)
  *   AF_x      = (bases in aligned chunks of x) / L_x
- *   ANI%      = 100 * (M/T)^(1/k); 0 if no chunk aligned or (AF_q < min_af and AF_r < min_af)
+ *   p0        = (L_q + L_r) / 4^k      -- chance that a k-mer occurs somewhere in a genome of the mean length
+ *   c         = max(0, (M/T - p0) / (1 - p0))   -- observed containment = c + (1 - c) p0 (matches are by value, unchained)
+ *   ANI%      = 100 * c^(1/k); 0 if no chunk aligned or (AF_q < min_af and AF_r < min_af)
  *   returned  = strtof(sprintf("%.2f", ANI%))   -- skani prints two decimals, galah parses f32
  */
 #define _GNU_SOURCE
@@ -200,7 +202,15 @@ float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_f
     const chunk_frac med = fr[(n - 1) / 2];
     free(fr);
     if (afq < (double)min_af_fraction && afr < (double)min_af_fraction) return 0.0f;
-    double ani = 100.0 * pow((double)med.m / (double)med.t, 1.0 / (double)q->k);
+    /* chance matches: seeds are matched by value against the whole other genome (no chaining), so a query seed whose
+     * k-mer mutated still "matches" when the k-mer happens to occur anywhere in the other genome -- probability
+     * p0 = L / (4^k / 2) with L the mean of the two lengths (there are 4^k / 2 canonical k-mers, k odd).  The observed
+     * containment is c + (1 - c) p0; solve for c.  (+0.03 ANI points at 95 % for 2 Mb genomes, +0.2 at 88 % for 5 Mb.) */
+    const double c_obs = (double)med.m / (double)med.t;
+    const double p0 = q->k <= 31 ? (double)(q->length + r->length) / (double)(1ull << (2 * q->k)) : 0.0;
+    double c = p0 < 1.0 ? (c_obs - p0) / (1.0 - p0) : 0.0;
+    if (c < 0.0) c = 0.0;
+    double ani = 100.0 * pow(c, 1.0 / (double)q->k);
     char txt[64];
     snprintf(txt, sizeof txt, "%.2f", ani);
     return strtof(txt, NULL);
