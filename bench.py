@@ -209,6 +209,8 @@ def main():
         alg = {  # ALGORITHMIC bytes per launch on THIS rank (DESIGN.md "Kernels")
             "sketch_kmers": float(job.local_bases),                              # 1 B per input base
             "pair_intersect_tile": 16.0 * args.sketch_size * job.last_pairs_compared,  # 2*s*8 B per pair
+            # the inverted-index form covers ALL pairs of the gathered matrix in one launch (on every rank when N > 1)
+            "pair_join": 16.0 * args.sketch_size * n_pairs_total,
             "ani_seeds": float(job.local_bases),
         }
         kern = {}
@@ -239,9 +241,12 @@ def main():
                                     "floor_ms_per_launch": alg[dom] / 64.0 * 230.0 / (1024 * 2.3e9) * 1e3,
                                     "frac": (alg[dom] / 64.0 * 230.0 / (1024 * 2.3e9) * 1e3) / kern[dom]["avg_ms"]}
                                    if dom == "sketch_kmers" else None),
-                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 55 of its ~95 "
+                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 51 of its ~98 "
                              "VALU instructions per base (DESIGN.md); the HBM fraction is reported because the tier "
-                             "asks for it.  pair_intersect_tile is the HBM-roofline kernel of the path, see 'kernels'")}
+                             "asks for it.  The pair kernel (pair_intersect_tile, or pair_join from 2000 genomes) is "
+                             "the HBM-roofline kernel of the path: see 'kernels' for its achieved GB/s (algorithmic "
+                             "2*s*8 B per pair; above the HBM peak because tiles are reused from LDS / the join never "
+                             "touches non-sharing pairs)")}
         out = {
             "metric": "genome-pairs/sec (MinHash+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -251,7 +256,9 @@ def main():
                                    f"members, ~95% ANI), finch precluster s={args.sketch_size} k={args.kmer} at "
                                    f"{args.precluster_ani}% + ANI at {args.ani}%, greedy clustering",
                        "genomes": n, "genomes_per_gpu": n // world, "genome_length": args.length, "pairs": n_pairs_total,
-                       "parallelism": f"pair-tiles x{world}" if world > 1 else "single"},
+                       "parallelism": (f"genomes sharded x{world}: sketch + ANI where a genome lives, sketch matrix "
+                                       f"all-gathered, pair stage on the gathered matrix (join form replicated, "
+                                       f"dense forms dealt by tile)") if world > 1 else "single"},
             "genomes_per_s": n * args.steps / elapsed,
             "roofline": roofline,
             "kernels": kern,
