@@ -615,11 +615,11 @@ def test_empty_and_single_inputs(ctx):
 
 
 def test_randomised_differential_runs():
-    """A short run of the two fuzzers (tests/fuzz_sketch.py, tests/fuzz_pairs.py; seed 4 of the latter is the run that
-    found the empty-sketch case of the join form)."""
+    """A short run of the fuzzers (tests/fuzz_sketch.py, tests/fuzz_pairs.py -- seed 4 of it is the run that found the
+    empty-sketch case of the join form -- and tests/fuzz_ani.py: related genomes with indels, shuffles, repeats)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for script, args in (("fuzz_pairs.py", ["45", "4"]), ("fuzz_sketch.py", ["12", "21"])):
+    for script, args in (("fuzz_pairs.py", ["45", "4"]), ("fuzz_sketch.py", ["12", "21"]), ("fuzz_ani.py", ["25", "3"])):
         r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
