@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HASH_CYCLES = 218.0   # SIMD-cycles per wave-position of the hash filter alone (scripts/ubench/int_ops "filter_block")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -234,14 +235,14 @@ def main():
                                      if traffic is not None else "PMC passes are collected for the 1-GPU run only"),
                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "valu": valu,  # SQ_INSTS_VALU per launch and SIMD-cycles per VALU instruction, same PMC file
-                    # the kernel's own roof: MurmurHash3_x64_128 of every 21-mer is 51 instructions that cannot be
-                    # tabulated, measured in isolation at 230 SIMD-cycles per wave-position (scripts/ubench/int_ops.hip
-                    # "hash_block", independent of occupancy); 1024 SIMDs at the 2.3 GHz the PMC pass shows
-                    "issue_roof": ({"hash_cycles_per_wave_position": 230.0, "simds": 1024, "clock_ghz": 2.3,
-                                    "floor_ms_per_launch": alg[dom] / 64.0 * 230.0 / (1024 * 2.3e9) * 1e3,
-                                    "frac": (alg[dom] / 64.0 * 230.0 / (1024 * 2.3e9) * 1e3) / kern[dom]["avg_ms"]}
+                    # the kernel's own roof: the filter form of MurmurHash3_x64_128 of every 21-mer is 47 instructions that
+                    # cannot be tabulated, measured in isolation at 218 SIMD-cycles per wave-position (scripts/ubench/int_ops.hip
+                    # "filter_block", independent of occupancy); 1024 SIMDs at the 2.3 GHz the PMC pass shows
+                    "issue_roof": ({"hash_cycles_per_wave_position": HASH_CYCLES, "simds": 1024, "clock_ghz": 2.3,
+                                    "floor_ms_per_launch": alg[dom] / 64.0 * HASH_CYCLES / (1024 * 2.3e9) * 1e3,
+                                    "frac": (alg[dom] / 64.0 * HASH_CYCLES / (1024 * 2.3e9) * 1e3) / kern[dom]["avg_ms"]}
                                    if dom == "sketch_kmers" else None),
-                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 51 of its ~98 "
+                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 47 of its ~94 "
                              "VALU instructions per base (DESIGN.md); the HBM fraction is reported because the tier "
                              "asks for it.  The pair kernel (pair_intersect_tile, or pair_join from 2000 genomes) is "
                              "the HBM-roofline kernel of the path: see 'kernels' for its achieved GB/s (algorithmic "

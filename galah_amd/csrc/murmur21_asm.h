@@ -41,31 +41,35 @@
     "v_lshl_add_u64 v[50:51], v[50:51], 0, v[48:49]\n"                                  \
     GHIP_XORSHIFT33("v48", "v49")                                                       \
     GHIP_MULC(40, 41, 42, 43, "v48", "v49", "%[f1lo]", "%[f1hi]")                       \
-    GHIP_XORSHIFT33("v40", "v41")                                                       \
-    GHIP_MULC(44, 45, 46, 47, "v40", "v41", "%[f2lo]", "%[f2hi]")                       \
-    /* fmix64(h1) = v[44:45] and fmix64(h2) = v[48:49] up to their last xor-shift, which only changes the */ \
-    /* low words: the high word of the result is v45 + v49 (+ carry)                                      */ \
+    GHIP_XORSHIFT33("v40", "v41")           /* a = v[40:41]: fmix64(h1) short of its last multiply */ \
     GHIP_XORSHIFT33("v50", "v51")                                                       \
-    GHIP_MULC(40, 41, 42, 43, "v50", "v51", "%[f1lo]", "%[f1hi]")                       \
-    GHIP_XORSHIFT33("v40", "v41")                                                       \
-    GHIP_MULC(48, 49, 46, 47, "v40", "v41", "%[f2lo]", "%[f2hi]")                       \
-    "v_add3_u32 %[s1], v45, v49, 1\n"
+    GHIP_MULC(44, 45, 46, 47, "v50", "v51", "%[f1lo]", "%[f1hi]")                       \
+    GHIP_XORSHIFT33("v44", "v45")           /* b = v[44:45]: the same for h2 */         \
+    /* a*f2 + b*f2 = (a + b)*f2: ONE multiply gives the high word the filter needs */   \
+    "v_lshl_add_u64 v[48:49], v[40:41], 0, v[44:45]\n"                                  \
+    "v_mad_u64_u32 v[42:43], vcc, v49, %[f2lo], 0\n"                                    \
+    "v_mad_u64_u32 v[42:43], vcc, v48, %[f2hi], v[42:43]\n"                             \
+    "v_mad_u64_u32 v[50:51], vcc, v48, %[f2lo], 0\n"                                    \
+    "v_add3_u32 %[s1], v51, v42, 1\n"
 
-// Returns s1 = hi32(F1) + hi32(F2) + 1 and the two unfinished halves F1, F2.  The hash is
-// h = murmur21_finish(F1, F2); h <= thr implies s1 <= murmur21_filter_bound(thr) -- the last xor-shifts and the
-// 64-bit add are only spent on the ~1/2000 hashes that pass this one 32-bit compare.
+// The hash is h = fin(a*f2) + fin(b*f2) with fin(x) = x ^ (x >> 33), f2 = 0xc4ceb9fe1a85ec53 and a, b the two halves
+// short of their last multiply.  fin() only changes the low 31 bits, so hi32(h) = hi32(a*f2) + hi32(b*f2) + carry, and
+// a*f2 + b*f2 = (a + b)*f2 has the high word G = hi32(a*f2) + hi32(b*f2) + carry': hi32(h) is G - 1, G or G + 1
+// (mod 2^32).  The filter therefore needs ONE 64-bit multiply instead of two: it returns s1 = G + 1 (mod 2^32), and
+// h <= thr implies s1 <= murmur21_filter_bound(thr).  The two real multiplies, the xor-shifts and the 64-bit add are
+// only spent on the ~1/2000 hashes that pass this one 32-bit compare (murmur21_finish).
 template <bool SEED0>
 __device__ __forceinline__ uint32_t murmur21_filter(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t t0,
-                                                     uint32_t t1, uint32_t seed, uint64_t &F1, uint64_t &F2) {
+                                                     uint32_t t1, uint32_t seed, uint64_t &A, uint64_t &B) {
     uint32_t s1;
     const uint64_t k52 = 0x52dce729ull, k38 = 0x38495ab5ull, seed64 = seed;
 #define GHIP_MURMUR21_OPERANDS                                                                                       \
-    [s1] "=v"(s1), "={v[44:45]}"(F1), "={v[48:49]}"(F2)                                                              \
+    [s1] "=&v"(s1), "=&{v[40:41]}"(A), "=&{v[44:45]}"(B)                                                              \
         : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [t0] "v"(t0), [t1] "v"(t1),                        \
         [c1lo] "s"(0x114253d5u), [c1hi] "s"(0x87c37b91u), [c2lo] "s"(0x2745937fu), [c2hi] "s"(0x4cf5ad43u),          \
         [f1lo] "s"(0xed558ccdu), [f1hi] "s"(0xff51afd7u), [f2lo] "s"(0x1a85ec53u), [f2hi] "s"(0xc4ceb9feu),          \
         [k52] "s"(k52), [k38] "s"(k38), [seed] "s"(seed), [seed64] "s"(seed64)                                       \
-        : "v40", "v41", "v42", "v43", "v46", "v47", "v50", "v51", "v52", "vcc"
+        : "v42", "v43", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "vcc"
     if constexpr (SEED0) {
         asm volatile(GHIP_MURMUR21_BODY("", "", "") : GHIP_MURMUR21_OPERANDS);
     } else {
@@ -77,19 +81,22 @@ __device__ __forceinline__ uint32_t murmur21_filter(uint32_t a0, uint32_t a1, ui
     return s1;
 }
 
-__device__ __forceinline__ uint64_t murmur21_finish(uint64_t F1, uint64_t F2) { return (F1 ^ (F1 >> 33)) + (F2 ^ (F2 >> 33)); }
+__device__ __forceinline__ uint64_t murmur21_finish(uint64_t A, uint64_t B) {
+    const uint64_t F1 = A * 0xc4ceb9fe1a85ec53ull, F2 = B * 0xc4ceb9fe1a85ec53ull;
+    return (F1 ^ (F1 >> 33)) + (F2 ^ (F2 >> 33));
+}
 
-// Largest s1 for which a hash <= thr is possible.  With S = hi32(F1) + hi32(F2) mod 2^32 = s1 - 1 the hash's high
-// word is S or S + 1 (mod 2^32), so h <= thr needs S <= hi32(thr) or S = 2^32 - 1, i.e. s1 in [0, hi32(thr) + 1].
+// Largest s1 for which a hash <= thr is possible: hi32(h) <= hi32(thr) = t needs G in {2^32 - 1} u [0, t + 1],
+// i.e. s1 = G + 1 (mod 2^32) in [0, t + 2].
 __device__ __forceinline__ uint32_t murmur21_filter_bound(uint64_t thr) {
     const uint32_t th = (uint32_t)(thr >> 32);
-    return th == 0xffffffffu ? 0xffffffffu : th + 1u;
+    return th >= 0xfffffffeu ? 0xffffffffu : th + 2u;
 }
 
 template <bool SEED0>
 __device__ __forceinline__ uint64_t murmur21_core(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t t0,
                                                    uint32_t t1, uint32_t seed) {
-    uint64_t F1, F2;
-    murmur21_filter<SEED0>(a0, a1, b0, b1, t0, t1, seed, F1, F2);
-    return murmur21_finish(F1, F2);
+    uint64_t A, B;
+    murmur21_filter<SEED0>(a0, a1, b0, b1, t0, t1, seed, A, B);
+    return murmur21_finish(A, B);
 }

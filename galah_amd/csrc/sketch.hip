@@ -184,7 +184,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word)
     auto finish = [&](const Pend &p, const int b, const uint32_t inword) {
         const uint32_t a1 = (uint32_t)(p.A >> 32) + p.ax, b1 = (uint32_t)(p.B >> 32) + p.bx;
-        uint64_t F1, F2;
+        uint64_t F1, F2;  // the two halves of the hash short of their last multiply (murmur21_asm.h)
 #ifdef GHIP_DBG_NOHASH  // timing experiment only: wrong results
         F1 = ((p.A ^ p.B ^ p.T) + (((uint64_t)a1 << 32) | b1)) * 0x9e3779b97f4a7c15ull; F2 = 0;
         const uint32_t s1 = (uint32_t)(F1 >> 32) + 1u;

@@ -137,6 +137,16 @@ __global__ void k_hash_block(uint64_t *out, uint32_t seed) {   // the 55-instruc
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+__global__ void k_filter_block(uint64_t *out, uint32_t seed) {  // what the hot loop runs per position: the filter form only
+    uint32_t a0 = seed + threadIdx.x, a1 = seed * 3 + threadIdx.x, b0 = a0 ^ 0x1234567, b1 = a1 + 99, t0 = a0 * 7, t1 = a1 * 11;
+    uint32_t acc = 0;
+    for (int i = 0; i < REPB; i++) {
+        uint64_t A, B;
+        const uint32_t s1 = murmur21_filter<true>(a0, a1, b0, b1, t0, t1, 0, A, B);
+        acc += s1; a0 = (uint32_t)A; a1 ^= (uint32_t)B;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
 __global__ void k_cmp_cnd(uint64_t *out, uint32_t seed) {      // v_cmp_lt_u64 + 2 v_cndmask (canonical select)
     uint64_t a = seed + threadIdx.x, b = seed * 77ull + threadIdx.x * 3, acc = 0;
     for (int i = 0; i < REPB * 8; i++) {
@@ -249,6 +259,7 @@ int main() {
     run("v_min_u32_e32", k_min, d_out, 1);
     run("v_mov_b32_e32", k_mov, d_out, 1);
     run_block("hash_block", k_hash_block, d_out, REPB);
+    run_block("filter_block", k_filter_block, d_out, REPB);
     for (int w : {1, 2, 3, 4, 5, 6, 8}) run_block_occ("hash_block", k_hash_block, d_out, REPB, w);
     run_block("cmp64+cndmask", k_cmp_cnd, d_out, REPB * 8);
     run_block("select_c", k_select_c, d_out, REPB * 8);
