@@ -342,4 +342,5 @@ def cluster_pairs(n_genomes: int, pairs: np.ndarray, ani_threshold: float, pair_
     finally:
         L.ghip_free(members)
         L.ghip_free(offsets)
-    return [[int(x) for x in mem[off[c]:off[c + 1]]] for c in range(nc.value)]
+    mem_l, off_l = mem.tolist(), off.tolist()   # plain ints: slicing numpy scalars cluster by cluster is ~10x slower
+    return [mem_l[off_l[c]:off_l[c + 1]] for c in range(nc.value)]
