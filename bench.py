@@ -185,6 +185,12 @@ def main():
 
     for _ in range(args.warmup):
         job.step()
+    # Host runtime hygiene, not part of the path: torch alone leaves ~170 000 long-lived objects, and a full (gen-2)
+    # cycle collection over them costs 20-35 ms -- triggered every few steps at 10 000 genomes, where a step builds
+    # thousands of small cluster lists.  Park everything that exists now in the permanent generation.
+    import gc
+    gc.collect()
+    gc.freeze()
     job.reset_stage_timers()
     ctx.profile(True)
     ctx.profile_reset()
