@@ -20,7 +20,17 @@ def _sorted_key(ids: Key) -> Key:
 
 class SortedPairGenomeDistanceCache:
     def __init__(self):
-        self._d: Dict[Key, Optional[np.float32]] = {}
+        self._dict: Optional[Dict[Key, Optional[np.float32]]] = {}
+        self._src: Optional[np.ndarray] = None   # from_pairs: the back-end's sorted edge list; the map is built on first use
+
+    @property
+    def _d(self) -> Dict[Key, Optional[np.float32]]:
+        if self._dict is None:
+            p = self._src
+            lo = np.minimum(p["i"], p["j"]).tolist()
+            hi = np.maximum(p["i"], p["j"]).tolist()
+            self._dict = dict(zip(zip(lo, hi), list(p["ani"].astype(np.float32))))
+        return self._dict
 
     def insert(self, genome_ids: Key, distance: Optional[float]) -> None:
         self._d[_sorted_key(genome_ids)] = None if distance is None else np.float32(distance)
@@ -45,7 +55,7 @@ class SortedPairGenomeDistanceCache:
         return out
 
     def __len__(self) -> int:
-        return len(self._d)
+        return len(self._src) if self._dict is None else len(self._dict)
 
     def items(self) -> List[Tuple[Key, Optional[np.float32]]]:
         return sorted(self._d.items())
@@ -75,9 +85,12 @@ class SortedPairGenomeDistanceCache:
 
     @staticmethod
     def from_pairs(pairs: np.ndarray) -> "SortedPairGenomeDistanceCache":
+        """From a back-end's edge list (unique unordered pairs).  The map itself is only built when something asks
+        for it: galah_amd.cluster hands the edge list straight to the host clusterer, and a Python dict of 45 000
+        tuple keys costs more than the whole GPU pipeline."""
         c = SortedPairGenomeDistanceCache()
-        for p in pairs:
-            c.insert((int(p["i"]), int(p["j"])), p["ani"])
+        c._src = np.array(pairs, copy=True)
+        c._dict = None
         return c
 
 

@@ -7,6 +7,8 @@ Returns Vec<Vec<usize>> with the representative first in each inner list.
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import logging
 from typing import List, Optional, Sequence
 
@@ -18,10 +20,23 @@ from .engine import cluster_pairs
 log = logging.getLogger("galah_amd")
 
 
+@contextlib.contextmanager
+def _cycle_collector_paused():
+    """cluster() builds thousands of small lists and no reference cycles; a full cycle collection that happens to be
+    due in the middle of it walks every long-lived object of the process (20-35 ms with torch imported) -- more
+    than the GPU work of a thousand genomes.  Hold the collector off for the duration of the call."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def _pairs_of(cache) -> np.ndarray:
-    pairs = getattr(cache, "_pairs", None)
-    if pairs is not None and len(pairs) == len(cache):
-        return pairs
+    if getattr(cache, "_dict", 0) is None and getattr(cache, "_src", None) is not None:
+        return cache._src   # still the back-end's edge list, nothing was inserted or looked up
     items = cache.items()
     out = np.zeros(len(items), dtype=PAIR_DTYPE)
     for x, ((i, j), v) in enumerate(items):
@@ -56,7 +71,6 @@ def _distances_and_index(genomes, preclusterer, clusterer):
     sk.free()
     clusterer.adopt_index(idx, None, genomes)
     cache = SortedPairGenomeDistanceCache.from_pairs(pairs)
-    cache._pairs = pairs
     preclusterer.last_pairs = pairs
     return cache
 
@@ -64,6 +78,11 @@ def _distances_and_index(genomes, preclusterer, clusterer):
 def cluster(genomes: Sequence[str], preclusterer, clusterer, cluster_contigs: bool = False,
             contig_names: Optional[Sequence[str]] = None,
             reference_genomes: Optional[Sequence[str]] = None) -> List[List[int]]:
+    with _cycle_collector_paused():
+        return _cluster(genomes, preclusterer, clusterer, cluster_contigs, contig_names, reference_genomes)
+
+
+def _cluster(genomes, preclusterer, clusterer, cluster_contigs, contig_names, reference_genomes) -> List[List[int]]:
     clusterer.initialise()
     preclusterer_name = preclusterer.method_name()
     clusterer_name = clusterer.method_name()
