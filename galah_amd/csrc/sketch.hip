@@ -244,10 +244,18 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 const uint32_t f15 = ~(uint32_t)st.rc & amask;
                 const uint32_t r15 = ~(uint32_t)(st.fl >> ashift) & amask;
                 const uint32_t c15 = min(f15, r15);
+#ifdef GHIP_DBG_SEEDHASH1  // timing experiment only (scripts/sketch_variants.sh): wrong results
+                bool pass = seed_gate && (c15 * 0x9e3779b1u) < so.thr;
+#else
                 bool pass = seed_gate && ghip_seed::fmix32(c15) < so.thr;
+#endif
                 if (__builtin_amdgcn_ballot_w64(pass)) {  // validity only where some lane passed
                     pass = pass && (b - st.lastbad >= ak) && inword == 0;
+#ifdef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
+                    sb.n_lane += pass;
+#else
                     ghip_seed::seed_append(sl, so, sb, pass, c15, toff + (uint32_t)(b - (ak - 1)));
+#endif
                 }
             }
             if constexpr (HASH) {
