@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--species", type=int, default=100, help="species per GPU (total with --strong)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --species is the total, sharded over the ranks")
     ap.add_argument("--members", type=int, default=10)
