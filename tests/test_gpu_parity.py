@@ -315,7 +315,8 @@ def test_reference_membership_tests_through_hip(ctx):
 def test_reference_cli_expectations_through_hip(ctx):
     """tests/test_cmdline.rs through the GPU path: :36-61 + :304-352 (Parks2020_reduced order from the ingest's
     own genome statistics, then finch + ANI -> one cluster, representative S2M.16) and :262-302
-    (--min-aligned-fraction 0.2 -> one representative, 0.6 -> two)."""
+    (--min-aligned-fraction 0.2 -> one representative, 0.6 -> two); the representatives the output tests
+    :62-160 and :184-216 expect."""
     names = ["abisko_S1D21", "abisko_S2M16"]
     checkm = {"abisko_S1D21": (95.21, 0.00), "abisko_S2M16": (95.92, 0.65)}   # test_cmdline.rs:14-16
     g = ctx.genomes_from_files([fasta(n) for n in names], io_threads=2)
@@ -332,6 +333,15 @@ def test_reference_cli_expectations_through_hip(ctx):
     for min_af, want in ((0.2, [[0, 1]]), (0.6, [[0], [1]])):
         cl = galah_amd.HipAniClusterer(95.0, min_af, ctx=ctx, io_threads=2)
         assert sorted(galah_amd.cluster(paths, pre, cl)) == want
+    # :62-119 (symlink-directory tests): [set1/500kb, set1/1mbp] -> 500kb.fna is the only representative;
+    # :120-160 and :184-216 (name clash): both 500kb files are representatives, 1mbp.fna is not
+    cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=2)
+    assert galah_amd.cluster([fasta("set1_500kb"), fasta("set1_1mbp")], pre, cl) == [[0, 1]]
+    got = galah_amd.cluster([fasta("clash_500kb"), fasta("set1_500kb"), fasta("set1_1mbp")], pre, cl)
+    assert sorted(c[0] for c in got) == [0, 1] and [1, 2] in got
+    # :1100-1125 (membership only; the order there comes from CheckM2)
+    got = galah_amd.cluster([fasta(n) for n in ("set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16")], pre, cl)
+    assert sorted(sorted(c) for c in got) == [[0, 1], [2, 3]]
 
 
 def _dirty_streams(seed=5, n=6, length=20_000):

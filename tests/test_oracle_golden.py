@@ -142,4 +142,11 @@ def test_reference_cli_representative_list_and_github7():
     name_clash/500kb (the bigger precluster first; 1mbp joins 500kb).  :417-440 (github issue 7): the two antonio MAGs at
     --min-aligned-fraction 60 -> one cluster, representative MAG52."""
     assert _finch_plus_ani(["clash_500kb", "set1_500kb", "set1_1mbp"], 95.0, 0.15) == [[1, 2], [0]]
+    # :62-119 (symlink-directory tests): 500kb.fna is the only representative of [set1/500kb, set1/1mbp];
+    # :120-160 and :184-216 repeat the three-genome outcome above (both 500kb files representatives, 1mbp.fna not)
+    assert _finch_plus_ani(["set1_500kb", "set1_1mbp"], 95.0, 0.15) == [[0, 1]]
+    # :1100-1125 (needs CheckM2 for the order, so only the membership is checked): the four genomes fall into
+    # {S2M.16, S1D.21} and {500kb, 1mbp}
+    got = _finch_plus_ani(["set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16"], 95.0, 0.15)
+    assert sorted(sorted(c) for c in got) == [[0, 1], [2, 3]]
     assert _finch_plus_ani(["antonio_MAG52", "antonio_MAG189"], 95.0, 0.6) == [[0, 1]]
