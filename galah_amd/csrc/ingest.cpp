@@ -181,8 +181,10 @@ int ghip_parse_fasta(const uint8_t *buf, size_t n, const char *path, uint8_t *ou
             const size_t e = nl ? (size_t)(nl - buf) : n;
             size_t len = e - p;
             uint64_t cr = 0;
-            if (m + len <= cap && len >= 32 && kHaveAvx2 && line_acgt_avx2(buf + p, len, out + m)) {
-                m += len;
+            const size_t crlf = len && buf[e - 1] == '\r';  // a CRLF line: the fast path takes the part before the '\r'
+            if (m + len <= cap && len - crlf >= 32 && kHaveAvx2 && line_acgt_avx2(buf + p, len - crlf, out + m)) {
+                m += len - crlf;
+                cr = crlf;
             } else if (m + len <= cap) {
                 uint8_t *o = out + m;
                 size_t w = 0;
