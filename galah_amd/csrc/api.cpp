@@ -140,6 +140,19 @@ int d2h(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
 // Deterministic ANI index layout (shards must agree): Poisson(L/c) seeds, +10 % + 256 slack.
 uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) { return len / c + len / (10ull * c) + 256; }
 
+// fn(begin, end) over [0, n) on up to max_threads threads of at least min_per_thread items each (the caller's thread
+// takes the last range); spawning costs ~30 us per thread, so short loops stay serial (callers pass min_per_thread = 10 000)
+template <typename F>
+void parallel_ranges(size_t n, size_t min_per_thread, size_t max_threads, F &&fn) {
+    size_t t = std::min<size_t>({max_threads, n / std::max<size_t>(min_per_thread, 1), std::max<size_t>(1, std::thread::hardware_concurrency())});
+    if (t <= 1) { fn((size_t)0, n); return; }
+    const size_t per = (n + t - 1) / t;
+    std::vector<std::thread> pool;
+    for (size_t x = 0; x + 1 < t; x++) pool.emplace_back([&fn, x, per, n] { fn(std::min(n, x * per), std::min(n, (x + 1) * per)); });
+    fn(std::min(n, (t - 1) * per), n);
+    for (auto &th : pool) th.join();
+}
+
 uint32_t next_pow2(uint64_t x) {
     uint64_t p = 1;
     while (p < x) p <<= 1;
@@ -927,9 +940,11 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         break;
     }
     // exact reference arithmetic on the host: f64 ANI, threshold, `as f32`
+    // (serial on purpose: one f64 log per emitted pair is 1 ms per 45 000 pairs, and spawning threads on the 256-core
+    // host cost more than that -- measured 4.7 -> 6.6 ms for the stage at 10 000 genomes)
     size_t m = 0;
     for (size_t i = 0; i < host.size(); i++) {
-        double ani = finch_ani(host[i].common, host[i].total, k);
+        const double ani = finch_ani(host[i].common, host[i].total, k);
         if (ani >= thr) { host[i].ani = (float)ani; host[m++] = host[i]; }
     }
     host.resize(m);
@@ -1278,7 +1293,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
     // the f64 pow and the two-decimal rounding stay on the host (glibc's pow is what the oracle's parity is defined
-    // by): ~70 ns per pair, spread over a few threads for large batches
+    // by): ~70 ns per pair, spread over threads from 20 000 pairs on (below that spawning costs more than it saves)
     auto finish_range = [&](size_t p0, size_t p1) {
     for (size_t p = p0; p < p1; p++) {
         // res: [0] M and [1] T of the median-containment chunk, [2] aligned bases of q, [3] #aligned chunks, [5] bases of r
@@ -1301,14 +1316,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
         out_ani[p] = v;
     }
     };
-    const size_t nthreads = n < 20000 ? 1 : std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency()));
-    if (nthreads == 1) finish_range(0, n);
-    else {
-        std::vector<std::thread> pool;
-        const size_t per = (n + nthreads - 1) / nthreads;
-        for (size_t t = 0; t < nthreads; t++) pool.emplace_back(finish_range, std::min(n, t * per), std::min(n, (t + 1) * per));
-        for (auto &th : pool) th.join();
-    }
+    parallel_ranges(n, 12500, 16, finish_range);   // threads from 25 000 pairs on
     return GHIP_OK;
 }
 
