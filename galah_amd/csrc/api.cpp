@@ -483,7 +483,10 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         // as a pinned one, while hipStreamCreate costs 3.4 ms and hipHostMalloc 0.16 ms/MB -- so the workers keep plain
         // heap buffers and issue blocking copies; no per-thread stream, no pinned staging.
         // (Re-measured with the AVX2 line parser, A/B on one box: a pool of 16 pinned stream buffers is no faster than
-        // heap buffers -- workers 0.16 s vs 0.135 s for 5 GB.)
+        // heap buffers -- workers 0.16 s vs 0.135 s for 5 GB; one pinned buffer per thread: 0.135-0.14 s, the same.
+        // Shipping runs of ~6 files as one 32 MB copy is faster once warm (0.11 s) but its FIRST call in a process
+        // takes 0.28-0.33 s against 0.15 s here -- the runtime registers every new source buffer on first use, at a
+        // cost that grows with its size -- and a dereplication run ingests once.)
         auto worker = [&]() {
             if (hipSetDevice(ctx->device) != hipSuccess) { fail(GHIP_EHIP, "hipSetDevice failed in an ingest thread"); return; }
             std::vector<uint8_t> raw, heap_buf((size_t)max_cap + 64);
