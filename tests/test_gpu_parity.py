@@ -196,18 +196,22 @@ def test_calculate_ani_from_many_threads(ctx):
 
 
 def test_cluster_end_to_end_vs_oracle(ctx):
+    """Every fixture genome the reference's tests hold for this path (15 files; the multi-record contig file counts as
+    one genome here), three ANI thresholds, two aligned-fraction gates: clusters, order and representatives equal the
+    oracle's run of the reference's greedy algorithm."""
     names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52", "antonio_MAG189",
-             "set1_1mbp", "set1_500kb"]
+             "set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16", "abisko_S2D10", "clash_500kb",
+             "contigs_specific", "set2_1mbp", "set2_half"]
     paths = [fasta(n) for n in names]
     osk = [oracle.AniSketch.from_file(p) for p in paths]
     want_pairs = oracle.distances(paths, np.float32(0.9))
-    for thr in (95.0, 98.0, 99.0):
+    for thr, min_af in ((95.0, 0.15), (98.0, 0.15), (99.0, 0.15), (95.0, 0.6)):
         pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=4)
-        cl = galah_amd.HipAniClusterer(thr, 0.15, ctx=ctx, io_threads=4)
+        cl = galah_amd.HipAniClusterer(thr, min_af, ctx=ctx, io_threads=4)
         got = galah_amd.cluster(paths, pre, cl)
         want = oracle.cluster(len(paths), oracle.Cache.from_pairs(want_pairs), thr,
-                              lambda a, b: oracle.ani_pair(osk[a], osk[b], 0.15)[0])
-        assert got == want, (thr, got, want)
+                              lambda a, b: oracle.ani_pair(osk[a], osk[b], min_af)[0])
+        assert got == want, (thr, min_af, got, want)
         assert sorted(x for c in got for x in c) == list(range(len(paths)))
 
 
