@@ -442,7 +442,11 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<uint64_t> cap(n);
     uint64_t max_cap = 0;
-    for (size_t i = 0; i < n; i++) { cap[i] = ghip_stream_capacity_hint(paths[i]); max_cap = std::max(max_cap, cap[i]); }
+    // (five system calls per file: 5 ms per 1 000 files on one thread)
+    parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) cap[i] = ghip_stream_capacity_hint(paths[i]);
+    });
+    for (size_t i = 0; i < n; i++) max_cap = std::max(max_cap, cap[i]);
     const double w_hint = since(w0);
     bool overflow = false;
     {
