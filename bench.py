@@ -250,7 +250,7 @@ def main():
                                    if dom == "sketch_kmers" else None),
                     "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 47 of its ~94 "
                              "VALU instructions per base (DESIGN.md); the HBM fraction is reported because the tier "
-                             "asks for it.  The pair kernel (pair_intersect_tile, or pair_join from 2000 genomes) is "
+                             "asks for it.  The pair kernel (pair_intersect_tile, or pair_join from 1200 genomes) is "
                              "the HBM-roofline kernel of the path: see 'kernels' for its achieved GB/s (algorithmic "
                              "2*s*8 B per pair; above the HBM peak because tiles are reused from LDS / the join never "
                              "touches non-sharing pairs)")}

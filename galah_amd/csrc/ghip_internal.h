@@ -168,7 +168,8 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
                        ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
                        uint64_t *pairs_compared);
 
-constexpr size_t GHIP_JOIN_MIN_N = 2000;  // the inverted-index form of the pair stage takes over from here
+constexpr size_t GHIP_JOIN_MIN_N = 1200;  // the inverted-index form of the pair stage takes over from here (s = 1000: a tie with the
+                                          // dense probe kernel at 1 000 genomes, 0.93 vs 1.40 ms at 1 500)
 uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin);
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,

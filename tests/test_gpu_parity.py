@@ -416,7 +416,7 @@ def test_every_seed_of_dirty_streams(ctx, c):
 
 
 def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
-    """The inverted-index form (pairs_join.hip; automatic from N >= 2000) forced on small inputs: same bytes as
+    """The inverted-index form (pairs_join.hip; automatic from N >= 1200) forced on small inputs: same bytes as
     the oracle's pair loop, whole and sharded; and the inputs it must decline (threshold 0, empty sketches)
     still give the dense kernels' answer."""
     monkeypatch.setenv("GHIP_PAIR_KERNEL", "join")
