@@ -262,7 +262,7 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter2_kernel(const uint64_t
 }
 
 // ---- equal hashes inside a bucket -> one record per sharing genome pair ------------------------------------------
-// One wavefront per bucket.  The counting pass (EMIT = false) sorts the bucket by (hash, genome) in LDS -- a bitonic
+// One wavefront per bucket.  The counting pass (EMIT = false) sorts the bucket by hash in LDS -- a bitonic
 // network over the next power of two, 64 lanes -- writes it back sorted and counts, for every element, the later
 // elements of its run of equal hashes; the emitting pass (EMIT = true) reads the sorted bucket and writes those pairs
 // at rec_start[bucket].  (Comparing every element with every later one cost cnt^2 / 2 dependent LDS reads per bucket:
@@ -288,19 +288,34 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
     for (uint32_t e = lane; e < cnt; e += 64) { k[e] = keys[lo + e]; v[e] = vals[lo + e]; }
     if (lane == 0) lcnt[wave] = 0;
     if (!EMIT && cnt > 1) {
+        // Ascending-only bitonic network over the next power of two P: the first step of every merge pairs i with its
+        // mirror i ^ (kk - 1), the later ones with i + j, and every exchange moves the smaller hash down -- so
+        // positions >= cnt act as +infinity without being stored, and a step whose partner lies there is skipped.
+        // Only equal hashes have to end up adjacent: no tie-break, the genome ids are read only when a swap happens.
         uint32_t P = 64;
         while (P < cnt) P <<= 1;
-        for (uint32_t e = cnt + lane; e < P; e += 64) { k[e] = ~0ull; v[e] = ~0u; }   // pads sort behind every element
+        auto exchange = [&](uint32_t i, uint32_t x) {
+            if (x >= cnt) return;
+            const uint64_t ka = k[i], kb = k[x];
+            if (ka > kb) {
+                const uint32_t va = v[i], vb = v[x];
+                k[i] = kb; k[x] = ka; v[i] = vb; v[x] = va;
+            }
+        };
         for (uint32_t kk = 2; kk <= P; kk <<= 1) {
-            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t half = kk >> 1;
+            for (uint32_t t = lane; t < P / 2; t += 64) {
+                const uint32_t i = kk * (t / half) + (t % half);
+                exchange(i, i ^ (kk - 1));
+            }
+            for (uint32_t j = half >> 1; j > 0; j >>= 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t t = lane; t < P / 2; t += 64) {
-                    const uint32_t i = 2 * j * (t / j) + (t % j), x = i + j;   // j is a power of two: shifts and masks
-                    const uint64_t ka = k[i], kb = k[x];
-                    const uint32_t va = v[i], vb = v[x];
-                    const bool greater = ka > kb || (ka == kb && va > vb);
-                    if (greater == ((i & kk) == 0)) { k[i] = kb; k[x] = ka; v[i] = vb; v[x] = va; }
+                    const uint32_t i = 2 * j * (t / j) + (t % j);
+                    exchange(i, i + j);
                 }
             }
         }
