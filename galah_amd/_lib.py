@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GHIP_LIB_OVERRIDE") or os.path.join(_HERE, "libgalah_
 PAIR_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("common", "<u4"), ("total", "<u4"), ("ani", "<f4")])
 
 GHIP_OK = 0
-ERROR_NAMES = {1: "GHIP_EINVAL", 2: "GHIP_EIO", 3: "GHIP_EHIP", 4: "GHIP_ENOMEM", 5: "GHIP_EUNSUPPORTED"}
+ERROR_NAMES = {1: "GHIP_EINVAL", 2: "GHIP_EIO", 3: "GHIP_EHIP", 4: "GHIP_ENOMEM", 5: "GHIP_EUNSUPPORTED", 6: "GHIP_ECALLBACK"}
 
 ANI_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
 

@@ -62,6 +62,12 @@ class HipAniClusterer:
         self._index = ctx.ani_index_build(self._genomes, ANI_K, self.seed_compression, ANI_CHUNK)
         self._path_index = {p: i for i, p in enumerate(genome_fasta_paths)}
 
+    def prepared_for(self, genome_fasta_paths: Sequence[str]) -> bool:
+        """True when genome i of the device index is genome_fasta_paths[i] for every i."""
+        pi = self._path_index
+        return (self._index is not None and len(pi) == len(genome_fasta_paths)
+                and all(pi.get(g) == i for i, g in enumerate(genome_fasta_paths)))
+
     def prepare_from_genomes(self, genomes, names: Optional[Sequence[str]] = None) -> None:
         ctx = self._context()
         self._genomes = genomes

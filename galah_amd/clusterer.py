@@ -114,7 +114,9 @@ def _cluster(genomes, preclusterer, clusterer, cluster_contigs, contig_names, re
     if skip_clusterer:
         return cluster_pairs(n, pairs, threshold, None, True)
     if hasattr(clusterer, "calculate_ani_indices"):
-        if getattr(clusterer, "_index", None) is None or len(getattr(clusterer, "_path_index", {})) != len(genomes):
+        # edge indices are positions in `genomes`: the clusterer's device index serves them only if it was built for
+        # this list in this order (not for another list of the same length, not grown by calculate_ani())
+        if not clusterer.prepared_for(genomes):
             clusterer.prepare(list(genomes))
         idx = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
         pair_ani = clusterer.calculate_ani_indices(idx) if len(pairs) else np.zeros(0, np.float32)

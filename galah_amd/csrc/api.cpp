@@ -910,7 +910,8 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     if ((rc = dmalloc(ctx, &d_count, 1))) return rc;
     tmp.add(d_count);
     std::vector<ghip_pair> host;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    bool listed = false;  // an attempt whose candidate list held every hit
+    for (int attempt = 0; attempt < 4 && !listed; attempt++) {
         ghip_pair *d_out = nullptr;
         if ((rc = dmalloc(ctx, &d_out, cap))) return rc;
         DeviceFree t2(ctx); t2.add(d_out);
@@ -944,8 +945,9 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if (cnt > cap) { cap = cnt; continue; }  // list overflowed: rerun with room for every hit
         host.resize(cnt);
         if ((rc = d2h(ctx, host.data(), d_out, cnt))) return rc;
-        break;
+        listed = true;
     }
+    if (!listed) return ghip_set_error(ctx, GHIP_EHIP, "precluster candidate list overflowed on every attempt");
     // exact reference arithmetic on the host: f64 ANI, threshold, `as f32`
     // (serial on purpose: one f64 log per emitted pair is 1 ms per 45 000 pairs, and spawning threads on the 256-core
     // host cost more than that -- measured 4.7 -> 6.6 ms for the stage at 10 000 genomes)

@@ -42,7 +42,9 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
                             uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters) {
     if (!out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
     if (n_pairs && !pairs) return GHIP_EINVAL;
-    if (!skip_clusterer && !pair_ani && !ani_cb) return GHIP_EINVAL;
+    // an ANI source is only needed when there is an edge to ask about: unrelated genomes (no precluster pair) are
+    // singleton clusters whatever the clusterer (clusterer.rs:182-259 never calls calculate_ani then)
+    if (n_pairs && !skip_clusterer && !pair_ani && !ani_cb) return GHIP_EINVAL;
     for (size_t e = 0; e < n_pairs; e++)
         if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return GHIP_EINVAL;
 
@@ -101,10 +103,12 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
             else { ani_state[e] = 2; ani_val[e] = pair_ani[e]; }
         }
     }
+    bool aborted = false;  // the callback returned < 0: the host's calculate_ani failed (a Rust panic, a Python exception)
     auto edge_ani = [&](uint32_t e, uint32_t rep_genome, uint32_t genome) {
-        if (ani_state[e] == 0) {  // ClusterDistanceFinder::calculate_ani(rep, genome)
+        if (ani_state[e] == 0 && !aborted) {  // ClusterDistanceFinder::calculate_ani(rep, genome)
             float v = 0.0f;
             int has = ani_cb(user, rep_genome, genome, &v);
+            if (has < 0) { aborted = true; has = 0; }
             ani_state[e] = has ? 2 : 1;
             ani_val[e] = v;
         }
@@ -144,6 +148,7 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
                 }
             }
             is_rep[gi] = rep ? 1 : 0;
+            if (aborted) return GHIP_ECALLBACK;
         }
         // ---- find_precluster_cluster_memberships (clusterer.rs:350-449) ----
         for (uint32_t li = 0; li < m; li++) {
@@ -162,6 +167,7 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
                 // so among equal ANIs the lowest-index representative is kept.
                 if (!have || v > best || (v == best && lj < best_local)) { have = true; best = v; best_local = lj; }
             }
+            if (aborted) return GHIP_ECALLBACK;
             if (!have) return GHIP_EINVAL;  // reference: best_rep.unwrap() panics (clusterer.rs:444)
             assign[gi] = orig[best_local];
         }

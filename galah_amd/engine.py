@@ -321,8 +321,16 @@ def cluster_pairs(n_genomes: int, pairs: np.ndarray, ani_threshold: float, pair_
         pa = np.ascontiguousarray(pair_ani, dtype=np.float32)
         assert pa.shape[0] == pairs.shape[0]
 
+    failure = []
+
     def _cb(_user, a, b, out):
-        r = ani_callback(int(a), int(b))
+        # an exception must not vanish inside ctypes (it would read as calculate_ani == None and the clustering would
+        # go on): stash it, tell ghip_cluster to stop (< 0), re-raise below -- the reference would panic here
+        try:
+            r = ani_callback(int(a), int(b))
+        except BaseException as e:  # noqa: BLE001
+            failure.append(e)
+            return -1
         if r is None:
             return 0
         out[0] = np.float32(r)
@@ -333,6 +341,8 @@ def cluster_pairs(n_genomes: int, pairs: np.ndarray, ani_threshold: float, pair_
     rc = L.ghip_cluster(n_genomes, pairs.ctypes.data, pairs.shape[0], pa.ctypes.data if pa is not None else None,
                         1 if skip_clusterer else 0, np.float32(ani_threshold), cb, None,
                         C.byref(members), C.byref(offsets), C.byref(nc))
+    if failure:
+        raise failure[0]
     if rc != 0:
         raise GalahHipError(rc, "ghip_cluster failed (no representative with a known ANI, or bad input)")
     try:

@@ -33,6 +33,7 @@ extern "C" {
 #define GHIP_EHIP 3     /* HIP runtime error (no device, OOM, launch failure) */
 #define GHIP_ENOMEM 4   /* host allocation failure */
 #define GHIP_EUNSUPPORTED 5 /* mode the finch back-end refuses (src/finch.rs:14-15,26-41) */
+#define GHIP_ECALLBACK 6    /* the ANI callback of ghip_cluster returned < 0 (its calculate_ani failed) */
 
 #define GHIP_ABI_VERSION 1
 
@@ -200,6 +201,8 @@ int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, 
  * is 0, `ani_cb` is called like ClusterDistanceFinder::calculate_ani(genome_a, genome_b).
  * Output: clusters as members[offsets[c] .. offsets[c+1]), representative first
  * (src/cluster_argument_parsing.rs:730); free both with ghip_free(). */
+/* Callback return: 1 = Some(*ani), 0 = None, < 0 = calculate_ani failed (the reference would panic): ghip_cluster
+ * stops asking and returns GHIP_ECALLBACK.  With n_pairs == 0 neither pair_ani nor ani_cb is needed. */
 typedef int (*ghip_ani_callback)(void *user, uint32_t genome_a, uint32_t genome_b, float *ani);
 int ghip_cluster(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
                  int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, void *user,

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -206,14 +207,18 @@ public:
         ghip_genomes_free(g);
         if (rc != GHIP_OK) throw std::runtime_error("Failed to build the ANI index: " + hip_->last_error());
         for (size_t i = 0; i < genomes.size(); i++) path_index_.emplace(genomes[i], (uint32_t)i);
+        order_ = genomes;
     }
-    bool prepared_for(const std::vector<std::string> &genomes) const { return index_ && path_index_.size() == genomes.size(); }
+    // the index serves `genomes` only if genome i of the list is genome i of the index: same paths, same order (an
+    // index grown by calculate_ani()/prepare_missing, or built for another list of the same length, does not)
+    bool prepared_for(const std::vector<std::string> &genomes) const { return index_ && order_ == genomes; }
     // take an index built elsewhere (galah::cluster builds sketches and index from one pass over the bases)
     void adopt_index(ghip_ani_index *index, const std::vector<std::string> &genomes) {
         ghip_ani_index_free(index_);
         index_ = index;
         path_index_.clear();
         for (size_t i = 0; i < genomes.size(); i++) path_index_.emplace(genomes[i], (uint32_t)i);
+        order_ = genomes;
     }
     uint32_t seed_compression() const { return small_genomes ? 30 : 125; }
     const std::shared_ptr<HipContext> &context() const { return hip_; }
@@ -247,8 +252,7 @@ public:
 
 private:
     void prepare_missing(const std::string &f1, const std::string &f2) {  // calculate_ani on an un-prepared pair
-        std::vector<std::string> g;
-        for (auto &kv : path_index_) g.push_back(kv.first);
+        std::vector<std::string> g = order_;  // keep the indices of the genomes already prepared
         if (!path_index_.count(f1)) g.push_back(f1);
         if (!path_index_.count(f2) && f2 != f1) g.push_back(f2);
         prepare(g);
@@ -256,6 +260,7 @@ private:
     std::shared_ptr<HipContext> hip_;
     ghip_ani_index *index_ = nullptr;
     std::unordered_map<std::string, uint32_t> path_index_;
+    std::vector<std::string> order_;  // genome i of the index
     std::shared_mutex mu_;  // calculate_ani: shared for lookups, exclusive while (re)indexing
 };
 
@@ -311,7 +316,7 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
         edges.push_back(ghip_pair{(uint32_t)kv.first.first, (uint32_t)kv.first.second, 0, 0, *kv.second});
     }
     std::vector<float> pair_ani;
-    struct CbState { ClusterDistanceFinder *c; const std::vector<std::string> *g; } st{&clusterer, &genomes};
+    struct CbState { ClusterDistanceFinder *c; const std::vector<std::string> *g; std::exception_ptr failed; } st{&clusterer, &genomes, nullptr};
     ghip_ani_callback cb = nullptr;
     if (!skip_clusterer) {
         if (auto *hipani = dynamic_cast<HipAniClusterer *>(&clusterer)) {
@@ -323,10 +328,15 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
         } else {
             cb = [](void *user, uint32_t a, uint32_t b, float *out) -> int {
                 auto *s = static_cast<CbState *>(user);
-                auto v = s->c->calculate_ani((*s->g)[a], (*s->g)[b]);
-                if (!v) return 0;
-                *out = *v;
-                return 1;
+                try {  // no exception may cross the C ABI: stop the clusterer (< 0) and rethrow below
+                    auto v = s->c->calculate_ani((*s->g)[a], (*s->g)[b]);
+                    if (!v) return 0;
+                    *out = *v;
+                    return 1;
+                } catch (...) {
+                    s->failed = std::current_exception();
+                    return -1;
+                }
             };
         }
     }
@@ -336,6 +346,7 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
     const int rc = ghip_cluster(n, edges.data(), edges.size(), pair_ani.empty() ? nullptr : pair_ani.data(),
                                 skip_clusterer ? 1 : 0, clusterer.get_ani_threshold(), cb, &st, &members, &offsets,
                                 &n_clusters);
+    if (st.failed) std::rethrow_exception(st.failed);
     if (rc != GHIP_OK)  // best_rep.unwrap() on None (src/clusterer.rs:444)
         throw std::runtime_error("called `Option::unwrap()` on a `None` value: a genome has no representative");
     std::vector<std::vector<size_t>> out(n_clusters);

@@ -144,6 +144,24 @@ int main(int argc, char **argv) {
         CHECK(same);
         CHECK(want[0 * 6 + 1] > 95.0f && want[4 * 6 + 5] > 95.0f && want[0 * 6 + 4] == 0.0f);
     }
+    {   // unrelated genomes: no precluster pair at all -> one singleton cluster each, through the batched ANI clusterer
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        galah::HipAniClusterer cl(hip, 95.0f, 0.15f);
+        CHECK((galah::cluster({fa("abisko_S1X13"), fa("antonio_MAG52"), fa("set1_1mbp")}, pre, cl) ==
+               std::vector<std::vector<size_t>>{{0}, {1}, {2}}));
+    }
+    {   // a clusterer prepared for ANOTHER list of the same length (or the same genomes in another order) must be
+        // re-prepared: edge indices are positions in the list given to cluster()
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);
+        galah::HipAniClusterer fresh(hip, 95.0f, 0.15f), stale(hip, 95.0f, 0.15f);
+        std::vector<std::string> fwd = {fa("set1_500kb"), fa("set1_1mbp"), fa("antonio_MAG52"), fa("antonio_MAG189")};
+        std::vector<std::string> rev(fwd.rbegin(), fwd.rend());
+        stale.prepare(rev);
+        CHECK(!stale.prepared_for(fwd) && stale.prepared_for(rev));
+        galah::FinchPreclusterer other(std::make_shared<galah::HipContext>(0), 0.9f, 1000, 21);  // other context: no fused ingest
+        CHECK((galah::cluster(fwd, other, stale) == galah::cluster(fwd, pre, fresh)));
+        CHECK(stale.prepared_for(fwd));
+    }
     std::printf(failures ? "%d check(s) failed\n" : "host mirror: all reference tests passed\n", failures);
     return failures ? 1 : 0;
 }

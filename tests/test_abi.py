@@ -192,3 +192,37 @@ def test_gunzip_paths_agree(tmp_path):
     assert got["one.fna.gz"] == got["two.fna.gz"] == f"{len(want)} {zlib.crc32(want)} (1, {seq.count(b'N')}, {len(seq)})"
     assert got["cut.fna.gz"].startswith("error") and got["junk.fna.gz"].startswith("error") and got["crc.fna.gz"].startswith("error")
     assert got["dense.fna.gz"].startswith("3000001 ")
+
+
+def test_unrelated_genomes_are_singletons_without_an_ani_source():
+    """No precluster pair at all (a set of unrelated genomes): singleton clusters, and no ANI source is needed --
+    the C++ mirror passes NULL for both pair_ani and the callback then (include/galah_hip.hpp)."""
+    import ctypes as C
+    L = _lib.lib()
+    members, offsets, nc = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+    rc = L.ghip_cluster(3, None, 0, None, 0, np.float32(95.0), C.cast(None, _lib.ANI_CALLBACK), None,
+                        C.byref(members), C.byref(offsets), C.byref(nc))
+    assert rc == 0 and nc.value == 3
+    L.ghip_free(members)
+    L.ghip_free(offsets)
+    assert cluster_pairs(3, np.zeros(0, dtype=PAIR_DTYPE), np.float32(95.0), None, False) == [[0], [1], [2]]
+    assert cluster_pairs(3, np.zeros(0, dtype=PAIR_DTYPE), np.float32(95.0), np.zeros(0, np.float32)) == [[0], [1], [2]]
+    # with an edge and no ANI source it is still a bad call
+    one = np.array([(0, 1, 0, 0, 0.97)], dtype=PAIR_DTYPE)
+    with pytest.raises(galah_amd.GalahHipError):
+        cluster_pairs(2, one, np.float32(95.0), None, False)
+
+
+def test_ani_callback_exception_propagates():
+    """calculate_ani raising inside the ctypes callback must surface as that exception (the reference would panic),
+    not read as `None` and let the clustering carry on."""
+    pairs = np.array([(0, 1, 0, 0, 0.97), (1, 2, 0, 0, 0.98), (2, 3, 0, 0, 0.99)], dtype=PAIR_DTYPE)
+    calls = []
+
+    def boom(a, b):
+        calls.append((a, b))
+        raise ValueError("skani exploded")
+
+    with pytest.raises(ValueError, match="skani exploded"):
+        cluster_pairs(4, pairs, np.float32(95.0), None, False, ani_callback=boom)
+    assert len(calls) == 1   # ghip_cluster stopped asking after the failure

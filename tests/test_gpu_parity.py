@@ -195,6 +195,31 @@ def test_calculate_ani_from_many_threads(ctx):
     assert want[(0, 1)] > 95 and want[(4, 5)] > 95 and want[(0, 4)] == 0
 
 
+def test_reused_ani_clusterer_is_checked_by_identity_not_by_count(ctx):
+    """A HipAniClusterer prepared for another list of the same length, or grown by calculate_ani() (its index is then
+    in first-seen order, not the caller's), must not answer edge indices of a new list from its stale index: cluster()
+    re-prepares it.  A different context keeps the fused one-ingest path out of the way."""
+    names = ["set1_500kb", "set1_1mbp", "antonio_MAG52", "antonio_MAG189"]
+    paths = [fasta(n) for n in names]
+    other = galah_amd.Context(0)
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=other, io_threads=2)
+    want = galah_amd.cluster(paths, pre, galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=2))
+    assert want == [[0, 1], [2, 3]]
+    stale = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=2)
+    stale.prepare(paths[::-1])                       # same genomes, reversed: same count, wrong positions
+    assert not stale.prepared_for(paths) and stale.prepared_for(paths[::-1])
+    assert galah_amd.cluster(paths, pre, stale) == want
+    grown = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=2)
+    grown.calculate_ani(paths[3], paths[2])          # index order: 3, 2
+    grown.calculate_ani(paths[1], paths[0])          # ... then 1, 0
+    assert len(grown._path_index) == 4 and not grown.prepared_for(paths)
+    assert galah_amd.cluster(paths, pre, grown) == want
+    # unrelated genomes (no precluster pair): singletons, through the batched clusterer
+    lone = [fasta("abisko_S1X13"), fasta("antonio_MAG52"), fasta("set1_1mbp")]
+    assert galah_amd.cluster(lone, pre, galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx)) == [[0], [1], [2]]
+    other.close()
+
+
 def test_cluster_end_to_end_vs_oracle(ctx):
     """Every fixture genome the reference's tests hold for this path (15 files; the multi-record contig file counts as
     one genome here), three ANI thresholds, two aligned-fraction gates: clusters, order and representatives equal the
