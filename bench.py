@@ -6,22 +6,33 @@ in HBM: MinHash sketch (k=21, s=1000) -> all-vs-all precluster pairs at 90 % -> 
 ANI on the surviving pairs -> host greedy clustering at 95 %.  value = genome pairs / second
 (all N(N-1)/2 pairs of the workload divided by the whole-step wall time, max over ranks).
 
-Default workload = BASELINE.json configs[1]: 1 000 synthetic ~5 Mb genomes (100 species x 10
-members at ~95 % pairwise identity), sketch size 1000, one MI355X.  With --gpus N every rank brings
-ITS OWN 1 000 genomes (weak scaling: N x 1 000 genomes in total, the shape of configs[2] = 10 000 genomes
-on 8 GPUs): genomes are sketched where they live, the sketch matrix is all-gathered over RCCL, the
-(N x 1 000)^2 / 2 pair tiles are dealt block-cyclically, ANI runs where a pair's first genome lives.
-The metric counts ALL pairs of the workload, which grow quadratically with the genome count, so
-`value` grows faster than N under weak scaling; `genomes_per_s` in the same line is the linear figure.
---strong keeps the total at --species x --members genomes and shards them instead.
+Workloads (BASELINE.json):
+  --gpus 1            configs[1]: 1 000 synthetic ~5 Mb genomes (100 species x 10 members at ~95 % identity), s = 1000.
+  --gpus N (N > 1)    1 250 genomes per GPU, i.e. configs[2] -- 10 000 genomes -- on 8 GPUs (weak scaling: per-GPU
+                      sketch/ANI work is fixed, the all-vs-all pair count grows as N^2, so `value` grows faster than N;
+                      `genomes_per_s` is the linear figure).  --total-genomes T pins the total instead (strong scaling).
+Genomes are sketched where they live, the sketch matrix is all-gathered over RCCL, the pair stage runs on the
+gathered matrix, ANI runs where a pair's first genome lives.
 
-Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline leg.
+Launch: the driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; a plain
+`python bench.py --gpus N` re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous).
+GHIP_BENCH_BACKEND=gloo lets the ranks share the GPUs of a smaller box (functional check, not a measurement).
+
+At N = 1 the same process then also reports (skipped with --no-extras):
+  north_star_10k   10 000 x 5 Mb on the ONE GPU with its own CPU baseline and the >= 10x check (BASELINE north_star)
+  wall_clock       BASELINE metric 2: FASTA files in -> clusters out (1 000 genomes written to /dev/shm, plain and gzip)
+  skani            run-time probe for a `skani` binary (ANI parity is unpinned without one)
+
+Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline legs and the parity asserts.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,8 +41,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HASH_CYCLES = 218.0   # SIMD-cycles per wave-position of the hash filter alone (scripts/ubench/int_ops "filter_block")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+GENOMES_PER_GPU_1 = 1000     # configs[1]
+GENOMES_PER_GPU_N = 1250     # configs[2] = 10 000 genomes on 8 GPUs
 
 
 def parse():
@@ -39,7 +51,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--species", type=int, default=100, help="species per GPU (total with --strong)")
+    ap.add_argument("--species", type=int, default=None, help="species per GPU (default 100 at --gpus 1, 125 per GPU above)")
+    ap.add_argument("--total-genomes", type=int, default=None, help="total genomes sharded over the ranks (strong scaling)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --species is the total, sharded over the ranks")
     ap.add_argument("--members", type=int, default=10)
     ap.add_argument("--length", type=int, default=5_000_000)
@@ -51,6 +64,7 @@ def parse():
     ap.add_argument("--ani", type=float, default=95.0)
     ap.add_argument("--min-aligned-fraction", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the north_star_10k / wall_clock / skani legs")
     ap.add_argument("--cpu-sample-genomes", type=int, default=32)
     ap.add_argument("--cpu-pair-sample", type=int, default=2000, help="genomes whose all-vs-all pair loop the CPU baseline times")
     return ap.parse_args()
@@ -78,73 +92,261 @@ def pmc_traffic(kernel: str):
         return None, None, None
 
 
-def cpu_baseline(args, hashes, lens, n_pairs_total, min_ani, gpu_pairs=None):
-    """Times the CPU oracle (a port of src/finch.rs:48-97; the Rust reference cannot be built
-    here) on this host's cores, on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+class CpuRates:
+    """Rates of the CPU oracle (a port of src/finch.rs:48-97; the Rust reference cannot be built here) on this host's
+    cores, measured once on a bounded sample and applied to both workloads (1 000 and 10 000 genomes)."""
+
+    def __init__(self, args, hashes, lens, min_ani, gpu_pairs):
+        from concurrent.futures import ThreadPoolExecutor
+
+        import oracle
+
+        self.cores = cores = os.cpu_count() or 1
+        n = hashes.shape[0]
+        self.sample = sample = min(max(args.cpu_sample_genomes, cores), n)
+        genomes = [oracle.synth_genome(args.seed, g // args.members, g % args.members, args.length, args.sub_rate)
+                   for g in range(sample)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:  # finch sketches files in parallel (rayon); ctypes drops the GIL
+            sk = list(ex.map(lambda b: oracle.sketch_bytes(b, args.kmer, args.sketch_size, 0), genomes))
+        self.t_sketch_sample = time.perf_counter() - t0
+        for i in range(sample):
+            assert np.array_equal(sk[i], hashes[i, : lens[i]]), "GPU sketch differs from the CPU oracle"
+        # pair loop: the whole matrix up to --cpu-pair-sample genomes, else its leading square block
+        self.m = m = min(n, args.cpu_pair_sample)
+        self.p_sample = m * (m - 1) // 2
+        t0 = time.perf_counter()
+        serial = oracle.distances_from_sketches(hashes[:m], lens[:m], min_ani, args.kmer, threads=1)  # src/finch.rs:75-76 is serial
+        self.t_pairs_serial = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        par = oracle.distances_from_sketches(hashes[:m], lens[:m], min_ani, args.kmer, threads=cores)
+        self.t_pairs_par = time.perf_counter() - t0
+        assert serial.tobytes() == par.tobytes()
+        self.serial_pairs = serial
+        self.check_pairs(gpu_pairs)
+        # ANI leg: sketch the sample and time a sample of candidate pairs
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            ask = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b), genomes))
+        self.t_ani_sketch_sample = time.perf_counter() - t0
+        cand = [(int(p["i"]), int(p["j"])) for p in serial if p["i"] < sample and p["j"] < sample][:64]
+        t0 = time.perf_counter()
+        for a, b in cand:
+            oracle.ani_pair(ask[a], ask[b], args.min_aligned_fraction / 100.0)
+        self.n_ani_timed = len(cand)
+        self.t_ani_pair = (time.perf_counter() - t0) / max(len(cand), 1)
+
+    def check_pairs(self, gpu_pairs):
+        """Parity on the sampled block: every precluster pair, integers and f32 bits."""
+        sub = gpu_pairs[(gpu_pairs["i"] < self.m) & (gpu_pairs["j"] < self.m)]
+        assert sub.tobytes() == self.serial_pairs.tobytes(), "GPU precluster pairs differ from the CPU oracle"
+
+    def baseline(self, n: int, n_pairs_total: int, n_cand_total: int):
+        cores = self.cores
+        scale = n / self.sample
+        pscale = n_pairs_total / max(self.p_sample, 1)
+        t_fixed = (self.t_sketch_sample + self.t_ani_sketch_sample) * scale + self.t_ani_pair * n_cand_total / cores
+        t_b1 = t_fixed + self.t_pairs_serial * pscale
+        t_b2 = t_fixed + self.t_pairs_par * pscale
+        return {
+            "value": n_pairs_total / t_b2, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle (C port of finch path, -O3, {cores} threads): MinHash-sketched {self.sample} of {n} genomes in "
+                       f"{self.t_sketch_sample:.2f}s and ANI-sketched them in {self.t_ani_sketch_sample:.2f}s (scaled x{scale:.1f}); "
+                       f"{self.p_sample}-pair loop of {self.m} genomes (scaled x{pscale:.1f} to {n_pairs_total} pairs) serial "
+                       f"{self.t_pairs_serial:.2f}s / parallel {self.t_pairs_par:.2f}s; "
+                       f"{self.n_ani_timed} ANI pairs at {self.t_ani_pair * 1e3:.2f} ms each x {n_cand_total} candidates / {cores} cores; "
+                       f"value = B2 (all stages parallel)"),
+            "b1_faithful_serial_pair_loop_value": n_pairs_total / t_b1,
+            "pair_stage_only_pairs_per_s": {"serial": self.p_sample / self.t_pairs_serial, "parallel": self.p_sample / self.t_pairs_par},
+        }
+
+
+# ------------------------------------------------------------------------------------------------ extra legs (N = 1)
+def north_star_10k(args, ctx, rates, min_ani, ani_thr, min_af):
+    """BASELINE north_star: >= 10x the CPU baseline's genome-pairs/s on 10 000 x 5 Mb at 95 % ANI on ONE MI355X.
+    Same generator, same step; 50 GB of bases resident in HBM."""
+    from galah_amd import distributed as gd
+    n_species, members = 1000, args.members
+    n = n_species * members
+    n_pairs = n * (n - 1) // 2
+    job = gd.DereplicationJob(ctx, 0, 1, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size, min_ani=min_ani,
+                              ani_threshold=ani_thr, min_af=min_af)
+    job.load_synthetic(args.seed, members, args.length, args.sub_rate)
+    job.step()  # warm-up
+    job.reset_stage_timers()
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = job.step()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    stats = ctx.kernel_stats()
+    out = {"workload": f"{n} synthetic genomes x {args.length} bp on 1 GPU ({n * args.length / 1e9:.0f} GB of bases in HBM)",
+           "genomes": n, "pairs": n_pairs, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "value": n_pairs * steps / elapsed, "unit": "genome-pairs/s",
+           "stage_ms_per_step": job.stage_ms(),
+           "kernel_avg_ms": {k: v[1] / v[0] for k, v in stats.items() if v[0]},
+           "result": {"precluster_pairs": int(res["n_pairs"]), "clusters": int(res["n_clusters"])}}
+    sk = out["kernel_avg_ms"].get("sketch_kmers")
+    if sk:
+        out["sketch_kmers_GBps"] = job.local_bases / (sk * 1e-3) / 1e9
+        out["sketch_kmers_frac_of_hbm_peak"] = out["sketch_kmers_GBps"] / HBM_PEAK_GBS
+    if rates is not None:
+        rates.check_pairs(res["pairs"])   # the leading block of the 10k run is the same genomes: same pairs, bit for bit
+        cb = rates.baseline(n, n_pairs, int(res["n_pairs"]))
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_b2"] = out["value"] / cb["value"]
+        out["target_10x_met"] = bool(out["value"] >= 10.0 * cb["value"])
+    del job
+    return out
+
+
+def _fasta_bytes(seq: np.ndarray, name: str) -> bytes:
+    pad = (-len(seq)) % 80
+    body = np.concatenate([seq, np.full(pad, ord("A"), np.uint8)]).reshape(-1, 80)
+    body = np.concatenate([body, np.full((body.shape[0], 1), ord("\n"), np.uint8)], axis=1).tobytes()
+    if pad:
+        body = body[: len(body) - pad - 1] + b"\n"
+    return f">{name} synthetic\n".encode() + body
+
+
+def wall_clock(args, ctx):
+    """BASELINE metric 2 (`galah cluster`: src/cluster_argument_parsing.rs:545-716 is files in -> clusters out): the
+    headline's 1 000 genomes written as 80-column FASTA (plain and gzip level 1), then
+    galah_amd.cluster(paths, FinchPreclusterer, HipAniClusterer) timed first-call and warm."""
+    import tempfile
+    import zlib
     from concurrent.futures import ThreadPoolExecutor
 
-    import oracle
+    import galah_amd
 
-    cores = os.cpu_count() or 1
-    sample = min(max(args.cpu_sample_genomes, cores), args.species * args.members)
-    genomes = [oracle.synth_genome(args.seed, g // args.members, g % args.members, args.length, args.sub_rate)
-               for g in range(sample)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:  # finch sketches files in parallel (rayon); ctypes drops the GIL
-        sk = list(ex.map(lambda b: oracle.sketch_bytes(b, args.kmer, args.sketch_size, 0), genomes))
-    t_sketch_sample = time.perf_counter() - t0
-    for i in range(sample):
-        assert np.array_equal(sk[i], hashes[i, : lens[i]]), "GPU sketch differs from the CPU oracle"
-    n = hashes.shape[0]
-    # pair loop: the whole matrix up to --cpu-pair-sample genomes, else its leading square block (scaled by pair count)
-    m = min(n, args.cpu_pair_sample)
-    p_sample = m * (m - 1) // 2
-    pscale = n_pairs_total / max(p_sample, 1)
-    t0 = time.perf_counter()
-    serial = oracle.distances_from_sketches(hashes[:m], lens[:m], min_ani, args.kmer, threads=1)  # src/finch.rs:75-76 is serial
-    t_pairs_serial = (time.perf_counter() - t0) * pscale
-    t0 = time.perf_counter()
-    par = oracle.distances_from_sketches(hashes[:m], lens[:m], min_ani, args.kmer, threads=cores)
-    t_pairs_par = (time.perf_counter() - t0) * pscale
-    assert serial.tobytes() == par.tobytes()
-    if gpu_pairs is not None:  # parity at full size (or on the sampled block): every precluster pair, integers and f32 bits
-        sub = gpu_pairs[(gpu_pairs["i"] < m) & (gpu_pairs["j"] < m)]
-        assert sub.tobytes() == serial.tobytes(), "GPU precluster pairs differ from the CPU oracle"
-    n_cand_total = len(gpu_pairs) if gpu_pairs is not None else int(len(serial) * pscale)
-    # ANI leg: sketch a sample and time a sample of candidate pairs
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        ask = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b), genomes))
-    t_ani_sketch_sample = time.perf_counter() - t0
-    cand = [(int(p["i"]), int(p["j"])) for p in serial if p["i"] < sample and p["j"] < sample][:64]
-    t0 = time.perf_counter()
-    for a, b in cand:
-        oracle.ani_pair(ask[a], ask[b], args.min_aligned_fraction / 100.0)
-    t_ani_pair = (time.perf_counter() - t0) / max(len(cand), 1)
-    scale = n / sample
-    t_b1 = t_sketch_sample * scale + t_pairs_serial + t_ani_sketch_sample * scale + t_ani_pair * n_cand_total / cores
-    t_b2 = t_sketch_sample * scale + t_pairs_par + t_ani_sketch_sample * scale + t_ani_pair * n_cand_total / cores
-    return {
-        "value": n_pairs_total / t_b2, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle (C port of finch path, -O3, {cores} threads): MinHash-sketched {sample} of {n} genomes in "
-                   f"{t_sketch_sample:.2f}s and ANI-sketched them in {t_ani_sketch_sample:.2f}s (scaled x{scale:.1f}); "
-                   f"{p_sample}-pair loop of {m} genomes (scaled x{pscale:.1f} to {n_pairs_total} pairs) serial "
-                   f"{t_pairs_serial:.2f}s / parallel {t_pairs_par:.2f}s; "
-                   f"{len(cand)} ANI pairs at {t_ani_pair * 1e3:.2f} ms each; value = B2 (all stages parallel)"),
-        "b1_faithful_serial_pair_loop_value": n_pairs_total / t_b1,
-        "pair_stage_only_pairs_per_s": {"serial": n_pairs_total / t_pairs_serial, "parallel": n_pairs_total / t_pairs_par},
-    }
+    n = 100 * args.members
+    need = n * (args.length + args.length // 80 + 64) * 1.4
+    base = next((d for d in ("/dev/shm", "/tmp") if os.path.isdir(d) and shutil.disk_usage(d).free > need), None)
+    if base is None:
+        return {"skipped": "no scratch directory with %.1f GB free" % (need / 1e9)}
+    d = tempfile.mkdtemp(prefix="ghip_files_", dir=base)
+    try:
+        g = ctx.genomes_synthetic(args.seed, 100, args.members, args.length, args.sub_rate)
+        t0 = time.perf_counter()
+        seqs = [g.to_host(i) for i in range(n)]   # to_host goes through the one context: serial
+        del g
+
+        def write(i):
+            data = _fasta_bytes(seqs[i], f"genome{i}")
+            p = os.path.join(d, f"g{i:05d}.fna")
+            with open(p, "wb") as f:
+                f.write(data)
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)  # gzip container, level 1
+            with open(p + ".gz", "wb") as f:
+                f.write(co.compress(data) + co.flush())
+            return p
+
+        threads = min(64, os.cpu_count() or 1)
+        with ThreadPoolExecutor(threads) as ex:
+            paths = list(ex.map(write, range(n)))
+        del seqs
+        t_write = time.perf_counter() - t0
+        gz = [p + ".gz" for p in paths]
+        out = {"workload": f"{n} FASTA files x {args.length} bp (80 columns) in {base}", "genomes": n, "io_threads": threads,
+               "files_written_s": t_write, "plain_bytes": sum(os.path.getsize(p) for p in paths),
+               "gz_bytes": sum(os.path.getsize(p) for p in gz)}
+
+        def run(ps):
+            pre = galah_amd.FinchPreclusterer(float(parse_percentage(args.precluster_ani)), args.sketch_size, args.kmer, ctx=ctx, io_threads=threads)
+            cl = galah_amd.HipAniClusterer(float(parse_percentage(args.ani)) * 100.0, float(parse_percentage(args.min_aligned_fraction)),
+                                           ctx=ctx, io_threads=threads)
+            t0 = time.perf_counter()
+            clusters = galah_amd.cluster(ps, pre, cl)
+            return time.perf_counter() - t0, clusters
+
+        t_first, c0 = run(paths)
+        t_warm, c1 = min((run(paths) for _ in range(3)), key=lambda x: x[0])
+        t_gz, c2 = min((run(gz) for _ in range(2)), key=lambda x: x[0])
+        assert c0 == c1 == c2, "clusters differ between runs / between plain and gzip input"
+        t0 = time.perf_counter()
+        gg = ctx.genomes_from_files(paths, threads)
+        t_ingest = time.perf_counter() - t0
+        gg.free()
+        out.update({"plain_first_call_s": t_first, "plain_s": t_warm, "gz_s": t_gz, "clusters": len(c0),
+                    "ingest_only_s": t_ingest, "ingest_GBps": out["plain_bytes"] / t_ingest / 1e9,
+                    "after_ingest_s": t_warm - t_ingest,
+                    "pairs_per_s_end_to_end": n * (n - 1) // 2 / t_warm,
+                    "genomes_per_s_end_to_end": n / t_warm})
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def skani_probe(ctx):
+    """if a `skani` binary is on PATH, compare the build-defined ANI with it on the fixture genomes."""
+    exe = shutil.which("skani")
+    if not exe:
+        return "absent -- ANI parity unpinned (no skani binary on this box; the estimator is build-defined, DESIGN.md section 5)"
+    try:
+        import gzip
+        import tempfile
+
+        import galah_amd
+        names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52", "antonio_MAG189",
+                 "set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16", "abisko_S2D10", "set2_1mbp", "set2_half"]
+        src = [os.path.join(ROOT, "tests", "golden", "fasta", x + ".fna.gz") for x in names]
+        d = tempfile.mkdtemp(prefix="ghip_skani_")
+        plain = []
+        for s, x in zip(src, names):
+            p = os.path.join(d, x + ".fna")
+            with gzip.open(s, "rb") as fi, open(p, "wb") as fo:
+                shutil.copyfileobj(fi, fo)
+            plain.append(p)
+        cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=4)
+        cl.prepare(plain)
+        worst, n_cmp, disagree = 0.0, 0, 0
+        for a in range(len(plain)):
+            for b in range(a + 1, len(plain)):
+                r = subprocess.run([exe, "dist", "--min-af", "15", "-q", plain[a], "-r", plain[b]], capture_output=True, text=True, timeout=120)
+                rows = [ln.split("\t") for ln in r.stdout.strip().splitlines()[1:]]
+                theirs = float(rows[0][2]) if rows else 0.0
+                ours = float(cl.calculate_ani(plain[a], plain[b]))
+                if theirs > 0 and ours > 0:
+                    worst = max(worst, abs(theirs - ours))
+                    n_cmp += 1
+                disagree += int((theirs >= 95.0) != (ours >= 95.0))
+        shutil.rmtree(d, ignore_errors=True)
+        return {"binary": exe, "pairs_both_reported": n_cmp, "max_abs_delta_ani_points": worst, "threshold_95_disagreements": disagree}
+    except Exception as e:  # a probe must never fail the bench
+        return f"present at {exe} but the probe failed: {e!r}"
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     import torch
 
@@ -165,9 +367,19 @@ def main():
             dist.init_process_group(backend)
     ctx = galah_amd.Context(device)
 
-    if not args.strong:
-        args.species *= world   # weak scaling: every rank brings --species species of its own
-    n = args.species * args.members
+    # ---- workload shape
+    if args.total_genomes is not None:
+        n = args.total_genomes
+        assert n % args.members == 0, "--total-genomes must be a multiple of --members"
+        scaling = "strong"
+    elif args.strong:
+        n = (args.species or 100) * args.members
+        scaling = "strong"
+    else:
+        per_gpu = args.species * args.members if args.species else (GENOMES_PER_GPU_1 if world == 1 else GENOMES_PER_GPU_N)
+        n = per_gpu * world
+        scaling = "weak"
+    n_species = n // args.members
     n_pairs_total = n * (n - 1) // 2
     min_ani = parse_percentage(args.precluster_ani)           # fraction (finch.rs:5-6)
     ani_thr = np.float32(parse_percentage(args.ani) * np.float32(100.0))  # percent (cluster_argument_parsing.rs:1328)
@@ -202,12 +414,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
+    stage_ms = job.stage_ms()
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        per_rank = [None] * world   # per-rank stage times and kernel averages (outside the timed region)
+        dist.all_gather_object(per_rank, {"rank": rank, "device": device, "genomes": job.count, "stage_ms": stage_ms,
+                                          "kernel_avg_ms": {k: v[1] / v[0] for k, v in ctx.kernel_stats().items() if v[0]}})
     stats = ctx.kernel_stats()
-    stage_ms = job.stage_ms()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -216,8 +432,8 @@ def main():
         alg = {  # ALGORITHMIC bytes per launch on THIS rank (DESIGN.md "Kernels")
             "sketch_kmers": float(job.local_bases),                              # 1 B per input base
             "pair_intersect_tile": 16.0 * args.sketch_size * job.last_pairs_compared,  # 2*s*8 B per pair
-            # the inverted-index form covers ALL pairs of the gathered matrix in one launch (on every rank when N > 1)
-            "pair_join": 16.0 * args.sketch_size * n_pairs_total,
+            # the inverted-index form covers the pairs of the gathered matrix that fall to this rank
+            "pair_join": 16.0 * args.sketch_size * max(job.last_pairs_compared, 1),
             "ani_seeds": float(job.local_bases),
         }
         kern = {}
@@ -235,46 +451,70 @@ def main():
                 kern[k] = e
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
         traffic, traffic_tag, valu = pmc_traffic(dom) if world == 1 else (None, None, None)
+        issue_roof = None
+        if dom == "sketch_kmers":
+            # the kernel's own roof, MEASURED in this run: the filter form of MurmurHash3_x64_128 (the 47 instructions of
+            # murmur21_asm.h that cannot be tabulated) issued for as many wave-positions as one launch hashes, on all
+            # SIMDs, nothing else in the loop (ghip_selftest_hash_floor)
+            floor_ms = ctx.hash_floor_ms(int(alg[dom]) // 64)
+            issue_roof = {"what": "MurmurHash3 filter instructions alone for the launch's wave-positions, measured in this run",
+                          "floor_ms_per_launch": floor_ms, "frac": floor_ms / kern[dom]["avg_ms"]}
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
                     "traffic_unit": ("bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag
                                      if traffic is not None else "PMC passes are collected for the 1-GPU run only"),
                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "valu": valu,  # SQ_INSTS_VALU per launch and SIMD-cycles per VALU instruction, same PMC file
-                    # the kernel's own roof: the filter form of MurmurHash3_x64_128 of every 21-mer is 47 instructions that
-                    # cannot be tabulated, measured in isolation at 218 SIMD-cycles per wave-position (scripts/ubench/int_ops.hip
-                    # "filter_block", independent of occupancy); 1024 SIMDs at the 2.3 GHz the PMC pass shows
-                    "issue_roof": ({"hash_cycles_per_wave_position": HASH_CYCLES, "simds": 1024, "clock_ghz": 2.3,
-                                    "floor_ms_per_launch": alg[dom] / 64.0 * HASH_CYCLES / (1024 * 2.3e9) * 1e3,
-                                    "frac": (alg[dom] / 64.0 * HASH_CYCLES / (1024 * 2.3e9) * 1e3) / kern[dom]["avg_ms"]}
-                                   if dom == "sketch_kmers" else None),
-                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is 47 of its ~94 "
+                    "issue_roof": issue_roof,
+                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is about half of its "
                              "VALU instructions per base (DESIGN.md); the HBM fraction is reported because the tier "
                              "asks for it.  The pair kernel (pair_intersect_tile, or pair_join from 1200 genomes) is "
                              "the HBM-roofline kernel of the path: see 'kernels' for its achieved GB/s (algorithmic "
                              "2*s*8 B per pair; above the HBM peak because tiles are reused from LDS / the join never "
                              "touches non-sharing pairs)")}
+        gather_bytes = n * (args.sketch_size * 8 + 4)
         out = {
             "metric": "genome-pairs/sec (MinHash+ANI)", "value": value, "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"{n} synthetic genomes x {args.length} bp ({args.species} species x {args.members} "
+            "config": {"workload": f"{n} synthetic genomes x {args.length} bp ({n_species} species x {args.members} "
                                    f"members, ~95% ANI), finch precluster s={args.sketch_size} k={args.kmer} at "
-                                   f"{args.precluster_ani}% + ANI at {args.ani}%, greedy clustering",
+                                   f"{args.precluster_ani}% + ANI at {args.ani}%, greedy clustering"
+                                   + (" = BASELINE configs[1]" if (n, world) == (1000, 1) else "")
+                                   + (" = BASELINE configs[2]" if (n, world) == (10000, 8) else ""),
                        "genomes": n, "genomes_per_gpu": n // world, "genome_length": args.length, "pairs": n_pairs_total,
                        "parallelism": (f"genomes sharded x{world}: sketch + ANI where a genome lives, sketch matrix "
-                                       f"all-gathered, pair stage on the gathered matrix (join form replicated, "
-                                       f"dense forms dealt by tile)") if world > 1 else "single"},
+                                       f"all-gathered ({gather_bytes / 1e6:.1f} MB), pair stage on the gathered matrix "
+                                       f"dealt over the ranks, candidate lists and ANI values all-gathered") if world > 1 else "single",
+                       "backend": backend if world > 1 else None},
             "genomes_per_s": n * args.steps / elapsed,
             "roofline": roofline,
             "kernels": kern,
             "stage_ms_per_step": stage_ms,
             "result": {"precluster_pairs": int(result["n_pairs"]), "clusters": int(result["n_clusters"])},
         }
+        if world > 1:
+            out["allgather_sketches"] = {"bytes": gather_bytes, "ms": stage_ms.get("allgather_sketches"),
+                                         "GBps": gather_bytes / max(stage_ms.get("allgather_sketches", 0.0) * 1e-3, 1e-9) / 1e9}
+            out["per_rank"] = per_rank
+        rates = None
         if not args.no_cpu_baseline and world == 1:
             hashes, lens = job.sketches_to_host()
-            out["cpu_baseline"] = cpu_baseline(args, hashes, lens, n_pairs_total, min_ani, result["pairs"])
+            rates = CpuRates(args, hashes, lens, min_ani, result["pairs"])
+            out["cpu_baseline"] = rates.baseline(n, n_pairs_total, len(result["pairs"]))
+        if world == 1 and not args.no_extras:
+            del job, result
+            gc.unfreeze()
+            gc.collect()
+            for name, fn in (("north_star_10k", lambda: north_star_10k(args, ctx, rates, min_ani, ani_thr, min_af)),
+                             ("wall_clock", lambda: wall_clock(args, ctx)), ("skani", lambda: skani_probe(ctx))):
+                try:
+                    out[name] = fn()
+                except AssertionError:
+                    raise   # a parity failure is a failure of the bench
+                except Exception as e:  # an extra leg (e.g. no room for 50 GB) must not cost the headline
+                    out[name] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ghip_profile_enable": (_int, [_vp, _int]),
     "ghip_profile_reset": (_int, [_vp]),
     "ghip_kernel_stats": (_int, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "ghip_selftest_hash_floor": (_int, [_vp, _u64, C.POINTER(C.c_double)]),
     "ghip_genomes_from_files": (_int, [_vp, C.POINTER(C.c_char_p), _sz, _int, _pp]),
     "ghip_genomes_from_host": (_int, [_vp, _vp, _vp, _sz, _pp]),
     "ghip_genomes_synthetic": (_int, [_vp, _u64, _u32, _u32, _u64, C.c_double, _pp]),

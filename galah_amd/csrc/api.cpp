@@ -332,6 +332,13 @@ extern "C" int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *la
     return GHIP_OK;
 }
 
+extern "C" int ghip_selftest_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *out_ms) {
+    if (!ctx || !out_ms || wave_positions == 0) return GHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return ghip_launch_hash_floor(ctx, wave_positions, out_ms);
+}
+
 extern "C" void ghip_free(void *p) { free(p); }
 
 // ------------------------------------------------------------------------------------ genomes

@@ -151,6 +151,7 @@ struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the 
 };
 
 void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes);
+int ghip_launch_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *ms);
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,
                               const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,

@@ -541,7 +541,43 @@ __global__ __launch_bounds__(256) void sanitize_bases_kernel(uint4 *__restrict__
     }
 }
 
+// The sketch pass's own roof, measurable on any box: nothing but the filter form of MurmurHash3_x64_128 (the 47
+// instructions that cannot be tabulated, murmur21_asm.h), `iters` dependent evaluations per wave, 8 waves per SIMD.
+__global__ __launch_bounds__(256) void hash_floor_kernel(uint32_t *__restrict__ out, uint32_t iters, uint32_t seed) {
+    uint32_t a0 = seed + threadIdx.x, a1 = seed * 3u + blockIdx.x, b0 = a0 ^ 0x1234567u, b1 = a1 + 99u, t0 = a0 * 7u, t1 = a1 * 11u;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < iters; i++) {
+        uint64_t A, B;
+        const uint32_t s1 = murmur21_filter<true>(a0, a1, b0, b1, t0, t1, 0, A, B);
+        acc += s1; a0 = (uint32_t)A; a1 ^= (uint32_t)B;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 }  // namespace
+
+// Runs the hash-only kernel for `wave_positions` wave-level hash evaluations spread over every SIMD; *ms = its duration.
+int ghip_launch_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *ms) {
+    const unsigned blocks = (unsigned)ctx->num_cus * 8u;   // 256 threads = 4 waves: 8 waves per SIMD
+    const uint64_t waves = (uint64_t)blocks * 4u;
+    const uint32_t iters = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(wave_positions / waves, 1), 1u << 30);
+    uint32_t *d_out = (uint32_t *)ghip_pool_alloc(ctx, (size_t)blocks * 256 * sizeof(uint32_t));
+    if (!d_out) return GHIP_EHIP;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(hash_floor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_out, std::min(iters, 1000u), 1u);  // warm-up
+    hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(hash_floor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters, 2u);
+    hipEventRecord(e1, ctx->stream);
+    float t = 0.f;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    ghip_pool_free(ctx, d_out);
+    if (!ok) return ghip_set_error(ctx, GHIP_EHIP, "hash_floor kernel failed");
+    // scale to exactly wave_positions (iters was rounded down to a whole number per wave)
+    *ms = (double)t * (double)wave_positions / ((double)iters * (double)waves);
+    return GHIP_OK;
+}
 
 void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
                        uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr) {

@@ -170,6 +170,12 @@ class Context:
             out[k] = (int(n.value), float(ms.value))
         return out
 
+    def hash_floor_ms(self, wave_positions: int) -> float:
+        """Duration of the MurmurHash3 filter instructions alone for `wave_positions` wave-level evaluations."""
+        ms = C.c_double(0)
+        check(_lib.lib().ghip_selftest_hash_floor(self._h, wave_positions, C.byref(ms)), self._h)
+        return float(ms.value)
+
     # ---- ingest
     def genomes_from_files(self, paths: Sequence[str], io_threads: int = 1) -> Genomes:
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])

@@ -70,6 +70,11 @@ int ghip_profile_enable(ghip_ctx *ctx, int enable);
 int ghip_profile_reset(ghip_ctx *ctx);
 int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
 
+/* Measures the sketch pass's own roof on this device: the MurmurHash3_x64_128 filter instructions alone (no bases, no
+ * tables, no selection), issued for `wave_positions` wave-level evaluations on all SIMDs; *out_ms = kernel duration.
+ * bench.py reports sketch_kmers against it (bases per launch / 64 wave-positions). */
+int ghip_selftest_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *out_ms);
+
 /* ---------------------------------------------------------------- genome ingest
  * Device format of one genome: stream G = for each FASTA record, needletail-normalised bytes
  * followed by one 'N' (k-mers never span records, src/finch.rs:69 -> finch sketch_stream).
