@@ -353,18 +353,17 @@ def main():
     import galah_amd
     from galah_amd import distributed as gd
 
-    # one rank per GPU over RCCL ("nccl").  GHIP_BENCH_BACKEND=gloo lets several ranks share the GPUs of a smaller box
-    # (device = local_rank mod #GPUs, tensors staged through the host): a functional check of this script's N > 1
-    # path, not a measurement.
-    backend = os.environ.get("GHIP_BENCH_BACKEND", "nccl")
+    # One rank per GPU.  torch.distributed is the control plane only (rendezvous, barrier, the timing reduction, the
+    # 128-byte RCCL id) and runs on gloo; the data plane is the library's own RCCL communicator (ncclAllGather over xGMI,
+    # galah_amd/csrc/comm.cpp).  GHIP_BENCH_BACKEND=gloo swaps the data plane for the library's host-callback transport so
+    # that several ranks can share the GPUs of a smaller box (device = local_rank mod #GPUs): a functional check of this
+    # script's N > 1 path, not a measurement.
+    backend = os.environ.get("GHIP_BENCH_BACKEND", "rccl")
     device = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
     ctx = galah_amd.Context(device)
 
     # ---- workload shape
@@ -386,7 +385,8 @@ def main():
     min_af = float(parse_percentage(args.min_aligned_fraction))
 
     job = gd.DereplicationJob(ctx, rank, world, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size,
-                              min_ani=min_ani, ani_threshold=ani_thr, min_af=min_af)
+                              min_ani=min_ani, ani_threshold=ani_thr, min_af=min_af, backend=backend)
+    transport = job.comm.transport
     job.load_synthetic(args.seed, args.members, args.length, args.sub_rate)  # untimed: inputs resident in HBM
 
     def barrier():
@@ -417,7 +417,7 @@ def main():
     stage_ms = job.stage_ms()
     per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         per_rank = [None] * world   # per-rank stage times and kernel averages (outside the timed region)
@@ -487,7 +487,7 @@ def main():
                        "parallelism": (f"genomes sharded x{world}: sketch + ANI where a genome lives, sketch matrix "
                                        f"all-gathered ({gather_bytes / 1e6:.1f} MB), pair stage on the gathered matrix "
                                        f"dealt over the ranks, candidate lists and ANI values all-gathered") if world > 1 else "single",
-                       "backend": backend if world > 1 else None},
+                       "transport": transport},
             "genomes_per_s": n * args.steps / elapsed,
             "roofline": roofline,
             "kernels": kern,

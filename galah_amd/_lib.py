@@ -79,10 +79,37 @@ SIGNATURES = {
     "ghip_ani_index_layout": (_int, [_vp, _vp]),
     "ghip_ani_index_meta": (_int, [_vp, _vp, _vp, _vp]),
     "ghip_ani_index_wrap_device": (_int, [_vp, _sz, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp]),
+    "ghip_comm_unique_id": (_int, [_vp]),
+    "ghip_comm_init_rank": (_int, [_vp, _u32, _u32, _vp, _pp]),
+    "ghip_comm_init_local": (_int, [_pp, _u32, _pp]),
+    "ghip_comm_init_callback": (_int, [_vp, _u32, _u32, _vp, _vp, _pp]),
+    "ghip_comm_destroy": (None, [_vp]),
+    "ghip_comm_rank": (_u32, [_vp]),
+    "ghip_comm_world": (_u32, [_vp]),
+    "ghip_comm_transport": (C.c_char_p, [_vp]),
+    "ghip_comm_last_error": (C.c_char_p, [_vp]),
+    "ghip_comm_allgather_device": (_int, [_vp, _vp, _vp, _sz]),
+    "ghip_comm_allgather_host": (_int, [_vp, _vp, _sz, _vp]),
+    "ghip_shard_range": (None, [_sz, _u32, _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    "ghip_allgather_sketches": (_int, [_vp, _vp, _sz, _pp]),
+    "ghip_allgather_pairs": (_int, [_vp, _vp, _sz, _pp, C.POINTER(_sz)]),
+    "ghip_exchange_ani_index": (_int, [_vp, _vp, _sz, _vp, _sz, _pp, _vp]),
+    "ghip_distances_and_ani_ranks": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _f32, _u32, _u32, _u32, _f32, _pp, _pp,
+                                            C.POINTER(_sz), _pp, _vp]),
+    "ghip_cluster_files_multi": (_int, [_pp, _u32, C.POINTER(C.c_char_p), _sz, _u32, _u32, _f32, _f32, _f32, _u32, _int, _pp, _pp,
+                                        C.POINTER(_sz)]),
     "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
     "ghip_free": (None, [_vp]),
 }
 
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class RankTimes(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("sketch_ms", "allgather_sketches_ms", "pairs_ms", "allgather_pairs_ms",
+                                          "exchange_ani_index_ms", "ani_pairs_ms", "gather_ani_ms")] + [("pairs_compared", C.c_uint64)]
 
 
 class AniLayout(C.Structure):

@@ -917,6 +917,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     if ((rc = dmalloc(ctx, &d_count, 1))) return rc;
     tmp.add(d_count);
     std::vector<ghip_pair> host;
+    bool filter_share = false;  // dense pass over ALL pairs, this rank's (i + j) mod world share picked on the host
     bool listed = false;  // an attempt whose candidate list held every hit
     for (int attempt = 0; attempt < 4 && !listed; attempt++) {
         ghip_pair *d_out = nullptr;
@@ -924,14 +925,20 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         DeviceFree t2(ctx); t2.add(d_out);
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         uint64_t compared = 0;
-        bool joined = false;
-        if (want_join && (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
-                                               replicate_join ? 0 : rank, replicate_join ? 1 : world,
-                                               d_out, d_count, cap, &compared, &joined))) return rc;
+        bool joined = false, late = false;
+        if (want_join && !filter_share &&
+            (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
+                                  replicate_join ? 0 : rank, replicate_join ? 1 : world,
+                                  d_out, d_count, cap, &compared, &joined, &late))) return rc;
         if (joined && replicate_join) {  // every rank holds every pair; book an equal share of the comparisons
             compared = P / world + (rank < P % world ? 1 : 0);
             if (out_replicated) *out_replicated = 1;
         }
+        // The sharded join declined AFTER the point where all ranks decide alike (this rank's own records overflowed a
+        // table): the other ranks deliver their (i + j) mod world shares, so this one must deliver exactly its own --
+        // a dense pass over every pair, filtered on the host below.
+        if (late && world > 1 && !replicate_join) filter_share = true;
+        const uint32_t drank = filter_share ? 0 : rank, dworld = filter_share ? 1 : world;
         if (!joined && use_probe && !probe_checked) {
             if ((rc = prepare_probe(ctx, sk))) return rc;
             use_probe = sk->probe_flags == 0;
@@ -940,10 +947,10 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if (joined) {
         } else if (use_probe) {
             ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, n, s, sk->probe_cb, sk->d_row_start,
-                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, rank, world, d_out, d_count, cap);
-            compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, rank, world);
+                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, d_out, d_count, cap);
+            compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, drank, dworld);
         } else {
-            ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, rank, world, d_out, d_count, cap, &compared);
+            ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, drank, dworld, d_out, d_count, cap, &compared);
         }
         ctx->last_pairs = compared;
         unsigned long long cnt = 0;
@@ -960,6 +967,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     // host cost more than that -- measured 4.7 -> 6.6 ms for the stage at 10 000 genomes)
     size_t m = 0;
     for (size_t i = 0; i < host.size(); i++) {
+        if (filter_share && (host[i].i + host[i].j) % world != rank) continue;
         const double ani = finch_ani(host[i].common, host[i].total, k);
         if (ani >= thr) { host[i].ani = (float)ani; host[m++] = host[i]; }
     }
@@ -990,7 +998,12 @@ extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, flo
 extern "C" int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
                                      uint32_t world, ghip_pair **out_pairs, size_t *out_n, int *out_replicated) {
     if (!out_replicated) return GHIP_EINVAL;
-    return precluster_impl(ctx, sk, min_ani, rank, world, world > 1, out_pairs, out_n, out_replicated);
+    // Default: the pair work is SHARDED -- dense forms by tile, the join form by (i + j) mod world at record emission
+    // (its element stage, one pass over all N*s hashes, runs on every rank).  GHIP_JOIN_RANKS=replicate makes every
+    // rank run the whole join and keep the whole list instead (no candidate exchange; DESIGN.md section 6 has both timings).
+    const char *mode = getenv("GHIP_JOIN_RANKS");
+    const bool replicate = world > 1 && mode && !strcmp(mode, "replicate");
+    return precluster_impl(ctx, sk, min_ani, rank, world, replicate, out_pairs, out_n, out_replicated);
 }
 
 extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, ghip_pair **out_pairs, size_t *out_n) {

@@ -1,0 +1,637 @@
+// Multi-GPU exchange behind the C ABI (include/galah_hip.h "multi-GPU"): the two real exchange steps of the path --
+// all-gather of the packed sketch matrix, gather of candidate lists / ANI index slices / ANI values -- over one of
+// three transports that share every line of the logic above the two primitives (all-gather of device bytes, all-gather
+// of host bytes):
+//   RCCL      one process per GPU: ncclAllGather over xGMI on the context's stream.  librccl is bound at run time
+//             (dlopen), so the library loads on hosts without it and shares the copy a host such as PyTorch mapped.
+//   LOCAL     one process, one context (and one thread) per GPU -- how a single-process host like galah's CLI drives
+//             8 devices: every rank pulls its peers' blocks with hipMemcpyPeerAsync (xGMI peer copies).
+//   CALLBACK  the host supplies an all-gather of host bytes (MPI, gloo, a test harness); device payloads are staged
+//             through host memory.  The functional fallback, and what the CPU tests drive.
+// Reference: the finch path has no multi-process form (src/finch.rs:74-96 is one serial loop); this is the sharding
+// SURVEY.md section 8(e) specifies: genomes in contiguous blocks, full sketch matrix everywhere, pair work dealt over
+// the ranks, a pair's ANI computed where its first genome lives.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <thread>
+
+#include "ghip_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- RCCL, bound lazily
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+
+Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.handle) break;
+        }
+        if (!x.handle) { x.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return x; }
+        x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
+        x.AllGather = (decltype(x.AllGather))dlsym(x.handle, "ncclAllGather");
+        x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
+        x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
+        if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.CommDestroy || !x.GetErrorString) x.err = "librccl lacks an expected symbol";
+        return x;
+    }();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- LOCAL transport state
+struct LocalGroup {
+    uint32_t world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> slot;   // what each rank published for the collective in flight
+    std::vector<int> device;
+    std::atomic<int> refs{0};
+    std::atomic<int> failed{0};       // a rank hit an error: every later barrier returns it instead of waiting for ever
+
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen || failed.load(); });
+        return failed.load() == 0;
+    }
+    void fail() { failed = 1; std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+};
+
+enum Transport { T_SELF = 0, T_RCCL = 1, T_LOCAL = 2, T_CALLBACK = 3 };
+
+}  // namespace
+
+struct ghip_comm {
+    ghip_ctx *ctx = nullptr;   // may be NULL for a CALLBACK communicator used for host payloads only
+    uint32_t rank = 0, world = 1;
+    Transport transport = T_SELF;
+    ncclComm_t nccl = nullptr;
+    LocalGroup *group = nullptr;
+    ghip_allgather_fn fn = nullptr;
+    void *user = nullptr;
+    std::string err;
+};
+
+namespace {
+
+int cerr_(ghip_comm *c, int code, const std::string &msg) {
+    c->err = msg;
+    if (c->ctx) ghip_set_error(c->ctx, code, msg);
+    if (c->group) c->group->fail();
+    return code;
+}
+
+struct PoolBuf {  // device scratch from the context's pool
+    ghip_ctx *ctx;
+    void *p = nullptr;
+    PoolBuf(ghip_ctx *c, size_t bytes) : ctx(c) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipSetDevice(ctx->device);
+        p = ghip_pool_alloc(ctx, std::max<size_t>(bytes, 16));
+    }
+    ~PoolBuf() {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipStreamSynchronize(ctx->stream);
+        ghip_pool_free(ctx, p);
+    }
+    void *release() { void *q = p; p = nullptr; return q; }
+};
+
+#define COMM_HIP(c, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return cerr_((c), GHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// every rank contributes `bytes` from d_send; d_recv (world * bytes) receives the blocks in rank order
+int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t bytes) {
+    if (bytes == 0) return GHIP_OK;
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return cerr_(c, GHIP_EINVAL, "this communicator has no device context");
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    switch (c->transport) {
+    case T_SELF:
+        COMM_HIP(c, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return GHIP_OK;
+    case T_RCCL: {
+        ncclResult_t r = rccl().AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream);
+        if (r != ncclSuccess) return cerr_(c, GHIP_EHIP, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        return GHIP_OK;
+    }
+    case T_LOCAL: {
+        LocalGroup *g = c->group;
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));   // my block is written before anyone reads it
+        g->slot[c->rank] = d_send;
+        if (!g->barrier()) return cerr_(c, GHIP_EHIP, "a peer rank failed");
+        for (uint32_t r = 0; r < c->world; r++)           // pull: own block first is as good as any order
+            COMM_HIP(c, hipMemcpyPeerAsync((char *)d_recv + (size_t)r * bytes, ctx->device, g->slot[r], g->device[r], bytes, ctx->stream));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        if (!g->barrier()) return cerr_(c, GHIP_EHIP, "a peer rank failed");   // peers are done reading my block
+        return GHIP_OK;
+    }
+    case T_CALLBACK: {
+        std::vector<uint8_t> hs(bytes), hr(bytes * c->world);
+        COMM_HIP(c, hipMemcpyAsync(hs.data(), d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        if (c->fn(c->user, hs.data(), bytes, hr.data()) != 0) return cerr_(c, GHIP_ECALLBACK, "the host all-gather callback failed");
+        COMM_HIP(c, hipMemcpyAsync(d_recv, hr.data(), hr.size(), hipMemcpyHostToDevice, ctx->stream));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        return GHIP_OK;
+    }
+    }
+    return GHIP_EINVAL;
+}
+
+int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv) {
+    if (bytes == 0) return GHIP_OK;
+    switch (c->transport) {
+    case T_SELF: memcpy(recv, send, bytes); return GHIP_OK;
+    case T_CALLBACK:
+        if (c->fn(c->user, send, bytes, recv) != 0) return cerr_(c, GHIP_ECALLBACK, "the host all-gather callback failed");
+        return GHIP_OK;
+    case T_LOCAL: {
+        LocalGroup *g = c->group;
+        g->slot[c->rank] = send;
+        if (!g->barrier()) return cerr_(c, GHIP_EHIP, "a peer rank failed");
+        for (uint32_t r = 0; r < c->world; r++) memcpy((char *)recv + (size_t)r * bytes, g->slot[r], bytes);
+        if (!g->barrier()) return cerr_(c, GHIP_EHIP, "a peer rank failed");
+        return GHIP_OK;
+    }
+    case T_RCCL: {  // small host payloads ride the same collective through two pool buffers
+        ghip_ctx *ctx = c->ctx;
+        const size_t padded = (bytes + 15) / 16 * 16;
+        PoolBuf ds(ctx, padded), dr(ctx, padded * c->world);
+        if (!ds.p || !dr.p) return cerr_(c, GHIP_EHIP, "out of device memory for a host collective");
+        std::vector<uint8_t> hr(padded * c->world);
+        COMM_HIP(c, hipSetDevice(ctx->device));
+        COMM_HIP(c, hipMemcpyAsync(ds.p, send, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = allgather_device(c, ds.p, dr.p, padded);
+        if (rc) return rc;
+        COMM_HIP(c, hipMemcpyAsync(hr.data(), dr.p, hr.size(), hipMemcpyDeviceToHost, ctx->stream));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        for (uint32_t r = 0; r < c->world; r++) memcpy((char *)recv + (size_t)r * bytes, hr.data() + (size_t)r * padded, bytes);
+        return GHIP_OK;
+    }
+    }
+    return GHIP_EINVAL;
+}
+
+// variable-length host all-gather: sizes first, then blocks padded to the largest
+int allgatherv_host(ghip_comm *c, const void *send, size_t bytes, std::vector<uint8_t> &out, std::vector<uint64_t> &sizes) {
+    sizes.assign(c->world, 0);
+    const uint64_t mine = bytes;
+    int rc = allgather_host(c, &mine, sizeof(mine), sizes.data());
+    if (rc) return rc;
+    const uint64_t m = *std::max_element(sizes.begin(), sizes.end());
+    uint64_t total = 0;
+    for (uint64_t s : sizes) total += s;
+    out.resize(total);
+    if (m == 0) return GHIP_OK;
+    std::vector<uint8_t> sp(m, 0), rp(m * c->world);
+    if (bytes) memcpy(sp.data(), send, bytes);
+    if ((rc = allgather_host(c, sp.data(), m, rp.data()))) return rc;
+    uint64_t at = 0;
+    for (uint32_t r = 0; r < c->world; r++) { if (sizes[r]) memcpy(out.data() + at, rp.data() + (size_t)r * m, sizes[r]); at += sizes[r]; }
+    return GHIP_OK;
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" int ghip_comm_unique_id(uint8_t id[GHIP_UNIQUE_ID_BYTES]) {
+    if (!id) return GHIP_EINVAL;
+    static_assert(GHIP_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    if (!rccl().err.empty()) return ghip_set_error(nullptr, GHIP_EUNSUPPORTED, rccl().err);
+    ncclUniqueId u;
+    ncclResult_t r = rccl().GetUniqueId(&u);
+    if (r != ncclSuccess) return ghip_set_error(nullptr, GHIP_EHIP, std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r));
+    memcpy(id, u.internal, GHIP_UNIQUE_ID_BYTES);
+    return GHIP_OK;
+}
+
+extern "C" int ghip_comm_init_rank(ghip_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t id[GHIP_UNIQUE_ID_BYTES], ghip_comm **out) {
+    if (!ctx || !out || world == 0 || rank >= world || !id) return GHIP_EINVAL;
+    *out = nullptr;
+    if (!rccl().err.empty()) return ghip_set_error(ctx, GHIP_EUNSUPPORTED, rccl().err);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, GHIP_UNIQUE_ID_BYTES);
+    ncclComm_t nc = nullptr;
+    ncclResult_t r = rccl().CommInitRank(&nc, (int)world, u, (int)rank);
+    if (r != ncclSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    ghip_comm *c = new ghip_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->transport = T_RCCL; c->nccl = nc;
+    *out = c;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_comm_init_local(ghip_ctx *const *ctxs, uint32_t world, ghip_comm **out_comms) {
+    if (!ctxs || !out_comms || world == 0) return GHIP_EINVAL;
+    for (uint32_t r = 0; r < world; r++) if (!ctxs[r]) return GHIP_EINVAL;
+    LocalGroup *g = new LocalGroup();
+    g->world = world;
+    g->slot.assign(world, nullptr);
+    g->device.resize(world);
+    for (uint32_t r = 0; r < world; r++) g->device[r] = ctxs[r]->device;
+    for (uint32_t r = 0; r < world; r++) {   // direct xGMI reads of the peers' HBM (best effort: staged copies work without it)
+        if (hipSetDevice(ctxs[r]->device) != hipSuccess) continue;
+        for (uint32_t q = 0; q < world; q++)
+            if (g->device[q] != g->device[r]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, g->device[r], g->device[q]) == hipSuccess && can) {
+                    hipError_t e = hipDeviceEnablePeerAccess(g->device[q], 0);
+                    if (e != hipSuccess) (void)hipGetLastError();   // already enabled
+                }
+            }
+    }
+    for (uint32_t r = 0; r < world; r++) {
+        ghip_comm *c = new ghip_comm();
+        c->ctx = ctxs[r]; c->rank = r; c->world = world; c->transport = world == 1 ? T_SELF : T_LOCAL; c->group = g;
+        g->refs++;
+        out_comms[r] = c;
+    }
+    return GHIP_OK;
+}
+
+extern "C" int ghip_comm_init_callback(ghip_ctx *ctx, uint32_t rank, uint32_t world, ghip_allgather_fn fn, void *user, ghip_comm **out) {
+    if (!out || world == 0 || rank >= world || (world > 1 && !fn)) return GHIP_EINVAL;
+    ghip_comm *c = new ghip_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->transport = world == 1 ? T_SELF : T_CALLBACK; c->fn = fn; c->user = user;
+    *out = c;
+    return GHIP_OK;
+}
+
+extern "C" void ghip_comm_destroy(ghip_comm *c) {
+    if (!c) return;
+    if (c->nccl) rccl().CommDestroy(c->nccl);
+    if (c->group && --c->group->refs == 0) delete c->group;
+    delete c;
+}
+
+extern "C" uint32_t ghip_comm_rank(const ghip_comm *c) { return c ? c->rank : 0; }
+extern "C" uint32_t ghip_comm_world(const ghip_comm *c) { return c ? c->world : 0; }
+extern "C" const char *ghip_comm_transport(const ghip_comm *c) {
+    if (!c) return "";
+    switch (c->transport) { case T_SELF: return "self"; case T_RCCL: return "rccl"; case T_LOCAL: return "local-peer-copy"; case T_CALLBACK: return "host-callback"; }
+    return "";
+}
+extern "C" const char *ghip_comm_last_error(const ghip_comm *c) { return c ? c->err.c_str() : ""; }
+
+extern "C" int ghip_comm_allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank) {
+    if (!c || (bytes_per_rank && (!d_send || !d_recv))) return GHIP_EINVAL;
+    return allgather_device(c, d_send, d_recv, bytes_per_rank);
+}
+
+extern "C" int ghip_comm_allgather_host(ghip_comm *c, const void *send, size_t bytes_per_rank, void *recv) {
+    if (!c || (bytes_per_rank && (!send || !recv))) return GHIP_EINVAL;
+    return allgather_host(c, send, bytes_per_rank, recv);
+}
+
+// ------------------------------------------------------------------------------------------------ sharding rules
+extern "C" void ghip_shard_range(size_t n_total, uint32_t rank, uint32_t world, size_t *first, size_t *count, size_t *block) {
+    const size_t b = world ? (n_total + world - 1) / world : n_total;
+    const size_t f = std::min(n_total, (size_t)rank * b);
+    if (first) *first = f;
+    if (count) *count = std::min(b, n_total - f);
+    if (block) *block = b;
+}
+
+// ------------------------------------------------------------------------------------------------ sketch matrix
+// The one bulk exchange of the path: N*s*8 bytes, once.  Every rank contributes `block` rows (its count
+// rows, the rest padding), every rank ends with the matrix of all n_total genomes.
+extern "C" int ghip_allgather_sketches(ghip_comm *c, const ghip_sketches *local, size_t n_total, ghip_sketches **out_full) {
+    if (!c || !local || !out_full) return GHIP_EINVAL;
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return GHIP_EINVAL;
+    size_t first, count, block;
+    ghip_shard_range(n_total, c->rank, c->world, &first, &count, &block);
+    if (local->n != count) return cerr_(c, GHIP_EINVAL, "local sketch count does not match this rank's block");
+    const uint32_t s = local->s;
+    const size_t rows = block * c->world;
+    PoolBuf sendh(ctx, block * (size_t)s * 8), sendl(ctx, block * 4), recvh(ctx, rows * (size_t)s * 8), recvl(ctx, rows * 4);
+    if (!sendh.p || !sendl.p || !recvh.p || !recvl.p) return cerr_(c, GHIP_EHIP, "out of device memory for the sketch all-gather");
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    if (count < block) {  // padding rows: empty sketches (never read: the matrix is cut at n_total)
+        COMM_HIP(c, hipMemsetAsync((char *)sendh.p + count * (size_t)s * 8, 0xff, (block - count) * (size_t)s * 8, ctx->stream));
+        COMM_HIP(c, hipMemsetAsync((char *)sendl.p + count * 4, 0, (block - count) * 4, ctx->stream));
+    }
+    int rc = count ? ghip_sketches_copy_into(ctx, local, sendh.p, sendl.p) : GHIP_OK;
+    if (rc) return rc;
+    if ((rc = allgather_device(c, sendh.p, recvh.p, block * (size_t)s * 8))) return rc;
+    if ((rc = allgather_device(c, sendl.p, recvl.p, block * 4))) return rc;
+    ghip_sketches *full = nullptr;
+    if ((rc = ghip_sketches_wrap_device(ctx, recvh.p, recvl.p, n_total, s, local->k, &full))) return rc;
+    full->owned = true;   // the handle now owns the two gather buffers (pool blocks)
+    recvh.release(); recvl.release();
+    *out_full = full;
+    return GHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ candidate lists
+// Every rank holds a share sorted by (i, j); all end with the whole list in (i, j) order (k-way merge of the runs).
+extern "C" int ghip_allgather_pairs(ghip_comm *c, const ghip_pair *local, size_t n_local, ghip_pair **out_all, size_t *out_n) {
+    if (!c || !out_all || !out_n || (n_local && !local)) return GHIP_EINVAL;
+    std::vector<uint8_t> all;
+    std::vector<uint64_t> sizes;
+    int rc = allgatherv_host(c, local, n_local * sizeof(ghip_pair), all, sizes);
+    if (rc) return rc;
+    const size_t n = all.size() / sizeof(ghip_pair);
+    ghip_pair *res = (ghip_pair *)malloc(std::max<size_t>(n, 1) * sizeof(ghip_pair));
+    if (!res) return GHIP_ENOMEM;
+    const ghip_pair *src = reinterpret_cast<const ghip_pair *>(all.data());
+    // merge the world sorted runs pairwise (log2(world) passes over the list)
+    std::vector<size_t> bounds{0};
+    for (uint64_t sz : sizes) bounds.push_back(bounds.back() + sz / sizeof(ghip_pair));
+    std::vector<ghip_pair> a(src, src + n), b(n);
+    auto key = [](const ghip_pair &p) { return ((uint64_t)p.i << 32) | p.j; };
+    while (bounds.size() > 2) {
+        std::vector<size_t> nb{0};
+        for (size_t r = 0; r + 1 < bounds.size(); r += 2) {
+            const size_t lo = bounds[r], mid = bounds[r + 1], hi = r + 2 < bounds.size() ? bounds[r + 2] : mid;
+            std::merge(a.begin() + lo, a.begin() + mid, a.begin() + mid, a.begin() + hi, b.begin() + lo,
+                       [&](const ghip_pair &x, const ghip_pair &y) { return key(x) < key(y); });
+            nb.push_back(hi);
+        }
+        a.swap(b);
+        bounds.swap(nb);
+    }
+    if (n) memcpy(res, a.data(), n * sizeof(ghip_pair));
+    *out_all = res; *out_n = n;
+    return GHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ANI index slices
+namespace {
+
+struct IndexField { const void *src; size_t esz; const std::vector<uint64_t> *start; uint64_t fixed; };  // per-genome slots: start[g+1]-start[g], or `fixed`
+
+}  // namespace
+
+// A pair's ANI is computed on the rank that owns its FIRST genome; that rank needs the index slices of second genomes
+// it does not own.  `pairs` is the whole list (identical on every rank).  On return *out_index serves this rank's pairs:
+// the local index itself (*out_index == local, nothing was exchanged) or a combined index = local genomes followed by
+// every exchanged genome in ascending order; out_local_ids[g] maps global genome ids to positions in that index
+// (UINT32_MAX: not present on this rank).
+extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local, size_t n_total, const ghip_pair *pairs,
+                                       size_t n_pairs, ghip_ani_index **out_index, uint32_t *out_local_ids /* [n_total] */) {
+    if (!c || !local || !out_index || !out_local_ids || (n_pairs && !pairs)) return GHIP_EINVAL;
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return GHIP_EINVAL;
+    size_t first, count, block;
+    ghip_shard_range(n_total, c->rank, c->world, &first, &count, &block);
+    if (local->n != count) return cerr_(c, GHIP_EINVAL, "local ANI index does not match this rank's block");
+    for (size_t g = 0; g < n_total; g++) out_local_ids[g] = UINT32_MAX;
+    for (size_t g = 0; g < count; g++) out_local_ids[first + g] = (uint32_t)g;
+    // second genomes of pairs that span two ranks, ascending, the same list on every rank
+    std::vector<uint8_t> mark(n_total, 0);
+    for (size_t x = 0; x < n_pairs; x++) {
+        if (pairs[x].i >= n_total || pairs[x].j >= n_total) return cerr_(c, GHIP_EINVAL, "pair index out of range");
+        if (pairs[x].i / block != pairs[x].j / block) mark[pairs[x].j] = 1;
+    }
+    std::vector<uint32_t> needed;
+    for (size_t g = 0; g < n_total; g++) if (mark[g]) needed.push_back((uint32_t)g);
+    if (needed.empty() || c->world == 1) { *out_index = const_cast<ghip_ani_index *>(local); return GHIP_OK; }
+
+    std::vector<uint32_t> send;   // local ids of my genomes that somebody needs
+    for (uint32_t g : needed) if (g >= first && g < first + count) send.push_back((uint32_t)(g - first));
+    // per-genome metadata of what I send: length, seed capacity, seed count
+    std::vector<uint64_t> meta(3 * send.size());
+    for (size_t x = 0; x < send.size(); x++) {
+        const uint32_t g = send[x];
+        meta[3 * x] = local->glen[g];
+        meta[3 * x + 1] = local->seed_start[g + 1] - local->seed_start[g];
+        meta[3 * x + 2] = local->seed_count[g];
+    }
+    std::vector<uint8_t> meta_all;
+    std::vector<uint64_t> meta_sizes;
+    int rc = allgatherv_host(c, meta.data(), meta.size() * 8, meta_all, meta_sizes);
+    if (rc) return rc;
+    const size_t n_recv = meta_all.size() / 24;
+    if (n_recv != needed.size()) return cerr_(c, GHIP_EINVAL, "ranks disagree on the genomes to exchange");
+    const uint64_t *rm = reinterpret_cast<const uint64_t *>(meta_all.data());
+
+    // combined metadata: local genomes, then the exchanged ones (owners ascending == genome ids ascending)
+    const size_t nc = count + n_recv;
+    std::vector<uint64_t> glen(nc), cap(nc);
+    std::vector<uint32_t> cnt(nc);
+    for (size_t g = 0; g < count; g++) { glen[g] = local->glen[g]; cap[g] = local->seed_start[g + 1] - local->seed_start[g]; cnt[g] = local->seed_count[g]; }
+    for (size_t x = 0; x < n_recv; x++) { glen[count + x] = rm[3 * x]; cap[count + x] = rm[3 * x + 1]; cnt[count + x] = (uint32_t)rm[3 * x + 2]; }
+    for (size_t x = 0; x < n_recv; x++) if (out_local_ids[needed[x]] == UINT32_MAX) out_local_ids[needed[x]] = (uint32_t)(count + x);
+    std::vector<uint64_t> cseed(nc + 1, 0), cchunk(nc + 1, 0);
+    for (size_t g = 0; g < nc; g++) {
+        cseed[g + 1] = cseed[g] + cap[g];
+        cchunk[g + 1] = cchunk[g] + (glen[g] + local->chunk - 1) / local->chunk;
+    }
+    const uint64_t bins = GHIP_ANI_BIN_COUNT + 1;
+    std::vector<uint64_t> lbin(count + 1), cbin(nc + 1);
+    for (size_t g = 0; g <= count; g++) lbin[g] = g * bins;
+    for (size_t g = 0; g <= nc; g++) cbin[g] = g * bins;
+
+    // the flat arrays of the index: element size, per-genome slot offsets (local layout, combined layout)
+    struct Field { const void *src; size_t esz; const std::vector<uint64_t> *lstart; const std::vector<uint64_t> *cstart; void *dst; };
+    Field fields[4] = {
+        {local->d_seed_code, sizeof(uint32_t), &local->seed_start, &cseed, nullptr},
+        {local->d_seed_chunk, sizeof(*local->d_seed_chunk), &local->seed_start, &cseed, nullptr},
+        {local->d_bin_start, sizeof(uint32_t), &lbin, &cbin, nullptr},
+        {local->d_chunk_total, sizeof(uint32_t), &local->chunk_start, &cchunk, nullptr},
+    };
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    std::vector<void *> owned;
+    auto drop = [&]() { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->stream); for (void *p : owned) ghip_pool_free(ctx, p); };
+    for (Field &f : fields) {
+        PoolBuf dst(ctx, std::max<uint64_t>((*f.cstart)[nc], 1) * f.esz);
+        if (!dst.p) { drop(); return cerr_(c, GHIP_EHIP, "out of device memory for the combined ANI index"); }
+        f.dst = dst.release();
+        owned.push_back(f.dst);
+        // local part: one copy
+        const uint64_t lbytes = (*f.lstart)[count] * f.esz;
+        if (lbytes) COMM_HIP(c, hipMemcpyAsync(f.dst, f.src, lbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        // what I send, packed back to back
+        uint64_t mine = 0;
+        for (uint32_t g : send) mine += ((*f.lstart)[g + 1] - (*f.lstart)[g]) * f.esz;
+        std::vector<uint64_t> sizes(c->world, 0);
+        if ((rc = allgather_host(c, &mine, 8, sizes.data()))) { drop(); return rc; }
+        const uint64_t m = (*std::max_element(sizes.begin(), sizes.end()) + 15) / 16 * 16;
+        if (m == 0) continue;
+        PoolBuf sb(ctx, m), rb(ctx, m * c->world);
+        if (!sb.p || !rb.p) { drop(); return cerr_(c, GHIP_EHIP, "out of device memory for the ANI index exchange"); }
+        uint64_t at = 0;
+        for (uint32_t g : send) {
+            const uint64_t b = ((*f.lstart)[g + 1] - (*f.lstart)[g]) * f.esz;
+            if (b) COMM_HIP(c, hipMemcpyAsync((char *)sb.p + at, (const char *)f.src + (*f.lstart)[g] * f.esz, b, hipMemcpyDeviceToDevice, ctx->stream));
+            at += b;
+        }
+        if ((rc = allgather_device(c, sb.p, rb.p, m))) { drop(); return rc; }
+        // the ranks' packed runs, in rank order, are the exchanged genomes in ascending order
+        uint64_t dst_at = (*f.cstart)[count] * f.esz;
+        for (uint32_t r = 0; r < c->world; r++) {
+            if (sizes[r]) COMM_HIP(c, hipMemcpyAsync((char *)f.dst + dst_at, (const char *)rb.p + (size_t)r * m, sizes[r], hipMemcpyDeviceToDevice, ctx->stream));
+            dst_at += sizes[r];
+        }
+        if (dst_at != (*f.cstart)[nc] * f.esz) { drop(); return cerr_(c, GHIP_EINVAL, "ANI index exchange: sizes do not add up"); }
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));   // sb/rb go back to the pool
+    }
+    ghip_ani_index *idx = nullptr;
+    rc = ghip_ani_index_wrap_device(ctx, nc, local->k, local->c, local->chunk, glen.data(), cap.data(), cnt.data(), fields[0].dst,
+                                    fields[1].dst, fields[2].dst, fields[3].dst, &idx);
+    if (rc) { drop(); return rc; }
+    idx->owned = true;   // the combined arrays belong to the handle
+    *out_index = idx;
+    return GHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one whole pass
+// FinchPreclusterer::distances + the batched ClusterDistanceFinder::calculate_ani of one dereplication job, on this
+// rank's block of genomes; every rank returns the same (pairs, ani).
+extern "C" int ghip_distances_and_ani_ranks(ghip_comm *c, const ghip_genomes *local, size_t n_total, uint32_t k, uint32_t s,
+                                            uint64_t seed, float min_ani, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk,
+                                            float min_aligned_fraction, ghip_pair **out_pairs, float **out_ani, size_t *out_n,
+                                            ghip_sketches **out_sketches /* nullable */, ghip_rank_times *times /* nullable */) {
+    if (!c || !local || !out_pairs || !out_ani || !out_n) return GHIP_EINVAL;
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return GHIP_EINVAL;
+    *out_pairs = nullptr; *out_ani = nullptr; *out_n = 0;
+    if (out_sketches) *out_sketches = nullptr;
+    ghip_rank_times tm{};
+    size_t first, count, block;
+    ghip_shard_range(n_total, c->rank, c->world, &first, &count, &block);
+    if (local->n != count) return cerr_(c, GHIP_EINVAL, "local genome count does not match this rank's block");
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](double &slot) { slot += ms_since(t0); t0 = std::chrono::steady_clock::now(); };
+
+    ghip_sketches *sk_l = nullptr, *sk = nullptr;
+    ghip_ani_index *idx_l = nullptr, *idx = nullptr;
+    ghip_pair *mine = nullptr, *all = nullptr;
+    size_t n_mine = 0, n_all = 0;
+    std::vector<uint32_t> local_ids;
+    float *ani = nullptr;
+    auto cleanup = [&]() {
+        if (sk && sk != sk_l && !(out_sketches && *out_sketches == sk)) ghip_sketches_free(sk);
+        if (sk_l && !(out_sketches && *out_sketches == sk_l)) ghip_sketches_free(sk_l);
+        if (idx && idx != idx_l) ghip_ani_index_free(idx);
+        if (idx_l) ghip_ani_index_free(idx_l);
+        if (mine && mine != all) ghip_free(mine);
+    };
+    int rc = ghip_sketch_and_index(ctx, local, k, s, seed, ani_k, ani_c, ani_chunk, &sk_l, &idx_l);
+    if (rc) { if (c->group) c->group->fail(); cleanup(); return rc; }
+    lap(tm.sketch_ms);
+    if (c->world == 1) sk = sk_l;
+    else if ((rc = ghip_allgather_sketches(c, sk_l, n_total, &sk))) { cleanup(); return rc; }
+    lap(tm.allgather_sketches_ms);
+    int replicated = 0;
+    rc = ghip_precluster_ranks(ctx, sk, min_ani, c->rank, c->world, &mine, &n_mine, &replicated);
+    if (rc) { if (c->group) c->group->fail(); cleanup(); return rc; }
+    tm.pairs_compared = ghip_last_pairs_compared(ctx);
+    lap(tm.pairs_ms);
+    if (c->world == 1 || replicated) { all = mine; n_all = n_mine; }
+    else if ((rc = ghip_allgather_pairs(c, mine, n_mine, &all, &n_all))) { cleanup(); return rc; }
+    lap(tm.allgather_pairs_ms);
+    local_ids.resize(std::max<size_t>(n_total, 1));
+    if ((rc = ghip_exchange_ani_index(c, idx_l, n_total, all, n_all, &idx, local_ids.data()))) { cleanup(); if (all) ghip_free(all); return rc; }
+    lap(tm.exchange_ani_index_ms);
+    // my share: the pairs whose first genome I own -- a consecutive run of the (i, j)-sorted list
+    size_t lo = 0, hi = 0;
+    {
+        auto owner = [&](const ghip_pair &p) { return p.i / block; };
+        lo = std::partition_point(all, all + n_all, [&](const ghip_pair &p) { return owner(p) < c->rank; }) - all;
+        hi = std::partition_point(all, all + n_all, [&](const ghip_pair &p) { return owner(p) <= c->rank; }) - all;
+    }
+    std::vector<uint32_t> pi(2 * (hi - lo));
+    for (size_t x = lo; x < hi; x++) { pi[2 * (x - lo)] = local_ids[all[x].i]; pi[2 * (x - lo) + 1] = local_ids[all[x].j]; }
+    std::vector<float> ani_mine(hi - lo);
+    if (hi > lo && (rc = ghip_ani_pairs(ctx, idx, pi.data(), hi - lo, min_aligned_fraction, ani_mine.data(), nullptr))) {
+        if (c->group) c->group->fail();
+        cleanup(); ghip_free(all); return rc;
+    }
+    lap(tm.ani_pairs_ms);
+    ani = (float *)malloc(std::max<size_t>(n_all, 1) * sizeof(float));
+    if (!ani) { cleanup(); ghip_free(all); return GHIP_ENOMEM; }
+    if (c->world == 1) { if (n_all) memcpy(ani, ani_mine.data(), n_all * sizeof(float)); }
+    else {  // the ranks' runs are consecutive in rank order: a variable-length gather IS the whole array
+        std::vector<uint8_t> got;
+        std::vector<uint64_t> sizes;
+        if ((rc = allgatherv_host(c, ani_mine.data(), ani_mine.size() * sizeof(float), got, sizes))) { cleanup(); ghip_free(all); free(ani); return rc; }
+        if (got.size() != n_all * sizeof(float)) { cleanup(); ghip_free(all); free(ani); return cerr_(c, GHIP_EINVAL, "ANI gather: sizes do not add up"); }
+        if (n_all) memcpy(ani, got.data(), got.size());
+    }
+    lap(tm.gather_ani_ms);
+    if (out_sketches) *out_sketches = sk;
+    cleanup();
+    *out_pairs = all; *out_ani = ani; *out_n = n_all;
+    if (times) *times = tm;
+    return GHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one process, many GPUs
+extern "C" int ghip_cluster_files_multi(ghip_ctx *const *ctxs, uint32_t world, const char *const *paths, size_t n, uint32_t k,
+                                        uint32_t s, float min_ani, float ani_threshold, float min_af, uint32_t ani_c,
+                                        int io_threads, uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters) {
+    if (!ctxs || world == 0 || !out_members || !out_offsets || !out_n_clusters || (n && !paths)) return GHIP_EINVAL;
+    std::vector<ghip_comm *> comms(world, nullptr);
+    int rc = ghip_comm_init_local(ctxs, world, comms.data());
+    if (rc) return rc;
+    std::vector<int> rcs(world, GHIP_OK);
+    ghip_pair *pairs0 = nullptr;
+    float *ani0 = nullptr;
+    size_t n0 = 0;
+    auto work = [&](uint32_t r) {
+        size_t first, count, block;
+        ghip_shard_range(n, r, world, &first, &count, &block);
+        ghip_genomes *g = nullptr;
+        int e = ghip_genomes_from_files(ctxs[r], paths + first, count, std::max(1, io_threads / (int)world), &g);
+        if (e) { comms[r]->group->fail(); rcs[r] = e; return; }
+        ghip_pair *p = nullptr;
+        float *a = nullptr;
+        size_t np = 0;
+        e = ghip_distances_and_ani_ranks(comms[r], g, n, k, s, 0, min_ani, 15, ani_c ? ani_c : 125, 20000, min_af, &p, &a, &np, nullptr, nullptr);
+        ghip_genomes_free(g);
+        rcs[r] = e;
+        if (e == GHIP_OK && r == 0) { pairs0 = p; ani0 = a; n0 = np; }
+        else { ghip_free(p); ghip_free(a); }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t r = 1; r < world; r++) pool.emplace_back(work, r);
+    work(0);
+    for (auto &t : pool) t.join();
+    // report the rank that actually failed, not the peers its failure released from a collective
+    int culprit = -1;
+    for (uint32_t r = 0; r < world && culprit < 0; r++)
+        if (rcs[r] && !strstr(ghip_last_error(ctxs[r]), "a peer rank failed")) culprit = (int)r;
+    for (uint32_t r = 0; r < world && culprit < 0; r++) if (rcs[r]) culprit = (int)r;
+    if (culprit >= 0) {
+        rc = rcs[culprit];
+        const std::string msg = std::string("rank ") + std::to_string(culprit) + ": " + ghip_last_error(ctxs[culprit]);
+        ghip_set_error(ctxs[0], rc, msg);
+    }
+    for (uint32_t r = 0; r < world; r++) ghip_comm_destroy(comms[r]);
+    if (rc) { ghip_free(pairs0); ghip_free(ani0); return rc; }
+    rc = ghip_cluster(n, pairs0, n0, ani0, 0, ani_threshold, nullptr, nullptr, out_members, out_offsets, out_n_clusters);
+    ghip_free(pairs0);
+    ghip_free(ani0);
+    return rc;
+}

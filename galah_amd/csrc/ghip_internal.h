@@ -174,7 +174,7 @@ constexpr size_t GHIP_JOIN_MIN_N = 1200;  // the inverted-index form of the pair
 uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin);
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
-                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used);
+                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline);
 
 size_t ghip_probe_table_slots(uint32_t s);
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,

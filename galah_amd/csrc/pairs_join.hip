@@ -272,7 +272,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
                                                                     const uint32_t *__restrict__ start2,
                                                                     uint32_t *__restrict__ rec_count, const uint32_t *__restrict__ rec_start,
                                                                     uint64_t *__restrict__ rec, uint32_t *__restrict__ flags,
-                                                                    unsigned long long *__restrict__ rec_total) {
+                                                                    unsigned long long *__restrict__ rec_total, uint32_t rank, uint32_t world) {
     __shared__ uint64_t lk[J_WAVES][J_ELEM_CAP];
     __shared__ uint32_t lv[J_WAVES][J_ELEM_CAP];
     __shared__ uint32_t lcnt[J_WAVES];
@@ -325,22 +325,32 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // Multi-GPU: a rank only materialises the records of ITS genome pairs, (i + j) mod world == rank -- every record
+    // of a pair then lives on one rank, so the per-pair counts of the reduce stage are complete there.  The element
+    // stage above is the same on every rank; the decisions to decline use rec_total, which counts the records of ALL
+    // ranks, so every rank decides alike.
     const uint32_t out0 = EMIT ? rec_start[bucket] : 0u;
-    uint32_t found = 0;
+    uint32_t found = 0, found_all = 0;
     for (uint32_t a = lane; a < cnt; a += 64) {
         const uint64_t ka = k[a];
         const uint32_t ga = v[a];
         for (uint32_t b = a + 1; b < cnt && k[b] == ka; b++) {
             const uint32_t gb = v[b];
             if (gb == ga) continue;  // a sketch row is distinct; guards caller-supplied matrices
+            found_all++;
+            if (world > 1 && (ga + gb) % world != rank) continue;
             if (EMIT) rec[out0 + atomicAdd(&lcnt[wave], 1u)] = ((uint64_t)min(ga, gb) << 32) | max(ga, gb);
             else found++;
         }
     }
     if (!EMIT) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) found += __shfl_xor(found, off, 64);
-        if (lane == 0) { rec_count[bucket] = found; if (found) atomicAdd(rec_total, (unsigned long long)found); }  // 64-bit: the 32-bit offsets may wrap
+        for (int off = 32; off > 0; off >>= 1) { found += __shfl_xor(found, off, 64); found_all += __shfl_xor(found_all, off, 64); }
+        if (lane == 0) {
+            rec_count[bucket] = found;
+            if (found_all) atomicAdd(rec_total, (unsigned long long)found_all);  // 64-bit: the 32-bit offsets may wrap
+            if (found) atomicAdd(rec_total + 1, (unsigned long long)found);
+        }
     }
 }
 
@@ -480,8 +490,9 @@ uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin) {
 // *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
-                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used) {
+                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline) {
     *used = false;
+    if (late_decline) *late_decline = false;
     if (cmin_floor == 0 || cmin_floor == 0xffffu || n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
     std::vector<uint32_t> lens(n);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(lens.data(), d_lens, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -494,10 +505,10 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     // Only the dense forms enumerate those pairs.
     if (n_empty >= 1) return GHIP_OK;
     struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
-    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 4);  // [0] flags, [1] largest element bucket, [2..3] u64 record total
+    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 6);  // [0] flags, [1] largest element bucket, [2..3] u64 records of all ranks, [4..5] of this rank
     if (!d_flags) return GHIP_EHIP;
     unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_flags + 2);
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 6 * sizeof(uint32_t), ctx->stream));
 
     ghip_prof_begin(ctx, "pair_join");
     // 1. elements -> 65536 hash buckets
@@ -510,21 +521,22 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
     if (!d_rcount || !d_rstart) { ghip_prof_end(ctx); return GHIP_EHIP; }
     hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total);
+                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total, rank, world);
     if ((rc = scan_counters(ctx, own.p, d_rcount, enb, d_rstart, nullptr))) { ghip_prof_end(ctx); return rc; }
     uint32_t flags[2];
-    unsigned long long total_rec = 0;
+    unsigned long long totals[2] = {0, 0};   // records of all ranks (what every rank decides on), records of this rank
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&total_rec, d_total, sizeof(total_rec), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long total_rec = totals[0];
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     // a dense pass costs ~1 ns per pair, a record ~0.3 ns: beyond 4 records per pair the dense kernel is the better tool
     if ((flags[0] & 1u) || total_rec > 4 * P + (1u << 20) || total_rec >= (1ull << 31)) { ghip_prof_end(ctx); return GHIP_OK; }
-    const uint32_t n_rec = (uint32_t)total_rec;
+    const uint32_t n_rec = (uint32_t)totals[1];
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) { ghip_prof_end(ctx); return GHIP_EHIP; }
     hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total);
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total, rank, world);
     // 3. records -> 65536 pair buckets -> common per pair -> candidates
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
@@ -538,6 +550,9 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (flags[0] & 2u) {  // a record bucket overflowed its table: discard what was written, let a dense kernel run
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+        // (with world > 1 this decision is this rank's alone -- its own records filled the table -- so the caller must
+        // produce exactly this rank's (i + j) mod world share by other means: *late_decline)
+        if (late_decline) *late_decline = true;
         return GHIP_OK;
     }
     if (pairs_compared) {  // pairs this rank is responsible for: (i + j) mod world == rank

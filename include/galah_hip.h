@@ -198,6 +198,64 @@ int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, 
                                const uint32_t *seed_count, void *d_seed_code, void *d_seed_chunk,
                                void *d_bin_start, void *d_chunk_total, ghip_ani_index **out);
 
+/* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)
+ * The finch path of the reference is one serial loop in one process (src/finch.rs:74-96); this is its sharded form
+ * (SURVEY.md 8e): genomes in contiguous blocks (rank r owns [r*B, min((r+1)*B, N)), B = ceil(N / world)), every rank
+ * sketches its block, the packed sketch matrix is all-gathered once, the pair work is dealt over the ranks, a pair's ANI
+ * is computed where its first genome lives.  One communicator per (rank, context); three transports, same logic:
+ *   ghip_comm_init_rank      one process per GPU: RCCL (ncclAllGather over xGMI).  Rank 0 makes the id with
+ *                            ghip_comm_unique_id and ships its 128 bytes to the other ranks by any means.
+ *   ghip_comm_init_local     ONE process driving `world` contexts, one thread per context (galah's `cluster` CLI is a
+ *                            single process): peer copies over xGMI (hipMemcpyPeer), no RCCL needed.
+ *   ghip_comm_init_callback  the host supplies an all-gather of host bytes (MPI, gloo, ...); device payloads are staged
+ *                            through host memory.  ctx may be NULL for a communicator used for host payloads only.
+ * Collectives must be called by every rank of the group, in the same order. */
+typedef struct ghip_comm ghip_comm;
+#define GHIP_UNIQUE_ID_BYTES 128
+/* all-gather of host bytes: recv[r*bytes .. (r+1)*bytes) = rank r's send; return 0 on success */
+typedef int (*ghip_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
+int ghip_comm_unique_id(uint8_t id[GHIP_UNIQUE_ID_BYTES]);
+int ghip_comm_init_rank(ghip_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t id[GHIP_UNIQUE_ID_BYTES], ghip_comm **out);
+int ghip_comm_init_local(ghip_ctx *const *ctxs, uint32_t world, ghip_comm **out_comms /* [world] */);
+int ghip_comm_init_callback(ghip_ctx *ctx, uint32_t rank, uint32_t world, ghip_allgather_fn fn, void *user, ghip_comm **out);
+void ghip_comm_destroy(ghip_comm *comm);
+uint32_t ghip_comm_rank(const ghip_comm *comm);
+uint32_t ghip_comm_world(const ghip_comm *comm);
+const char *ghip_comm_transport(const ghip_comm *comm);   /* "rccl", "local-peer-copy", "host-callback", "self" */
+const char *ghip_comm_last_error(const ghip_comm *comm);
+int ghip_comm_allgather_device(ghip_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+int ghip_comm_allgather_host(ghip_comm *comm, const void *send, size_t bytes_per_rank, void *recv);
+/* the block of rank `rank`: first genome, number of genomes, block size B */
+void ghip_shard_range(size_t n_total, uint32_t rank, uint32_t world, size_t *first, size_t *count, size_t *block);
+/* local = the sketches of this rank's block -> the matrix of all n_total genomes on every rank (N*s*8 bytes, once) */
+int ghip_allgather_sketches(ghip_comm *comm, const ghip_sketches *local, size_t n_total, ghip_sketches **out_full);
+/* every rank's share of the candidate list (sorted by (i, j)) -> the whole list in (i, j) order on every rank */
+int ghip_allgather_pairs(ghip_comm *comm, const ghip_pair *local, size_t n_local, ghip_pair **out_all, size_t *out_n);
+/* The ANI index slices a rank needs but does not own (second genomes of pairs whose first genome it owns; `pairs` is
+ * the whole list).  *out_index = `local` itself when nothing had to move, else a new handle (free it) = local genomes
+ * followed by the exchanged ones; out_local_ids[g] = position of global genome g in it, UINT32_MAX if absent. */
+int ghip_exchange_ani_index(ghip_comm *comm, const ghip_ani_index *local, size_t n_total, const ghip_pair *pairs,
+                            size_t n_pairs, ghip_ani_index **out_index, uint32_t *out_local_ids /* [n_total] */);
+typedef struct {   /* wall milliseconds of one ghip_distances_and_ani_ranks call on this rank */
+    double sketch_ms, allgather_sketches_ms, pairs_ms, allgather_pairs_ms, exchange_ani_index_ms, ani_pairs_ms, gather_ani_ms;
+    uint64_t pairs_compared;   /* genome pairs this rank's pair stage was responsible for */
+} ghip_rank_times;
+/* One whole pass on this rank's block `local` of the n_total genomes: FinchPreclusterer::distances (src/finch.rs:48-97)
+ * plus the batched ClusterDistanceFinder::calculate_ani (src/skani.rs:708-716) of every surviving pair.  Every rank
+ * returns the same pairs (sorted by (i, j), global indices) and ANI values (percent); free both with ghip_free().
+ * out_sketches (nullable): the gathered sketch matrix (free with ghip_sketches_free). */
+int ghip_distances_and_ani_ranks(ghip_comm *comm, const ghip_genomes *local, size_t n_total, uint32_t k, uint32_t s,
+                                 uint64_t seed, float min_ani_fraction, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk,
+                                 float min_aligned_fraction, ghip_pair **out_pairs, float **out_ani_percent, size_t *out_n,
+                                 ghip_sketches **out_sketches, ghip_rank_times *times /* nullable */);
+/* Files in -> clusters out on `world` GPUs driven by ONE process (what galah's `cluster` does, src/clusterer.rs:14-152
+ * with the finch preclusterer and the batched ANI clusterer): one thread per context ingests and sketches its block of
+ * the file list, the exchanges above run over peer copies, the greedy clusterer runs on the caller's thread.
+ * Output as ghip_cluster. */
+int ghip_cluster_files_multi(ghip_ctx *const *ctxs, uint32_t world, const char *const *paths, size_t n, uint32_t k, uint32_t s,
+                             float min_ani_fraction, float ani_threshold_percent, float min_aligned_fraction, uint32_t ani_c,
+                             int io_threads, uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters);
+
 /* ---------------------------------------------------------------- host clusterer
  * clusterer::cluster from the precluster cache onwards (src/clusterer.rs:56-152):
  * partition_sketches, find_precluster_cluster_representatives, ..._memberships.

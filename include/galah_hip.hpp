@@ -356,4 +356,32 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same `cluster` on SEVERAL GPUs driven by this one process (galah's CLI is a single process): one context and one
+// thread per device, genomes in contiguous blocks, sketch matrix all-gathered by peer copies over xGMI, pair work dealt
+// over the devices, ANI where a pair's first genome lives, greedy clusterer on the caller's thread
+// (ghip_cluster_files_multi).  Same clusters as cluster(genomes, FinchPreclusterer, HipAniClusterer) on one device.
+inline std::vector<std::vector<size_t>> cluster_multi_gpu(const std::vector<std::shared_ptr<HipContext>> &hips,
+                                                          const std::vector<std::string> &genomes, const FinchPreclusterer &pre,
+                                                          const HipAniClusterer &cl) {
+    cl.initialise();
+    if (pre.low_memory) throw std::runtime_error("Low-memory clustering currently only supported with skani preclusterer");
+    if (hips.empty()) throw std::runtime_error("cluster_multi_gpu needs at least one HIP context");
+    std::vector<ghip_ctx *> ctxs;
+    for (auto &h : hips) ctxs.push_back(h->get());
+    auto paths = detail::c_paths(genomes);
+    uint32_t *members = nullptr;
+    uint64_t *offsets = nullptr;
+    size_t n_clusters = 0;
+    const int rc = ghip_cluster_files_multi(ctxs.data(), (uint32_t)ctxs.size(), paths.data(), paths.size(), pre.kmer_length,
+                                            (uint32_t)pre.num_kmers, pre.min_ani, cl.threshold, cl.min_aligned_threshold,
+                                            cl.seed_compression(), std::max(pre.threads, cl.threads), &members, &offsets, &n_clusters);
+    if (rc != GHIP_OK) throw std::runtime_error("Failed to sketch genomes with finch: " + hips[0]->last_error());
+    std::vector<std::vector<size_t>> out(n_clusters);
+    for (size_t c = 0; c < n_clusters; c++) out[c].assign(members + offsets[c], members + offsets[c + 1]);
+    ghip_free(members);
+    ghip_free(offsets);
+    return out;
+}
+
 }  // namespace galah

@@ -162,6 +162,39 @@ int main(int argc, char **argv) {
         CHECK((galah::cluster(fwd, other, stale) == galah::cluster(fwd, pre, fresh)));
         CHECK(stale.prepared_for(fwd));
     }
+    {   // one process, several GPUs (here: three contexts on the one device, the peer-copy transport): same clusters
+        galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21, false, 4);
+        galah::HipAniClusterer cl(hip, 95.0f, 0.15f, false, 4);
+        std::vector<std::string> all = abisko;
+        for (const char *x : {"antonio_MAG52", "antonio_MAG189", "set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16"}) all.push_back(fa(x));
+        const auto want = galah::cluster(all, pre, cl);
+        std::vector<std::shared_ptr<galah::HipContext>> three = {std::make_shared<galah::HipContext>(0), std::make_shared<galah::HipContext>(0),
+                                                                 std::make_shared<galah::HipContext>(0)};
+        CHECK((galah::cluster_multi_gpu(three, all, pre, cl) == want));
+        CHECK((galah::cluster_multi_gpu({hip}, all, pre, cl) == want));
+        // the communicator entry points directly: two ranks on threads, a device all-gather and a candidate-list merge
+        ghip_ctx *ctxs[2] = {three[0]->get(), three[1]->get()};
+        ghip_comm *comms[2] = {nullptr, nullptr};
+        CHECK(ghip_comm_init_local(ctxs, 2, comms) == GHIP_OK);
+        CHECK(std::string(ghip_comm_transport(comms[0])) == "local-peer-copy" && ghip_comm_world(comms[1]) == 2 && ghip_comm_rank(comms[1]) == 1);
+        bool ok[2] = {false, false};
+        auto rank = [&](int r) {
+            ghip_pair mine[2] = {{(uint32_t)r, 5, 1, 2, 0.9f}, {(uint32_t)(r + 2), 7, 3, 4, 0.95f}};   // sorted shares
+            ghip_pair *allp = nullptr;
+            size_t n = 0;
+            if (ghip_allgather_pairs(comms[r], mine, 2, &allp, &n) != GHIP_OK || n != 4) return;
+            ok[r] = allp[0].i == 0 && allp[1].i == 1 && allp[2].i == 2 && allp[3].i == 3 && allp[3].j == 7;
+            ghip_free(allp);
+            uint64_t v = 40 + r, got[2] = {0, 0};
+            ok[r] = ok[r] && ghip_comm_allgather_host(comms[r], &v, sizeof v, got) == GHIP_OK && got[0] == 40 && got[1] == 41;
+        };
+        std::thread t1(rank, 1);
+        rank(0);
+        t1.join();
+        CHECK(ok[0] && ok[1]);
+        ghip_comm_destroy(comms[0]);
+        ghip_comm_destroy(comms[1]);
+    }
     std::printf(failures ? "%d check(s) failed\n" : "host mirror: all reference tests passed\n", failures);
     return failures ? 1 : 0;
 }

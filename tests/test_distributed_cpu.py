@@ -1,20 +1,18 @@
-"""world_size > 1 exchange logic on CPU: gloo backend, the oracle-backed FakeEngine in place of
-the HIP engine.  Checks that the sharded job returns exactly the single-process result."""
+"""world_size > 1 on CPU: the library's exchange logic (galah_amd/csrc/comm.cpp) over its host-callback transport fed by
+torch.distributed's gloo backend -- no GPU, no compute.  What runs here is what the GPU ranks run above the two
+primitives: the variable-length gathers, the (i, j) merge of candidate shares, the sharding rules."""
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import oracle  # noqa: E402
-from galah_amd.distributed import DereplicationJob, shard_range, tile_pairs_of_rank  # noqa: E402
-
-SEED, MEMBERS, LENGTH, RATE, N = 5, 3, 60_000, 0.0253, 11  # 11 genomes: ragged last shard
+from galah_amd import PAIR_DTYPE  # noqa: E402
+from galah_amd.distributed import Comm, shard_range, tile_pairs_of_rank  # noqa: E402
 
 
 def _free_port():
@@ -23,56 +21,71 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, replicate=False):
-    from fake_engine import FakeEngine
+def _share(rank, world, n=200, seed=3):
+    """Deterministic candidate list; rank's share = pairs with (i + j) % world == rank (the join form's deal)."""
+    rng = np.random.default_rng(seed)
+    rows = sorted({(int(a), int(b)) for a, b in rng.integers(0, n, size=(900, 2)) if a < b})
+    allp = np.zeros(len(rows), dtype=PAIR_DTYPE)
+    for x, (i, j) in enumerate(rows):
+        allp[x] = (i, j, (i * 7 + j) % 1000, 1000 + (i + j) % 900, np.float32(0.9 + ((i * 31 + j) % 100) / 1000.0))
+    mine = allp[(allp["i"] + allp["j"]) % world == rank]
+    return allp, mine
+
+
+def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    engine = FakeEngine()
-    engine.replicate = replicate   # True: the pair stage hands every rank the whole list (what the join form does)
-    job = DereplicationJob(None, rank, world, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0),
-                           min_af=0.15, engine=engine)
-    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
-    res = job.step()
-    compared = torch.tensor([job.last_pairs_compared], dtype=torch.int64)
-    dist.all_reduce(compared)
-    if rank == 0:
-        q.put({"clusters": res["clusters"], "pairs": res["pairs"].tobytes(), "ani": res["pair_ani"].tobytes(),
-               "compared": int(compared.item())})
+    comm = Comm.from_torch_gloo(None, rank, world)   # no device context: host payloads only
+    assert (comm.rank, comm.world, comm.transport) == (rank, world, "host-callback")
+    out = {"rank": rank}
+    # fixed-size host all-gather
+    got = comm.allgather_host(np.arange(5, dtype=np.int64) + 100 * rank)
+    out["fixed"] = got.tolist()
+    # candidate shares -> whole list in (i, j) order; rank 1 also contributes nothing in a second round (ragged)
+    allp, mine = _share(rank, world)
+    merged = comm.allgather_pairs(mine)
+    out["merged_ok"] = merged.tobytes() == allp.tobytes()
+    merged2 = comm.allgather_pairs(mine if rank != 1 else mine[:0])
+    want2 = allp[(allp["i"] + allp["j"]) % world != 1]
+    out["ragged_ok"] = merged2.tobytes() == want2.tobytes()
+    out["empty_ok"] = len(comm.allgather_pairs(mine[:0])) == 0
+    # a device collective on a communicator without a device context is an error, not a crash
+    try:
+        comm.allgather_device(0, 0, 16)
+        out["nodev"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["nodev"] = type(e).__name__
+    q.put(out)
     dist.barrier()
+    comm.close()
     dist.destroy_process_group()
 
 
-def _single():
-    from fake_engine import FakeEngine
-    job = DereplicationJob(None, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0),
-                           min_af=0.15, engine=FakeEngine())
-    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
-    return job.step()
-
-
-@pytest.mark.parametrize("world,replicate", [(2, False), (3, False), (2, True)])
-def test_sharded_job_equals_single_process(world, replicate):
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_logic_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, replicate)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    outs = sorted((q.get(timeout=300) for _ in range(world)), key=lambda o: o["rank"])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    want = _single()
-    assert got["compared"] == N * (N - 1) // 2
-    assert got["pairs"] == want["pairs"].tobytes()
-    assert got["ani"] == want["pair_ani"].tobytes()
-    assert got["clusters"] == want["clusters"]
-    # and the single-process FakeEngine agrees with the plain oracle end to end
-    streams = [oracle.synth_genome(SEED, g // MEMBERS, g % MEMBERS, LENGTH, RATE) for g in range(N)]
-    sks = [oracle.AniSketch.from_bytes(s) for s in streams]
-    for p, a in zip(want["pairs"], want["pair_ani"]):
-        assert np.float32(oracle.ani_pair(sks[p["i"]], sks[p["j"]], 0.15)[0]) == a
+    for r, o in enumerate(outs):
+        assert o["fixed"] == [[100 * x + y for y in range(5)] for x in range(world)]
+        assert o["merged_ok"] and o["ragged_ok"] and o["empty_ok"]
+        assert o["nodev"] == "GalahHipError"
+
+
+def test_single_rank_communicator_needs_no_transport():
+    comm = Comm.single(None)
+    assert (comm.rank, comm.world, comm.transport) == (0, 1, "self")
+    allp, _ = _share(0, 1)
+    assert comm.allgather_pairs(allp).tobytes() == allp.tobytes()
+    assert comm.allgather_host(np.float32([1.5, 2.5])).tolist() == [[1.5, 2.5]]
 
 
 def test_shard_ranges_cover_and_tiles_partition():

@@ -1,14 +1,20 @@
-"""The real HipEngine under world_size 2: two processes sharing the one GPU of the test box,
-gloo backend (RCCL refuses two ranks on one device).  Exercises every C-ABI call of the
-sharded path -- synthetic_range, copy_into, wrap_device, precluster_shard, ANI export/wrap --
-and checks the result against the single-process HIP run and the oracle."""
+"""The multi-GPU path on the one GPU of the test box, through every transport of the C ABI's communicator
+(galah_amd/csrc/comm.cpp):
+  host-callback   2, 3 and 8 processes sharing the GPU, torch.distributed gloo underneath (RCCL refuses two ranks on one
+                  device): sharded join, sharded dense forms, replicated join, ANI index exchange across block boundaries;
+  local           one process, several contexts on threads (peer copies) -- the single-process driver;
+  rccl            a one-rank RCCL communicator: the real ncclCommInitRank / ncclAllGather entry points.
+Every result is compared with the single-rank HIP run, itself checked against the oracle."""
 import os
 import socket
+import threading
 
 import numpy as np
 import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+from conftest import fasta
 
 pytestmark = pytest.mark.gpu
 
@@ -21,78 +27,84 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, N=N, LENGTH=LENGTH):
+def _worker(rank, world, port, q, n=N, length=LENGTH, env=None, min_ani=0.9):
     import torch
 
     import galah_amd
     from galah_amd.distributed import DereplicationJob
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.update(env or {})
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = galah_amd.Context(0)
-    job = DereplicationJob(ctx, rank, world, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
-    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
+    job = DereplicationJob(ctx, rank, world, n_genomes=n, min_ani=np.float32(min_ani), ani_threshold=np.float32(95.0), min_af=0.15,
+                           backend="gloo")
+    assert job.comm.transport == "host-callback"
+    job.load_synthetic(SEED, MEMBERS, length, RATE)
     for _ in range(2):  # twice: the memory pool and the wrapped handles must survive re-use
         res = job.step()
+    compared = job.comm.allgather_host(np.array([job.last_pairs_compared], dtype=np.int64)).sum()
     if rank == 0:
         hashes, lens = job.sketches_to_host()
         q.put({"clusters": res["clusters"], "pairs": res["pairs"].tobytes(), "ani": res["pair_ani"].tobytes(),
-               "hashes": hashes.tobytes(), "lens": lens.tobytes()})
+               "hashes": hashes.tobytes(), "lens": lens.tobytes(), "compared": int(compared), "stages": job.stage_ms()})
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
 
 
-def test_three_ranks_join_form_equals_single_rank(ctx):
-    """N = 2100 short genomes on three ranks (ragged shards): the pair stage switches to the join form, which every
-    rank runs in full and keeps whole (ghip_precluster_ranks: no exchange of candidate lists); families straddle the shard boundaries, so the ANI index
-    slices are exchanged too."""
-    import oracle
-    from galah_amd.distributed import DereplicationJob
-    n, length = 2100, 30_000
+def _run(world, **kw):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, 3, port, q, n, length)) for r in range(3)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, q), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=900)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
-    job = DereplicationJob(ctx, 0, 1, n_genomes=n, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
+    return got
+
+
+def _single(ctx, n=N, length=LENGTH, min_ani=0.9):
+    from galah_amd.distributed import DereplicationJob
+    job = DereplicationJob(ctx, 0, 1, n_genomes=n, min_ani=np.float32(min_ani), ani_threshold=np.float32(95.0), min_af=0.15)
     job.load_synthetic(SEED, MEMBERS, length, RATE)
     want = job.step()
     hashes, lens = job.sketches_to_host()
+    return want, hashes, lens
+
+
+def _same(got, want, hashes, lens):
     assert got["hashes"] == hashes.tobytes() and got["lens"] == lens.tobytes()
     assert got["pairs"] == want["pairs"].tobytes()
     assert got["ani"] == want["pair_ani"].tobytes()
     assert got["clusters"] == want["clusters"]
+
+
+@pytest.mark.parametrize("mode", ["shard", "replicate"])
+def test_three_ranks_join_form_equals_single_rank(ctx, mode):
+    """N = 2100 short genomes on three ranks (ragged shards): the pair stage takes the join form -- sharded at record
+    emission by (i + j) mod world with the shares gathered and merged (default), or run whole on every rank
+    (GHIP_JOIN_RANKS=replicate).  Families straddle the shard boundaries, so ANI index slices are exchanged too."""
+    import oracle
+    n, length = 2100, 30_000
+    got = _run(3, n=n, length=length, env={"GHIP_JOIN_RANKS": mode})
+    want, hashes, lens = _single(ctx, n, length)
+    _same(got, want, hashes, lens)
+    assert got["compared"] == n * (n - 1) // 2          # the ranks' shares partition the triangle
     assert want["pairs"].tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32).tobytes()
+    if mode == "replicate":
+        assert got["stages"]["allgather_pairs"] < 0.5   # nothing to gather
 
 
 def test_two_ranks_one_gpu_equals_single_rank(ctx):
     import oracle
-    from galah_amd.distributed import DereplicationJob
-    mpc = mp.get_context("spawn")
-    q = mpc.Queue()
-    port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=600)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    job = DereplicationJob(ctx, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
-    job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
-    want = job.step()
-    hashes, lens = job.sketches_to_host()
-    assert got["hashes"] == hashes.tobytes() and got["lens"] == lens.tobytes()
-    assert got["pairs"] == want["pairs"].tobytes()
-    assert got["ani"] == want["pair_ani"].tobytes()
-    assert got["clusters"] == want["clusters"]
+    got = _run(2)
+    want, hashes, lens = _single(ctx)
+    _same(got, want, hashes, lens)
     # oracle end to end
     streams = [oracle.synth_genome(SEED, g // MEMBERS, g % MEMBERS, LENGTH, RATE) for g in range(N)]
     opairs = oracle.distances_from_sketches(hashes, lens, np.float32(0.9))
@@ -102,49 +114,119 @@ def test_two_ranks_one_gpu_equals_single_rank(ctx):
     assert want["clusters"] == oc
 
 
-def _nccl_single_rank(port, q):
-    """The collectives of galah_amd.distributed.Exchange issued on a ONE-rank RCCL group: RCCL refuses two ranks on
-    one device, so this is as far as the `nccl` backend can be exercised on a one-GPU box -- dtypes, device
-    tensors, object collectives and the bench's timing reduction all go through the real RCCL entry points."""
+def test_eight_ranks_dense_forms_straddling_families(ctx):
+    """The shape of the 8-GPU bench on one box: 8 ranks, 100 genomes in blocks of 13 (families of 3 straddle nearly every
+    block boundary: ANI index slices move between most ranks), the dense pair kernel dealt by tile and the shares
+    gathered -- and the same with a threshold of 0, where the join form declines and EVERY pair is a candidate."""
+    got = _run(8, n=100, length=60_000)
+    want, hashes, lens = _single(ctx, 100, 60_000)
+    _same(got, want, hashes, lens)
+    assert got["compared"] == 100 * 99 // 2
+    got0 = _run(8, n=40, length=40_000, min_ani=0.0)
+    want0, hashes0, lens0 = _single(ctx, 40, 40_000, min_ani=0.0)
+    _same(got0, want0, hashes0, lens0)
+    assert len(want0["pairs"]) == 40 * 39 // 2
+
+
+def test_local_transport_threads_equal_single_rank(ctx):
+    """One process, three contexts on the same device, one thread each: the peer-copy transport."""
+    import galah_amd
+    from galah_amd.distributed import DereplicationJob, local_comms
+    world, n, length = 3, 41, 120_000
+    ctxs = [galah_amd.Context(0) for _ in range(world)]
+    comms = local_comms(ctxs)
+    assert [c.transport for c in comms] == ["local-peer-copy"] * world
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            job = DereplicationJob(ctxs[r], r, world, n_genomes=n, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0),
+                                   min_af=0.15, comm=comms[r])
+            job.load_synthetic(SEED, MEMBERS, length, RATE)
+            for _ in range(2):
+                res = job.step()
+            out[r] = (res, job.sketches_to_host() if r == 0 else None)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errs, errs
+    want, hashes, lens = _single(ctx, n, length)
+    res0, (h0, l0) = out[0]
+    assert h0.tobytes() == hashes.tobytes() and l0.tobytes() == lens.tobytes()
+    assert res0["pairs"].tobytes() == want["pairs"].tobytes() and res0["pair_ani"].tobytes() == want["pair_ani"].tobytes()
+    assert res0["clusters"] == want["clusters"]
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_single_process_multi_context_driver_on_files(ctx):
+    """ghip_cluster_files_multi: files in -> clusters out with several contexts driven by one process equals
+    galah_amd.cluster on one context (which the parity suite pins to the oracle)."""
+    import galah_amd
+    from galah_amd.distributed import cluster_files_multi
+    names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52", "antonio_MAG189",
+             "set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16", "abisko_S2D10", "clash_500kb", "set2_1mbp", "set2_half"]
+    paths = [fasta(x) for x in names]
+    want = galah_amd.cluster(paths, galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=4),
+                             galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=4))
+    for world in (1, 2, 4):
+        ctxs = [galah_amd.Context(0) for _ in range(world)]
+        assert cluster_files_multi(ctxs, paths, 0.9, 95.0, 0.15, io_threads=8) == want, world
+        for c in ctxs:
+            c.close()
+    # a failure on one rank (unreadable file in the last block) surfaces as an error, not a hang
+    ctxs = [galah_amd.Context(0) for _ in range(2)]
+    with pytest.raises(galah_amd.GalahHipError):
+        cluster_files_multi(ctxs, paths[:3] + ["/nonexistent/genome.fna"], 0.9, 95.0, 0.15)
+    for c in ctxs:
+        c.close()
+
+
+def _rccl_single_rank(port, q):
+    """RCCL refuses two ranks on one device, so a ONE-rank communicator is as far as the transport can be exercised on a
+    one-GPU box: unique id, ncclCommInitRank, ncclAllGather on device and (staged) host payloads, and a whole job."""
     import torch
 
     import galah_amd
-    from galah_amd.distributed import DereplicationJob, Exchange
+    from galah_amd.distributed import Comm, DereplicationJob
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    ex = Exchange(0, 1, force=True)      # issue the collectives on the one-rank group instead of short-circuiting
-    assert not ex.stage_on_host
-    h = torch.arange(6 * 8, dtype=torch.int64, device="cuda").reshape(6, 8) - 3
-    assert torch.equal(ex.all_gather_blocks(h, 5), h[:5])                  # sketch rows (i64 view of u64 hashes)
-    lens = torch.arange(6, dtype=torch.int32, device="cuda")
-    assert torch.equal(ex.all_gather_blocks(lens, 6), lens)
-    codes = torch.arange(50, dtype=torch.int16, device="cuda")             # ANI index slices travel as raw bytes
-    assert torch.equal(ex.all_gather_flat(codes, [50]), codes)
-    assert ex.all_gather_flat(codes[:0], [0]).numel() == 0
-    ani = np.linspace(90, 100, 37).astype(np.float32)                      # ANI results: host array, one collective
-    assert ex.all_gather_host_array(ani, [37]).tobytes() == ani.tobytes()
-    pairs = np.zeros(3, dtype=galah_amd.PAIR_DTYPE); pairs["i"] = [1, 2, 3]
-    assert ex.all_gather_object(pairs)[0].tobytes() == pairs.tobytes()     # the share of a dense pair stage
-    t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
-    # and a whole job on the one-rank group (world 1 short-circuits the exchange, the group is live underneath)
+    dist.init_process_group("gloo", rank=0, world_size=1)
     ctx = galah_amd.Context(0)
-    job = DereplicationJob(ctx, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15)
+    comm = Comm.from_torch_rccl(ctx, 0, 1)
+    assert comm.transport == "rccl" and comm.world == 1
+    src = torch.arange(4096, dtype=torch.int64, device="cuda") * 3 - 7
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    comm.allgather_device(src.data_ptr(), dst.data_ptr(), src.numel() * 8)
+    ok = bool(torch.equal(src, dst))
+    ok = ok and comm.allgather_host(np.float32([1.25, 2.5, 3.75])).tolist() == [[1.25, 2.5, 3.75]]
+    pairs = np.zeros(3, dtype=galah_amd.PAIR_DTYPE); pairs["i"] = [1, 2, 3]; pairs["j"] = [4, 5, 6]
+    ok = ok and comm.allgather_pairs(pairs).tobytes() == pairs.tobytes()
+    job = DereplicationJob(ctx, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15, comm=comm)
     job.load_synthetic(SEED, MEMBERS, LENGTH, RATE)
     res = job.step()
-    q.put({"ok": float(t.item()) == 1.25, "clusters": len(res["clusters"])})
+    q.put({"ok": ok, "clusters": res["clusters"], "pairs": res["pairs"].tobytes()})
+    comm.close()
     dist.destroy_process_group()
     ctx.close()
 
 
-def test_rccl_entry_points_on_one_rank():
+def test_rccl_transport_on_one_rank(ctx):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    p = mpc.Process(target=_nccl_single_rank, args=(_free_port(), q))
+    p = mpc.Process(target=_rccl_single_rank, args=(_free_port(), q))
     p.start()
     got = q.get(timeout=600)
     p.join(timeout=120)
-    assert p.exitcode == 0 and got["ok"] and got["clusters"] > 0
+    assert p.exitcode == 0 and got["ok"]
+    want, _, _ = _single(ctx)
+    assert got["clusters"] == want["clusters"] and got["pairs"] == want["pairs"].tobytes()
