@@ -468,13 +468,24 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
                 assert compared == n * (n - 1) // 2
                 merged = np.sort(np.concatenate(parts), order=["i", "j"])
                 assert merged.tobytes() == want.tobytes()
-                # the multi-rank entry point: the join form hands every rank the whole list, nothing to exchange
+                # the multi-rank entry point: by default the join form is sharded too (records only of the rank's
+                # (i + j) mod world pairs); with GHIP_JOIN_RANKS=replicate it hands every rank the whole list
+                parts, compared = [], 0
+                for r in range(world):
+                    part, replicated = ctx.precluster_ranks(sk, np.float32(thr), r, world)
+                    compared += ctx.last_pairs_compared
+                    assert not replicated and all((part["i"] + part["j"]) % world == r)
+                    parts.append(part)
+                assert compared == n * (n - 1) // 2
+                assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
+                monkeypatch.setenv("GHIP_JOIN_RANKS", "replicate")
                 compared = 0
                 for r in range(world):
                     whole, replicated = ctx.precluster_ranks(sk, np.float32(thr), r, world)
                     compared += ctx.last_pairs_compared
                     assert replicated and whole.tobytes() == want.tobytes()
                 assert compared == n * (n - 1) // 2
+                monkeypatch.delenv("GHIP_JOIN_RANKS")
         else:  # declined: the dense forms give each rank its share
             parts = []
             for r in range(3):
