@@ -110,10 +110,11 @@ __device__ __forceinline__ void load_kmer_luts(KmerLuts &L, const KmerLuts *__re
     for (uint32_t i = threadIdx.x; i < sizeof(KmerLuts) / 16; i += blockDim.x) dst[i] = src[i];
 }
 
-struct Roll21 {  // per-lane rolling state of the 21-mer window
-    uint64_t fl;      // forward strand, little-endian 2-bit codes (first base in bits 1:0)
-    uint64_t rc;      // reverse complement, little-endian (= mask - forward big-endian)
-    int32_t lastbad;  // byte index (lane-relative) of the last non-ACGT byte in the words before the current one
+struct Win21 {  // per-lane window state, refreshed once per 4-byte word
+    uint32_t wlo, whi;  // W (48 bits): forward 2-bit codes of the last 24 bases, the oldest in bits 1:0
+    uint32_t rlo, rhi;  // R: complement codes of the same bases, the NEWEST in bits 1:0 (bits >= 48 hold stale bases)
+    int32_t lim21;      // last bad byte + 21: the 21-mer ending at byte b is clean iff lim21 <= b (and no bad byte of b's own word precedes it)
+    int32_t lim15;      // last bad byte + seed k
 };
 
 // SEEDS = true: the same pass also emits the FracMinHash seeds of the ANI index (ani.hip), whose
@@ -130,7 +131,6 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     uint32_t seed, uint64_t *__restrict__ cand, uint32_t *__restrict__ cand_count, ghip_seed::SeedOut so,
     const KmerLuts *__restrict__ g_luts) {
     constexpr int K = 21;
-    constexpr uint64_t mask = (1ull << (2 * K)) - 1;
     __shared__ __attribute__((aligned(16))) KmerLuts luts;
     __shared__ __attribute__((aligned(16))) unsigned char sl_raw[SEEDS ? sizeof(ghip_seed::SeedLds) : 16];
     ghip_seed::SeedLds &sl = *reinterpret_cast<ghip_seed::SeedLds *>(sl_raw);  // only touched when SEEDS
@@ -178,11 +178,11 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     __shared__ uint32_t cand_wave_n[GHIP_SKETCH_THREADS / 64], cand_base;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t cand_n = 0;  // wave-uniform
-    Roll21 st{0, 0, -1};
+    Win21 st{0, 0, 0, 0, K - 1, ak - 1};   // "last bad byte" = -1
     struct Pend { uint64_t A, B, T; uint32_t ax, bx; } pend{};  // table terms of the position whose hash is pending
     // hash one position from its table terms and append it to the genome's candidate list if it is under the
-    // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word)
-    auto finish = [&](const Pend &p, const int b, const uint32_t inword) {
+    // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word up to b)
+    auto finish = [&](const Pend &p, const int b, const uint32_t inword) __attribute__((always_inline)) {
         const uint32_t a1 = (uint32_t)(p.A >> 32) + p.ax, b1 = (uint32_t)(p.B >> 32) + p.bx;
         uint64_t F1, F2;  // the two halves of the hash short of their last multiply (murmur21_asm.h)
 #ifdef GHIP_DBG_NOHASH  // timing experiment only: wrong results
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         bool hit = s1 <= thr_bound;  // necessary for h <= thr (murmur21_asm.h)
         if (__builtin_amdgcn_ballot_w64(hit)) {
             const uint64_t h = murmur21_finish(F1, F2);
-            hit = hit && h <= thr && (b - st.lastbad >= K) && inword == 0;
+            hit = hit && h <= thr && st.lim21 <= b && inword == 0;
             const unsigned long long m = __ballot(hit);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (hit) {
@@ -224,74 +224,96 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         for (uint32_t i = threadIdx.x & 63u; i < mine; i += 64)
             if (base + i < ccap) cand[cstart + base + i] = cand_lds[wave][i];
     };
-    // one 4-byte word: decode once (SWAR), then per byte roll both strands; HASH: hash the 21-mer ending there
-    auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, const bool seed_gate, const bool have_pend) {
+    // One 4-byte word.  The four codes are decoded together (SWAR) and packed by two multiplies -- (t * 0x01041040) >> 24 =
+    // c0 | c1<<2 | c2<<4 | c3<<6 and ((t ^ 3333) * 0x40100401) >> 24 = the complements in reverse order; the partial
+    // products fall into distinct 2-bit fields, so nothing carries -- and shifted into the two 24-base windows ONCE; the
+    // four 21-mers ending in this word are bit fields of the windows (one v_alignbit + one v_bfe per strand and position),
+    // instead of two 64-bit shift/or/and chains per byte.  SLOW: some lane of the wave holds a non-ACGT byte in this word
+    // (wave-uniform, rare): only then are the per-byte bad-byte masks evaluated; otherwise a window is clean iff
+    // lim <= b, tested for the ~1/2000 hash survivors and the ~1/125 seed candidates only.
+    auto word_impl = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto slow_tag, const bool seed_gate, const bool have_pend) __attribute__((always_inline)) {
         constexpr bool HASH = decltype(hash_tag)::value;
         constexpr bool SEED_HERE = SEEDS && decltype(seed_tag)::value;
+        constexpr bool SLOW = decltype(slow_tag)::value;
         const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;   // A0 C1 G2 T3 per byte
-        const uint32_t tc = t ^ 0x03030303u;                       // complement
-        const uint32_t bad4 = w & 0x08080808u;                     // bit 3: not one of A,C,G,T
+        const uint32_t fm = t * 0x01041040u, rm = (t ^ 0x03030303u) * 0x40100401u;
+        [[maybe_unused]] const uint32_t bad4 = w & 0x08080808u;    // bit 3: not one of A,C,G,T
+        {   // W = (W >> 8) | (fpack << 40);  R = (R << 8) | rpack
+            const uint32_t nwlo = __builtin_amdgcn_alignbit(st.whi, st.wlo, 8);
+            const uint32_t nwhi = __builtin_amdgcn_perm(fm, st.whi, 0x0c0c0701u);   // byte 0 = whi.byte1, byte 1 = fm.byte3
+            const uint32_t nrhi = __builtin_amdgcn_alignbit(st.rhi, st.rlo, 24);
+            const uint32_t nrlo = __builtin_amdgcn_alignbit(st.rlo, rm, 24);
+            st.wlo = nwlo; st.whi = nwhi; st.rlo = nrlo; st.rhi = nrhi;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t code = (t >> (8 * j)) & 3u, ccode = (tc >> (8 * j)) & 3u;
-            st.fl = (st.fl >> 2) | ((uint64_t)code << (2 * (K - 1)));
-            st.rc = ((st.rc << 2) | ccode) & mask;
             const int b = b0 + j;
-            [[maybe_unused]] const uint32_t inword = bad4 & (0xffffffffu >> (8 * (3 - j)));  // bad bytes 0..j of this word
+            [[maybe_unused]] const uint32_t inword = SLOW ? (bad4 & (0xffffffffu >> (8 * (3 - j)))) : 0u;  // bad bytes 0..j of this word
+            const int fs = 2 * j, rs = 6 - 2 * j;
+            const uint32_t flo = fs ? __builtin_amdgcn_alignbit(st.whi, st.wlo, fs) : st.wlo;
+            const uint32_t rlo = rs ? __builtin_amdgcn_alignbit(st.rhi, st.rlo, rs) : st.rlo;
             if constexpr (SEED_HERE) {
                 // so.k-mer ending here: forward big-endian code = complement of rc's low bits; reverse
                 // complement = complement of the top so.k bases of the forward little-endian code
-                const uint32_t f15 = ~(uint32_t)st.rc & amask;
-                const uint32_t r15 = ~(uint32_t)(st.fl >> ashift) & amask;
+                const uint32_t f15 = ~rlo & amask;
+                const uint32_t r15 = ~(uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift)) & amask;
                 const uint32_t c15 = min(f15, r15);
 #ifdef GHIP_DBG_SEEDHASH1  // timing experiment only (scripts/sketch_variants.sh): wrong results
-                bool pass = seed_gate && (c15 * 0x9e3779b1u) < so.thr;
+                const bool pass = seed_gate && (c15 * 0x9e3779b1u) < so.thr;
 #else
-                bool pass = seed_gate && ghip_seed::fmix32(c15) < so.thr;
+                const bool pass = seed_gate && ghip_seed::fmix32(c15) < so.thr;
 #endif
-                if (__builtin_amdgcn_ballot_w64(pass)) {  // validity only where some lane passed
-                    pass = pass && (b - st.lastbad >= ak) && inword == 0;
+                if (pass) {  // ~1/125 of the lanes: validity only here
+                    const bool ok = st.lim15 <= b && inword == 0;
 #ifdef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
-                    sb.n_lane += pass;
+                    sb.n_lane += ok;
 #else
-                    ghip_seed::seed_append(sl, so, sb, pass, c15, toff + (uint32_t)(b - (ak - 1)));
+                    ghip_seed::seed_append(sl, so, sb, ok, c15, toff + (uint32_t)(b - (ak - 1)));
 #endif
                 }
             }
             if constexpr (HASH) {
                 // software pipeline: issue this position's five table reads, then hash the PREVIOUS position
                 // (its reads were issued one step ago), so LDS latency hides behind ~240 cycles of hashing
-                const uint64_t canon = st.rc < st.fl ? st.rc : st.fl;
-                const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+                const uint32_t fhi = __builtin_amdgcn_ubfe(st.whi, fs, 10), rhi = __builtin_amdgcn_ubfe(st.rhi, rs, 10);
+                const bool use_rc = (((uint64_t)rhi << 32) | rlo) < (((uint64_t)fhi << 32) | flo);
+                const uint32_t lo = use_rc ? rlo : flo, hi = use_rc ? rhi : fhi;
                 Pend cur;
 #ifdef GHIP_DBG_NOLDS  // timing experiment only (scripts/sketch_variants.sh): wrong results
-                cur.A = canon ^ 0x1234u; cur.B = canon + 77u; cur.T = canon >> 3; cur.ax = lo; cur.bx = hi;
+                cur.A = lo ^ 0x1234u; cur.B = lo + 77u; cur.T = hi >> 3; cur.ax = lo; cur.bx = hi;
 #else
                 cur.A = luts.c1[lo & 0xffu]; cur.B = luts.c2[(lo >> 16) & 0xffu]; cur.T = luts.tail[hi];
                 cur.ax = reinterpret_cast<const uint32_t *>(luts.c1)[2 * ((lo >> 8) & 0xffu)];  // low words only
                 cur.bx = reinterpret_cast<const uint32_t *>(luts.c2)[2 * (lo >> 24)];
 #endif
                 // the previous position is byte j-1 of this word, or byte 3 of the word before (whose bad
-                // bytes are already folded into lastbad)
-                if (j > 0 || have_pend) finish(pend, b - 1, j > 0 ? (bad4 & (0xffffffffu >> (8 * (4 - j)))) : 0u);
+                // bytes are already folded into lim21)
+                if (j > 0 || have_pend) finish(pend, b - 1, (SLOW && j > 0) ? (bad4 & (0xffffffffu >> (8 * (4 - j)))) : 0u);
                 pend = cur;
             }
         }
-        if (__builtin_amdgcn_ballot_w64(bad4 != 0)) {  // wave-uniform: rare
-            asm volatile("" ::: "memory");  // keep this a branch: if-converted it costs 9 instructions per word
-            if (bad4) st.lastbad = b0 + 3 - (int)(__builtin_clz(bad4) >> 3);
+        if constexpr (SLOW) {
+            if (bad4) {
+                const int lastbad = b0 + 3 - (int)(__builtin_clz(bad4) >> 3);
+                st.lim21 = lastbad + K;
+                st.lim15 = lastbad + ak;
+            }
         }
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    // warm-up: bytes 0..19 only roll the state -- except in the first wave of a genome, whose lane 0
+    auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, const bool seed_gate, const bool have_pend) __attribute__((always_inline)) {
+        if (__builtin_amdgcn_ballot_w64((w & 0x08080808u) != 0)) word_impl(w, b0, hash_tag, seed_tag, T_{}, seed_gate, have_pend);
+        else word_impl(w, b0, hash_tag, seed_tag, F_{}, seed_gate, have_pend);
+    };
+    // warm-up: bytes 0..19 only fill the windows -- except in the first wave of a genome, whose lane 0
     // owns the seeds that end before byte 20
     const uint32_t warm[5] = {q0.x, q0.y, q0.z, q0.w, q1.x};
     if (SEEDS && wk.chunk == 0 && threadIdx.x < 64) {
         const bool first = threadIdx.x == 0;
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            // bytes b < ak-1 cannot end a seed: the validity window b - lastbad >= ak with lastbad = -1 says so
+            // bytes b < ak-1 cannot end a seed: lim15 = ak - 1 says so
             word(warm[i], 4 * i, F_{}, T_{}, first, false);
         }
     } else {
