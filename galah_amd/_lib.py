@@ -114,7 +114,7 @@ class RankTimes(C.Structure):
 
 class AniLayout(C.Structure):
     _fields_ = [("n", C.c_size_t), ("n_seed_slots", C.c_uint64), ("n_bin_slots", C.c_uint64),
-                ("n_chunk_slots", C.c_uint64), ("d_seed_code", C.c_void_p), ("d_seed_chunk", C.c_void_p),
+                ("n_chunk_slots", C.c_uint64), ("d_seed_code", C.c_void_p), ("d_seed_loc", C.c_void_p),
                 ("d_bin_start", C.c_void_p), ("d_chunk_total", C.c_void_p)]
 
 

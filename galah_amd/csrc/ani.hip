@@ -1,24 +1,25 @@
 // ANI on candidate pairs, batched on gfx950: replaces the per-pair `skani dist` subprocess of
 // SkaniClusterer::calculate_ani (reference src/skani.rs:708-788).  Build-defined estimator in
-// skani's style (FracMinHash seeds k=15 c=125, 20 kb chunks, containment^(1/k), aligned-
-// fraction gate, two-decimal percent) -- skani parity is UNPINNED, see DESIGN.md "ANI".
+// skani's style (FracMinHash seeds k=15 c=125, 20 kb chunks, seed matches colinear within a chunk,
+// containment^(1/k), aligned-fraction gate, two-decimal percent) -- skani parity is UNPINNED, see
+// DESIGN.md "ANI" and oracle/galah_oracle_ani.c (the definition this file reproduces bit for bit).
 // The device does integer work only; the host finishes pow/rounding.
 //
-//   ani_seeds : pass over the base stream; canonical 2-bit k-mer (k <= 16, fits u32) ->
-//               fmix32 (bijective); seeds with fmix32(code) < 2^32/c are appended as (code u32,
-//               chunk u16) and counted per chunk.  The mix is a bijection, so "same hash" ==
-//               "same code" and the 4-byte code is what is stored and compared.
-//   ani_bin   : per genome, counting sort of the seed list by the top 14 bits of a 32-bit
+//   ani_seeds : pass over the base stream; canonical 2-bit k-mer (k <= 16, fits u32) -> multiplicative
+//               mix (bijective); seeds with mix(code) < 2^32/c are appended as (code u32, loc u32 =
+//               chunk << 16 | strand << 15 | offset in chunk) and counted per chunk.
+//   ani_bin   : per genome, counting sort of the seed list by the top 14 bits of a second
 //               multiplicative hash of the code; writes the binned list and its bin offsets
 //               (CSR).  Every genome uses the same bin function, so two genomes can be joined
 //               bin by bin -- no hash table, no atomics on the device-wide memory.
-//   ani_pairs : one workgroup per PAIR (both directions at once): lane b joins bin b of the
-//               two genomes (~2.4 x 2.4 seeds), counting matched seeds per 20 kb chunk of
-//               each genome in LDS; a chunk is aligned iff M_c*10000 >= 510*T_c; emits the
-//               (M_c, T_c) of the lower-median containment over the aligned chunks of both
-//               directions (rank selection, exact cross-multiplied compares), their number, and
-//               the aligned bases per direction.  All four streams (two
-//               bin-offset arrays, two code arrays) are read front to back, coalesced.
+//   ani_pairs : one workgroup per PAIR (both directions at once): a wave stages the seeds of 64
+//               consecutive bins of both genomes in LDS and joins them; every anchor (equal codes)
+//               gives an orientation and a diagonal, i.e. one of 16 bands; per chunk and band the
+//               seeds with an anchor there are counted in LDS (u16 votes); M_c = the votes of the
+//               bands that hold >= 3 seeds (colinear matches only), capped at T_c; a chunk is
+//               aligned iff M_c*10000 >= 510*T_c; emits the (M_c, T_c) of the lower-median containment
+//               over the aligned chunks of both directions (rank selection, exact), their number,
+//               and the aligned bases per direction.
 #include "ghip_internal.h"
 #include "seed_common.h"
 
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 rev = (rev >> 2) | ((3u - code) << top);
                 good = valid ? good + 1 : 0;
                 const uint32_t canon = min(fwd, rev);
-                const bool pass = b < NB && b >= (int)K - 1 && good >= K && fmix32(canon) < so.thr;
-                seed_append(sl, so, sb, pass, canon, toff + (uint32_t)(b - ((int)K - 1)));
+                const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_mix(canon) < so.thr;
+                seed_append(sl, so, sb, pass, canon, toff + (uint32_t)(b - ((int)K - 1)), rev < fwd ? 1u : 0u);
             }
         }
     }
@@ -84,14 +85,14 @@ constexpr uint32_t BIN_COUNT = GHIP_ANI_BIN_COUNT, BIN_THREADS = 1024;
 // Counting sort in LDS; the order inside a bin is arbitrary.  bin_start[g][b] is relative to the
 // genome's first seed slot, so shards can be concatenated.
 __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
-    const uint32_t *__restrict__ in_code, const uint16_t *__restrict__ in_chunk,
-    uint32_t *__restrict__ out_code, uint16_t *__restrict__ out_chunk,
+    const uint32_t *__restrict__ in_code, const uint32_t *__restrict__ in_loc,
+    uint32_t *__restrict__ out_code, uint32_t *__restrict__ out_loc,
     const uint64_t *__restrict__ seed_start, const uint32_t *__restrict__ seed_count,
     uint32_t *__restrict__ bin_start, uint32_t *__restrict__ pos_tmp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);  // BIN_COUNT counters
-    constexpr uint32_t BIN_WINDOW = 10880;  // 64 KiB / 6 B per seed, rounded down to a multiple of 64
-    static_assert(BIN_WINDOW * 6 <= BIN_COUNT * 4, "the output window reuses the histogram's LDS");
+    constexpr uint32_t BIN_WINDOW = 8192;  // 64 KiB / 8 B per seed
+    static_assert(BIN_WINDOW * 8 <= BIN_COUNT * 4, "the output window reuses the histogram's LDS");
     __shared__ uint32_t wave_tot[BIN_THREADS / 64];
     const uint32_t g = blockIdx.x;
     const uint64_t s0 = seed_start[g];
@@ -138,17 +139,17 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     // Scatter through an LDS window and write each window out contiguously: scattering 4-byte
     // stores straight to HBM costs a whole sector per seed (PMC: 3.3 GB written for 0.27 GB).
     uint32_t *w_code = hist;                                               // BIN_WINDOW x 4 B (the histogram is dead)
-    uint16_t *w_chunk = reinterpret_cast<uint16_t *>(hist + BIN_WINDOW);   // BIN_WINDOW x 2 B
+    uint32_t *w_loc = hist + BIN_WINDOW;                                   // BIN_WINDOW x 4 B
     for (uint32_t w0 = 0; w0 < n; w0 += BIN_WINDOW) {
         for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
             const uint32_t p = (narrow ? (uint32_t)pos16[i] : pos_tmp[s0 + i]) - w0;
-            if (p < BIN_WINDOW) { w_code[p] = in_code[s0 + i]; w_chunk[p] = in_chunk[s0 + i]; }
+            if (p < BIN_WINDOW) { w_code[p] = in_code[s0 + i]; w_loc[p] = in_loc[s0 + i]; }
         }
         __syncthreads();
         const uint32_t m = min(BIN_WINDOW, n - w0);
         for (uint32_t k = threadIdx.x; k < m; k += BIN_THREADS) {
             out_code[s0 + w0 + k] = w_code[k];
-            out_chunk[s0 + w0 + k] = w_chunk[k];
+            out_loc[s0 + w0 + k] = w_loc[k];
         }
         __syncthreads();
     }
@@ -156,15 +157,44 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
 
 constexpr uint32_t ANI_PAIR_THREADS = 512;
 constexpr uint32_t ANI_PAIR_WAVES = ANI_PAIR_THREADS / 64;
-constexpr uint32_t ANI_STAGE = 448;  // seeds of 64 consecutive bins staged per wave and genome (expected ~154)
+constexpr uint32_t ANI_STAGE = 384;  // seeds of 64 consecutive bins staged per wave and genome (expected ~154 for 5 Mb at c = 125)
+constexpr uint32_t ANI_BAND_SHIFT = 12, ANI_MIN_COLINEAR = 3;   // 4 kb diagonal bands; >= 3 seeds of a chunk must agree (oracle: GO_ANI_*)
+constexpr uint32_t ANI_VOTE_WORDS = 8;                          // 16 bands x u16 per chunk
+
+// location word of a seed: chunk << 16 | strand << 15 | offset in chunk
+__device__ __forceinline__ uint32_t loc_pos(uint32_t loc, uint32_t chunk) { return (loc >> 16) * chunk + (loc & 0x7fffu); }
+
+// band of the anchor (q seed, r seed): orientation and diagonal (oracle/galah_oracle_ani.c)
+__device__ __forceinline__ uint32_t anchor_band(uint32_t qloc, uint32_t qpos, uint32_t rloc, uint32_t chunk) {
+    const uint32_t o = ((qloc ^ rloc) >> 15) & 1u, rpos = loc_pos(rloc, chunk);
+    const uint32_t d = o ? rpos + qpos : rpos - qpos;
+    return ((d >> ANI_BAND_SHIFT) & 7u) | (o << 3);
+}
+
+// one vote per set bit of `mask` for chunk `c`: u16 counters, two per LDS word (a counter never exceeds the seeds of a
+// chunk, <= 32768, so halves cannot carry into each other)
+__device__ __forceinline__ void cast_votes(uint32_t *votes, uint32_t c, uint32_t mask) {
+    while (mask) {
+        const uint32_t band = (uint32_t)__builtin_ctz(mask);
+        mask &= mask - 1;
+        atomicAdd(&votes[c * ANI_VOTE_WORDS + (band >> 1)], 1u << (16u * (band & 1u)));
+    }
+}
 
 // Appends (M_c << 32 | T_c) of every aligned chunk (M_c*10000 >= 510*T_c) to `list` and returns this
-// thread's share of the aligned bases.
-__device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *mc, const uint32_t *tc, uint32_t nch, uint64_t L,
+// thread's share of the aligned bases.  M_c = votes of the bands holding >= ANI_MIN_COLINEAR seeds, capped at T_c.
+__device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *votes, const uint32_t *tc, uint32_t nch, uint64_t L,
                                                               uint32_t chunk, unsigned long long *list, uint32_t *n_al) {
     unsigned long long bases = 0;
     for (uint32_t c = threadIdx.x; c < nch; c += blockDim.x) {
-        const unsigned long long t = tc[c], m = mc[c];
+        const unsigned long long t = tc[c];
+        unsigned long long m = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < ANI_VOTE_WORDS; w++) {
+            const uint32_t v = votes[c * ANI_VOTE_WORDS + w], lo = v & 0xffffu, hi = v >> 16;
+            m += (lo >= ANI_MIN_COLINEAR ? lo : 0u) + (hi >= ANI_MIN_COLINEAR ? hi : 0u);
+        }
+        if (m > t) m = t;
         if (t >= 1 && m * 10000ull >= 510ull * t) {
             list[atomicAdd(n_al, 1u)] = (m << 32) | t;
             const uint64_t lo = (uint64_t)c * chunk;
@@ -180,12 +210,12 @@ __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *mc
 
 // The 64 bins a wave joins in one round are consecutive, so their seeds form ONE contiguous run
 // per genome: the wave copies both runs into its private LDS stage with coalesced loads and every
-// lane then joins its own bin out of LDS.  (Walking the bins straight from global memory chained
+// lane then joins its own seeds out of LDS.  (Walking the bins straight from global memory chained
 // ~25 dependent L2 round trips per lane and bin.)  A round whose run exceeds the stage -- a
-// pathologically repetitive genome -- falls back to the global-memory walk for that round only.
+// pathologically repetitive or a very large genome -- falls back to the global-memory walk for that round only.
 __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ seed_code,
-    const uint16_t *__restrict__ seed_chunk, const uint64_t *__restrict__ seed_start,
+    const uint32_t *__restrict__ seed_loc, const uint64_t *__restrict__ seed_start,
     const uint32_t *__restrict__ bin_start, const uint32_t *__restrict__ chunk_total,
     const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, uint32_t chunk,
     uint32_t ro_cap, uint64_t *__restrict__ out) {
@@ -193,9 +223,9 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     __shared__ unsigned long long red[6];
     __shared__ uint32_t n_al;
     __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE];
-    __shared__ uint16_t st_chunk[ANI_PAIR_WAVES][2][ANI_STAGE];
-    __shared__ uint8_t st_flag[ANI_PAIR_WAVES][ANI_STAGE];  // r seed of the stage matched by some q seed
-    uint32_t *mcq = reinterpret_cast<uint32_t *>(smem_raw);
+    __shared__ uint32_t st_loc[ANI_PAIR_WAVES][2][ANI_STAGE];
+    __shared__ uint32_t st_mask[ANI_PAIR_WAVES][ANI_STAGE / 2];  // band mask (16 bits) of every staged r seed, two per word
+    uint32_t *vq = reinterpret_cast<uint32_t *>(smem_raw);
 
     // physical block b runs on XCD b % 8: give each XCD runs of 32 consecutive pairs (one precluster's
     // genomes are then re-read from that XCD's L2)
@@ -205,23 +235,23 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t q = pairs[2 * pair], r = pairs[2 * pair + 1];
     const uint32_t nchq = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
     const uint32_t nchr = (uint32_t)(chunk_start[r + 1] - chunk_start[r]);
-    uint32_t *mcr = mcq + nchq;
-    unsigned long long *list = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)(nchq + nchr) * 4 + 7) & ~(size_t)7));
-    for (uint32_t i = threadIdx.x; i < nchq + nchr; i += blockDim.x) mcq[i] = 0;
+    uint32_t *vr = vq + (size_t)nchq * ANI_VOTE_WORDS;
+    unsigned long long *list = reinterpret_cast<unsigned long long *>(vr + (size_t)nchr * ANI_VOTE_WORDS);
+    for (uint32_t i = threadIdx.x; i < (nchq + nchr) * ANI_VOTE_WORDS; i += blockDim.x) vq[i] = 0;
     if (threadIdx.x < 6) red[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_al = 0;
     __syncthreads();
 
     const uint32_t *qb = bin_start + (uint64_t)q * (BIN_COUNT + 1), *rb = bin_start + (uint64_t)r * (BIN_COUNT + 1);
     const uint32_t *qc = seed_code + seed_start[q], *rc = seed_code + seed_start[r];
-    const uint16_t *qk = seed_chunk + seed_start[q], *rk = seed_chunk + seed_start[r];
+    const uint32_t *ql = seed_loc + seed_start[q], *rl = seed_loc + seed_start[r];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t *sq = st_code[wave][0], *sr = st_code[wave][1];
-    uint16_t *kq = st_chunk[wave][0], *kr = st_chunk[wave][1];
-    uint8_t *rf = st_flag[wave];
+    uint32_t *lq = st_loc[wave][0], *lr = st_loc[wave][1];
+    uint32_t *rm = st_mask[wave];
     // stage offsets of the round's r bins: dynamic LDS behind the aligned-chunk list, ro_cap entries per wave
     uint16_t *ro = reinterpret_cast<uint16_t *>(list + (nchq + nchr)) + (size_t)wave * ro_cap;
-    for (uint32_t k = lane; k < ANI_STAGE; k += 64) rf[k] = 0;
+    for (uint32_t k = lane; k < ANI_STAGE / 2; k += 64) rm[k] = 0;
     // Bins joined per wave and round: 64 for bacterial-size genomes (~154 seeds per run at c = 125); small genomes
     // and contigs take 256 or 1024 bins per round so that a run still holds ~190 seeds and the fixed cost of a round
     // (bounds, barriers, three short loops) is paid 8 or 2 times per wave instead of 32.
@@ -245,19 +275,19 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             {   // both runs in one loop: the four loads of an iteration are in flight together
                 const uint32_t nqs = q_hi - q_lo, nrs = r_hi - r_lo;
                 for (uint32_t k = lane; k < max(nqs, nrs); k += 64) {
-                    uint32_t c1 = 0, c2 = 0;
-                    uint16_t h1 = 0, h2 = 0;
-                    if (k < nqs) { c1 = qc[q_lo + k]; h1 = qk[q_lo + k]; }
-                    if (k < nrs) { c2 = rc[r_lo + k]; h2 = rk[r_lo + k]; }
-                    if (k < nqs) { sq[k] = c1; kq[k] = h1; }
-                    if (k < nrs) { sr[k] = c2; kr[k] = h2; }
+                    uint32_t c1 = 0, c2 = 0, h1 = 0, h2 = 0;
+                    if (k < nqs) { c1 = qc[q_lo + k]; h1 = ql[q_lo + k]; }
+                    if (k < nrs) { c2 = rc[r_lo + k]; h2 = rl[r_lo + k]; }
+                    if (k < nqs) { sq[k] = c1; lq[k] = h1; }
+                    if (k < nrs) { sr[k] = c2; lr[k] = h2; }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // Flattened join: q seeds are dealt to the lanes one each (not one BIN per lane, whose cost is the
             // largest bin of the wave squared); a seed's bin, hence its short r range, follows from its code.
-            // Matched r seeds are flagged and counted in a second balanced pass.
+            // Every anchor sets its band in the q seed's mask (a register) and in the r seed's mask (LDS); the
+            // votes of the r seeds are cast in a second balanced pass.
             const uint32_t nq = q_hi - q_lo, nr = r_hi - r_lo;
             ro[lane] = (uint16_t)(rs - r_lo);            // r range of bin b0 + x = [ro[x], ro[x + 1])
             for (uint32_t u = 64 + lane; u < rbins; u += 64) ro[u] = (uint16_t)(rb[b0 + u] - r_lo);
@@ -274,35 +304,55 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                 uint32_t mm = 0;
 #pragma unroll
                 for (uint32_t u = 0; u < 8; u++) mm |= (uint32_t)((j0 + u < jz) & (sr[min(j0 + u, ANI_STAGE - 1)] == c)) << u;
-                bool hit = mm != 0;
-                for (uint32_t j = j0 + 8; j < jz; j++)
-                    if (sr[j] == c) { hit = true; rf[j] = 1; }
-                while (mm) {
-                    rf[j0 + (uint32_t)__builtin_ctz(mm)] = 1;
-                    mm &= mm - 1;
+                bool any = mm != 0;
+                for (uint32_t j = j0 + 8; j < jz; j++) any |= (sr[j] == c);
+                if (any) {   // ~half of the seeds of related genomes
+                    const uint32_t qloc = lq[i], qpos = loc_pos(qloc, chunk);
+                    uint32_t qmask = 0;
+                    while (mm) {
+                        const uint32_t j = j0 + (uint32_t)__builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const uint32_t band = anchor_band(qloc, qpos, lr[j], chunk);
+                        qmask |= 1u << band;
+                        atomicOr(&rm[j >> 1], (1u << band) << (16u * (j & 1u)));
+                    }
+                    for (uint32_t j = j0 + 8; j < jz; j++)
+                        if (sr[j] == c) {
+                            const uint32_t band = anchor_band(qloc, qpos, lr[j], chunk);
+                            qmask |= 1u << band;
+                            atomicOr(&rm[j >> 1], (1u << band) << (16u * (j & 1u)));
+                        }
+                    cast_votes(vq, qloc >> 16, qmask);
                 }
-                if (hit) atomicAdd(&mcq[kq[i]], 1u);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t j = lane; j < nr; j += 64)
-                if (rf[j]) { rf[j] = 0; atomicAdd(&mcr[kr[j]], 1u); }
+            for (uint32_t w = lane; w < (nr + 1) / 2; w += 64) {
+                const uint32_t m2 = rm[w];
+                if (m2) {
+                    rm[w] = 0;
+                    if (m2 & 0xffffu) cast_votes(vr, lr[2 * w] >> 16, m2 & 0xffffu);
+                    if (m2 >> 16) cast_votes(vr, lr[2 * w + 1] >> 16, m2 >> 16);
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
-        } else {  // a run longer than the stage (a pathologically repetitive genome): lane-per-bin walk in global memory
+        } else {  // a run longer than the stage: lane-per-bin walk in global memory
             for (uint32_t u = lane; u < rbins; u += 64) {
                 const uint32_t qs = qb[b0 + u], qe = qb[b0 + u + 1], rs_ = rb[b0 + u], re = rb[b0 + u + 1];
                 for (uint32_t i = qs; i < qe; i++) {
-                    const uint32_t c = qc[i];
-                    bool hit = false;
-                    for (uint32_t j = rs_; j < re; j++) hit |= (rc[j] == c);
-                    if (hit) atomicAdd(&mcq[qk[i]], 1u);
+                    const uint32_t c = qc[i], qloc = ql[i], qpos = loc_pos(qloc, chunk);
+                    uint32_t qmask = 0;
+                    for (uint32_t j = rs_; j < re; j++)
+                        if (rc[j] == c) qmask |= 1u << anchor_band(qloc, qpos, rl[j], chunk);
+                    if (qmask) cast_votes(vq, qloc >> 16, qmask);
                 }
                 for (uint32_t j = rs_; j < re; j++) {
-                    const uint32_t c = rc[j];
-                    bool hit = false;
-                    for (uint32_t i = qs; i < qe; i++) hit |= (qc[i] == c);
-                    if (hit) atomicAdd(&mcr[rk[j]], 1u);
+                    const uint32_t c = rc[j], rloc = rl[j];
+                    uint32_t rmask = 0;
+                    for (uint32_t i = qs; i < qe; i++)
+                        if (qc[i] == c) { const uint32_t qloc = ql[i]; rmask |= 1u << anchor_band(qloc, loc_pos(qloc, chunk), rloc, chunk); }
+                    if (rmask) cast_votes(vr, rloc >> 16, rmask);
                 }
             }
         }
@@ -310,8 +360,8 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     __syncthreads();
     // (M_c, T_c) of the aligned chunks of both directions, then the LOWER MEDIAN containment M_c/T_c
     // by rank selection (exact: fractions compared by cross-multiplication)
-    const unsigned long long bq = collect_aligned(mcq, chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
-    const unsigned long long br = collect_aligned(mcr, chunk_total + chunk_start[r], nchr, glen[r], chunk, list, &n_al);
+    const unsigned long long bq = collect_aligned(vq, chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
+    const unsigned long long br = collect_aligned(vr, chunk_total + chunk_start[r], nchr, glen[r], chunk, list, &n_al);
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[2], bq); atomicAdd(&red[5], br); }
     __syncthreads();
     const uint32_t n = n_al;
@@ -364,11 +414,11 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
 }  // namespace
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
-                           uint32_t *d_seed_code, uint16_t *d_seed_chunk, const uint64_t *d_seed_start,
+                           uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    ghip_seed::SeedOut so{k, ~0u / c, chunk, d_seed_code, d_seed_chunk, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start};
+    ghip_seed::SeedOut so{k, ~0u / c, chunk, d_seed_code, d_seed_loc, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start};
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),
@@ -376,8 +426,8 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
     ghip_prof_end(ctx);
 }
 
-void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint16_t *in_chunk, uint32_t *out_code,
-                         uint16_t *out_chunk, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
+void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint32_t *in_loc, uint32_t *out_code,
+                         uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp) {
     if (n == 0) return;
     static bool attr_set = false;
@@ -387,7 +437,7 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
     }
     ghip_prof_begin(ctx, "ani_bin");
     hipLaunchKernelGGL(ani_bin_kernel, dim3((unsigned)n), dim3(BIN_THREADS), BIN_COUNT * sizeof(uint32_t), ctx->stream,
-                       in_code, in_chunk, out_code, out_chunk, d_seed_start, d_seed_count, d_bin_start, d_pos_tmp);
+                       in_code, in_loc, out_code, out_loc, d_seed_start, d_seed_count, d_bin_start, d_pos_tmp);
     ghip_prof_end(ctx);
 }
 
@@ -398,10 +448,11 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
     // costs 16 KiB of LDS per workgroup, which large-genome runs keep for a third resident workgroup per CU
     uint32_t ro_cap = 66;
     for (uint32_t c : idx->seed_count) if (c <= 12000) { ro_cap = 1026; break; }
-    if ((size_t)2 * max_chunks * 12 + 16 + (size_t)ANI_PAIR_WAVES * 1026 * 2 > 160 * 1024 - 46 * 1024) ro_cap = 66;  // 46 KiB static
-    const size_t lds = (size_t)2 * max_chunks * (sizeof(uint32_t) + sizeof(uint64_t)) + 16   // counters + aligned-chunk list
-                       + (size_t)ANI_PAIR_WAVES * ro_cap * sizeof(uint16_t);                  // r-bin offsets of a round
-    static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand (+43 KiB static stage)
+    constexpr size_t STATIC_LDS = 64 * 1024;   // seed stage (code + loc, both genomes) + band masks, rounded up
+    const size_t per_chunk = ANI_VOTE_WORDS * sizeof(uint32_t) + sizeof(uint64_t);   // votes + aligned-chunk list entry
+    if ((size_t)2 * max_chunks * per_chunk + 16 + (size_t)ANI_PAIR_WAVES * 1026 * 2 > 160 * 1024 - STATIC_LDS) ro_cap = 66;
+    const size_t lds = (size_t)2 * max_chunks * per_chunk + 16 + (size_t)ANI_PAIR_WAVES * ro_cap * sizeof(uint16_t);   // + r-bin offsets of a round
+    static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand
     if (lds > attr_lds) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
@@ -409,7 +460,7 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
     ghip_prof_begin(ctx, "ani_pairs");
     const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
     hipLaunchKernelGGL(ani_pairs_kernel, dim3(grid), dim3(ANI_PAIR_THREADS), lds, ctx->stream, d_pairs, (uint32_t)n_pairs,
-                       idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
+                       idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
                        idx->d_chunk_start, idx->d_glen, idx->chunk, ro_cap, d_out);
     ghip_prof_end(ctx);
 }

@@ -1014,12 +1014,12 @@ extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min
 static void free_index_arrays_locked(ghip_ani_index *idx) {
     ghip_ctx *ctx = idx->ctx;
     if (idx->owned) {
-        ghip_pool_free(ctx, idx->d_seed_code); ghip_pool_free(ctx, idx->d_seed_chunk);
+        ghip_pool_free(ctx, idx->d_seed_code); ghip_pool_free(ctx, idx->d_seed_loc);
         ghip_pool_free(ctx, idx->d_bin_start); ghip_pool_free(ctx, idx->d_chunk_total);
     }
     ghip_pool_free(ctx, idx->d_seed_start); ghip_pool_free(ctx, idx->d_seed_count);
     ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen);
-    idx->d_seed_code = nullptr; idx->d_seed_chunk = nullptr; idx->d_bin_start = nullptr; idx->d_chunk_total = nullptr;
+    idx->d_seed_code = nullptr; idx->d_seed_loc = nullptr; idx->d_bin_start = nullptr; idx->d_chunk_total = nullptr;
     idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_chunk_start = nullptr;
     idx->d_glen = nullptr;
 }
@@ -1046,8 +1046,8 @@ extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
 // kernel or ride along with the MinHash pass (ghip_sketch_and_index)
 static int index_new(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk, ghip_ani_index **out,
                      std::vector<uint64_t> &cap) {
-    if (k < 1 || k > 16 || c < 1 || chunk < 1 || chunk > (1u << 24))
-        return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters (k must be 1..=16, chunk 1..=2^24)");
+    if (k < 1 || k > 16 || c < 1 || chunk < 1 || chunk > GHIP_ANI_MAX_CHUNK_LEN)
+        return ghip_set_error(ctx, GHIP_EINVAL, "bad ANI sketch parameters (k must be 1..=16, chunk 1..=32768)");
     const size_t n = g->n;
     ghip_ani_index *idx = new ghip_ani_index();
     ctx->live_handles++;
@@ -1061,7 +1061,7 @@ static int index_new(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t 
     }
     if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) {
         free_index_locked(idx);
-        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");
+        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (at most 1250 chunks per genome: 25 Mb at the default 20 kb chunk, 40 Mb at 32768)");
     }
     cap.resize(n);
     for (size_t i = 0; i < n; i++) cap[i] = ghip_ani_seed_capacity(g->lens[i], c);
@@ -1078,7 +1078,7 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
     hipStreamSynchronize(ctx->stream);
     free_index_arrays_locked(idx);
     if ((rc = dmalloc(ctx, &idx->d_seed_code, idx->seed_start[n]))) return rc;
-    if ((rc = dmalloc(ctx, &idx->d_seed_chunk, idx->seed_start[n]))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_seed_loc, idx->seed_start[n]))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_seed_count, n))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) return rc;
@@ -1093,7 +1093,7 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
 }
 
 static ghip_seed_args index_seed_args(const ghip_ani_index *idx) {
-    return ghip_seed_args{idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start,
+    return ghip_seed_args{idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
                           idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start};
 }
 
@@ -1113,7 +1113,7 @@ static int index_seed_standalone(ghip_ctx *ctx, const ghip_genomes *g, ghip_ani_
     for (int attempt = 0; attempt < 2; attempt++) {
         int rc = index_alloc_seeds(ctx, idx, cap);
         if (rc) return rc;
-        ghip_launch_ani_seeds(ctx, g, idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_chunk, idx->d_seed_start,
+        ghip_launch_ani_seeds(ctx, g, idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
                               idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
         bool overflow = false;
         if ((rc = index_check_seeds(ctx, idx, cap, &overflow))) return rc;
@@ -1126,14 +1126,14 @@ static int index_seed_standalone(ghip_ctx *ctx, const ghip_genomes *g, ghip_ani_
 static int index_finish(ghip_ctx *ctx, ghip_ani_index *idx) {
     const size_t n = idx->n;
     int rc;
-    uint32_t *d_code2 = nullptr, *d_pos = nullptr; uint16_t *d_chunk2 = nullptr;
+    uint32_t *d_code2 = nullptr, *d_pos = nullptr, *d_chunk2 = nullptr;
     if (!(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) &&
         !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n])) &&
         !(rc = dmalloc(ctx, &d_pos, idx->seed_start[n]))) {
-        ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_chunk, d_code2, d_chunk2, idx->d_seed_start,
+        ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_loc, d_code2, d_chunk2, idx->d_seed_start,
                             idx->d_seed_count, idx->d_bin_start, d_pos);
         std::swap(idx->d_seed_code, d_code2);
-        std::swap(idx->d_seed_chunk, d_chunk2);
+        std::swap(idx->d_seed_loc, d_chunk2);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
             rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
     }
@@ -1270,7 +1270,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
             }
         }
         const uint64_t n_seed = idx->seed_start[n], n_chunk = idx->chunk_start[n];
-        if (!(rc = dmalloc(ctx, &idx->d_seed_code, n_seed)) && !(rc = dmalloc(ctx, &idx->d_seed_chunk, n_seed)) &&
+        if (!(rc = dmalloc(ctx, &idx->d_seed_code, n_seed)) && !(rc = dmalloc(ctx, &idx->d_seed_loc, n_seed)) &&
             !(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) && !(rc = dmalloc(ctx, &idx->d_chunk_total, n_chunk)) &&
             !(rc = dmalloc(ctx, &idx->d_seed_start, n + 1)) && !(rc = dmalloc(ctx, &idx->d_seed_count, n)) &&
             !(rc = dmalloc(ctx, &idx->d_chunk_start, n + 1)) && !(rc = dmalloc(ctx, &idx->d_glen, n)) &&
@@ -1282,7 +1282,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
                 const uint64_t ns = b->seed_start[b->n], nc = b->chunk_start[b->n];
                 hipError_t e = hipSuccess;
                 if (ns) e = hipMemcpyAsync(idx->d_seed_code + at_seed, b->d_seed_code, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
-                if (ns && e == hipSuccess) e = hipMemcpyAsync(idx->d_seed_chunk + at_seed, b->d_seed_chunk, ns * sizeof(uint16_t), hipMemcpyDeviceToDevice, ctx->stream);
+                if (ns && e == hipSuccess) e = hipMemcpyAsync(idx->d_seed_loc + at_seed, b->d_seed_loc, ns * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
                 if (b->n && e == hipSuccess) e = hipMemcpyAsync(idx->d_bin_start + at_g * (GHIP_ANI_BIN_COUNT + 1), b->d_bin_start, b->n * (size_t)(GHIP_ANI_BIN_COUNT + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
                 if (nc && e == hipSuccess) e = hipMemcpyAsync(idx->d_chunk_total + at_chunk, b->d_chunk_total, nc * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
                 if (e != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index concatenation failed"); break; }
@@ -1334,11 +1334,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
         float v = 0.0f;
         if (n_aligned != 0 && T != 0 && !(afq < (double)min_af && afr < (double)min_af)) {
             // skani prints ANI with two decimals and galah parses that text as f32 (src/skani.rs:770)
-            // chance matches of mutated seeds against the whole other genome: observed = c + (1 - c) p0 (oracle header)
-            const double c_obs = (double)M / (double)T;
-            const double p0 = idx->k <= 31 ? (double)(idx->glen[q] + idx->glen[r]) / (double)(1ull << (2 * idx->k)) : 0.0;
-            double c = p0 < 1.0 ? (c_obs - p0) / (1.0 - p0) : 0.0;
-            if (c < 0.0) c = 0.0;
+            const double c = (double)M / (double)T;   // colinear seed matches only (ani.hip): no chance-match term
             double ani = 100.0 * std::pow(c, 1.0 / (double)idx->k);
             v = two_decimals_as_f32(ani);
         }
@@ -1355,7 +1351,7 @@ extern "C" int ghip_ani_index_layout(const ghip_ani_index *idx, ghip_ani_layout 
     out->n_seed_slots = idx->seed_start[idx->n];
     out->n_bin_slots = (uint64_t)idx->n * (GHIP_ANI_BIN_COUNT + 1);
     out->n_chunk_slots = idx->chunk_start[idx->n];
-    out->d_seed_code = idx->d_seed_code; out->d_seed_chunk = idx->d_seed_chunk;
+    out->d_seed_code = idx->d_seed_code; out->d_seed_loc = idx->d_seed_loc;
     out->d_bin_start = idx->d_bin_start; out->d_chunk_total = idx->d_chunk_total;
     return GHIP_OK;
 }
@@ -1372,9 +1368,9 @@ extern "C" int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_l
 
 extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, uint32_t chunk,
                                           const uint64_t *genome_len, const uint64_t *seed_cap,
-                                          const uint32_t *seed_count, void *d_seed_code, void *d_seed_chunk,
+                                          const uint32_t *seed_count, void *d_seed_code, void *d_seed_loc,
                                           void *d_bin_start, void *d_chunk_total, ghip_ani_index **out) {
-    if (!ctx || !out || chunk == 0 || chunk > (1u << 24) || (n && (!genome_len || !seed_cap || !seed_count))) return GHIP_EINVAL;
+    if (!ctx || !out || chunk == 0 || chunk > GHIP_ANI_MAX_CHUNK_LEN || (n && (!genome_len || !seed_cap || !seed_count))) return GHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ghip_ani_index *idx = new ghip_ani_index();
@@ -1390,7 +1386,7 @@ extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, u
         idx->seed_start[i + 1] = idx->seed_start[i] + seed_cap[i];
         idx->chunk_start[i + 1] = idx->chunk_start[i] + nch;
     }
-    idx->d_seed_code = (uint32_t *)d_seed_code; idx->d_seed_chunk = (uint16_t *)d_seed_chunk;
+    idx->d_seed_code = (uint32_t *)d_seed_code; idx->d_seed_loc = (uint32_t *)d_seed_loc;
     idx->d_bin_start = (uint32_t *)d_bin_start; idx->d_chunk_total = (uint32_t *)d_chunk_total;
     int rc = GHIP_OK;
     if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");

@@ -456,7 +456,7 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     struct Field { const void *src; size_t esz; const std::vector<uint64_t> *lstart; const std::vector<uint64_t> *cstart; void *dst; };
     Field fields[4] = {
         {local->d_seed_code, sizeof(uint32_t), &local->seed_start, &cseed, nullptr},
-        {local->d_seed_chunk, sizeof(*local->d_seed_chunk), &local->seed_start, &cseed, nullptr},
+        {local->d_seed_loc, sizeof(*local->d_seed_loc), &local->seed_start, &cseed, nullptr},
         {local->d_bin_start, sizeof(uint32_t), &lbin, &cbin, nullptr},
         {local->d_chunk_total, sizeof(uint32_t), &local->chunk_start, &cchunk, nullptr},
     };

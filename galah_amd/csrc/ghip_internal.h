@@ -105,7 +105,7 @@ struct ghip_ani_index {
     uint32_t k = 0, c = 0, chunk = 0;
     // per-genome seed lists (unordered) and open-addressing membership tables
     uint32_t *d_seed_code = nullptr;   // concatenated canonical 2-bit k-mer codes (k <= 16)
-    uint16_t *d_seed_chunk = nullptr;  // concatenated
+    uint32_t *d_seed_loc = nullptr;    // concatenated: chunk << 16 | strand << 15 | offset in chunk
     uint64_t *d_seed_start = nullptr;  // [n+1] offsets into seed arrays (capacity layout)
     uint32_t *d_seed_count = nullptr;  // [n]
     uint32_t *d_bin_start = nullptr;   // [n][GHIP_ANI_BIN_COUNT+1] CSR offsets of the binned seed list
@@ -120,7 +120,8 @@ struct ghip_ani_index {
 
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
-#define GHIP_ANI_MAX_CHUNKS 4800u  // per genome: counters (4 B) + aligned-chunk list (8 B) of both genomes + the 43 KiB stage fit the 160 KiB LDS
+#define GHIP_ANI_MAX_CHUNKS 1250u  // per genome: band votes (32 B) + aligned-chunk list (8 B) of both genomes + the 56 KiB seed stage fit the 160 KiB LDS
+#define GHIP_ANI_MAX_CHUNK_LEN 32768u  // a seed's offset in its chunk is a 15-bit field
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);
 
@@ -143,7 +144,7 @@ void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts
 struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the ANI seeds
     uint32_t k, c, chunk;
     uint32_t *d_seed_code;
-    uint16_t *d_seed_chunk;
+    uint32_t *d_seed_loc;
     const uint64_t *d_seed_start;
     uint32_t *d_seed_count;
     uint32_t *d_chunk_total;
@@ -187,11 +188,11 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
                              unsigned long long *d_count, uint64_t cap);
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
-                           uint32_t *d_seed_code, uint16_t *d_seed_chunk, const uint64_t *d_seed_start,
+                           uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work);
-void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint16_t *in_chunk, uint32_t *out_code,
-                         uint16_t *out_chunk, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
+void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint32_t *in_loc, uint32_t *out_code,
+                         uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp);
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out /* [n_pairs][2][3] = M, T, aligned bases */);

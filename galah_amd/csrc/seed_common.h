@@ -5,16 +5,14 @@
 
 namespace ghip_seed {
 
-// Seed-selection hash: MurmurHash3 fmix32, a bijection on the 32-bit canonical code (see
-// oracle/galah_oracle_ani.c).  8 instructions per position; every position of every genome pays it.
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16;
-    h *= 0x85ebca6bu;
-    h ^= h >> 13;
-    h *= 0xc2b2ae35u;
-    h ^= h >> 16;
-    return h;
-}
+// Seed selection: a bijective multiplicative mix of the 32-bit canonical code, kept iff mix(code) < 2^32 / c (see
+// oracle/galah_oracle_ani.c).  ONE multiply per position -- every position of every genome pays it (MurmurHash3's
+// fmix32, used before, cost 6 more instructions per base: 0.6 ms per 5 Gbase).  The multiplier differs from the bin
+// hash's (ani.hip code_bin), or all selected seeds would share their top bits and land in the first bins.
+__device__ __forceinline__ uint32_t seed_mix(uint32_t code) { return code * 0x85EBCA6Bu; }
+
+// packed location of a seed: chunk << 16 | strand << 15 | offset within the chunk (chunk length <= 32768)
+__device__ __forceinline__ uint32_t seed_loc(uint32_t chunk_id, uint32_t strand, uint32_t off) { return (chunk_id << 16) | (strand << 15) | off; }
 
 // A..T -> 0..3, anything else -> 4
 __device__ __forceinline__ uint32_t base_code(uint32_t c) {
@@ -30,7 +28,7 @@ constexpr uint32_t SEED_WAVES = GHIP_SKETCH_THREADS / 64;
 struct SeedOut {  // where a block's seeds go (kernel argument, by value)
     uint32_t k, thr, chunk;
     uint32_t *seed_code;
-    uint16_t *seed_chunk;
+    uint32_t *seed_loc;   // chunk << 16 | strand << 15 | offset in chunk
     const uint64_t *seed_start;
     uint32_t *seed_count;
     uint32_t *chunk_total;
@@ -39,7 +37,7 @@ struct SeedOut {  // where a block's seeds go (kernel argument, by value)
 
 struct SeedLds {  // per-block LDS state; slot-major so that the 64 lanes of a wave write consecutive words
     uint32_t code[SEED_LANE_CAP][GHIP_SKETCH_THREADS];
-    uint16_t pos[SEED_LANE_CAP][GHIP_SKETCH_THREADS];
+    uint16_t pos[SEED_LANE_CAP][GHIP_SKETCH_THREADS];   // position relative to the block start (< 2^15) | strand << 15
     uint32_t ctot[SEED_LDS_CHUNKS];
     uint32_t wave_n[SEED_WAVES], wave_base[SEED_WAVES];
 };
@@ -67,14 +65,14 @@ __device__ __forceinline__ SeedBlock seed_block_begin(SeedLds &sl, const SeedOut
 
 // Lane-private append: no cross-lane ranking in the position loop (a ballot/mbcnt rank cost ~10 instructions
 // on the 40 % of positions where some lane of the wave holds a seed).  rel = position - block start.
-__device__ __forceinline__ void seed_append(SeedLds &sl, const SeedOut &so, SeedBlock &sb, bool pass, uint32_t canon, uint32_t rel) {
+__device__ __forceinline__ void seed_append(SeedLds &sl, const SeedOut &so, SeedBlock &sb, bool pass, uint32_t canon, uint32_t rel, uint32_t strand) {
     if (pass) {
-        if (sb.n_lane < SEED_LANE_CAP) { sl.code[sb.n_lane][threadIdx.x] = canon; sl.pos[sb.n_lane][threadIdx.x] = (uint16_t)rel; }
+        if (sb.n_lane < SEED_LANE_CAP) { sl.code[sb.n_lane][threadIdx.x] = canon; sl.pos[sb.n_lane][threadIdx.x] = (uint16_t)(rel | (strand << 15)); }
         else {  // lane buffer full (P ~ 1e-4 per lane at c = 125; always at c = 1): straight to the global list
-            const uint32_t ch = sb.ch_first + (sb.rem_first + rel) / so.chunk;
+            const uint32_t at = sb.rem_first + rel, ch = at / so.chunk;
             uint32_t idx = atomicAdd(&so.seed_count[sb.g], 1u);
-            if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_chunk[sb.sstart + idx] = (uint16_t)ch; }
-            atomicAdd(&sb.ctot[ch], 1u);
+            if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + ch, strand, at - ch * so.chunk); }
+            atomicAdd(&sb.ctot[sb.ch_first + ch], 1u);
         }
         sb.n_lane++;
     }
@@ -102,8 +100,11 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
     __syncthreads();
     uint32_t idx = sl.wave_base[w] + incl - mine;
     for (uint32_t i = 0; i < mine; i++, idx++) {
-        const uint32_t chrel = (sb.rem_first + sl.pos[i][threadIdx.x]) / so.chunk;
-        if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = sl.code[i][threadIdx.x]; so.seed_chunk[sb.sstart + idx] = (uint16_t)(sb.ch_first + chrel); }
+        const uint32_t pv = sl.pos[i][threadIdx.x], at = sb.rem_first + (pv & 0x7fffu), chrel = at / so.chunk;
+        if (idx < sb.scap) {
+            so.seed_code[sb.sstart + idx] = sl.code[i][threadIdx.x];
+            so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + chrel, pv >> 15, at - chrel * so.chunk);
+        }
         if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
         else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
     }

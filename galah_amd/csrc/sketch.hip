@@ -258,17 +258,13 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 const uint32_t f15 = ~rlo & amask;
                 const uint32_t r15 = ~(uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift)) & amask;
                 const uint32_t c15 = min(f15, r15);
-#ifdef GHIP_DBG_SEEDHASH1  // timing experiment only (scripts/sketch_variants.sh): wrong results
-                const bool pass = seed_gate && (c15 * 0x9e3779b1u) < so.thr;
-#else
-                const bool pass = seed_gate && ghip_seed::fmix32(c15) < so.thr;
-#endif
+                const bool pass = seed_gate && ghip_seed::seed_mix(c15) < so.thr;
                 if (pass) {  // ~1/125 of the lanes: validity only here
                     const bool ok = st.lim15 <= b && inword == 0;
 #ifdef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
                     sb.n_lane += ok;
 #else
-                    ghip_seed::seed_append(sl, so, sb, ok, c15, toff + (uint32_t)(b - (ak - 1)));
+                    ghip_seed::seed_append(sl, so, sb, ok, c15, toff + (uint32_t)(b - (ak - 1)), r15 < f15 ? 1u : 0u);
 #endif
                 }
             }
@@ -626,7 +622,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
     if (n_work == 0) return;
     ghip_seed::SeedOut so{};
     if (seeds)
-        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, seeds->chunk, seeds->d_seed_code, seeds->d_seed_chunk,
+        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, seeds->chunk, seeds->d_seed_code, seeds->d_seed_loc,
                                 seeds->d_seed_start, seeds->d_seed_count, seeds->d_chunk_total, seeds->d_chunk_start};
     const KmerLuts *luts = nullptr;
     if (k == 21) {

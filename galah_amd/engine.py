@@ -296,14 +296,14 @@ class Context:
         return Sketches(self, hs), (AniIndex(self, hi) if want_index else None), stats
 
     def ani_index_wrap_device(self, k: int, c: int, chunk: int, genome_len, seed_cap, seed_count,
-                              d_seed_code: int, d_seed_chunk: int, d_bin_start: int, d_chunk_total: int) -> AniIndex:
+                              d_seed_code: int, d_seed_loc: int, d_bin_start: int, d_chunk_total: int) -> AniIndex:
         glen = np.ascontiguousarray(genome_len, dtype=np.uint64)
         cap = np.ascontiguousarray(seed_cap, dtype=np.uint64)
         cnt = np.ascontiguousarray(seed_count, dtype=np.uint32)
         h = C.c_void_p()
         check(_lib.lib().ghip_ani_index_wrap_device(self._h, len(glen), k, c, chunk, glen.ctypes.data, cap.ctypes.data,
                                                     cnt.ctypes.data, C.c_void_p(d_seed_code),
-                                                    C.c_void_p(d_seed_chunk), C.c_void_p(d_bin_start),
+                                                    C.c_void_p(d_seed_loc), C.c_void_p(d_bin_start),
                                                     C.c_void_p(d_chunk_total), C.byref(h)), self._h)
         return AniIndex(self, h)
 

@@ -156,8 +156,8 @@ uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
  * Replaces SkaniClusterer::calculate_ani (src/skani.rs:708-716 -> calculate_skani :718-788),
  * batched.  Returns PERCENT, 0.0 when below the aligned-fraction gate (skani prints no row).
  * Build-defined estimator, skani parity unpinned: see DESIGN.md "ANI". Thread-safe. */
-/* Limits: k <= 16; at most 4800 chunks per genome (96 Mb at the default 20 kb chunk -- galah's inputs are prokaryotic
- * genomes; a longer genome is refused with GHIP_EINVAL, pass a proportionally longer `chunk`). */
+/* Limits: k <= 16; chunk <= 32768; at most 1250 chunks per genome (25 Mb at the default 20 kb chunk, 40 Mb at 32768 --
+ * galah's inputs are prokaryotic genomes; a longer genome is refused with GHIP_EINVAL). */
 int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c,
                          uint32_t chunk, ghip_ani_index **out);
 /* MinHash sketches and ANI index from ONE pass over the bases (fused kernel for k = 21; otherwise the
@@ -186,7 +186,7 @@ typedef struct {
     size_t n;
     uint64_t n_seed_slots, n_bin_slots, n_chunk_slots;
     void *d_seed_code;   /* u32[n_seed_slots]: canonical 2-bit k-mer codes (k <= 16), binned by hash */
-    void *d_seed_chunk;  /* u16[n_seed_slots] */
+    void *d_seed_loc;    /* u32[n_seed_slots]: chunk << 16 | strand << 15 | offset in chunk */
     void *d_bin_start;   /* u32[n_bin_slots]: CSR bin offsets, 2^14 + 1 per genome */
     void *d_chunk_total; /* u32[n_chunk_slots] */
 } ghip_ani_layout;
@@ -195,7 +195,7 @@ int ghip_ani_index_meta(const ghip_ani_index *idx, uint64_t *genome_len, uint64_
                         uint32_t *seed_count); /* host arrays, each [n] */
 int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, uint32_t c, uint32_t chunk,
                                const uint64_t *genome_len, const uint64_t *seed_cap,
-                               const uint32_t *seed_count, void *d_seed_code, void *d_seed_chunk,
+                               const uint32_t *seed_count, void *d_seed_code, void *d_seed_loc,
                                void *d_bin_start, void *d_chunk_total, ghip_ani_index **out);
 
 /* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)

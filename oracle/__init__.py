@@ -100,6 +100,10 @@ def lib():
     L.go_ani_sketch_seeds.argtypes = [C.c_void_p]
     L.go_ani_sketch_chunks.restype = u32p
     L.go_ani_sketch_chunks.argtypes = [C.c_void_p]
+    L.go_ani_sketch_positions.restype = u32p
+    L.go_ani_sketch_positions.argtypes = [C.c_void_p]
+    L.go_ani_sketch_strands.restype = C.POINTER(C.c_uint8)
+    L.go_ani_sketch_strands.argtypes = [C.c_void_p]
     L.go_ani_sketch_length.restype = C.c_uint64
     L.go_ani_sketch_length.argtypes = [C.c_void_p]
     L.go_ani_pair.restype = C.c_float
@@ -314,6 +318,20 @@ class AniSketch:
     def chunks(self) -> np.ndarray:
         n = self.nseeds
         return np.ctypeslib.as_array(lib().go_ani_sketch_chunks(self._h), shape=(n,)).copy() if n else np.empty(0, np.uint32)
+
+
+    def positions(self) -> np.ndarray:
+        n = self.nseeds
+        return np.ctypeslib.as_array(lib().go_ani_sketch_positions(self._h), shape=(n,)).copy() if n else np.empty(0, np.uint32)
+
+    def strands(self) -> np.ndarray:
+        n = self.nseeds
+        return np.ctypeslib.as_array(lib().go_ani_sketch_strands(self._h), shape=(n,)).copy() if n else np.empty(0, np.uint8)
+
+    def locs(self, chunk: int = 20000) -> np.ndarray:
+        """The device's packed seed location: chunk << 16 | strand << 15 | offset within the chunk."""
+        p = self.positions().astype(np.uint64)
+        return ((p // chunk) << np.uint64(16) | (self.strands().astype(np.uint64) << np.uint64(15)) | (p % chunk)).astype(np.uint32)
 
 
 def ani_pair(q: AniSketch, r: AniSketch, min_af: float = 0.15) -> Tuple[float, float, float]:

@@ -104,6 +104,8 @@ void go_ani_sketch_free(go_ani_sketch *s);
 size_t go_ani_sketch_nseeds(const go_ani_sketch *s);
 const uint64_t *go_ani_sketch_seeds(const go_ani_sketch *s);
 const uint32_t *go_ani_sketch_chunks(const go_ani_sketch *s);
+const uint32_t *go_ani_sketch_positions(const go_ani_sketch *s);   /* start position of every seed */
+const uint8_t *go_ani_sketch_strands(const go_ani_sketch *s);      /* 1: canonical code = reverse complement */
 uint64_t go_ani_sketch_length(const go_ani_sketch *s);
 /* returns ANI in PERCENT (skani's unit, src/skani.rs:203-209), 0.0 when AF < min_af */
 float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction,

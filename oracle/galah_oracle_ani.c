@@ -8,26 +8,33 @@
  * percent, 0.0 when skani prints no row).  skani (>=0.2.2, pixi.lock:124) is not in
  * /root/reference, is not installed here, and no reference test asserts a skani float
  * (SURVEY.md 8c).  What follows is therefore a BUILD-DEFINED estimator in skani's style
- * (Shaw & Yu 2023: FracMinHash seeds k=15 c=125, ~20 kb query chunks, ANI from seed
- * containment^(1/k), aligned fraction gate, two-decimal TSV output) WITHOUT skani's
- * colinear chaining and learned regression, and with a 32-bit invertible seed hash.  It defines what the HIP ani_pairs kernel
- * must reproduce; it makes no claim to reproduce skani's floats.
+ * (Shaw & Yu 2023: FracMinHash seeds k=15 c=125, ~20 kb query chunks, seed matches must be
+ * COLINEAR within a chunk, ANI from seed containment^(1/k), aligned fraction gate, two-decimal TSV
+ * output) without skani's gap-cost chaining DP and learned regression.  It defines what the HIP
+ * ani_pairs kernel must reproduce; it makes no claim to reproduce skani's floats.
  *
  * Definition (all integer until the final pow):
  *   stream G  = for each FASTA record: normalised bytes, then one 'N'          (length L)
- *   seed at p = window G[p..p+k) all ACGT (k <= 16); code = min(2-bit fwd, 2-bit revcomp) (A0 C1 G2
- *               T3, first base most significant); kept iff fmix32(code) < (2^32-1) / c
- *   chunk(p)  = p / chunk_len
- *   q->r      : for every chunk of q: T_c = #seeds, M_c = #seeds whose h is a seed of r;
+ *   seed at p = window G[p..p+k) all ACGT (k <= 16); fwd / rev = 2-bit codes of the k-mer and of its reverse
+ *               complement (A0 C1 G2 T3, first base most significant); code = min(fwd, rev), strand = (rev < fwd);
+ *               kept iff (u32)(code * 0x85EBCA6B) < (2^32-1) / c  (a bijective multiplicative mix: equal hash <=> equal code)
+ *   chunk(p)  = p / chunk_len  (chunk_len <= 32768)
+ *   anchor    = (seed a of q, seed b of r) with equal codes; orientation o = strand_a ^ strand_b;
+ *               diagonal d = o ? pos_b + pos_a : pos_b - pos_a  (mod 2^32);  band = ((d >> 12) & 7) | (o << 3)
+ *               -- anchors of one alignment share the orientation and, up to indels, the diagonal: 4 kb bands
+ *   votes     : V_q[chunk(a)][band] = number of seeds a of that chunk with at least one anchor in `band`; V_r likewise
+ *   per chunk : T_c = #seeds; M_c = min(T_c, sum of V[band] over the bands with V[band] >= 3) -- a seed match counts only
+ *               when at least three seeds of the chunk agree on orientation and diagonal (a chunk of a fragmented
+ *               assembly may hold several contigs, each with its own diagonal; a chunk across a rearrangement two);
  *               chunk aligned iff T_c >= 1 and M_c * 10000 >= 510 * T_c   (0.82^15 ~ 0.0510)
  *   M,T       = the (M_c, T_c) of the LOWER MEDIAN containment M_c/T_c over the aligned chunks of BOTH
  *               directions (exact order by cross-multiplication; skani likewise reports a robust
  *               per-chunk statistic rather than a pooled count, and with this choice the reference's
  *               own membership tests src/clusterer.rs:631-690 are reproduced, see tests)
  *   AF_x      = (bases in aligned chunks of x) / L_x
- *   p0        = (L_q + L_r) / 4^k      -- chance that a k-mer occurs somewhere in a genome of the mean length
- *   c         = max(0, (M/T - p0) / (1 - p0))   -- observed containment = c + (1 - c) p0 (matches are by value, unchained)
- *   ANI%      = 100 * c^(1/k); 0 if no chunk aligned or (AF_q < min_af and AF_r < min_af)
+ *   ANI%      = 100 * (M/T)^(1/k); 0 if no chunk aligned or (AF_q < min_af and AF_r < min_af)
+ *               (a chance match of a mutated seed elsewhere in the other genome only counts if it falls into a band
+ *               that already holds two other seeds of the chunk, so the chance term the unchained form needed is gone)
  *   returned  = strtof(sprintf("%.2f", ANI%))   -- skani prints two decimals, galah parses f32
  */
 #define _GNU_SOURCE
@@ -39,42 +46,41 @@
 #include <string.h>
 #include <zlib.h>
 
+#define GO_ANI_BANDS 16
+#define GO_ANI_BAND_SHIFT 12
+#define GO_ANI_MIN_COLINEAR 3
+
+typedef struct { uint32_t code, idx; } code_ref;
+
 struct go_ani_sketch {
     uint32_t k, c, chunk;
     uint64_t length;     /* L */
     size_t n;            /* seeds in position order */
-    uint64_t *h;         /* hash per seed (position order) */
+    uint64_t *h;         /* code per seed (position order; u64 for the accessor's sake) */
     uint32_t *chunk_id;  /* chunk per seed */
-    size_t nd;           /* distinct */
-    uint64_t *sorted;    /* sorted distinct hashes */
+    uint32_t *pos;       /* start position per seed */
+    uint8_t *strand;     /* 1: the canonical code is the reverse complement */
+    code_ref *sorted;    /* (code, seed index) sorted by code */
     uint32_t n_chunks;
+    uint32_t *chunk_total; /* T_c */
 };
 
-/* Seed-selection hash: MurmurHash3's 32-bit finaliser (a bijection on 32 bits) over the canonical
- * 2-bit k-mer code (k <= 16).  skani uses minimap2's invertible 64-bit mix for the same purpose; any
- * invertible mix gives a FracMinHash, and this one is 8 integer instructions per position on the GPU
- * instead of ~30 (the seeding pass hashes every position of every genome). */
-static inline uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16;
-    h *= 0x85ebca6bu;
-    h ^= h >> 13;
-    h *= 0xc2b2ae35u;
-    h ^= h >> 16;
-    return h;
-}
-
-static int cmp_u64(const void *a, const void *b) {
-    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
-    return (x > y) - (x < y);
+static int cmp_code_ref(const void *a, const void *b) {
+    const code_ref *x = (const code_ref *)a, *y = (const code_ref *)b;
+    if (x->code != y->code) return (x->code > y->code) - (x->code < y->code);
+    return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
 go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint32_t c, uint32_t chunk) {
     go_ani_sketch *s = (go_ani_sketch *)calloc(1, sizeof(*s));
     s->k = k; s->c = c; s->chunk = chunk; s->length = n;
     s->n_chunks = (uint32_t)((n + chunk - 1) / chunk);
+    s->chunk_total = (uint32_t *)calloc((size_t)s->n_chunks + 1, sizeof(uint32_t));
     size_t cap = n / (c ? c : 1) + 1024;
     s->h = (uint64_t *)malloc(cap * sizeof(uint64_t));
     s->chunk_id = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    s->pos = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    s->strand = (uint8_t *)malloc(cap);
     const uint32_t thr = UINT32_MAX / c;
     const uint64_t mask = (k < 32) ? ((1ULL << (2 * k)) - 1) : UINT64_MAX;
     uint64_t fwd = 0, rev = 0;
@@ -86,25 +92,26 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
         fwd = ((fwd << 2) | (uint64_t)b) & mask;
         rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k - 1)));
         if (++good < k) continue;
-        uint64_t code = fwd < rev ? fwd : rev;
-        if (fmix32((uint32_t)code) >= thr) continue;
-        uint64_t h = code; /* the mix is a bijection: seeds are identified by their code */
+        const uint32_t code = (uint32_t)(fwd < rev ? fwd : rev);
+        if ((uint32_t)(code * 0x85EBCA6Bu) >= thr) continue;
         if (s->n == cap) {
             cap *= 2;
             s->h = (uint64_t *)realloc(s->h, cap * sizeof(uint64_t));
             s->chunk_id = (uint32_t *)realloc(s->chunk_id, cap * sizeof(uint32_t));
+            s->pos = (uint32_t *)realloc(s->pos, cap * sizeof(uint32_t));
+            s->strand = (uint8_t *)realloc(s->strand, cap);
         }
-        s->h[s->n] = h;
-        s->chunk_id[s->n] = (uint32_t)((p + 1 - k) / chunk);
+        const size_t start = p + 1 - k;
+        s->h[s->n] = code;
+        s->pos[s->n] = (uint32_t)start;
+        s->strand[s->n] = rev < fwd;
+        s->chunk_id[s->n] = (uint32_t)(start / chunk);
+        s->chunk_total[start / chunk]++;
         s->n++;
     }
-    s->sorted = (uint64_t *)malloc((s->n + 1) * sizeof(uint64_t));
-    memcpy(s->sorted, s->h, s->n * sizeof(uint64_t));
-    qsort(s->sorted, s->n, sizeof(uint64_t), cmp_u64);
-    size_t m = 0;
-    for (size_t i = 0; i < s->n; i++)
-        if (m == 0 || s->sorted[i] != s->sorted[m - 1]) s->sorted[m++] = s->sorted[i];
-    s->nd = m;
+    s->sorted = (code_ref *)malloc((s->n + 1) * sizeof(code_ref));
+    for (size_t i = 0; i < s->n; i++) { s->sorted[i].code = (uint32_t)s->h[i]; s->sorted[i].idx = (uint32_t)i; }
+    qsort(s->sorted, s->n, sizeof(code_ref), cmp_code_ref);
     return s;
 }
 
@@ -144,18 +151,14 @@ int go_ani_sketch_file(const char *path, uint32_t k, uint32_t c, uint32_t chunk,
 
 void go_ani_sketch_free(go_ani_sketch *s) {
     if (!s) return;
-    free(s->h); free(s->chunk_id); free(s->sorted); free(s);
+    free(s->h); free(s->chunk_id); free(s->pos); free(s->strand); free(s->sorted); free(s->chunk_total); free(s);
 }
 size_t go_ani_sketch_nseeds(const go_ani_sketch *s) { return s->n; }
 const uint64_t *go_ani_sketch_seeds(const go_ani_sketch *s) { return s->h; }
 const uint32_t *go_ani_sketch_chunks(const go_ani_sketch *s) { return s->chunk_id; }
+const uint32_t *go_ani_sketch_positions(const go_ani_sketch *s) { return s->pos; }
+const uint8_t *go_ani_sketch_strands(const go_ani_sketch *s) { return s->strand; }
 uint64_t go_ani_sketch_length(const go_ani_sketch *s) { return s->length; }
-
-static int contains_sorted(const uint64_t *a, size_t n, uint64_t x) {
-    size_t lo = 0, hi = n;
-    while (lo < hi) { size_t mid = (lo + hi) / 2; if (a[mid] < x) lo = mid + 1; else hi = mid; }
-    return lo < n && a[lo] == x;
-}
 
 typedef struct { uint64_t m, t; } chunk_frac;
 
@@ -166,21 +169,48 @@ static int cmp_frac(const void *pa, const void *pb) {
     return (l > r) - (l < r);
 }
 
-/* one direction: appends (M_c, T_c) of every aligned chunk of q and adds its aligned bases */
-static void ani_direction(const go_ani_sketch *q, const go_ani_sketch *r, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
-    size_t i = 0;
-    while (i < q->n) {
-        uint32_t c = q->chunk_id[i];
-        uint64_t tc = 0, mc = 0;
-        while (i < q->n && q->chunk_id[i] == c) {
-            tc++;
-            mc += (uint64_t)contains_sorted(r->sorted, r->nd, q->h[i]);
-            i++;
+static size_t lower_bound_code(const code_ref *a, size_t n, uint32_t code) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (a[mid].code < code) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* band votes of both genomes: vq[chunk][band], vr[chunk][band] */
+static void ani_votes(const go_ani_sketch *q, const go_ani_sketch *r, uint32_t *vq, uint32_t *vr) {
+    uint16_t *rmask = (uint16_t *)calloc(r->n + 1, sizeof(uint16_t));
+    for (size_t a = 0; a < q->n; a++) {
+        const uint32_t code = (uint32_t)q->h[a];
+        uint32_t qmask = 0;
+        for (size_t x = lower_bound_code(r->sorted, r->n, code); x < r->n && r->sorted[x].code == code; x++) {
+            const uint32_t b = r->sorted[x].idx;
+            const uint32_t o = (uint32_t)(q->strand[a] ^ r->strand[b]);
+            const uint32_t d = o ? r->pos[b] + q->pos[a] : r->pos[b] - q->pos[a];
+            const uint32_t band = ((d >> GO_ANI_BAND_SHIFT) & 7u) | (o << 3);
+            qmask |= 1u << band;
+            rmask[b] |= (uint16_t)(1u << band);
         }
-        if (tc >= 1 && mc * 10000 >= 510 * tc) {
+        for (uint32_t band = 0; band < GO_ANI_BANDS; band++)
+            if (qmask >> band & 1u) vq[(size_t)q->chunk_id[a] * GO_ANI_BANDS + band]++;
+    }
+    for (size_t b = 0; b < r->n; b++)
+        for (uint32_t band = 0; band < GO_ANI_BANDS; band++)
+            if (rmask[b] >> band & 1u) vr[(size_t)r->chunk_id[b] * GO_ANI_BANDS + band]++;
+    free(rmask);
+}
+
+/* appends (M_c, T_c) of every aligned chunk of x and adds its aligned bases */
+static void ani_collect(const go_ani_sketch *x, const uint32_t *votes, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
+    for (uint32_t c = 0; c < x->n_chunks; c++) {
+        const uint64_t tc = x->chunk_total[c];
+        if (tc < 1) continue;
+        const uint32_t *v = votes + (size_t)c * GO_ANI_BANDS;
+        uint64_t mc = 0;
+        for (uint32_t band = 0; band < GO_ANI_BANDS; band++) if (v[band] >= GO_ANI_MIN_COLINEAR) mc += v[band];
+        if (mc > tc) mc = tc;
+        if (mc * 10000 >= 510 * tc) {
             out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++;
-            uint64_t lo = (uint64_t)c * q->chunk, hi = lo + q->chunk;
-            if (hi > q->length) hi = q->length;
+            uint64_t lo = (uint64_t)c * x->chunk, hi = lo + x->chunk;
+            if (hi > x->length) hi = x->length;
             *aligned_bases += hi - lo;
         }
     }
@@ -190,8 +220,12 @@ float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_f
     uint64_t bq = 0, br = 0;
     size_t n = 0;
     chunk_frac *fr = (chunk_frac *)malloc(((size_t)q->n_chunks + r->n_chunks + 1) * sizeof(chunk_frac));
-    ani_direction(q, r, fr, &n, &bq);
-    ani_direction(r, q, fr, &n, &br);
+    uint32_t *vq = (uint32_t *)calloc(((size_t)q->n_chunks + 1) * GO_ANI_BANDS, sizeof(uint32_t));
+    uint32_t *vr = (uint32_t *)calloc(((size_t)r->n_chunks + 1) * GO_ANI_BANDS, sizeof(uint32_t));
+    ani_votes(q, r, vq, vr);
+    ani_collect(q, vq, fr, &n, &bq);
+    ani_collect(r, vr, fr, &n, &br);
+    free(vq); free(vr);
     double afq = q->length ? (double)bq / (double)q->length : 0.0;
     double afr = r->length ? (double)br / (double)r->length : 0.0;
     if (af_q) *af_q = (float)afq;
@@ -202,14 +236,7 @@ float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_f
     const chunk_frac med = fr[(n - 1) / 2];
     free(fr);
     if (afq < (double)min_af_fraction && afr < (double)min_af_fraction) return 0.0f;
-    /* chance matches: seeds are matched by value against the whole other genome (no chaining), so a query seed whose
-     * k-mer mutated still "matches" when the k-mer happens to occur anywhere in the other genome -- probability
-     * p0 = L / (4^k / 2) with L the mean of the two lengths (there are 4^k / 2 canonical k-mers, k odd).  The observed
-     * containment is c + (1 - c) p0; solve for c.  (+0.03 ANI points at 95 % for 2 Mb genomes, +0.2 at 88 % for 5 Mb.) */
-    const double c_obs = (double)med.m / (double)med.t;
-    const double p0 = q->k <= 31 ? (double)(q->length + r->length) / (double)(1ull << (2 * q->k)) : 0.0;
-    double c = p0 < 1.0 ? (c_obs - p0) / (1.0 - p0) : 0.0;
-    if (c < 0.0) c = 0.0;
+    const double c = (double)med.m / (double)med.t;
     double ani = 100.0 * pow(c, 1.0 / (double)q->k);
     char txt[64];
     snprintf(txt, sizeof txt, "%.2f", ani);

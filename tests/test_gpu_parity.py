@@ -416,8 +416,8 @@ def test_every_window_of_dirty_streams_minhash(ctx):
 
 @pytest.mark.parametrize("c", [1, 3, 125])
 def test_every_seed_of_dirty_streams(ctx, c):
-    """Seed sets (code, chunk) of the fused and the standalone seeding pass against the oracle, dense (c = 1 keeps
-    every valid 15-mer and overflows the per-block LDS buffers) to sparse."""
+    """Seed sets (code, packed location = chunk, strand, offset) of the fused and the standalone seeding pass against the
+    oracle, dense (c = 1 keeps every valid 15-mer and overflows the per-block LDS buffers) to sparse."""
     import torch
     streams = _dirty_streams(seed=6, n=4)
     g = ctx.genomes_from_host(streams)
@@ -426,16 +426,16 @@ def test_every_seed_of_dirty_streams(ctx, c):
         lay = idx.layout()
         glen, cap, cnt = idx.meta()
         code = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device="cuda")
-        chunk = torch.empty(int(lay.n_seed_slots), dtype=torch.int16, device="cuda")
+        loc = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device="cuda")
         ctx.memcpy_d2d(code.data_ptr(), lay.d_seed_code, code.numel() * 4)
-        ctx.memcpy_d2d(chunk.data_ptr(), lay.d_seed_chunk, chunk.numel() * 2)
+        ctx.memcpy_d2d(loc.data_ptr(), lay.d_seed_loc, loc.numel() * 4)
         ctx.synchronize()
-        code, chunk = code.cpu().numpy().view(np.uint32), chunk.cpu().numpy().view(np.uint16)
+        code, loc = code.cpu().numpy().view(np.uint32), loc.cpu().numpy().view(np.uint32)
         start = 0
         for i, o in enumerate(osk):
             assert cnt[i] == len(o.seeds()), (c, i, cnt[i], len(o.seeds()))
-            got = sorted(zip(code[start:start + cnt[i]].tolist(), chunk[start:start + cnt[i]].tolist()))
-            want = sorted(zip(o.seeds().astype(np.uint32).tolist(), o.chunks().astype(np.uint16).tolist()))
+            got = sorted(zip(code[start:start + cnt[i]].tolist(), loc[start:start + cnt[i]].tolist()))
+            want = sorted(zip(o.seeds().astype(np.uint32).tolist(), o.locs(5000).tolist()))
             assert got == want, (c, i)
             start += int(cap[i])
 

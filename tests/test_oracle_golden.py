@@ -108,9 +108,9 @@ CONTIG_CLUSTERS = [[0, 1, 2, 3, 4, 5], [6], [7], [8]]
 
 
 def test_reference_contig_expectation_needs_dense_seeds():
-    """On 1 kb contigs the FracMinHash ANI keeps ~30 seeds at c = 30 (skani's --small-genomes density): the estimate's
-    standard error (~1.5 ANI points) does not separate 96 % from 94 % at the 95 % threshold.  With every 15-mer as a seed
-    (c = 1) the build-defined estimator reproduces the reference's expected contig clusters."""
+    """On 1 kb contigs the FracMinHash ANI keeps ~35 seeds at c = 30 (skani's --small-genomes density): the estimate's
+    standard error (~1.5 ANI points) cannot be relied on to separate 96 % from 94 % at the 95 % threshold.  With every
+    15-mer as a seed (c = 1) the build-defined estimator reproduces the reference's expected contig clusters."""
     from conftest import fasta_records
     names, seqs = fasta_records("contigs_specific")
     assert names[5].startswith("96ANI") and names[6].startswith("94ANI") and len(names) == 9
@@ -126,8 +126,11 @@ def test_reference_contig_expectation_needs_dense_seeds():
     dense = [oracle.AniSketch.from_bytes(s, 15, 1, 20000) for s in seqs]
     got = oracle.cluster(n, cache, 95.0, lambda a, b: oracle.ani_pair(dense[a], dense[b], 0.15)[0])
     assert got == CONTIG_CLUSTERS
+    assert oracle.ani_pair(dense[0], dense[5], 0.15)[0] >= 95.0 > oracle.ani_pair(dense[0], dense[6], 0.15)[0]
+    # at c = 30 a 1 kb contig keeps ~35 seeds: one seed more or less moves the estimate by ~0.2 ANI points at 95 %, the
+    # binomial standard error is ~1.5 -- which side of 95 % the 96 % variant lands on is luck of the seed hash
     sparse = [oracle.AniSketch.from_bytes(s, 15, 30, 20000) for s in seqs]
-    assert oracle.ani_pair(sparse[0], sparse[5], 0.15)[0] < 95.0 <= oracle.ani_pair(dense[0], dense[5], 0.15)[0]
+    assert all(25 <= sparse[i].nseeds <= 45 for i in range(7))
 
 
 def _finch_plus_ani(names, thr, min_af):
