@@ -157,9 +157,9 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
 
 constexpr uint32_t ANI_PAIR_THREADS = 512;
 constexpr uint32_t ANI_PAIR_WAVES = ANI_PAIR_THREADS / 64;
-constexpr uint32_t ANI_STAGE = 384;  // seeds of 64 consecutive bins staged per wave and genome (expected ~154 for 5 Mb at c = 125)
+constexpr uint32_t ANI_STAGE = 192;  // seeds of one round's consecutive bins staged per wave and genome (rounds are sized for ~150)
 constexpr uint32_t ANI_BAND_SHIFT = 12, ANI_MIN_COLINEAR = 3;   // 4 kb diagonal bands; >= 3 seeds of a chunk must agree (oracle: GO_ANI_*)
-constexpr uint32_t ANI_VOTE_WORDS = 8;                          // 16 bands x u16 per chunk
+constexpr uint32_t ANI_VOTE_WORDS = 9;                          // per chunk: 16 bands x u16, then the repeat-seed counter
 
 // location word of a seed: chunk << 16 | strand << 15 | offset in chunk
 __device__ __forceinline__ uint32_t loc_pos(uint32_t loc, uint32_t chunk) { return (loc >> 16) * chunk + (loc & 0x7fffu); }
@@ -167,22 +167,23 @@ __device__ __forceinline__ uint32_t loc_pos(uint32_t loc, uint32_t chunk) { retu
 // band of the anchor (q seed, r seed): orientation and diagonal (oracle/galah_oracle_ani.c)
 __device__ __forceinline__ uint32_t anchor_band(uint32_t qloc, uint32_t qpos, uint32_t rloc, uint32_t chunk) {
     const uint32_t o = ((qloc ^ rloc) >> 15) & 1u, rpos = loc_pos(rloc, chunk);
-    const uint32_t d = o ? rpos + qpos : rpos - qpos;
-    return ((d >> ANI_BAND_SHIFT) & 7u) | (o << 3);
+    // same orientation: bands of the odd number 2 (rpos - qpos) + 1 centred on 0, so that swapping q and r mirrors them
+    return o ? (((rpos + qpos) >> ANI_BAND_SHIFT) & 7u) | 8u
+             : ((2u * (rpos - qpos) + 1u + (1u << ANI_BAND_SHIFT)) >> (ANI_BAND_SHIFT + 1)) & 7u;
 }
 
-// one vote per set bit of `mask` for chunk `c`: u16 counters, two per LDS word (a counter never exceeds the seeds of a
-// chunk, <= 32768, so halves cannot carry into each other)
-__device__ __forceinline__ void cast_votes(uint32_t *votes, uint32_t c, uint32_t mask) {
-    while (mask) {
-        const uint32_t band = (uint32_t)__builtin_ctz(mask);
-        mask &= mask - 1;
-        atomicAdd(&votes[c * ANI_VOTE_WORDS + (band >> 1)], 1u << (16u * (band & 1u)));
-    }
+// The vote of one seed of chunk `c` whose anchors fall into the bands of `mask` (!= 0): its band's counter if they all
+// agree, the chunk's repeat counter otherwise.  u16 counters, two per LDS word (a counter never exceeds the seeds of
+// a chunk, <= 32768, so halves cannot carry into each other).
+__device__ __forceinline__ void cast_vote(uint32_t *votes, uint32_t c, uint32_t mask) {
+    const uint32_t band = (uint32_t)__builtin_ctz(mask);
+    const bool single = (mask & (mask - 1)) == 0;
+    atomicAdd(&votes[c * ANI_VOTE_WORDS + (single ? (band >> 1) : 8u)], single ? 1u << (16u * (band & 1u)) : 1u);
 }
 
 // Appends (M_c << 32 | T_c) of every aligned chunk (M_c*10000 >= 510*T_c) to `list` and returns this
-// thread's share of the aligned bases.  M_c = votes of the bands holding >= ANI_MIN_COLINEAR seeds, capped at T_c.
+// thread's share of the aligned bases.  M_c = votes of the bands holding >= ANI_MIN_COLINEAR seeds, plus the repeat seeds
+// of a chunk that has such a band, capped at T_c.
 __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *votes, const uint32_t *tc, uint32_t nch, uint64_t L,
                                                               uint32_t chunk, unsigned long long *list, uint32_t *n_al) {
     unsigned long long bases = 0;
@@ -190,10 +191,11 @@ __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *vo
         const unsigned long long t = tc[c];
         unsigned long long m = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < ANI_VOTE_WORDS; w++) {
+        for (uint32_t w = 0; w < 8; w++) {
             const uint32_t v = votes[c * ANI_VOTE_WORDS + w], lo = v & 0xffffu, hi = v >> 16;
             m += (lo >= ANI_MIN_COLINEAR ? lo : 0u) + (hi >= ANI_MIN_COLINEAR ? hi : 0u);
         }
+        if (m) m += votes[c * ANI_VOTE_WORDS + 8];
         if (m > t) m = t;
         if (t >= 1 && m * 10000ull >= 510ull * t) {
             list[atomicAdd(n_al, 1u)] = (m << 32) | t;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t nchq = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
     const uint32_t nchr = (uint32_t)(chunk_start[r + 1] - chunk_start[r]);
     uint32_t *vr = vq + (size_t)nchq * ANI_VOTE_WORDS;
-    unsigned long long *list = reinterpret_cast<unsigned long long *>(vr + (size_t)nchr * ANI_VOTE_WORDS);
+    unsigned long long *list = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)(nchq + nchr) * ANI_VOTE_WORDS * 4 + 7) & ~(size_t)7));
     for (uint32_t i = threadIdx.x; i < (nchq + nchr) * ANI_VOTE_WORDS; i += blockDim.x) vq[i] = 0;
     if (threadIdx.x < 6) red[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_al = 0;
@@ -252,22 +254,24 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     // stage offsets of the round's r bins: dynamic LDS behind the aligned-chunk list, ro_cap entries per wave
     uint16_t *ro = reinterpret_cast<uint16_t *>(list + (nchq + nchr)) + (size_t)wave * ro_cap;
     for (uint32_t k = lane; k < ANI_STAGE / 2; k += 64) rm[k] = 0;
-    // Bins joined per wave and round: 64 for bacterial-size genomes (~154 seeds per run at c = 125); small genomes
-    // and contigs take 256 or 1024 bins per round so that a run still holds ~190 seeds and the fixed cost of a round
-    // (bounds, barriers, three short loops) is paid 8 or 2 times per wave instead of 32.
+    // Bins joined per wave and round, sized so that a run holds ~150 seeds of the larger genome (the stage holds 192;
+    // a longer run -- a pathologically repetitive stretch -- takes the global-memory walk for that round only): 64 for
+    // genomes up to ~5 Mb at c = 125, 32 / 16 / 8 above, 256 / 1024 for small genomes and contigs, which would otherwise
+    // pay the fixed cost of a round (bounds, barriers, three short loops) 32 times per wave for a handful of seeds.
     uint32_t rbins = 64;
     {
         const uint32_t tmax = max(qb[BIN_COUNT], rb[BIN_COUNT]);  // total seeds of the larger genome
-        if (ro_cap > 1024) rbins = tmax <= 3000 ? 1024u : (tmax <= 12000 ? 256u : 64u);
+        if (tmax > 41000) rbins = tmax > 164000 ? 8u : (tmax > 82000 ? 16u : 32u);
+        else if (ro_cap > 1024) rbins = tmax <= 3000 ? 1024u : (tmax <= 12000 ? 256u : 64u);
     }
     // the bounds of the next round are fetched while this round is joined
-    uint32_t n_rs = rb[wave * rbins + lane], n_qlo = qb[wave * rbins], n_qhi = qb[wave * rbins + rbins], n_rhi = rb[wave * rbins + rbins];
+    uint32_t n_rs = rb[min(wave * rbins + lane, BIN_COUNT)], n_qlo = qb[wave * rbins], n_qhi = qb[wave * rbins + rbins], n_rhi = rb[wave * rbins + rbins];
     for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * rbins) {
         const uint32_t rs = n_rs, q_lo = n_qlo, q_hi = n_qhi, r_hi = n_rhi;
         const uint32_t r_lo = __shfl(rs, 0, 64);
         if (b0 + ANI_PAIR_WAVES * rbins < BIN_COUNT) {
             const uint32_t f = b0 + ANI_PAIR_WAVES * rbins;
-            n_rs = rb[f + lane]; n_qlo = qb[f]; n_qhi = qb[f + rbins]; n_rhi = rb[f + rbins];
+            n_rs = rb[min(f + lane, BIN_COUNT)]; n_qlo = qb[f]; n_qhi = qb[f + rbins]; n_rhi = rb[f + rbins];
         }
         if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
         const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             // Every anchor sets its band in the q seed's mask (a register) and in the r seed's mask (LDS); the
             // votes of the r seeds are cast in a second balanced pass.
             const uint32_t nq = q_hi - q_lo, nr = r_hi - r_lo;
-            ro[lane] = (uint16_t)(rs - r_lo);            // r range of bin b0 + x = [ro[x], ro[x + 1])
+            if (lane < rbins) ro[lane] = (uint16_t)(rs - r_lo);   // r range of bin b0 + x = [ro[x], ro[x + 1])
             for (uint32_t u = 64 + lane; u < rbins; u += 64) ro[u] = (uint16_t)(rb[b0 + u] - r_lo);
             if (lane == 63) ro[rbins] = (uint16_t)nr;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                             qmask |= 1u << band;
                             atomicOr(&rm[j >> 1], (1u << band) << (16u * (j & 1u)));
                         }
-                    cast_votes(vq, qloc >> 16, qmask);
+                    cast_vote(vq, qloc >> 16, qmask);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                 const uint32_t m2 = rm[w];
                 if (m2) {
                     rm[w] = 0;
-                    if (m2 & 0xffffu) cast_votes(vr, lr[2 * w] >> 16, m2 & 0xffffu);
-                    if (m2 >> 16) cast_votes(vr, lr[2 * w + 1] >> 16, m2 >> 16);
+                    if (m2 & 0xffffu) cast_vote(vr, lr[2 * w] >> 16, m2 & 0xffffu);
+                    if (m2 >> 16) cast_vote(vr, lr[2 * w + 1] >> 16, m2 >> 16);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -345,14 +349,14 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                     uint32_t qmask = 0;
                     for (uint32_t j = rs_; j < re; j++)
                         if (rc[j] == c) qmask |= 1u << anchor_band(qloc, qpos, rl[j], chunk);
-                    if (qmask) cast_votes(vq, qloc >> 16, qmask);
+                    if (qmask) cast_vote(vq, qloc >> 16, qmask);
                 }
                 for (uint32_t j = rs_; j < re; j++) {
                     const uint32_t c = rc[j], rloc = rl[j];
                     uint32_t rmask = 0;
                     for (uint32_t i = qs; i < qe; i++)
                         if (qc[i] == c) { const uint32_t qloc = ql[i]; rmask |= 1u << anchor_band(qloc, loc_pos(qloc, chunk), rloc, chunk); }
-                    if (rmask) cast_votes(vr, rloc >> 16, rmask);
+                    if (rmask) cast_vote(vr, rloc >> 16, rmask);
                 }
             }
         }
@@ -448,10 +452,10 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
     // costs 16 KiB of LDS per workgroup, which large-genome runs keep for a third resident workgroup per CU
     uint32_t ro_cap = 66;
     for (uint32_t c : idx->seed_count) if (c <= 12000) { ro_cap = 1026; break; }
-    constexpr size_t STATIC_LDS = 64 * 1024;   // seed stage (code + loc, both genomes) + band masks, rounded up
+    constexpr size_t STATIC_LDS = 30 * 1024;   // seed stage (code + loc, both genomes) + band masks, rounded up
     const size_t per_chunk = ANI_VOTE_WORDS * sizeof(uint32_t) + sizeof(uint64_t);   // votes + aligned-chunk list entry
-    if ((size_t)2 * max_chunks * per_chunk + 16 + (size_t)ANI_PAIR_WAVES * 1026 * 2 > 160 * 1024 - STATIC_LDS) ro_cap = 66;
-    const size_t lds = (size_t)2 * max_chunks * per_chunk + 16 + (size_t)ANI_PAIR_WAVES * ro_cap * sizeof(uint16_t);   // + r-bin offsets of a round
+    if ((size_t)2 * max_chunks * per_chunk + 24 + (size_t)ANI_PAIR_WAVES * 1026 * 2 > 160 * 1024 - STATIC_LDS) ro_cap = 66;
+    const size_t lds = (size_t)2 * max_chunks * per_chunk + 24 + (size_t)ANI_PAIR_WAVES * ro_cap * sizeof(uint16_t);   // + r-bin offsets of a round
     static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand
     if (lds > attr_lds) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

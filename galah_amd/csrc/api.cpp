@@ -1061,7 +1061,7 @@ static int index_new(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t 
     }
     if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) {
         free_index_locked(idx);
-        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (at most 1250 chunks per genome: 25 Mb at the default 20 kb chunk, 40 Mb at 32768)");
+        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (at most 1450 chunks per genome: 29 Mb at the default 20 kb chunk, 47 Mb at 32768)");
     }
     cap.resize(n);
     for (size_t i = 0; i < n; i++) cap[i] = ghip_ani_seed_capacity(g->lens[i], c);

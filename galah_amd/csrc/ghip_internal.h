@@ -120,7 +120,7 @@ struct ghip_ani_index {
 
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
-#define GHIP_ANI_MAX_CHUNKS 1250u  // per genome: band votes (32 B) + aligned-chunk list (8 B) of both genomes + the 56 KiB seed stage fit the 160 KiB LDS
+#define GHIP_ANI_MAX_CHUNKS 1450u  // per genome: band votes + repeat counter (36 B) + aligned-chunk list (8 B) of both genomes + the 28 KiB seed stage fit the 160 KiB LDS
 #define GHIP_ANI_MAX_CHUNK_LEN 32768u  // a seed's offset in its chunk is a 15-bit field
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);

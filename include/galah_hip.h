@@ -156,7 +156,7 @@ uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
  * Replaces SkaniClusterer::calculate_ani (src/skani.rs:708-716 -> calculate_skani :718-788),
  * batched.  Returns PERCENT, 0.0 when below the aligned-fraction gate (skani prints no row).
  * Build-defined estimator, skani parity unpinned: see DESIGN.md "ANI". Thread-safe. */
-/* Limits: k <= 16; chunk <= 32768; at most 1250 chunks per genome (25 Mb at the default 20 kb chunk, 40 Mb at 32768 --
+/* Limits: k <= 16; chunk <= 32768; at most 1450 chunks per genome (29 Mb at the default 20 kb chunk, 47 Mb at 32768 --
  * galah's inputs are prokaryotic genomes; a longer genome is refused with GHIP_EINVAL). */
 int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c,
                          uint32_t chunk, ghip_ani_index **out);

@@ -20,12 +20,17 @@
  *               kept iff (u32)(code * 0x85EBCA6B) < (2^32-1) / c  (a bijective multiplicative mix: equal hash <=> equal code)
  *   chunk(p)  = p / chunk_len  (chunk_len <= 32768)
  *   anchor    = (seed a of q, seed b of r) with equal codes; orientation o = strand_a ^ strand_b;
- *               diagonal d = o ? pos_b + pos_a : pos_b - pos_a  (mod 2^32);  band = ((d >> 12) & 7) | (o << 3)
- *               -- anchors of one alignment share the orientation and, up to indels, the diagonal: 4 kb bands
- *   votes     : V_q[chunk(a)][band] = number of seeds a of that chunk with at least one anchor in `band`; V_r likewise
- *   per chunk : T_c = #seeds; M_c = min(T_c, sum of V[band] over the bands with V[band] >= 3) -- a seed match counts only
- *               when at least three seeds of the chunk agree on orientation and diagonal (a chunk of a fragmented
- *               assembly may hold several contigs, each with its own diagonal; a chunk across a rearrangement two);
+ *               band = o ? ((pos_b + pos_a) >> 12 & 7) | 8 : ((2 (pos_b - pos_a) + 1 + 4096) >> 13) & 7   (mod 2^32)
+ *               -- anchors of one alignment share the orientation and, up to indels, the diagonal: 4 kb bands,
+ *               placed so that exchanging q and r only mirrors them (the estimate is symmetric)
+ *   votes     : a seed whose anchors all fall into ONE band votes for it: V_q[chunk(a)][band] = number of such seeds; a
+ *               seed with anchors in several bands (a repeat: insertion sequences, rRNA operons) is counted in
+ *               A_q[chunk(a)] instead; V_r, A_r likewise
+ *   per chunk : T_c = #seeds; S_c = sum of V[band] over the bands with V[band] >= 3 -- single-copy seed matches count
+ *               only when at least three seeds of the chunk agree on orientation and diagonal (a chunk of a
+ *               fragmented assembly may hold several contigs, each with its own diagonal; a chunk across a
+ *               rearrangement two); M_c = min(T_c, S_c + (S_c > 0 ? A_c : 0)) -- a repeat seed is a match, once, where
+ *               the chunk aligns anyway, and cannot align a chunk on its own;
  *               chunk aligned iff T_c >= 1 and M_c * 10000 >= 510 * T_c   (0.82^15 ~ 0.0510)
  *   M,T       = the (M_c, T_c) of the LOWER MEDIAN containment M_c/T_c over the aligned chunks of BOTH
  *               directions (exact order by cross-multiplication; skani likewise reports a robust
@@ -47,6 +52,7 @@
 #include <zlib.h>
 
 #define GO_ANI_BANDS 16
+#define GO_ANI_SLOTS 17   /* per chunk: 16 band counters + the seeds whose anchors fall into more than one band */
 #define GO_ANI_BAND_SHIFT 12
 #define GO_ANI_MIN_COLINEAR 3
 
@@ -184,17 +190,19 @@ static void ani_votes(const go_ani_sketch *q, const go_ani_sketch *r, uint32_t *
         for (size_t x = lower_bound_code(r->sorted, r->n, code); x < r->n && r->sorted[x].code == code; x++) {
             const uint32_t b = r->sorted[x].idx;
             const uint32_t o = (uint32_t)(q->strand[a] ^ r->strand[b]);
-            const uint32_t d = o ? r->pos[b] + q->pos[a] : r->pos[b] - q->pos[a];
-            const uint32_t band = ((d >> GO_ANI_BAND_SHIFT) & 7u) | (o << 3);
+            /* same orientation: bands of the odd number 2 (pos_b - pos_a) + 1, centred on 0 -- the boundaries are even, so
+             * swapping q and r negates the number and mirrors the bands: ANI(q, r) == ANI(r, q) */
+            const uint32_t band = o ? (((r->pos[b] + q->pos[a]) >> GO_ANI_BAND_SHIFT) & 7u) | 8u
+                                    : ((2u * (r->pos[b] - q->pos[a]) + 1u + (1u << GO_ANI_BAND_SHIFT)) >> (GO_ANI_BAND_SHIFT + 1)) & 7u;
             qmask |= 1u << band;
             rmask[b] |= (uint16_t)(1u << band);
         }
-        for (uint32_t band = 0; band < GO_ANI_BANDS; band++)
-            if (qmask >> band & 1u) vq[(size_t)q->chunk_id[a] * GO_ANI_BANDS + band]++;
+        if (qmask) vq[(size_t)q->chunk_id[a] * GO_ANI_SLOTS + ((qmask & (qmask - 1)) ? GO_ANI_BANDS : (uint32_t)__builtin_ctz(qmask))]++;
     }
-    for (size_t b = 0; b < r->n; b++)
-        for (uint32_t band = 0; band < GO_ANI_BANDS; band++)
-            if (rmask[b] >> band & 1u) vr[(size_t)r->chunk_id[b] * GO_ANI_BANDS + band]++;
+    for (size_t b = 0; b < r->n; b++) {
+        const uint32_t m = rmask[b];
+        if (m) vr[(size_t)r->chunk_id[b] * GO_ANI_SLOTS + ((m & (m - 1)) ? GO_ANI_BANDS : (uint32_t)__builtin_ctz(m))]++;
+    }
     free(rmask);
 }
 
@@ -203,9 +211,10 @@ static void ani_collect(const go_ani_sketch *x, const uint32_t *votes, chunk_fra
     for (uint32_t c = 0; c < x->n_chunks; c++) {
         const uint64_t tc = x->chunk_total[c];
         if (tc < 1) continue;
-        const uint32_t *v = votes + (size_t)c * GO_ANI_BANDS;
+        const uint32_t *v = votes + (size_t)c * GO_ANI_SLOTS;
         uint64_t mc = 0;
         for (uint32_t band = 0; band < GO_ANI_BANDS; band++) if (v[band] >= GO_ANI_MIN_COLINEAR) mc += v[band];
+        if (mc) mc += v[GO_ANI_BANDS];   /* repeats: matched once, and only in a chunk that aligns by its single-copy seeds */
         if (mc > tc) mc = tc;
         if (mc * 10000 >= 510 * tc) {
             out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++;
@@ -220,8 +229,8 @@ float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_f
     uint64_t bq = 0, br = 0;
     size_t n = 0;
     chunk_frac *fr = (chunk_frac *)malloc(((size_t)q->n_chunks + r->n_chunks + 1) * sizeof(chunk_frac));
-    uint32_t *vq = (uint32_t *)calloc(((size_t)q->n_chunks + 1) * GO_ANI_BANDS, sizeof(uint32_t));
-    uint32_t *vr = (uint32_t *)calloc(((size_t)r->n_chunks + 1) * GO_ANI_BANDS, sizeof(uint32_t));
+    uint32_t *vq = (uint32_t *)calloc(((size_t)q->n_chunks + 1) * GO_ANI_SLOTS, sizeof(uint32_t));
+    uint32_t *vr = (uint32_t *)calloc(((size_t)r->n_chunks + 1) * GO_ANI_SLOTS, sizeof(uint32_t));
     ani_votes(q, r, vq, vr);
     ani_collect(q, vq, fr, &n, &bq);
     ani_collect(r, vr, fr, &n, &br);

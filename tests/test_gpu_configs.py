@@ -187,3 +187,26 @@ def test_config2_full_length_genomes_sample_vs_oracle(ctx):
         a, b = pi[x]
         assert np.float32(oracle.ani_pair(ask[a], ask[b], 0.15)[0]) == ani[x]
     assert np.all((ani > 94.5) & (ani < 95.5))
+
+
+def test_ani_large_genomes_narrow_rounds(ctx):
+    """Genomes above ~5 Mb join fewer bins per round (32 / 16 / 8) so that a round's seeds still fit the LDS stage, and
+    hold more chunks than the default votes area: 9 Mb and 22 Mb pairs against the oracle, both orders."""
+    for length, rate in ((9_000_000, 0.02), (22_000_000, 0.03)):
+        g = ctx.genomes_synthetic(77, 1, 2, length, rate)
+        idx = ctx.ani_index_build(g)
+        ani, af = ctx.ani_pairs(idx, np.array([[0, 1], [1, 0]], dtype=np.uint32), 0.15, want_af=True)
+        sks = [oracle.AniSketch.from_bytes(g.to_host(i)) for i in range(2)]
+        want = oracle.ani_pair(sks[0], sks[1], 0.15)
+        assert ani[0] == np.float32(want[0]) and ani[1] == ani[0], (length, ani, want)
+        assert af[0, 0] == np.float32(want[1]) and af[0, 1] == np.float32(want[2])
+        assert 90.0 < ani[0] < 99.0
+        idx.free()
+        g.free()
+    # beyond the chunk counters the index is refused with a clear message, not computed wrongly
+    g = ctx.genomes_synthetic(78, 1, 1, 31_000_000, 0.0)
+    with pytest.raises(galah_amd.GalahHipError, match="too long"):
+        ctx.ani_index_build(g)
+    idx = ctx.ani_index_build(g, 15, 125, 32768)   # a proportionally longer chunk takes it
+    idx.free()
+    g.free()
