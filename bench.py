@@ -273,8 +273,22 @@ def wall_clock(args, ctx):
         gg = ctx.genomes_from_files(paths, threads)
         t_ingest = time.perf_counter() - t0
         gg.free()
+        # the box's own host-to-device rate (one pinned 1 GiB copy, second run): what the ingest can at best approach
+        import torch
+        src = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+        dst = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        h2d = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d = max(h2d, (1 << 30) / (time.perf_counter() - t0) / 1e9)
+        del src, dst
         out.update({"plain_first_call_s": t_first, "plain_s": t_warm, "gz_s": t_gz, "clusters": len(c0),
                     "ingest_only_s": t_ingest, "ingest_GBps": out["plain_bytes"] / t_ingest / 1e9,
+                    "h2d_pinned_GBps": h2d, "pcie_floor_s": out["plain_bytes"] / (h2d * 1e9),
+                    "plain_s_minus_pcie_floor_ms": (t_warm - out["plain_bytes"] / (h2d * 1e9)) * 1e3,
                     "after_ingest_s": t_warm - t_ingest,
                     "pairs_per_s_end_to_end": n * (n - 1) // 2 / t_warm,
                     "genomes_per_s_end_to_end": n / t_warm})

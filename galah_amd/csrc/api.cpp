@@ -3,6 +3,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,44 @@ void ghip_pool_free(ghip_ctx *ctx, void *p) {
         if (b.p == p) { b.used = false; return; }
 }
 
+void ghip_io_pool::run(int n, std::function<void(int)> fn) {
+    std::unique_lock<std::mutex> l(mu);
+    while ((int)threads.size() < n) {
+        const int id = (int)threads.size();
+        raw.emplace_back();
+        threads.emplace_back([this, id] {
+            uint64_t seen = 0;
+            for (;;) {
+                std::function<void(int)> f;
+                {
+                    std::unique_lock<std::mutex> lw(mu);
+                    cv_work.wait(lw, [&] { return stop || (generation != seen && id < active); });
+                    if (stop) return;
+                    seen = generation;
+                    f = job;
+                }
+                f(id);
+                std::lock_guard<std::mutex> ld(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        });
+    }
+    job = std::move(fn);
+    active = pending = n;
+    generation++;
+    cv_work.notify_all();
+    cv_done.wait(l, [&] { return pending == 0; });
+    active = 0;
+}
+
+void ghip_io_pool::shutdown() {
+    { std::lock_guard<std::mutex> l(mu); stop = true; }
+    cv_work.notify_all();
+    for (auto &t : threads) t.join();
+    threads.clear();
+    raw.clear();
+}
+
 static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     bool del;
     {
@@ -58,7 +97,10 @@ static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     }
     if (!del) return;
     hipSetDevice(ctx->device);
+    ctx->io.shutdown();
     for (auto &b : ctx->pool) hipFree(b.p);
+    for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+    for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -454,11 +496,20 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         for (size_t i = b; i < e; i++) cap[i] = ghip_stream_capacity_hint(paths[i]);
     });
     for (size_t i = 0; i < n; i++) max_cap = std::max(max_cap, cap[i]);
+    size_t n_gz = 0;
+    for (size_t i = 0; i < n; i++) { const size_t l = strlen(paths[i]); n_gz += (l > 3 && !strcmp(paths[i] + l - 3, ".gz")) ? 1 : 0; }
     const double w_hint = since(w0);
     bool overflow = false;
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        // `mu` is held for the set-up and the wrap-up only: the worker phase touches nothing of the context but its
+        // staging buffers and copy streams, so another thread may run kernels of a previous batch meanwhile
+        // (ghip_sketch_and_index_files overlaps the sketch pass of batch b with the ingest of batch b + 1)
+        std::lock_guard<std::mutex> ingest_lk(ctx->ingest_mu);
+        std::unique_lock<std::mutex> lk(ctx->mu);
         GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        for (hipStream_t &cs : ctx->copy_stream)
+            if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; (void)hipGetLastError(); }
+        hipStream_t fill_stream = ctx->copy_stream[0] ? ctx->copy_stream[0] : ctx->stream;
         ghip_genomes *g = new ghip_genomes();
         g->ctx = ctx;
         g->n = n;
@@ -470,13 +521,23 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         for (size_t i = 0; i < n; i++) { g->starts[i] = off; off += (cap[i] + GHIP_TAIL_PAD + 15) / 16 * 16; }
         g->total_alloc = off + 256;
         int rc = dmalloc(ctx, &g->d_bytes, g->total_alloc);
-        if (rc == GHIP_OK && hipMemsetAsync(g->d_bytes, 'N', g->total_alloc, ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed");
-        if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
+        if (rc == GHIP_OK && hipMemsetAsync(g->d_bytes, 'N', g->total_alloc, fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed");
+        if (rc == GHIP_OK && hipStreamSynchronize(fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
         if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
         const double w_alloc = since(w0) - w_hint;
 
         int threads = std::max(1, io_threads);
         threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n, 1));
+        // Plain files need ~0.2 thread-seconds per GB (read + parse) against 19 ms per GB of PCIe time: a dozen threads
+        // keep the copy streams busy, and many more concurrent readers of the page cache only slow each other down
+        // (64 threads: 4 thread-seconds of read() per 640 MB instead of 0.1).  Measured files -> clusters, 1 000 x 5 Mb:
+        // 154 / 123 / 142 / 150 ms with 8 / 12 / 16 / 24 threads.  gzip input is inflate-bound (CPU): every thread the
+        // caller offers is used.
+        {
+            const char *mt = getenv("GHIP_INGEST_THREADS_PLAIN");
+            const int plain_cap = mt ? std::max(1, atoi(mt)) : 12;
+            if (n_gz == 0) threads = std::min(threads, plain_cap);
+        }
         // two heap buffers of the largest file per thread: keep their total below 8 GiB
         threads = (int)std::min<uint64_t>((uint64_t)threads, std::max<uint64_t>(1, (8ull << 30) / (2 * (max_cap + 64))));
         std::atomic<size_t> next{0};
@@ -490,17 +551,72 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
             std::lock_guard<std::mutex> l2(emu);
             if (status.load() == GHIP_OK) { status = code; err = msg; }
         };
-        // Measured on the MI355X host (scripts/ubench/host_costs.cpp): a pageable H2D copy runs at 52-56 GB/s, the same
-        // as a pinned one, while hipStreamCreate costs 3.4 ms and hipHostMalloc 0.16 ms/MB -- so the workers keep plain
-        // heap buffers and issue blocking copies; no per-thread stream, no pinned staging.
-        // (Re-measured with the AVX2 line parser, A/B on one box: a pool of 16 pinned stream buffers is no faster than
-        // heap buffers -- workers 0.16 s vs 0.135 s for 5 GB; one pinned buffer per thread: 0.135-0.14 s, the same.
-        // Shipping runs of ~6 files as one 32 MB copy is faster once warm (0.11 s) but its FIRST call in a process
-        // takes 0.28-0.33 s against 0.15 s here -- the runtime registers every new source buffer on first use, at a
-        // cost that grows with its size -- and a dereplication run ingests once.)
-        auto worker = [&]() {
+        // Staging.  Measured on the MI355X host (scripts/ingest_probe.py): ONE pinned 5 GB copy runs at 53 GB/s, one
+        // pageable copy at 16-21 GB/s, blocking pageable copies from 16-128 threads level off at 36 GB/s whatever the
+        // thread count (the runtime stages them through its own pinned buffers) -- the 0.14 s floor of the previous
+        // ingest -- and pageable copies issued NEXT TO pinned asynchronous ones collapse to 3-10 GB/s.  So every copy
+        // leaves from a pinned buffer: the threads share a pool of 32 pinned slots (kept in the context: hipHostMalloc
+        // costs 0.16 ms/MB); a thread reads / inflates its file into its own heap buffer first (the CPU-heavy part, all
+        // io_threads at once), then takes a slot, parses into it, queues the asynchronous copy on one of two copy streams
+        // and hands the slot back "in flight"; the next taker waits for its event.  Files above GHIP_PINNED_SLOT_MAX (and
+        // everything when GHIP_INGEST=pageable) take blocking pageable copies.
+        constexpr size_t GHIP_PINNED_SLOT_MAX = 24u << 20;
+        constexpr size_t GHIP_PINNED_SLOTS = 32;
+        const char *ing = getenv("GHIP_INGEST");
+        const bool use_pinned = !(ing && !strcmp(ing, "pageable")) && ctx->copy_stream[0] && ctx->copy_stream[1];
+        const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, GHIP_PINNED_SLOT_MAX);
+        size_t n_slots = 0;
+        if (use_pinned) {
+            const size_t want = std::min<size_t>(GHIP_PINNED_SLOTS, (size_t)2 * threads);
+            if (ctx->ingest_slots.size() < want) ctx->ingest_slots.resize(want);
+            for (size_t x = 0; x < ctx->ingest_slots.size(); x++) {
+                ghip_ctx::pinned_slot &sl = ctx->ingest_slots[x];
+                if (x < want && sl.bytes < slot_bytes) {
+                    if (sl.p) hipHostFree(sl.p);
+                    sl.p = nullptr; sl.bytes = 0;
+                    if (hipHostMalloc((void **)&sl.p, slot_bytes, hipHostMallocDefault) == hipSuccess) sl.bytes = slot_bytes;
+                    else { sl.p = nullptr; (void)hipGetLastError(); }
+                }
+                if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) sl.ev = nullptr;
+                sl.state = 0;
+            }
+            // usable slots first
+            std::stable_partition(ctx->ingest_slots.begin(), ctx->ingest_slots.end(), [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= slot_bytes; });
+            for (auto &sl : ctx->ingest_slots) if (sl.p && sl.ev && sl.bytes >= slot_bytes) n_slots++;
+            n_slots = std::min(n_slots, want);
+        }
+        const double w_pin = since(w0) - w_hint - w_alloc;
+        std::mutex smu;
+        std::condition_variable scv;
+        // a slot for the calling thread: a free one, else the first one in flight (after its copy has finished)
+        auto take_slot = [&]() -> ghip_ctx::pinned_slot * {
+            std::unique_lock<std::mutex> l(smu);
+            for (;;) {
+                ghip_ctx::pinned_slot *inflight = nullptr;   // the copy queued longest ago finishes first
+                for (size_t x = 0; x < n_slots; x++) {
+                    ghip_ctx::pinned_slot &sl = ctx->ingest_slots[x];
+                    if (sl.state == 0) { sl.state = 1; return &sl; }
+                    if (sl.state == 2 && (!inflight || sl.seq < inflight->seq)) inflight = &sl;
+                }
+                if (inflight) {
+                    inflight->state = 1;   // mine; nobody else waits for it
+                    l.unlock();
+                    if (hipEventSynchronize(inflight->ev) != hipSuccess) { (void)hipGetLastError(); }
+                    return inflight;
+                }
+                scv.wait(l);   // every slot is being parsed into: wait for one to be handed back
+            }
+        };
+        uint64_t slot_seq = 0;
+        auto give_slot = [&](ghip_ctx::pinned_slot *sl, int state) {
+            { std::lock_guard<std::mutex> l(smu); sl->state = state; sl->seq = ++slot_seq; }
+            scv.notify_one();
+        };
+        auto worker = [&](int me) {
             if (hipSetDevice(ctx->device) != hipSuccess) { fail(GHIP_EHIP, "hipSetDevice failed in an ingest thread"); return; }
-            std::vector<uint8_t> raw, heap_buf((size_t)max_cap + 64);
+            hipStream_t cs = ctx->copy_stream[me & 1];
+            std::vector<uint8_t> &raw = ctx->io.raw[me];
+            std::vector<uint8_t> heap_buf;
             for (;;) {
                 if (status.load() != GHIP_OK || over.load()) break;
                 const size_t i = next.fetch_add(1);
@@ -510,32 +626,45 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 const auto t1 = std::chrono::steady_clock::now();
                 size_t len = 0;
                 std::string e;
-                uint8_t *stream_buf = heap_buf.data();
+                ghip_ctx::pinned_slot *slot = (n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
+                uint8_t *stream_buf;
+                if (slot) stream_buf = slot->p;
+                else {
+                    if (heap_buf.size() < (size_t)cap[i] + 64) heap_buf.resize((size_t)cap[i] + 64);
+                    stream_buf = heap_buf.data();
+                }
+                const auto t1b = std::chrono::steady_clock::now();
                 const int r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf, (size_t)cap[i], &len, g->stats[i], e);
                 const auto t2 = std::chrono::steady_clock::now();
                 t_read += std::chrono::duration<double>(t1 - t0).count();
-                t_parse += std::chrono::duration<double>(t2 - t1).count();
-                bool stop = false;
+                t_parse += std::chrono::duration<double>(t2 - t1b).count();
+                bool stop = false, inflight = false;
                 if (r != GHIP_OK) { fail(r, e); stop = true; }
                 else if (len > cap[i]) { over = true; stop = true; }  // capacity hint too small (multi-member gzip): two-phase form
                 else {
                     g->lens[i] = len;
-                    if (len && hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice) != hipSuccess) {
-                        fail(GHIP_EHIP, "ingest copy failed");
-                        stop = true;
-                    }
+                    hipError_t ce = hipSuccess;
+                    if (len && slot) {
+                        ce = hipMemcpyAsync(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice, cs);
+                        if (ce == hipSuccess) { ce = hipEventRecord(slot->ev, cs); inflight = true; }
+                    } else if (len) ce = hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice);
+                    if (ce != hipSuccess) { fail(GHIP_EHIP, "ingest copy failed"); stop = true; }
                 }
+                if (slot) give_slot(slot, inflight ? 2 : 0);
                 if (stop) break;
-                t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+                t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() + std::chrono::duration<double>(t1b - t1).count();
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < threads; t++) pool.emplace_back(worker);
-        worker();
-        for (auto &th : pool) th.join();
+        lk.unlock();
+        ctx->io.run(threads, worker);
+        // every queued copy has landed before the buffers are handed to the next call and the genomes to the kernels
+        for (hipStream_t cs : ctx->copy_stream)
+            if (cs && hipStreamSynchronize(cs) != hipSuccess) fail(GHIP_EHIP, "ingest copy failed");
+        lk.lock();
+        GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         if (dbg)
-            fprintf(stderr, "[ingest] %d threads, thread-seconds: read %.3f parse %.3f copy %.3f; wall: hints %.3f alloc+fill %.3f workers %.3f\n",
-                    threads, t_read.load(), t_parse.load(), t_alloc.load(), w_hint, w_alloc, since(w0) - w_hint - w_alloc);
+            fprintf(stderr, "[ingest] %d threads, %d pinned slots, thread-seconds: read %.3f parse %.3f copy/wait %.3f; wall: hints %.3f alloc+fill %.3f pinned setup %.3f workers %.3f\n",
+                    threads, (int)n_slots, t_read.load(), t_parse.load(), t_alloc.load(), w_hint, w_alloc, w_pin, since(w0) - w_hint - w_alloc - w_pin);
         overflow = over.load();
         rc = status.load();
         if (rc != GHIP_OK) ghip_set_error(ctx, rc, err);
@@ -1206,18 +1335,78 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
         for (auto *x : sks) ghip_sketches_free(x);
         for (auto *x : idxs) ghip_ani_index_free(x);
     };
-    size_t first = 0;
-    do {  // at least one (possibly empty) batch, so that n == 0 yields empty handles
+    // ---- plan the batches.  Two reasons to split: the HBM bound (batch_bytes), and OVERLAP -- while the kernels of batch b
+    // run (sketch + seed pass, ~2.2 ms per GB), the ingest threads already fill batch b + 1 over PCIe (~19 ms per GB):
+    // inputs above 1 GiB go in 8 pieces (at least 256 MiB each), ingested by a producer thread one piece ahead.
+    std::vector<uint64_t> caps(n);
+    parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b0, size_t e0) {
+        for (size_t i = b0; i < e0; i++) caps[i] = ghip_stream_capacity_hint(paths[i]) + GHIP_TAIL_PAD + 16;
+    });
+    uint64_t total_bytes = 0;
+    for (uint64_t c : caps) total_bytes += c;
+    uint64_t piece = batch_bytes;
+    {
+        const char *pl = getenv("GHIP_PIPELINE");
+        if (!(pl && !strcmp(pl, "0")) && total_bytes > (1ull << 30))
+            piece = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + 1, 256ull << 20));
+    }
+    std::vector<std::pair<size_t, size_t>> ranges;
+    for (size_t first = 0; first < n || ranges.empty();) {  // at least one (possibly empty) batch, so that n == 0 yields empty handles
         size_t last = first;
         uint64_t bytes = 0;
         while (last < n) {
-            const uint64_t c = ghip_stream_capacity_hint(paths[last]) + GHIP_TAIL_PAD + 16;
-            if (last > first && bytes + c > batch_bytes) break;
-            bytes += c;
+            if (last > first && bytes + caps[last] > piece) break;
+            bytes += caps[last];
             last++;
         }
+        ranges.push_back({first, last});
+        first = last;
+        if (n == 0) break;
+    }
+    // producer: ingests the batches in order, at most two ahead of the consumer
+    struct Ingested { ghip_genomes *g; int rc; };
+    std::vector<Ingested> ready(ranges.size(), Ingested{nullptr, GHIP_OK});
+    std::mutex qmu;
+    std::condition_variable qcv;
+    size_t produced = 0, consumed = 0;
+    bool abort_producer = false;
+    auto ingest = [&](size_t b) {
         ghip_genomes *g = nullptr;
-        int rc = ghip_genomes_from_files(ctx, paths + first, last - first, io_threads, &g);
+        const int rc = ghip_genomes_from_files(ctx, paths + ranges[b].first, ranges[b].second - ranges[b].first, io_threads, &g);
+        std::lock_guard<std::mutex> l(qmu);
+        ready[b] = Ingested{g, rc};
+        produced = b + 1;
+        qcv.notify_all();
+    };
+    std::thread producer;
+    if (ranges.size() > 1)
+        producer = std::thread([&] {
+            for (size_t b = 0; b < ranges.size(); b++) {
+                {
+                    std::unique_lock<std::mutex> l(qmu);
+                    qcv.wait(l, [&] { return abort_producer || b < consumed + 2; });
+                    if (abort_producer) return;
+                }
+                ingest(b);
+                if (ready[b].rc != GHIP_OK) return;
+            }
+        });
+    auto stop_producer = [&]() {
+        if (!producer.joinable()) return;
+        { std::lock_guard<std::mutex> l(qmu); abort_producer = true; qcv.notify_all(); }
+        producer.join();
+        for (auto &r : ready) if (r.g) { ghip_genomes_free(r.g); r.g = nullptr; }
+    };
+    for (size_t b = 0; b < ranges.size(); b++) {
+        if (ranges.size() == 1) ingest(0);
+        else {
+            std::unique_lock<std::mutex> l(qmu);
+            qcv.wait(l, [&] { return produced > b; });
+        }
+        ghip_genomes *g = ready[b].g;
+        ready[b].g = nullptr;
+        int rc = ready[b].rc;
+        const size_t first = ranges[b].first, last = ranges[b].second;
         ghip_sketches *sk = nullptr;
         ghip_ani_index *idx = nullptr;
         if (!rc) rc = out_idx ? ghip_sketch_and_index(ctx, g, k, s, seed, ani_k, ani_c, ani_chunk, &sk, &idx)
@@ -1228,11 +1417,19 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
                 out_stats[3 * i] = st.num_contigs; out_stats[3 * i + 1] = st.num_ambiguous_bases; out_stats[3 * i + 2] = st.n50;
             }
         if (g) ghip_genomes_free(g);
-        if (rc) { if (sk) ghip_sketches_free(sk); if (idx) ghip_ani_index_free(idx); drop(); return rc; }
+        { std::lock_guard<std::mutex> l(qmu); consumed = b + 1; qcv.notify_all(); }
+        if (rc) {
+            const std::string msg = ghip_last_error(ctx);   // the producer's later calls must not overwrite the cause
+            stop_producer();
+            if (sk) ghip_sketches_free(sk);
+            if (idx) ghip_ani_index_free(idx);
+            drop();
+            return ghip_set_error(ctx, rc, msg);
+        }
         sks.push_back(sk);
         if (out_idx) idxs.push_back(idx);
-        first = last;
-    } while (first < n);
+    }
+    if (producer.joinable()) producer.join();
     if (sks.size() == 1) {
         *out_sk = sks[0];
         if (out_idx) *out_idx = idxs[0];

@@ -5,7 +5,10 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -35,6 +38,22 @@ struct ghip_cmin_cache {  // device filter table of ghip_precluster, keyed by (m
     bool valid = false;
 };
 
+// Persistent I/O workers of a context (file ingest).  Threads and their read buffers outlive the calls: spawning 64
+// threads costs ~2 ms per call and, worse, every fresh thread page-faults a fresh multi-megabyte buffer under the
+// process-wide mmap lock -- with 8 pipelined batches per run that was 2-4 thread-seconds of "read" per batch.
+struct ghip_io_pool {
+    std::vector<std::thread> threads;
+    std::vector<std::vector<uint8_t>> raw;   // one read / inflate buffer per worker, kept mapped
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> job;
+    uint64_t generation = 0;
+    int active = 0, pending = 0;
+    bool stop = false;
+    void run(int n, std::function<void(int)> fn);   // fn(worker) on workers 0..n-1; returns when all are done
+    void shutdown();
+};
+
 struct ghip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -50,6 +69,13 @@ struct ghip_ctx {
     std::vector<ghip_pool_block> pool;
     ghip_cmin_cache cmin;
     uint64_t *d_kmer_luts = nullptr;  // MurmurHash3 first-stage tables of sketch_kmers21 (12 KiB, built once; pool-owned)
+    // ingest staging (ghip_genomes_from_files): pinned double buffers of the worker threads and two copy streams, kept
+    // for the life of the context (hipHostMalloc costs ~0.16 ms/MB, hipStreamCreate ~3 ms)
+    struct pinned_slot { uint8_t *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; int state = 0; uint64_t seq = 0; };   // state: 0 free, 1 owned by a thread, 2 copy in flight (seq = issue order)
+    std::vector<pinned_slot> ingest_slots;
+    ghip_io_pool io;
+    std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
     int live_handles = 0;   // genomes / sketches / ani indexes still alive
     bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };
