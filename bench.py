@@ -336,6 +336,50 @@ def skani_probe(ctx):
         return f"present at {exe} but the probe failed: {e!r}"
 
 
+def pmc_live(dom_kernel: str):
+    """HBM bytes per launch of the dominant kernel MEASURED by this run: two short child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate passes, kernel-trace only, as the guide's HBM
+    section prescribes), FETCH doubled for the 16 B/lane streaming kernels (gfx950 correction).  None if rocprofv3 is
+    not usable here."""
+    import csv
+    import glob
+    import re
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    label = {"sketch_kmers": "sketch_kmers21_kernel", "pair_intersect_tile": "pair_probe_tile_kernel"}.get(dom_kernel, dom_kernel + "_kernel")
+    wide = dom_kernel in ("sketch_kmers", "ani_seeds")
+    out = {}
+    d = tempfile.mkdtemp(prefix="ghip_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, c), "-o", c, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {c} exited {r.returncode}: {r.stderr[-300:]}"}
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, c, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if re.search(label, row["Kernel_Name"]) and row["Counter_Name"] == c:
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return {"error": f"no {label} rows in the {c} pass"}
+            out[c + "_KB_per_launch"] = tot / n
+            out["launches_" + c] = n
+        f_b, w_b = out["FETCH_SIZE_KB_per_launch"] * 1024, out["WRITE_SIZE_KB_per_launch"] * 1024
+        out["fetch_x2"] = wide
+        out["hbm_bytes_per_launch"] = (2 * f_b if wide else f_b) + w_b
+        return out
+    except Exception as e:  # noqa: BLE001 -- a counter pass must never cost the headline
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # ------------------------------------------------------------------------------------------------ launch
 def _free_port() -> int:
     with socket.socket() as s:
@@ -521,8 +565,17 @@ def main():
             del job, result
             gc.unfreeze()
             gc.collect()
+            def live_traffic():
+                t = pmc_live(dom)
+                if t and "hbm_bytes_per_launch" in t:   # measured in this run: replaces the recorded figure
+                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_unit"] = ("bytes/launch, measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                       "(separate passes, kernel-trace only; FETCH x2 for 16 B/lane streams on gfx950)")
+                return t if t is not None else "rocprofv3 not on PATH: roofline.traffic is the recorded figure"
+
             for name, fn in (("north_star_10k", lambda: north_star_10k(args, ctx, rates, min_ani, ani_thr, min_af)),
-                             ("wall_clock", lambda: wall_clock(args, ctx)), ("skani", lambda: skani_probe(ctx))):
+                             ("wall_clock", lambda: wall_clock(args, ctx)), ("skani", lambda: skani_probe(ctx)),
+                             ("pmc_live", live_traffic)):
                 try:
                     out[name] = fn()
                 except AssertionError:

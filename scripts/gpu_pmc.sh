@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o $C -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.json 2> $OUT/$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o $C -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/$C.json 2> $OUT/$C.err
   ls $OUT/$C | head
 done
 python - <<PY
@@ -23,7 +23,7 @@ for C in ("FETCH_SIZE","WRITE_SIZE"):
 PY
 # third pass: VALU occupancy of the issue pipe (the sketch/seed kernels are integer-VALU bound)
 cd /tmp
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/SQ -o SQ -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/SQ.json 2> $OUT/SQ.err
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/SQ -o SQ -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/SQ.json 2> $OUT/SQ.err
 python - <<PY
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
