@@ -1346,8 +1346,11 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
     for (uint64_t c : caps) total_bytes += c;
     uint64_t piece = batch_bytes;
     {
+        // (gzip input is inflate-bound on the host: cutting it into pieces only adds eight load-imbalanced tails)
+        size_t n_gz = 0;
+        for (size_t i = 0; i < n; i++) { const size_t l = strlen(paths[i]); n_gz += (l > 3 && !strcmp(paths[i] + l - 3, ".gz")) ? 1 : 0; }
         const char *pl = getenv("GHIP_PIPELINE");
-        if (!(pl && !strcmp(pl, "0")) && total_bytes > (1ull << 30))
+        if (!(pl && !strcmp(pl, "0")) && n_gz == 0 && total_bytes > (1ull << 30))
             piece = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + 1, 256ull << 20));
     }
     std::vector<std::pair<size_t, size_t>> ranges;
