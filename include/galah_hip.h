@@ -138,14 +138,16 @@ void ghip_sketches_free(ghip_sketches *sk);
  * The caller frees *out_pairs with ghip_free(). */
 int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
                     ghip_pair **out_pairs, size_t *out_n);
-/* Multi-GPU share: only the upper-triangle tiles t with t % world == rank (block-cyclic). */
+/* Multi-GPU share of the pair work: the dense forms deal the upper-triangle tiles block-cyclically (tile t -> rank
+ * t % world); the inverted-index form (N >= 1200) keeps the pairs with (i + j) % world == rank -- its element stage runs
+ * on every rank, its records are only materialised for the rank's own pairs.  Either way the shares of all ranks
+ * partition the triangle, and every rank takes the same form (the choice depends on the sketches alone). */
 int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
                           uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n);
-/* What a multi-rank job calls on every rank with the SAME full sketch matrix.  When the inverted-index form of the
- * pair stage runs (its cost is one pass over all N*s hashes and does not shard), every rank computes and returns the
- * WHOLE list and *out_replicated = 1: no exchange of candidate lists is needed.  Otherwise the rank's share as
- * ghip_precluster_shard and *out_replicated = 0.  The choice depends only on the sketches and the parameters, so
- * all ranks take the same branch. */
+/* What a multi-rank job calls on every rank with the SAME full sketch matrix: this rank's share as above and
+ * *out_replicated = 0 -- or, with GHIP_JOIN_RANKS=replicate in the environment and the inverted-index form running, the
+ * WHOLE list on every rank and *out_replicated = 1 (no exchange of candidate lists needed; DESIGN.md section 6 has both
+ * timings). */
 int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
                           uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n,
                           int *out_replicated);
@@ -155,7 +157,8 @@ uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
 /* ---------------------------------------------------------------- ANI on candidate pairs
  * Replaces SkaniClusterer::calculate_ani (src/skani.rs:708-716 -> calculate_skani :718-788),
  * batched.  Returns PERCENT, 0.0 when below the aligned-fraction gate (skani prints no row).
- * Build-defined estimator, skani parity unpinned: see DESIGN.md "ANI". Thread-safe. */
+ * Build-defined estimator (FracMinHash seeds, matches colinear within a chunk), skani parity unpinned: see DESIGN.md
+ * "ANI" and oracle/galah_oracle_ani.c.  Symmetric in the pair.  Thread-safe. */
 /* Limits: k <= 16; chunk <= 32768; at most 1450 chunks per genome (29 Mb at the default 20 kb chunk, 47 Mb at 32768 --
  * galah's inputs are prokaryotic genomes; a longer genome is refused with GHIP_EINVAL). */
 int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c,
