@@ -1504,23 +1504,26 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if (!ctx || !idx || !out_ani || (n && !pairs)) return GHIP_EINVAL;
     for (size_t i = 0; i < 2 * n; i++) if (pairs[i] >= idx->n) return ghip_set_error(ctx, GHIP_EINVAL, "genome index out of range");
     if (n == 0) return GHIP_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    DeviceFree tmp(ctx);
-    uint32_t *d_pairs = nullptr;
-    uint64_t *d_out = nullptr;
-    int rc;
-    if ((rc = dmalloc(ctx, &d_pairs, 2 * n))) return rc;
-    tmp.add(d_pairs);
-    if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
-    tmp.add(d_out);
-    if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
-    const size_t batch = (size_t)1 << 22;  // 512 threads per pair: keep each dispatch below 2^32 work-items
-    for (size_t off = 0; off < n; off += batch)
-        ghip_launch_ani_pairs(ctx, idx, d_pairs + 2 * off, std::min(batch, n - off), std::max<uint32_t>(idx->max_chunks, 1), d_out + 6 * off);
     std::vector<uint64_t> res(6 * n);
-    if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
-    { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
+    {   // the context is held for the device part only: the host finish below runs next to other callers' launches
+        // (calculate_ani arrives from many rayon workers at once, src/clusterer.rs:267-296)
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        DeviceFree tmp(ctx);
+        uint32_t *d_pairs = nullptr;
+        uint64_t *d_out = nullptr;
+        int rc;
+        if ((rc = dmalloc(ctx, &d_pairs, 2 * n))) return rc;
+        tmp.add(d_pairs);
+        if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
+        tmp.add(d_out);
+        if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
+        const size_t batch = (size_t)1 << 22;  // 512 threads per pair: keep each dispatch below 2^32 work-items
+        for (size_t off = 0; off < n; off += batch)
+            ghip_launch_ani_pairs(ctx, idx, d_pairs + 2 * off, std::min(batch, n - off), std::max<uint32_t>(idx->max_chunks, 1), d_out + 6 * off);
+        if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
+        { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
+    }
     // the f64 pow and the two-decimal rounding stay on the host (glibc's pow is what the oracle's parity is defined
     // by): ~70 ns per pair, spread over threads from 20 000 pairs on (below that spawning costs more than it saves)
     auto finish_range = [&](size_t p0, size_t p1) {

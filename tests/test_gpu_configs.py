@@ -210,3 +210,79 @@ def test_ani_large_genomes_narrow_rounds(ctx):
     idx = ctx.ani_index_build(g, 15, 125, 32768)   # a proportionally longer chunk takes it
     idx.free()
     g.free()
+
+
+def test_config4_full_size_100k_contig_sketches(ctx):
+    """configs[3] at its stated size: 100 000 contigs, small sketches (s' = 256): 5e9 pairs through the join form; the
+    expected list from the planted families (the oracle's pair loop per family); every 9th contig ragged."""
+    n, s = 100_000, 256
+    hashes, lens = planted_sketches(n, s, 14, q=0.7)
+    lens[::9] = 90
+    hashes[::9, 90:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    got = ctx.precluster(sk, np.float32(0.9))
+    assert ctx.last_pairs_compared == n * (n - 1) // 2
+    assert got.tobytes() == expected_pairs(hashes, lens, 0.9).tobytes()
+    sk.free()
+
+
+def test_config4_5000_real_contigs_files_to_clusters_small_genomes(ctx, tmp_path):
+    """5 000 contigs of 2-20 kb as FASTA files through the whole path with the small-genomes seed density
+    (FinchPreclusterer + HipAniClusterer(small_genomes=True), one ingest): clusters equal the oracle's run of the
+    reference's greedy algorithm on the oracle's sketches and ANI."""
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs, paths = [], []
+    for f in range(1000):
+        L = int(np.exp(rng.uniform(np.log(2000), np.log(20000))))
+        anc = rng.choice(acgt, size=L)
+        for m in range(5):
+            c = anc.copy()
+            mut = rng.random(L) < (0.01 if m < 3 else 0.04)
+            c[mut] = rng.choice(acgt, size=int(mut.sum()))
+            contigs.append(c)
+    for i, c in enumerate(contigs):
+        p = tmp_path / f"c{i:05d}.fna"
+        p.write_bytes(b">contig%d\n" % i + c.tobytes() + b"\n")
+        paths.append(str(p))
+    n = len(paths)
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=16)
+    cl = galah_amd.HipAniClusterer(95.0, 0.15, small_genomes=True, ctx=ctx, io_threads=16)
+    got = galah_amd.cluster(paths, pre, cl)
+    assert sorted(x for c in got for x in c) == list(range(n))
+    with ThreadPoolExecutor(os.cpu_count()) as ex:
+        osk = list(ex.map(lambda b: oracle.sketch_bytes(b.tobytes() + b"N", 21, 1000, 0), contigs))
+        ask = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b.tobytes() + b"N", 15, 30, 20000), contigs))
+    hashes = np.full((n, 1000), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, o in enumerate(osk):
+        hashes[i, : len(o)] = o
+        lens[i] = len(o)
+    opairs = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=os.cpu_count())
+    assert pre.last_pairs.tobytes() == opairs.tobytes()
+    want = oracle.cluster(n, oracle.Cache.from_pairs(opairs), 95.0, lambda a, b: oracle.ani_pair(ask[a], ask[b], 0.15)[0])
+    assert got == want
+    assert 1000 <= len(got) <= 2200   # ~1 000 families, the 4 %-mutated members partly on their own
+
+
+def test_config2_1000_full_length_genomes_sketch_stage_sampled(ctx):
+    """The sketch stage at configs[1] scale under pytest (bench.py checks the same inside its timed run): 1 000 x 5 Mb
+    through the fused pass; 24 sampled sketch rows and the seed counts of 8 genomes against the oracle, every row
+    strictly ascending and full."""
+    seed, members, length, rate = 42, 10, 5_000_000, 0.0253
+    g = ctx.genomes_synthetic(seed, 100, members, length, rate)
+    sk, idx = ctx.sketch_and_index(g, 21, 1000, 0)
+    hashes, lens = sk.to_host()
+    assert hashes.shape == (1000, 1000) and np.all(lens == 1000)
+    assert np.all(hashes[:, 1:] > hashes[:, :-1])
+    _, _, cnt = idx.meta()
+    rows = list(range(0, 1000, 43))[:24]
+    with ThreadPoolExecutor(os.cpu_count()) as ex:
+        streams = list(ex.map(lambda r: oracle.synth_genome(seed, r // members, r % members, length, rate), rows))
+        want = list(ex.map(lambda b: oracle.sketch_bytes(b, 21, 1000, 0), streams))
+        seeds = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b).nseeds, streams[:8]))
+    for r, w in zip(rows, want):
+        assert np.array_equal(hashes[r], w), r
+    assert [int(cnt[r]) for r in rows[:8]] == seeds
+    for h in (sk, idx, g):
+        h.free()

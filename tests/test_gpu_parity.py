@@ -561,6 +561,14 @@ def test_reference_contig_expectation_through_hip(ctx):
     for x, (a, b) in enumerate(pi):
         assert np.float32(oracle.ani_pair(osk[a], osk[b], 0.15)[0]) == ani[x], (names[a], names[b])
     assert galah_amd.cluster_pairs(len(seqs), pairs, np.float32(95.0), ani) == [[0, 1, 2, 3, 4, 5], [6], [7], [8]]
+    # and with the parameters `--small-genomes` would use (c = 30, ~35 seeds per contig: the estimate is noisy, but it is
+    # what it is on both sides): device == oracle, and with this seed hash the expected clusters come out too
+    idx30 = ctx.ani_index_build(g, 15, 30, 20000)
+    ani30 = ctx.ani_pairs(idx30, pi, 0.15)
+    osk30 = [oracle.AniSketch.from_bytes(s, 15, 30, 20000) for s in seqs]
+    for x, (a, b) in enumerate(pi):
+        assert np.float32(oracle.ani_pair(osk30[a], osk30[b], 0.15)[0]) == ani30[x], (names[a], names[b])
+    assert galah_amd.cluster_pairs(len(seqs), pairs, np.float32(95.0), ani30) == [[0, 1, 2, 3, 4, 5], [6], [7], [8]]
 
 
 def test_reference_cli_representative_list_and_github7_through_hip(ctx):
