@@ -264,49 +264,28 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
         if (tmax > 41000) rbins = tmax > 164000 ? 8u : (tmax > 82000 ? 16u : 32u);
         else if (ro_cap > 1024) rbins = tmax <= 3000 ? 1024u : (tmax <= 12000 ? 256u : 64u);
     }
-    // Software pipeline over the rounds: the bin bounds are fetched TWO rounds ahead and the seeds of the next round ONE
-    // round ahead, into registers (3 per lane and array), while the current round is joined out of LDS -- a round used to
-    // start with a dependent chain bounds -> seed loads -> LDS -> join, ~2 us of exposed global latency 32 times per wave.
-    struct Bounds { uint32_t rs, qlo, qhi, rhi; };   // rs is per lane (offset of r bin b + lane), the rest wave-uniform
-    auto load_bounds = [&](uint32_t b) -> Bounds {
-        if (b >= BIN_COUNT) return Bounds{0u, 0u, 0u, 0u};
-        return Bounds{rb[min(b + lane, BIN_COUNT)], qb[b], qb[b + rbins], rb[b + rbins]};
-    };
-    constexpr uint32_t NS = ANI_STAGE / 64;
-    uint32_t dqc[NS], dql[NS], drc[NS], drl[NS];
-    auto fetch = [&](const Bounds &B) {
-        const uint32_t rlo = __shfl(B.rs, 0, 64), nqs = B.qhi - B.qlo, nrs = B.rhi - rlo;
-        if (nqs == 0 || nrs == 0 || nqs > ANI_STAGE || nrs > ANI_STAGE) return;   // wave-uniform
-#pragma unroll
-        for (uint32_t u = 0; u < NS; u++) {
-            const uint32_t k = lane + 64u * u;
-            if (k < nqs) { dqc[u] = qc[B.qlo + k]; dql[u] = ql[B.qlo + k]; }
-            if (k < nrs) { drc[u] = rc[rlo + k]; drl[u] = rl[rlo + k]; }
-        }
-    };
-    const uint32_t stride = ANI_PAIR_WAVES * rbins;
-    Bounds cur = load_bounds(wave * rbins), nxt = load_bounds(wave * rbins + stride);
-    fetch(cur);
-    for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += stride) {
-        const Bounds B = cur;
-        cur = nxt;
-        nxt = load_bounds(b0 + 2 * stride);
-        const uint32_t rs = B.rs, q_lo = B.qlo, q_hi = B.qhi, r_hi = B.rhi;
+    // the bounds of the next round are fetched while this round is joined
+    uint32_t n_rs = rb[min(wave * rbins + lane, BIN_COUNT)], n_qlo = qb[wave * rbins], n_qhi = qb[wave * rbins + rbins], n_rhi = rb[wave * rbins + rbins];
+    for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * rbins) {
+        const uint32_t rs = n_rs, q_lo = n_qlo, q_hi = n_qhi, r_hi = n_rhi;
         const uint32_t r_lo = __shfl(rs, 0, 64);
-        const bool active = q_lo != q_hi && r_lo != r_hi;   // wave-uniform: else one genome has no seed in these bins
-        const bool staged = active && (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
-        if (staged) {   // this round's seeds: registers -> stage
-            const uint32_t nqs = q_hi - q_lo, nrs = r_hi - r_lo;
-#pragma unroll
-            for (uint32_t u = 0; u < NS; u++) {
-                const uint32_t k = lane + 64u * u;
-                if (k < nqs) { sq[k] = dqc[u]; lq[k] = dql[u]; }
-                if (k < nrs) { sr[k] = drc[u]; lr[k] = drl[u]; }
-            }
+        if (b0 + ANI_PAIR_WAVES * rbins < BIN_COUNT) {
+            const uint32_t f = b0 + ANI_PAIR_WAVES * rbins;
+            n_rs = rb[min(f + lane, BIN_COUNT)]; n_qlo = qb[f]; n_qhi = qb[f + rbins]; n_rhi = rb[f + rbins];
         }
-        fetch(cur);     // the next round's seeds, in flight during this round's join
-        if (!active) continue;
+        if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
+        const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
         if (staged) {
+            {   // both runs in one loop: the four loads of an iteration are in flight together
+                const uint32_t nqs = q_hi - q_lo, nrs = r_hi - r_lo;
+                for (uint32_t k = lane; k < max(nqs, nrs); k += 64) {
+                    uint32_t c1 = 0, c2 = 0, h1 = 0, h2 = 0;
+                    if (k < nqs) { c1 = qc[q_lo + k]; h1 = ql[q_lo + k]; }
+                    if (k < nrs) { c2 = rc[r_lo + k]; h2 = rl[r_lo + k]; }
+                    if (k < nqs) { sq[k] = c1; lq[k] = h1; }
+                    if (k < nrs) { sr[k] = c2; lr[k] = h2; }
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // Flattened join: q seeds are dealt to the lanes one each (not one BIN per lane, whose cost is the
