@@ -224,7 +224,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned long long red[6];
     __shared__ uint32_t n_al;
-    __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE];
+    __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE + 8];   // + 8: the branch-free compares read up to 8 entries past a bin
     __shared__ uint32_t st_loc[ANI_PAIR_WAVES][2][ANI_STAGE];
     __shared__ uint32_t st_mask[ANI_PAIR_WAVES][ANI_STAGE / 2];  // band mask (16 bits) of every staged r seed, two per word
     uint32_t *vq = reinterpret_cast<uint32_t *>(smem_raw);
@@ -254,6 +254,9 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     // stage offsets of the round's r bins: dynamic LDS behind the aligned-chunk list, ro_cap entries per wave
     uint16_t *ro = reinterpret_cast<uint16_t *>(list + (nchq + nchr)) + (size_t)wave * ro_cap;
     for (uint32_t k = lane; k < ANI_STAGE / 2; k += 64) rm[k] = 0;
+    // 2^32 - 1 is never a canonical code (its reverse complement, 0, is smaller): entries of the r stage that no round of
+    // this workgroup has written yet can never compare equal to a seed
+    for (uint32_t k = lane; k < ANI_STAGE + 8; k += 64) sr[k] = 0xffffffffu;
     // Bins joined per wave and round, sized so that a run holds ~150 seeds of the larger genome (the stage holds 192;
     // a longer run -- a pathologically repetitive stretch -- takes the global-memory walk for that round only): 64 for
     // genomes up to ~5 Mb at c = 125, 32 / 16 / 8 above, 256 / 1024 for small genomes and contigs, which would otherwise
@@ -304,10 +307,12 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                 const uint32_t j0 = ro[x], jz = ro[x + 1];
                 // the first 8 seeds of the bin branch-free (a bin holds ~2.4 seeds, more than 8 with P ~ 5e-4): an
                 // exec-masked loop over the bin costs ~6 scalar instructions per iteration and the kernel is as much
-                // scalar- as vector-issue bound; reads past the bin stay inside the stage and are masked off
+                // scalar- as vector-issue bound
+                // no bound check: an entry past the bin is a seed of ANOTHER bin (this round's next bin, or a stale one of
+                // an earlier round, or the never-a-code fill) -- a code determines its bin, so it cannot equal c
                 uint32_t mm = 0;
 #pragma unroll
-                for (uint32_t u = 0; u < 8; u++) mm |= (uint32_t)((j0 + u < jz) & (sr[min(j0 + u, ANI_STAGE - 1)] == c)) << u;
+                for (uint32_t u = 0; u < 8; u++) mm |= (uint32_t)(sr[j0 + u] == c) << u;
                 bool any = mm != 0;
                 for (uint32_t j = j0 + 8; j < jz; j++) any |= (sr[j] == c);
                 if (any) {   // ~half of the seeds of related genomes
