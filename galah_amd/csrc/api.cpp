@@ -507,8 +507,14 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         std::lock_guard<std::mutex> ingest_lk(ctx->ingest_mu);
         std::unique_lock<std::mutex> lk(ctx->mu);
         GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        for (hipStream_t &cs : ctx->copy_stream)
+        if (ctx->n_copy_streams == 0) {
+            const char *e = getenv("GHIP_COPY_STREAMS");
+            ctx->n_copy_streams = std::min(4, std::max(1, e ? atoi(e) : 2));
+        }
+        for (int x = 0; x < ctx->n_copy_streams; x++) {
+            hipStream_t &cs = ctx->copy_stream[x];
             if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; (void)hipGetLastError(); }
+        }
         hipStream_t fill_stream = ctx->copy_stream[0] ? ctx->copy_stream[0] : ctx->stream;
         ghip_genomes *g = new ghip_genomes();
         g->ctx = ctx;
@@ -563,7 +569,8 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         constexpr size_t GHIP_PINNED_SLOT_MAX = 24u << 20;
         constexpr size_t GHIP_PINNED_SLOTS = 32;
         const char *ing = getenv("GHIP_INGEST");
-        const bool use_pinned = !(ing && !strcmp(ing, "pageable")) && ctx->copy_stream[0] && ctx->copy_stream[1];
+        bool use_pinned = !(ing && !strcmp(ing, "pageable"));
+        for (int x = 0; x < ctx->n_copy_streams; x++) use_pinned = use_pinned && ctx->copy_stream[x];
         const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, GHIP_PINNED_SLOT_MAX);
         size_t n_slots = 0;
         if (use_pinned) {
@@ -614,7 +621,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         };
         auto worker = [&](int me) {
             if (hipSetDevice(ctx->device) != hipSuccess) { fail(GHIP_EHIP, "hipSetDevice failed in an ingest thread"); return; }
-            hipStream_t cs = ctx->copy_stream[me & 1];
+            hipStream_t cs = ctx->copy_stream[me % ctx->n_copy_streams];
             std::vector<uint8_t> &raw = ctx->io.raw[me];
             std::vector<uint8_t> heap_buf;
             for (;;) {

@@ -75,7 +75,8 @@ struct ghip_ctx {
     std::vector<pinned_slot> ingest_slots;
     ghip_io_pool io;
     std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
-    hipStream_t copy_stream[2] = {nullptr, nullptr};
+    hipStream_t copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_copy_streams = 0;   // streams in use (GHIP_COPY_STREAMS, default 2)
     int live_handles = 0;   // genomes / sketches / ani indexes still alive
     bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };
