@@ -668,7 +668,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         for (hipStream_t cs : ctx->copy_stream)
             if (cs && hipStreamSynchronize(cs) != hipSuccess) fail(GHIP_EHIP, "ingest copy failed");
         lk.lock();
-        GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        if (hipSetDevice(ctx->device) != hipSuccess) fail(GHIP_EHIP, "hipSetDevice failed");
         if (dbg)
             fprintf(stderr, "[ingest] %d threads, %d pinned slots, thread-seconds: read %.3f parse %.3f copy/wait %.3f; wall: hints %.3f alloc+fill %.3f pinned setup %.3f workers %.3f\n",
                     threads, (int)n_slots, t_read.load(), t_parse.load(), t_alloc.load(), w_hint, w_alloc, w_pin, since(w0) - w_hint - w_alloc - w_pin);
