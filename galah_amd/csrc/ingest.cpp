@@ -108,14 +108,23 @@ bool slurp(const char *path, std::vector<uint8_t> &buf) {
     const long sz = ftell(f);
     fseek(f, 0, SEEK_SET);
     if (sz < 0) { fclose(f); return false; }
-    std::vector<uint8_t> raw;
-    std::vector<uint8_t> &dst = buf;
-    dst.resize((size_t)sz);
-    const bool ok_read = sz == 0 || fread(dst.data(), 1, (size_t)sz, f) == (size_t)sz;
+    // The compressed image of a gzip file lives in a per-thread buffer, the inflated bytes go straight into `buf`: both
+    // keep their pages from file to file (the ingest workers are persistent threads).  Swapping the caller's buffer out
+    // for the compressed image, as this did before, made every gzip file page-fault a fresh multi-megabyte buffer -- with
+    // 64 threads under one mmap lock.
+    static thread_local std::vector<uint8_t> comp;
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, f);
+    const bool gz = sz >= 18 && got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    std::vector<uint8_t> &first = gz ? comp : buf;
+    first.resize((size_t)sz);
+    if (got) memcpy(first.data(), magic, got);
+    const bool ok_read = (size_t)sz <= got || fread(first.data() + got, 1, (size_t)sz - got, f) == (size_t)sz - got;
     fclose(f);
     if (!ok_read) return false;
-    if (sz < 18 || dst[0] != 0x1f || dst[1] != 0x8b) return true;  // plain
-    raw.swap(dst);
+    if (!gz) return true;  // plain
+    std::vector<uint8_t> &raw = comp;
+    std::vector<uint8_t> &dst = buf;
     size_t isize = (size_t)raw[sz - 4] | ((size_t)raw[sz - 3] << 8) | ((size_t)raw[sz - 2] << 16) | ((size_t)raw[sz - 1] << 24);
     isize = std::min<size_t>(isize, raw.size() * 16 + (1 << 16));  // only a first guess: a damaged trailer must not cost gigabytes
     if (gunzip_libdeflate(raw, dst, isize)) return true;
