@@ -1344,7 +1344,8 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
     };
     // ---- plan the batches.  Two reasons to split: the HBM bound (batch_bytes), and OVERLAP -- while the kernels of batch b
     // run (sketch + seed pass, ~2.2 ms per GB), the ingest threads already fill batch b + 1 over PCIe (~19 ms per GB):
-    // inputs above 1 GiB go in 8 pieces (at least 256 MiB each), ingested by a producer thread one piece ahead.
+    // inputs above 1 GiB go in 4 pieces (at least 512 MiB each; every piece costs ~2 ms of set-up, synchronisations and
+    // concatenation, so 8 pieces gave back what they hid), ingested by a producer thread one piece ahead.
     std::vector<uint64_t> caps(n);
     parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b0, size_t e0) {
         for (size_t i = b0; i < e0; i++) caps[i] = ghip_stream_capacity_hint(paths[i]) + GHIP_TAIL_PAD + 16;
@@ -1358,7 +1359,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
         for (size_t i = 0; i < n; i++) { const size_t l = strlen(paths[i]); n_gz += (l > 3 && !strcmp(paths[i] + l - 3, ".gz")) ? 1 : 0; }
         const char *pl = getenv("GHIP_PIPELINE");
         if (!(pl && !strcmp(pl, "0")) && n_gz == 0 && total_bytes > (1ull << 30))
-            piece = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + 1, 256ull << 20));
+            piece = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 4 + 1, 512ull << 20));
     }
     std::vector<std::pair<size_t, size_t>> ranges;
     for (size_t first = 0; first < n || ranges.empty();) {  // at least one (possibly empty) batch, so that n == 0 yields empty handles

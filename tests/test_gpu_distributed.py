@@ -128,6 +128,16 @@ def test_eight_ranks_dense_forms_straddling_families(ctx):
     assert len(want0["pairs"]) == 40 * 39 // 2
 
 
+def test_more_ranks_than_genomes(ctx):
+    """Five genomes on four ranks (blocks of two: the last rank owns one genome) and three genomes on four ranks (the last
+    rank owns NOTHING): empty shards go through every collective and the result is the single-rank one."""
+    for n in (5, 3):
+        got = _run(4, n=n, length=80_000)
+        want, hashes, lens = _single(ctx, n, 80_000)
+        _same(got, want, hashes, lens)
+        assert got["compared"] == n * (n - 1) // 2
+
+
 def test_local_transport_threads_equal_single_rank(ctx):
     """One process, three contexts on the same device, one thread each: the peer-copy transport."""
     import galah_amd
