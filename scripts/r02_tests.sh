@@ -1,2 +1,2 @@
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -22
+timeout 1200 python -m pytest tests/test_gpu_distributed.py -m gpu -q -x -k "more_ranks" 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -25
