@@ -29,6 +29,7 @@ int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg) {
 // ------------------------------------------------------------------------------------ memory pool
 void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes) {
     bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+    std::lock_guard<std::mutex> pl(ctx->pool_mu);
     ghip_pool_block *best = nullptr;
     for (auto &b : ctx->pool)
         if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) && (!best || b.bytes < best->bytes)) best = &b;
@@ -47,6 +48,7 @@ void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes) {
 
 void ghip_pool_free(ghip_ctx *ctx, void *p) {
     if (!p) return;
+    std::lock_guard<std::mutex> pl(ctx->pool_mu);
     for (auto &b : ctx->pool)
         if (b.p == p) { b.used = false; return; }
 }
@@ -240,7 +242,17 @@ struct DeviceFree {  // scratch buffers go back to the pool; ctx->mu is held by 
     template <typename T> void add(T *p) { ptrs.push_back((void *)p); }
 };
 
-int build_work(ghip_ctx *ctx, ghip_genomes *g) {
+// h2d on a given stream (the ingest keeps off the context's compute stream)
+template <typename T>
+int h2d_on(ghip_ctx *ctx, hipStream_t st, T *dst, const T *src, size_t count) {
+    if (count == 0) return GHIP_OK;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return GHIP_OK;
+}
+
+int build_work(ghip_ctx *ctx, ghip_genomes *g, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     std::vector<ghip_sketch_work> work;
     for (size_t i = 0; i < g->n; i++) {
         uint64_t chunks = (g->lens[i] + GHIP_SKETCH_CHUNK - 1) / GHIP_SKETCH_CHUNK;
@@ -249,13 +261,13 @@ int build_work(ghip_ctx *ctx, ghip_genomes *g) {
     g->n_work = work.size();
     int rc = dmalloc(ctx, &g->d_work, work.size());
     if (rc) return rc;
-    rc = h2d(ctx, g->d_work, work.data(), work.size());
+    rc = h2d_on(ctx, st, g->d_work, work.data(), work.size());
     if (rc) return rc;
     std::vector<uint32_t> ident(g->n);
     for (size_t i = 0; i < g->n; i++) ident[i] = (uint32_t)i;
     rc = dmalloc(ctx, &g->d_identity, g->n);
     if (rc) return rc;
-    return h2d(ctx, g->d_identity, ident.data(), g->n);
+    return h2d_on(ctx, st, g->d_identity, ident.data(), g->n);
 }
 
 // lays genomes out with 16-B aligned starts and GHIP_TAIL_PAD bytes of 'N' after each
@@ -501,11 +513,12 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
     const double w_hint = since(w0);
     bool overflow = false;
     {
-        // `mu` is held for the set-up and the wrap-up only: the worker phase touches nothing of the context but its
-        // staging buffers and copy streams, so another thread may run kernels of a previous batch meanwhile
-        // (ghip_sketch_and_index_files overlaps the sketch pass of batch b with the ingest of batch b + 1)
+        // The ingest never takes `mu` and never touches the context's compute stream: its device memory comes from the
+        // (internally locked) pool, its copies -- the small layout arrays too -- go over the copy streams.  Another thread
+        // may therefore hold `mu` for the length of its kernels meanwhile: ghip_sketch_and_index_files overlaps the
+        // sketch pass of batch b with the ingest of batch b + 1.  (While the set-up still took `mu`, batch b + 1 could
+        // not START before the kernels of batch b had finished: the two alternated instead of overlapping.)
         std::lock_guard<std::mutex> ingest_lk(ctx->ingest_mu);
-        std::unique_lock<std::mutex> lk(ctx->mu);
         GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         if (ctx->n_copy_streams == 0) {
             const char *e = getenv("GHIP_COPY_STREAMS");
@@ -662,13 +675,10 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() + std::chrono::duration<double>(t1b - t1).count();
             }
         };
-        lk.unlock();
         ctx->io.run(threads, worker);
         // every queued copy has landed before the buffers are handed to the next call and the genomes to the kernels
         for (hipStream_t cs : ctx->copy_stream)
             if (cs && hipStreamSynchronize(cs) != hipSuccess) fail(GHIP_EHIP, "ingest copy failed");
-        lk.lock();
-        if (hipSetDevice(ctx->device) != hipSuccess) fail(GHIP_EHIP, "hipSetDevice failed");
         if (dbg)
             fprintf(stderr, "[ingest] %d threads, %d pinned slots, thread-seconds: read %.3f parse %.3f copy/wait %.3f; wall: hints %.3f alloc+fill %.3f pinned setup %.3f workers %.3f\n",
                     threads, (int)n_slots, t_read.load(), t_parse.load(), t_alloc.load(), w_hint, w_alloc, w_pin, since(w0) - w_hint - w_alloc - w_pin);
@@ -679,8 +689,9 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
             g->total_bases = 0;
             for (uint64_t l : g->lens) g->total_bases += l;
             if ((rc = dmalloc(ctx, &g->d_starts, n)) == GHIP_OK && (rc = dmalloc(ctx, &g->d_lens, n)) == GHIP_OK &&
-                (rc = h2d(ctx, g->d_starts, g->starts.data(), n)) == GHIP_OK && (rc = h2d(ctx, g->d_lens, g->lens.data(), n)) == GHIP_OK)
-                rc = build_work(ctx, g);
+                (rc = h2d_on(ctx, fill_stream, g->d_starts, g->starts.data(), n)) == GHIP_OK &&
+                (rc = h2d_on(ctx, fill_stream, g->d_lens, g->lens.data(), n)) == GHIP_OK)
+                rc = build_work(ctx, g, fill_stream);
         }
         if (rc != GHIP_OK || overflow) { free_genomes_locked(g); if (rc != GHIP_OK) return rc; }
         else { *out = g; return GHIP_OK; }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -67,6 +68,8 @@ struct ghip_ctx {
     int num_cus = 256;
     // device-memory pool: hipMalloc/hipFree synchronise the device, so blocks are recycled
     std::vector<ghip_pool_block> pool;
+    std::mutex pool_mu;  // the pool itself: taken inside ghip_pool_alloc/free, so that the file ingest can allocate while
+                         // another call holds `mu` for the length of its kernels (lock order: mu, then pool_mu)
     ghip_cmin_cache cmin;
     uint64_t *d_kmer_luts = nullptr;  // MurmurHash3 first-stage tables of sketch_kmers21 (12 KiB, built once; pool-owned)
     // ingest staging (ghip_genomes_from_files): pinned double buffers of the worker threads and two copy streams, kept
@@ -77,12 +80,12 @@ struct ghip_ctx {
     std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
     hipStream_t copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_copy_streams = 0;   // streams in use (GHIP_COPY_STREAMS, default 2)
-    int live_handles = 0;   // genomes / sketches / ani indexes still alive
+    std::atomic<int> live_handles{0};   // genomes / sketches / ani indexes still alive
     bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };
 
-void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes);  // nullptr on failure (ctx->err set); ctx->mu held
-void ghip_pool_free(ghip_ctx *ctx, void *p);         // ctx->mu held
+void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes);  // nullptr on failure (ctx->err set); thread-safe
+void ghip_pool_free(ghip_ctx *ctx, void *p);         // thread-safe; the caller has made sure nothing in flight uses p
 
 struct ghip_sketch_work {  // one block of the k-mer pass
     uint32_t slot;   // index into the pending-genome arrays
