@@ -388,6 +388,23 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """STDOUT must carry exactly one JSON line: while libraries that chat on fd 1 initialise, fd 1 points at stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -422,7 +439,9 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo")
+        with stdout_to_stderr():   # gloo announces its connections ("[Gloo] Rank 0 is connected to ...") on STDOUT
+            dist.init_process_group("gloo")
+            dist.barrier()
     ctx = galah_amd.Context(device)
 
     # ---- workload shape
@@ -443,8 +462,9 @@ def main():
     ani_thr = np.float32(parse_percentage(args.ani) * np.float32(100.0))  # percent (cluster_argument_parsing.rs:1328)
     min_af = float(parse_percentage(args.min_aligned_fraction))
 
-    job = gd.DereplicationJob(ctx, rank, world, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size,
-                              min_ani=min_ani, ani_threshold=ani_thr, min_af=min_af, backend=backend)
+    with stdout_to_stderr():       # RCCL prints a version banner on STDOUT when its communicator comes up
+        job = gd.DereplicationJob(ctx, rank, world, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size,
+                                  min_ani=min_ani, ani_threshold=ani_thr, min_af=min_af, backend=backend)
     transport = job.comm.transport
     job.load_synthetic(args.seed, args.members, args.length, args.sub_rate)  # untimed: inputs resident in HBM
 
