@@ -423,6 +423,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # STDOUT must carry exactly one JSON line, and libraries chat on fd 1 whenever they like (gloo's connection notes,
+    # RCCL's version banner, ...): fd 1 points at stderr for the whole run; the line goes out through the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -465,7 +470,8 @@ def main():
     with stdout_to_stderr():       # RCCL prints a version banner on STDOUT when its communicator comes up
         job = gd.DereplicationJob(ctx, rank, world, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size,
                                   min_ani=min_ani, ani_threshold=ani_thr, min_af=min_af, backend=backend)
-    transport = job.comm.transport
+    comm = job.comm
+    transport = comm.transport
     job.load_synthetic(args.seed, args.members, args.length, args.sub_rate)  # untimed: inputs resident in HBM
 
     def barrier():
@@ -603,9 +609,12 @@ def main():
                     raise   # a parity failure is a failure of the bench
                 except Exception as e:  # an extra leg (e.g. no room for 50 GB) must not cost the headline
                     out[name] = {"error": repr(e)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    job = None
     if world > 1:
         dist.barrier()
+        comm.close()          # ncclCommDestroy on every rank, while the runtime is still up
         dist.destroy_process_group()
 
 
