@@ -197,12 +197,16 @@ int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv) {
     return GHIP_EINVAL;
 }
 
-// variable-length host all-gather: sizes first, then blocks padded to the largest
-int allgatherv_host(ghip_comm *c, const void *send, size_t bytes, std::vector<uint8_t> &out, std::vector<uint64_t> &sizes) {
-    sizes.assign(c->world, 0);
-    const uint64_t mine = bytes;
-    int rc = allgather_host(c, &mine, sizeof(mine), sizes.data());
-    if (rc) return rc;
+// variable-length host all-gather: sizes first (unless every rank already knows them: known_sizes), then blocks padded
+// to the largest
+int allgatherv_host(ghip_comm *c, const void *send, size_t bytes, std::vector<uint8_t> &out, std::vector<uint64_t> &sizes,
+                    bool known_sizes = false) {
+    int rc = GHIP_OK;
+    if (!known_sizes) {
+        sizes.assign(c->world, 0);
+        const uint64_t mine = bytes;
+        if ((rc = allgather_host(c, &mine, sizeof(mine), sizes.data()))) return rc;
+    } else if (sizes.size() != c->world || sizes[c->rank] != bytes) return cerr_(c, GHIP_EINVAL, "variable-length gather: inconsistent sizes");
     const uint64_t m = *std::max_element(sizes.begin(), sizes.end());
     uint64_t total = 0;
     for (uint64_t s : sizes) total += s;
@@ -574,8 +578,9 @@ extern "C" int ghip_distances_and_ani_ranks(ghip_comm *c, const ghip_genomes *lo
     if (c->world == 1) { if (n_all) memcpy(ani, ani_mine.data(), n_all * sizeof(float)); }
     else {  // the ranks' runs are consecutive in rank order: a variable-length gather IS the whole array
         std::vector<uint8_t> got;
-        std::vector<uint64_t> sizes;
-        if ((rc = allgatherv_host(c, ani_mine.data(), ani_mine.size() * sizeof(float), got, sizes))) { cleanup(); ghip_free(all); free(ani); return rc; }
+        std::vector<uint64_t> sizes(c->world, 0);   // every rank can count every rank's run from the list: one collective less
+        for (size_t x = 0; x < n_all; x++) sizes[all[x].i / block] += sizeof(float);
+        if ((rc = allgatherv_host(c, ani_mine.data(), ani_mine.size() * sizeof(float), got, sizes, true))) { cleanup(); ghip_free(all); free(ani); return rc; }
         if (got.size() != n_all * sizeof(float)) { cleanup(); ghip_free(all); free(ani); return cerr_(c, GHIP_EINVAL, "ANI gather: sizes do not add up"); }
         if (n_all) memcpy(ani, got.data(), got.size());
     }
