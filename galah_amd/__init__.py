@@ -9,13 +9,13 @@ Everything computes in libgalah_hip.so (include/galah_hip.h); importing the pack
 load the library, using it does -- and raises if the HIP extension has not been built.
 """
 from .cache import SortedPairGenomeDistanceCache
-from .engine import Context, cluster_pairs, device_count, fasta_stream
+from .engine import Context, cluster_pairs, cluster_pairs_lazy, device_count, fasta_stream
 from .finch import FinchPreclusterer, distances
 from .ani import HipAniClusterer
 from .clusterer import cluster
 from .quality import parks2020_reduced_score, quality_order_parks2020_reduced
 from ._lib import GalahHipError, PAIR_DTYPE
 
-__all__ = ["SortedPairGenomeDistanceCache", "Context", "cluster_pairs", "device_count", "fasta_stream", "FinchPreclusterer",
+__all__ = ["SortedPairGenomeDistanceCache", "Context", "cluster_pairs", "cluster_pairs_lazy", "device_count", "fasta_stream", "FinchPreclusterer",
            "distances", "HipAniClusterer", "cluster", "GalahHipError", "PAIR_DTYPE", "parks2020_reduced_score",
            "quality_order_parks2020_reduced"]

@@ -18,6 +18,7 @@ GHIP_OK = 0
 ERROR_NAMES = {1: "GHIP_EINVAL", 2: "GHIP_EIO", 3: "GHIP_EHIP", 4: "GHIP_ENOMEM", 5: "GHIP_EUNSUPPORTED", 6: "GHIP_ECALLBACK"}
 
 ANI_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
+ANI_BATCH_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_float))
 
 
 class GalahHipError(RuntimeError):
@@ -99,6 +100,7 @@ SIGNATURES = {
     "ghip_cluster_files_multi": (_int, [_pp, _u32, C.POINTER(C.c_char_p), _sz, _u32, _u32, _f32, _f32, _f32, _u32, _int, _pp, _pp,
                                         C.POINTER(_sz)]),
     "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
+    "ghip_cluster_lazy": (_int, [_sz, _vp, _sz, _f32, ANI_BATCH_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz), C.POINTER(_u64)]),
     "ghip_free": (None, [_vp]),
 }
 

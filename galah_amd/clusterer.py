@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from ._lib import PAIR_DTYPE
-from .engine import cluster_pairs
+from .engine import cluster_pairs, cluster_pairs_lazy
 
 log = logging.getLogger("galah_amd")
 
@@ -118,8 +118,11 @@ def _cluster(genomes, preclusterer, clusterer, cluster_contigs, contig_names, re
         # this list in this order (not for another list of the same length, not grown by calculate_ani())
         if not clusterer.prepared_for(genomes):
             clusterer.prepare(list(genomes))
+        # the ANI of a precluster pair is only ever needed when it touches a representative (clusterer.rs:194-204,
+        # 377-405): asked lazily, one batch per round of the greedy clusterer (ghip_cluster_lazy)
         idx = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
-        pair_ani = clusterer.calculate_ani_indices(idx) if len(pairs) else np.zeros(0, np.float32)
-        return cluster_pairs(n, pairs, threshold, pair_ani, False)
+        clusters, asked = cluster_pairs_lazy(n, pairs, threshold, lambda edges: clusterer.calculate_ani_indices(idx[edges]))
+        clusterer.last_pairs_asked = asked
+        return clusters
     return cluster_pairs(n, pairs, threshold, None, False,
                          ani_callback=lambda a, b: clusterer.calculate_ani(genomes[a], genomes[b]))

@@ -37,14 +37,16 @@ struct Dsu {
 
 }  // namespace
 
-extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
-                            int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, void *user,
-                            uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters) {
+static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
+                        int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, ghip_ani_batch_callback batch_cb,
+                        void *user, uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters,
+                        uint64_t *out_requested) {
     if (!out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
     if (n_pairs && !pairs) return GHIP_EINVAL;
+    if (out_requested) *out_requested = 0;
     // an ANI source is only needed when there is an edge to ask about: unrelated genomes (no precluster pair) are
     // singleton clusters whatever the clusterer (clusterer.rs:182-259 never calls calculate_ani then)
-    if (n_pairs && !skip_clusterer && !pair_ani && !ani_cb) return GHIP_EINVAL;
+    if (n_pairs && !skip_clusterer && !pair_ani && !ani_cb && !batch_cb) return GHIP_EINVAL;
     for (size_t e = 0; e < n_pairs; e++)
         if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return GHIP_EINVAL;
 
@@ -104,7 +106,57 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
         }
     }
     bool aborted = false;  // the callback returned < 0: the host's calculate_ani failed (a Rust panic, a Python exception)
+    std::vector<uint8_t> is_rep(n, 0);       // indexed by genome
+    if (batch_cb && !skip_clusterer && !pair_ani && n_pairs) {
+        // ---- lazy ANI in batches.  The greedy rules only ever look at edges that touch a REPRESENTATIVE (candidate
+        // representatives of a genome, clusterer.rs:194-204; representatives of a non-representative, :377-405), and which
+        // genomes are representatives unfolds in genome order.  So: all preclusters advance in lock step; a genome that
+        // no known representative covers becomes one and ALL its edges are requested; a precluster waits when its next
+        // genome has an unanswered edge to a representative; one callback per round answers every request of every
+        // precluster.  Rounds = (most representatives in one precluster) + 1; edges asked = those touching a
+        // representative -- what the reference computes one `skani dist` at a time (without its stop-early luck),
+        // typically a fifth to a half of all precluster pairs.
+        std::vector<uint32_t> scan(nsets, 0), req;
+        std::vector<uint8_t> requested(n_pairs, 0);
+        std::vector<float> answers;
+        for (;;) {
+            req.clear();
+            for (size_t s = 0; s < nsets; s++) {
+                const uint32_t *orig = members.data() + set_start[s];
+                const uint32_t m = set_size[s];
+                while (scan[s] < m) {
+                    const uint32_t li = scan[s], gi = orig[li];
+                    bool unknown = false, covered = false;
+                    for (uint64_t a = adj_start[gi]; a < adj_start[gi + 1]; a++) {
+                        const uint32_t lj = adj[a].nbr, e = adj[a].edge;
+                        if (lj >= li || !is_rep[orig[lj]]) continue;
+                        if (ani_state[e] == 0) unknown = true;
+                        else if (ani_state[e] == 2 && ani_val[e] >= ani_threshold) covered = true;
+                    }
+                    if (unknown && !covered) break;   // wait for this round's answers
+                    if (!covered) {
+                        is_rep[gi] = 1;
+                        for (uint64_t a = adj_start[gi]; a < adj_start[gi + 1]; a++) {
+                            const uint32_t e = adj[a].edge;
+                            if (ani_state[e] == 0 && !requested[e]) { requested[e] = 1; req.push_back(e); }
+                        }
+                    }
+                    scan[s]++;
+                }
+            }
+            if (req.empty()) break;
+            answers.assign(req.size(), 0.0f);
+            if (batch_cb(user, req.data(), req.size(), answers.data()) != 0) return GHIP_ECALLBACK;
+            if (out_requested) *out_requested += req.size();
+            for (size_t x = 0; x < req.size(); x++) {
+                if (std::isnan(answers[x])) ani_state[req[x]] = 1;
+                else { ani_state[req[x]] = 2; ani_val[req[x]] = answers[x]; }
+            }
+        }
+        std::fill(is_rep.begin(), is_rep.end(), 0);   // the loops below re-derive it from the answers (same decisions)
+    }
     auto edge_ani = [&](uint32_t e, uint32_t rep_genome, uint32_t genome) {
+        if (ani_state[e] == 0 && !aborted && !ani_cb) { aborted = true; return; }   // (lazy form: cannot happen)
         if (ani_state[e] == 0 && !aborted) {  // ClusterDistanceFinder::calculate_ani(rep, genome)
             float v = 0.0f;
             int has = ani_cb(user, rep_genome, genome, &v);
@@ -117,7 +169,6 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
     std::vector<uint32_t> out_m;
     std::vector<uint64_t> out_o{0};
     out_m.reserve(n);
-    std::vector<uint8_t> is_rep(n, 0);       // indexed by genome
     std::vector<uint32_t> assign(n, 0);      // genome -> representative genome
     struct Cand { uint32_t nbr_local; uint32_t edge; float pre; };
     std::vector<Cand> cand;
@@ -144,7 +195,7 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
                 edge_ani(c.edge, orig[c.nbr_local], gi);
                 if (ani_state[c.edge] == 2 && ani_val[c.edge] >= ani_threshold) {
                     rep = false;
-                    if (!skip_clusterer && !pair_ani) break;  // find_any stops on the first hit
+                    if (!skip_clusterer && !pair_ani && !batch_cb) break;  // find_any stops on the first hit
                 }
             }
             is_rep[gi] = rep ? 1 : 0;
@@ -198,4 +249,19 @@ extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, co
     *out_offsets = oo;
     *out_n_clusters = out_o.size() - 1;
     return GHIP_OK;
+}
+
+extern "C" int ghip_cluster(size_t n, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
+                            int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, void *user,
+                            uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters) {
+    return cluster_impl(n, pairs, n_pairs, pair_ani, skip_clusterer, ani_threshold, ani_cb, nullptr, user, out_members, out_offsets,
+                        out_n_clusters, nullptr);
+}
+
+extern "C" int ghip_cluster_lazy(size_t n, const ghip_pair *pairs, size_t n_pairs, float ani_threshold,
+                                 ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members, uint64_t **out_offsets,
+                                 size_t *out_n_clusters, uint64_t *out_pairs_requested) {
+    if (n_pairs && !batch_cb) return GHIP_EINVAL;
+    return cluster_impl(n, pairs, n_pairs, nullptr, 0, ani_threshold, nullptr, batch_cb, user, out_members, out_offsets, out_n_clusters,
+                        out_pairs_requested);
 }

@@ -267,13 +267,18 @@ class DereplicationJob:
 
     def __init__(self, ctx, rank: int, world: int, n_genomes: int, kmer: int = 21, sketch_size: int = 1000,
                  min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af: float = 0.15, comm: Optional[Comm] = None,
-                 backend: str = "rccl", ani_k: int = 15, ani_c: int = 125, ani_chunk: int = 20000):
+                 backend: str = "rccl", ani_k: int = 15, ani_c: int = 125, ani_chunk: int = 20000, lazy_ani: bool = False):
         self.ctx, self.rank, self.world, self.n = ctx, rank, world, n_genomes
         self.kmer, self.s = kmer, sketch_size
         self.ani_k, self.ani_c, self.ani_chunk = ani_k, ani_c, ani_chunk
         self.min_ani, self.ani_threshold, self.min_af = np.float32(min_ani), np.float32(ani_threshold), float(min_af)
         self.comm = comm if comm is not None else make_comm(ctx, rank, world, backend)
         self.first, self.count, self.block = shard_range(n_genomes, rank, world)
+        # one rank: ask the clusterer's ANI lazily, in batches, only for the pairs the greedy rules look at
+        # (ghip_cluster_lazy) -- what the reference does one `skani dist` at a time; several ranks compute every
+        # precluster pair's ANI in parallel shares instead (ghip_distances_and_ani_ranks)
+        self.lazy_ani = lazy_ani and world == 1
+        self.last_pairs_asked = 0
         self.genomes = None
         self._stage: Dict[str, float] = {}
         self._steps = 0
@@ -301,10 +306,40 @@ class DereplicationJob:
         """(u64[N][s], u32[N]) of the gathered matrix of the last step."""
         return self._full.to_host()
 
+    def _step_lazy(self) -> Dict:
+        from .engine import cluster_pairs_lazy
+        t0 = time.perf_counter()
+        sk, idx = self.ctx.sketch_and_index(self.genomes, self.kmer, self.s, 0, self.ani_k, self.ani_c, self.ani_chunk)
+        t1 = time.perf_counter()
+        pairs = self.ctx.precluster(sk, self.min_ani)
+        self.last_pairs_compared = self.ctx.last_pairs_compared
+        t2 = time.perf_counter()
+        pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
+        t_ani = [0.0]
+
+        def ani_of(edges):
+            a0 = time.perf_counter()
+            out = self.ctx.ani_pairs(idx, pi[edges], self.min_af)
+            t_ani[0] += time.perf_counter() - a0
+            return out
+
+        clusters, asked = cluster_pairs_lazy(self.n, pairs, self.ani_threshold, ani_of)
+        t3 = time.perf_counter()
+        idx.free()
+        self._full = sk
+        self.last_pairs_asked = asked
+        for k, v in (("sketch", t1 - t0), ("pairs", t2 - t1), ("ani_pairs", t_ani[0]), ("host_cluster", t3 - t2 - t_ani[0])):
+            self._stage[k] = self._stage.get(k, 0.0) + v * 1e3
+        self._steps += 1
+        return {"n_pairs": len(pairs), "n_clusters": len(clusters), "clusters": clusters, "pairs": pairs, "pair_ani": None,
+                "ani_pairs_asked": asked}
+
     def step(self) -> Dict:
         if self._full is not None:
             self._full.free()
             self._full = None
+        if self.lazy_ani:
+            return self._step_lazy()
         pairs, ani, times, self._full = self.comm.distances_and_ani(self.genomes, self.n, self.kmer, self.s, self.min_ani, self.ani_k,
                                                                     self.ani_c, self.ani_chunk, self.min_af, want_sketches=True)
         self.last_pairs_compared = times.pop("_pairs_compared")

@@ -360,3 +360,40 @@ def cluster_pairs(n_genomes: int, pairs: np.ndarray, ani_threshold: float, pair_
         L.ghip_free(offsets)
     mem_l, off_l = mem.tolist(), off.tolist()   # plain ints: slicing numpy scalars cluster by cluster is ~10x slower
     return [mem_l[off_l[c]:off_l[c + 1]] for c in range(nc.value)]
+
+
+def cluster_pairs_lazy(n_genomes: int, pairs: np.ndarray, ani_threshold: float, ani_of_edges) -> Tuple[List[List[int]], int]:
+    """ghip_cluster_lazy: the greedy clusterer with the ANI asked for in batches, only for the precluster pairs that touch
+    a representative.  ani_of_edges(edge_indices: uint32 array) -> float32 array (NaN = None), one call per round.
+    -> (clusters, number of pairs asked)."""
+    L = _lib.lib()
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    failure = []
+
+    def _cb(_user, edges, n, out):
+        try:
+            idx = np.ctypeslib.as_array(edges, shape=(n,))
+            vals = np.ascontiguousarray(ani_of_edges(idx), dtype=np.float32)
+            assert vals.shape == (n,)
+            C.memmove(out, vals.ctypes.data, 4 * n)
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- must not vanish inside ctypes
+            failure.append(e)
+            return 1
+
+    cb = _lib.ANI_BATCH_CALLBACK(_cb)
+    members, offsets, nc, asked = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_uint64(0)
+    rc = L.ghip_cluster_lazy(n_genomes, pairs.ctypes.data, pairs.shape[0], np.float32(ani_threshold), cb, None,
+                             C.byref(members), C.byref(offsets), C.byref(nc), C.byref(asked))
+    if failure:
+        raise failure[0]
+    if rc != 0:
+        raise GalahHipError(rc, "ghip_cluster_lazy failed (no representative with a known ANI, or bad input)")
+    try:
+        off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), shape=(nc.value + 1,)).copy()
+        mem = np.ctypeslib.as_array(C.cast(members, C.POINTER(C.c_uint32)), shape=(max(int(off[-1]), 1),)).copy()
+    finally:
+        L.ghip_free(members)
+        L.ghip_free(offsets)
+    mem_l, off_l = mem.tolist(), off.tolist()
+    return [mem_l[off_l[c]:off_l[c + 1]] for c in range(nc.value)], int(asked.value)

@@ -274,6 +274,17 @@ int ghip_cluster(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, const
                  int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, void *user,
                  uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters);
 
+/* The same with the clusterer's ANI asked for lazily, in batches: only the precluster pairs that touch a representative
+ * are ever needed (src/clusterer.rs:194-204, 377-405 -- what the reference computes one `skani dist` at a time), and which
+ * genomes are representatives unfolds in genome order, so all preclusters advance in lock step and one callback per round
+ * answers every request: edge_index[x] = index into `pairs`, out_ani[x] = ANI in the clusterer's unit (NaN = None);
+ * return 0, or non-zero to abort (GHIP_ECALLBACK).  Rounds = (most representatives in one precluster) + 1.  Same
+ * clusters as ghip_cluster with pair_ani for every pair.  *out_pairs_requested (nullable) = pairs asked in total. */
+typedef int (*ghip_ani_batch_callback)(void *user, const uint32_t *edge_index, size_t n, float *out_ani);
+int ghip_cluster_lazy(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, float ani_threshold,
+                      ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members, uint64_t **out_offsets,
+                      size_t *out_n_clusters, uint64_t *out_pairs_requested);
+
 void ghip_free(void *p);
 
 #ifdef __cplusplus

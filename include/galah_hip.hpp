@@ -267,8 +267,13 @@ private:
 // ---------------------------------------------------------------------------------------------------------------
 // clusterer::cluster (src/clusterer.rs:14-152).  Returns Vec<Vec<usize>>, the representative first in each cluster.
 // The O(N^2) host loops (partition_sketches, transform_ids) run on the sorted edge list inside ghip_cluster; a
-// HipAniClusterer is asked for the ANI of every precluster pair in one batch, any other ClusterDistanceFinder through
-// calculate_ani -- the clusters are the same because calculate_ani is a pure function of the pair.
+// HipAniClusterer is asked in batches for the pairs that touch a representative (ghip_cluster_lazy), any other
+// ClusterDistanceFinder through calculate_ani -- the clusters are the same because calculate_ani is a pure function of
+// the pair.
+inline uint64_t &last_ani_pairs_requested() {  // how many precluster pairs the last cluster() asked a HipAniClusterer for
+    static thread_local uint64_t v = 0;
+    return v;
+}
 inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &genomes,
                                                 PreclusterDistanceFinder &preclusterer, ClusterDistanceFinder &clusterer,
                                                 bool cluster_contigs = false,
@@ -315,16 +320,34 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
         if (!kv.second) throw std::runtime_error("precluster cache holds None: not produced by a precluster back-end");
         edges.push_back(ghip_pair{(uint32_t)kv.first.first, (uint32_t)kv.first.second, 0, 0, *kv.second});
     }
-    std::vector<float> pair_ani;
-    struct CbState { ClusterDistanceFinder *c; const std::vector<std::string> *g; std::exception_ptr failed; } st{&clusterer, &genomes, nullptr};
+    struct CbState {
+        ClusterDistanceFinder *c; const std::vector<std::string> *g; HipAniClusterer *hip; const std::vector<ghip_pair> *edges;
+        std::exception_ptr failed;
+    } st{&clusterer, &genomes, nullptr, &edges, nullptr};
     ghip_ani_callback cb = nullptr;
+    ghip_ani_batch_callback batch_cb = nullptr;
     if (!skip_clusterer) {
         if (auto *hipani = dynamic_cast<HipAniClusterer *>(&clusterer)) {
+            // the HIP clusterer is asked in BATCHES, and only for the pairs the greedy rules look at (those touching a
+            // representative) -- the reference's laziness (clusterer.rs:178-200, 301-334) without one launch per pair
             if (!hipani->prepared_for(genomes)) hipani->prepare(genomes);
-            std::vector<uint32_t> idx;
-            idx.reserve(2 * edges.size());
-            for (auto &e : edges) { idx.push_back(e.i); idx.push_back(e.j); }
-            pair_ani = hipani->calculate_ani_indices(idx);
+            st.hip = hipani;
+            batch_cb = [](void *user, const uint32_t *edge_idx, size_t n_edges, float *out) -> int {
+                auto *s = static_cast<CbState *>(user);
+                try {
+                    std::vector<uint32_t> idx(2 * n_edges);
+                    for (size_t x = 0; x < n_edges; x++) {
+                        idx[2 * x] = (*s->edges)[edge_idx[x]].i;
+                        idx[2 * x + 1] = (*s->edges)[edge_idx[x]].j;
+                    }
+                    auto v = s->hip->calculate_ani_indices(idx);
+                    std::copy(v.begin(), v.end(), out);
+                    return 0;
+                } catch (...) {
+                    s->failed = std::current_exception();
+                    return -1;
+                }
+            };
         } else {
             cb = [](void *user, uint32_t a, uint32_t b, float *out) -> int {
                 auto *s = static_cast<CbState *>(user);
@@ -343,9 +366,10 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
     uint32_t *members = nullptr;
     uint64_t *offsets = nullptr;
     size_t n_clusters = 0;
-    const int rc = ghip_cluster(n, edges.data(), edges.size(), pair_ani.empty() ? nullptr : pair_ani.data(),
-                                skip_clusterer ? 1 : 0, clusterer.get_ani_threshold(), cb, &st, &members, &offsets,
-                                &n_clusters);
+    const int rc = batch_cb ? ghip_cluster_lazy(n, edges.data(), edges.size(), clusterer.get_ani_threshold(), batch_cb, &st, &members,
+                                                &offsets, &n_clusters, &last_ani_pairs_requested())
+                            : ghip_cluster(n, edges.data(), edges.size(), nullptr, skip_clusterer ? 1 : 0,
+                                           clusterer.get_ani_threshold(), cb, &st, &members, &offsets, &n_clusters);
     if (st.failed) std::rethrow_exception(st.failed);
     if (rc != GHIP_OK)  // best_rep.unwrap() on None (src/clusterer.rs:444)
         throw std::runtime_error("called `Option::unwrap()` on a `None` value: a genome has no representative");

@@ -65,6 +65,8 @@ int main(int argc, char **argv) {
         auto clusters = sorted(galah::cluster(abisko, pre, cl));
         CHECK((clusters == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(pre.last_edges.size() == 6);
+        // the HIP clusterer is asked lazily: genome 0 is the representative, only its 3 edges are ever looked at
+        CHECK(galah::last_ani_pairs_requested() == 3);
     }
     {   // src/clusterer.rs:661-690: at 99 -> [[0,1,3],[2]]
         galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);

@@ -9,7 +9,7 @@ import pytest
 
 import galah_amd
 import oracle
-from galah_amd import _lib, PAIR_DTYPE, cluster_pairs
+from galah_amd import _lib, PAIR_DTYPE, cluster_pairs, cluster_pairs_lazy
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -226,3 +226,40 @@ def test_ani_callback_exception_propagates():
     with pytest.raises(ValueError, match="skani exploded"):
         cluster_pairs(4, pairs, np.float32(95.0), None, False, ani_callback=boom)
     assert len(calls) == 1   # ghip_cluster stopped asking after the failure
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_lazy_batched_clusterer_equals_full(seed):
+    """ghip_cluster_lazy asks only for precluster pairs that touch a representative, in rounds -- and returns the
+    clusters of the oracle's run of the reference's greedy algorithm with every ANI known."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(5, 160))
+    pairs = _random_graph(rng, n, rng.uniform(0.2, 0.95), int(rng.integers(1, 9)))
+    vals = np.round(rng.uniform(90, 100, size=(n, n)), 1).astype(np.float32)
+    vals = np.minimum(vals, vals.T)
+    vals[rng.random((n, n)) < 0.05] = 0.0
+    vals = np.minimum(vals, vals.T)
+    thr = np.float32([95.0, 93.0, 99.0][seed % 3])
+    want = oracle.cluster(n, oracle.Cache.from_pairs(pairs), thr, lambda a, b: float(vals[a, b]))
+    rounds = []
+
+    def answer(edges):
+        rounds.append(len(edges))
+        return np.array([vals[pairs["i"][e], pairs["j"][e]] for e in edges], dtype=np.float32)
+
+    got, asked = cluster_pairs_lazy(n, pairs, thr, answer)
+    assert got == want
+    assert asked == sum(rounds) <= len(pairs)
+    assert got == cluster_pairs(n, pairs, thr, np.array([vals[p["i"], p["j"]] for p in pairs], dtype=np.float32))
+    n_reps = len(want)
+    if len(pairs) > 30 and n_reps < n // 3:
+        assert asked < len(pairs)            # and it really is lazy when few genomes are representatives
+
+
+def test_lazy_clusterer_none_answers_and_failures():
+    pairs = np.array([(0, 1, 0, 0, 0.97), (1, 2, 0, 0, 0.98), (2, 3, 0, 0, 0.99)], dtype=PAIR_DTYPE)
+    # None (NaN) for the pair (0, 1): no ANI at or above the threshold -> 1 is a representative of its own
+    assert cluster_pairs_lazy(2, pairs[:1], np.float32(95.0), lambda e: np.full(len(e), np.nan, np.float32)) == ([[0], [1]], 1)
+    with pytest.raises(ValueError, match="boom"):
+        cluster_pairs_lazy(4, pairs, np.float32(95.0), lambda e: (_ for _ in ()).throw(ValueError("boom")))
+    assert cluster_pairs_lazy(3, np.zeros(0, dtype=PAIR_DTYPE), np.float32(95.0), None) == ([[0], [1], [2]], 0)

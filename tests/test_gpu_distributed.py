@@ -84,6 +84,26 @@ def _same(got, want, hashes, lens):
     assert got["clusters"] == want["clusters"]
 
 
+def test_lazy_ani_on_one_rank_equals_all_pairs(ctx):
+    """One rank asks the clusterer's ANI lazily and in batches (ghip_cluster_lazy: only pairs touching a representative,
+    the reference's laziness): same clusters as computing every precluster pair's ANI, with fewer pairs asked."""
+    from galah_amd.distributed import DereplicationJob
+    for n, members, length, min_ani in ((N, MEMBERS, LENGTH, 0.9), (120, 8, 60_000, 0.9), (40, 3, 40_000, 0.0)):
+        out = []
+        for lazy in (False, True):
+            job = DereplicationJob(ctx, 0, 1, n_genomes=n, min_ani=np.float32(min_ani), ani_threshold=np.float32(95.0), min_af=0.15,
+                                   lazy_ani=lazy)
+            job.load_synthetic(SEED, members, length, RATE)
+            for _ in range(2):
+                res = job.step()
+            out.append((res, job.last_pairs_asked))
+        (full, _), (lazy, asked) = out
+        assert lazy["clusters"] == full["clusters"] and lazy["pairs"].tobytes() == full["pairs"].tobytes()
+        assert lazy["ani_pairs_asked"] == asked <= len(full["pairs"])
+        if members == 8:
+            assert asked < len(full["pairs"])       # family of 8: 7 edges to the representative, the other 21 never asked
+
+
 @pytest.mark.parametrize("mode", ["shard", "replicate"])
 def test_three_ranks_join_form_equals_single_rank(ctx, mode):
     """N = 2100 short genomes on three ranks (ragged shards): the pair stage takes the join form -- sharded at record
