@@ -5,9 +5,9 @@
 // DESIGN.md "ANI" and oracle/galah_oracle_ani.c (the definition this file reproduces bit for bit).
 // The device does integer work only; the host finishes pow/rounding.
 //
-//   ani_seeds : pass over the base stream; canonical 2-bit k-mer (k <= 16, fits u32) -> multiplicative
-//               mix (bijective); seeds with mix(code) < 2^32/c are appended as (code u32, loc u32 =
-//               chunk << 16 | strand << 15 | offset in chunk) and counted per chunk.
+//   ani_seeds : pass over the base stream; 2-bit codes of the k-mer and of its reverse complement (k <= 16, fit u32);
+//               selected by a multiplicative mix of their strand-symmetric sum (seed_common.h); the seeds are appended
+//               as (canonical code u32, loc u32 = chunk << 16 | strand << 15 | offset in chunk) and counted per chunk.
 //   ani_bin   : per genome, counting sort of the seed list by the top 14 bits of a second
 //               multiplicative hash of the code; writes the binned list and its bin offsets
 //               (CSR).  Every genome uses the same bin function, so two genomes can be joined
@@ -69,13 +69,12 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 fwd = ((fwd << 2) | code) & mask;
                 rev = (rev >> 2) | ((3u - code) << top);
                 good = valid ? good + 1 : 0;
-                const uint32_t canon = min(fwd, rev);
-                const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_mix(canon) < so.thr;
-                seed_append(sl, so, sb, pass, canon, toff + (uint32_t)(b - ((int)K - 1)), rev < fwd ? 1u : 0u);
+                const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_selected(fwd, rev, so.mul, so.thr);
+                if (pass) seed_mark_at(sl, sb, fwd, (uint32_t)(b - ((int)K - 1)));
             }
         }
     }
-    seed_block_flush(sl, so, sb);
+    seed_block_flush<false>(sl, so, sb, toff, bytes + starts[g] + blk0);
 }
 
 __device__ __forceinline__ uint32_t code_bin(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - GHIP_ANI_BIN_BITS); }
@@ -427,7 +426,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
                            uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    ghip_seed::SeedOut so{k, ~0u / c, chunk, d_seed_code, d_seed_loc, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start};
+    ghip_seed::SeedOut so{k, ~0u / c, ghip_seed::seed_mul(k), chunk, d_seed_code, d_seed_loc, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start};
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),

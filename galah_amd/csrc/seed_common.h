@@ -5,11 +5,14 @@
 
 namespace ghip_seed {
 
-// Seed selection: a bijective multiplicative mix of the 32-bit canonical code, kept iff mix(code) < 2^32 / c (see
-// oracle/galah_oracle_ani.c).  ONE multiply per position -- every position of every genome pays it (MurmurHash3's
-// fmix32, used before, cost 6 more instructions per base: 0.6 ms per 5 Gbase).  The multiplier differs from the bin
-// hash's (ani.hip code_bin), or all selected seeds would share their top bits and land in the first bins.
-__device__ __forceinline__ uint32_t seed_mix(uint32_t code) { return code * 0x85EBCA6Bu; }
+// Seed selection (oracle/galah_oracle_ani.c): kept iff ((0 - 2 - fwd - rev) * mul) mod 2^32 < 2^32 / c with
+// mul = 0x85EBCA6B << (32 - 2k).  The key fwd + rev mod 4^k is strand-symmetric like the canonical code but needs no
+// masked min: the fused pass holds the COMPLEMENTS of both codes in the low 2k bits of two registers (with junk above),
+// their plain sum is 2(4^k - 1) - fwd - rev = -2 - fwd - rev mod 4^k, and the shifted multiplier drops the junk --
+// add, multiply, compare per position (MurmurHash3's fmix32 of the canonical code, round 1: 12 instructions; a
+// multiplicative mix of it, before: 6).  The multiplier differs from the bin hash's (ani.hip code_bin).
+__host__ __device__ __forceinline__ uint32_t seed_mul(uint32_t k) { return 0x85EBCA6Bu << (32u - 2u * k); }
+__device__ __forceinline__ bool seed_selected(uint32_t fwd, uint32_t rev, uint32_t mul, uint32_t thr) { return (0u - 2u - fwd - rev) * mul < thr; }
 
 // packed location of a seed: chunk << 16 | strand << 15 | offset within the chunk (chunk length <= 32768)
 __device__ __forceinline__ uint32_t seed_loc(uint32_t chunk_id, uint32_t strand, uint32_t off) { return (chunk_id << 16) | (strand << 15) | off; }
@@ -26,7 +29,7 @@ constexpr uint32_t SEED_LDS_CHUNKS = 64;   // per-block chunk counters
 constexpr uint32_t SEED_WAVES = GHIP_SKETCH_THREADS / 64;
 
 struct SeedOut {  // where a block's seeds go (kernel argument, by value)
-    uint32_t k, thr, chunk;
+    uint32_t k, thr, mul, chunk;   // mul = seed_mul(k)
     uint32_t *seed_code;
     uint32_t *seed_loc;   // chunk << 16 | strand << 15 | offset in chunk
     const uint64_t *seed_start;
@@ -36,17 +39,41 @@ struct SeedOut {  // where a block's seeds go (kernel argument, by value)
 };
 
 struct SeedLds {  // per-block LDS state; slot-major so that the 64 lanes of a wave write consecutive words
-    uint32_t code[SEED_LANE_CAP][GHIP_SKETCH_THREADS];
-    uint16_t pos[SEED_LANE_CAP][GHIP_SKETCH_THREADS];   // position relative to the block start (< 2^15) | strand << 15
+    uint32_t raw[SEED_LANE_CAP][GHIP_SKETCH_THREADS];   // forward code as the pass holds it (see seed_canon)
     uint32_t ctot[SEED_LDS_CHUNKS];
     uint32_t wave_n[SEED_WAVES], wave_base[SEED_WAVES];
 };
 
-struct SeedBlock {  // per-thread view of one block's seeding state
-    uint32_t g, ch_first, rem_first, scap, n_lane;
+// Per-thread view of one block's seeding state.  A lane owns 64 consecutive positions; WHICH of them hold a seed is a
+// 64-bit mask in registers (one v_or with a constant per append), so an append stores the code only -- one LDS write.
+// The store address is clamped to the last row: a lane with more than SEED_LANE_CAP seeds (P ~ 1e-4 at c = 125) loses
+// nothing, its mask still names every position, and the flush recomputes from the bases the codes that found no row.
+struct SeedBlock {
+    uint32_t g, ch_first, rem_first, scap;
     uint64_t sstart;
     uint32_t *ctot;
+    uint32_t slot, slot_last;   // BYTE offsets into SeedLds::raw: the lane's next free row / its last row
+    uint32_t m16;               // positions of the current 16-position group
+    uint64_t mask;              // positions of the groups already closed
 };
+
+// reverse complement of a k-base big-endian 2-bit code (k <= 16)
+__device__ __forceinline__ uint32_t revcomp_code(uint32_t f, uint32_t k) {
+    uint32_t x = __brev(f);                                           // bases reversed, bits inside each base swapped
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return ~x >> (32 - 2 * k);
+}
+
+// The position loop stores a seed's forward code only -- RAW: COMPLEMENTED ? its complement with junk above bit 2k (the
+// fused pass reads it straight out of its reverse-complement window) : the code itself; the canonical code and the strand
+// are worked out here, once per stored seed, not once per wave position.
+template <bool COMPLEMENTED>
+__device__ __forceinline__ void seed_canon(uint32_t raw, uint32_t k, uint32_t &canon, uint32_t &strand) {
+    const uint32_t mask = (k < 16) ? ((1u << (2 * k)) - 1) : ~0u;
+    const uint32_t f = (COMPLEMENTED ? ~raw : raw) & mask, r = revcomp_code(f, k);
+    canon = min(f, r);
+    strand = r < f ? 1u : 0u;
+}
 
 // call before the position loop (contains a __syncthreads)
 __device__ __forceinline__ SeedBlock seed_block_begin(SeedLds &sl, const SeedOut &so, uint32_t g, uint64_t blk0) {
@@ -57,31 +84,55 @@ __device__ __forceinline__ SeedBlock seed_block_begin(SeedLds &sl, const SeedOut
     sb.sstart = so.seed_start[g];
     sb.scap = (uint32_t)(so.seed_start[g + 1] - sb.sstart);
     sb.ctot = so.chunk_total + so.chunk_start[g];
-    sb.n_lane = 0;
+    sb.slot = 4 * threadIdx.x;
+    sb.slot_last = 4 * ((SEED_LANE_CAP - 1) * GHIP_SKETCH_THREADS + threadIdx.x);
+    sb.m16 = 0;
+    sb.mask = 0;
     if (threadIdx.x < SEED_LDS_CHUNKS) sl.ctot[threadIdx.x] = 0;
     __syncthreads();
     return sb;
 }
 
-// Lane-private append: no cross-lane ranking in the position loop (a ballot/mbcnt rank cost ~10 instructions
-// on the 40 % of positions where some lane of the wave holds a seed).  rel = position - block start.
-__device__ __forceinline__ void seed_append(SeedLds &sl, const SeedOut &so, SeedBlock &sb, bool pass, uint32_t canon, uint32_t rel, uint32_t strand) {
-    if (pass) {
-        if (sb.n_lane < SEED_LANE_CAP) { sl.code[sb.n_lane][threadIdx.x] = canon; sl.pos[sb.n_lane][threadIdx.x] = (uint16_t)(rel | (strand << 15)); }
-        else {  // lane buffer full (P ~ 1e-4 per lane at c = 125; always at c = 1): straight to the global list
-            const uint32_t at = sb.rem_first + rel, ch = at / so.chunk;
-            uint32_t idx = atomicAdd(&so.seed_count[sb.g], 1u);
-            if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + ch, strand, at - ch * so.chunk); }
-            atomicAdd(&sb.ctot[sb.ch_first + ch], 1u);
-        }
-        sb.n_lane++;
-    }
+// Lane-private append, inside the divergent `if (selected)`: min, store, add, or.  bit16 = the position's index in
+// its group of 16 (a constant in the unrolled fused loop).
+__device__ __forceinline__ void seed_mark(SeedLds &sl, SeedBlock &sb, uint32_t raw, uint32_t bit16) {
+    // an (empty) inline-asm statement makes the compiler keep the s_cbranch_execz around this block: without it the
+    // five instructions are if-converted and issue, EXEC = 0, on the 60 % of wave positions where no lane selected a seed
+#ifndef GHIP_DBG_IFCVT   // timing experiment only
+    asm volatile("");
+#endif
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(&sl.raw[0][0]) + min(sb.slot, sb.slot_last)) = raw;
+    sb.slot += 4 * GHIP_SKETCH_THREADS;
+    sb.m16 |= 1u << bit16;
+}
+// the same with a run-time position p in [0, 64) (standalone pass)
+__device__ __forceinline__ void seed_mark_at(SeedLds &sl, SeedBlock &sb, uint32_t raw, uint32_t p) {
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(&sl.raw[0][0]) + min(sb.slot, sb.slot_last)) = raw;
+    sb.slot += 4 * GHIP_SKETCH_THREADS;
+    sb.mask |= 1ull << p;
+}
+// after every 16 positions: group v of the lane's four
+__device__ __forceinline__ void seed_group_end(SeedBlock &sb, uint32_t v) {
+    sb.mask |= (uint64_t)sb.m16 << (16u * v);
+    sb.m16 = 0;
 }
 
-// call after the position loop by every thread of the block (contains __syncthreads)
-__device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so, SeedBlock &sb) {
+// A seed outside the lane's 64 positions (the fused pass: the few seeds of a genome that end before byte 20) goes
+// straight to the global list.
+__device__ __forceinline__ void seed_emit_global(const SeedOut &so, SeedBlock &sb, uint32_t canon, uint32_t strand, uint32_t rel) {
+    const uint32_t at = sb.rem_first + rel, ch = at / so.chunk;
+    const uint32_t idx = atomicAdd(&so.seed_count[sb.g], 1u);
+    if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + ch, strand, at - ch * so.chunk); }
+    atomicAdd(&sb.ctot[sb.ch_first + ch], 1u);
+}
+
+// call after the position loop by every thread of the block (contains __syncthreads).  rel0 = block-relative position
+// of the lane's first seed position (bit 0 of its mask); block_bases = the block's first base in the genome's stream.
+template <bool COMPLEMENTED>
+__device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so, SeedBlock &sb, uint32_t rel0, const uint8_t *block_bases) {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t mine = min(sb.n_lane, SEED_LANE_CAP);
+    uint64_t mask = sb.mask;
+    const uint32_t mine = (uint32_t)__popcll(mask);
     uint32_t incl = mine;  // inclusive scan over the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -100,10 +151,19 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
     __syncthreads();
     uint32_t idx = sl.wave_base[w] + incl - mine;
     for (uint32_t i = 0; i < mine; i++, idx++) {
-        const uint32_t pv = sl.pos[i][threadIdx.x], at = sb.rem_first + (pv & 0x7fffu), chrel = at / so.chunk;
+        const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t at = sb.rem_first + rel, chrel = at / so.chunk;
         if (idx < sb.scap) {
-            so.seed_code[sb.sstart + idx] = sl.code[i][threadIdx.x];
-            so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + chrel, pv >> 15, at - chrel * so.chunk);
+            uint32_t canon, strand;
+            if (i + 1 < SEED_LANE_CAP || mine <= SEED_LANE_CAP) seed_canon<COMPLEMENTED>(sl.raw[i][threadIdx.x], so.k, canon, strand);
+            else {  // no row of its own (the clamped stores overwrote the last one): the code again, from the bases
+                uint32_t f = 0;
+                for (uint32_t j = 0; j < so.k; j++) f = (f << 2) | (base_code(block_bases[rel + j]) & 3u);
+                seed_canon<false>(f, so.k, canon, strand);
+            }
+            so.seed_code[sb.sstart + idx] = canon;
+            so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + chrel, strand, at - chrel * so.chunk);
         }
         if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
         else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);

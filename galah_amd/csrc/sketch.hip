@@ -145,11 +145,10 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     const uint64_t p0 = blk0 + toff;
     const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's bytes
     ghip_seed::SeedBlock sb;
-    uint32_t amask = 0, ashift = 0;
+    uint32_t ashift = 0;
     int ak = 1;
     if constexpr (SEEDS) {
         sb = ghip_seed::seed_block_begin(sl, so, g, blk0);
-        amask = (so.k < 16) ? ((1u << (2 * so.k)) - 1) : ~0u;
         ashift = 2 * (K - so.k);  // the newest so.k bases of the 21-mer
         ak = (int)so.k;
     }
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     struct Pend { uint64_t A, B, T; uint32_t ax, bx; } pend{};  // table terms of the position whose hash is pending
     // hash one position from its table terms and append it to the genome's candidate list if it is under the
     // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word up to b)
-    auto finish = [&](const Pend &p, const int b, const uint32_t inword) __attribute__((always_inline)) {
+    auto finish = [&](const Pend &p, const int b, const uint32_t inword, const bool slow) __attribute__((always_inline)) {
         const uint32_t a1 = (uint32_t)(p.A >> 32) + p.ax, b1 = (uint32_t)(p.B >> 32) + p.bx;
         uint64_t F1, F2;  // the two halves of the hash short of their last multiply (murmur21_asm.h)
 #ifdef GHIP_DBG_NOHASH  // timing experiment only: wrong results
@@ -194,14 +193,14 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         // rare (~2.5*s survivors per genome): wave-private LDS buffer, one global atomic per block at the end --
         // the ~300 concurrent blocks of a genome would otherwise serialise on its counter inside the hot loop
         bool hit = s1 <= thr_bound;  // necessary for h <= thr (murmur21_asm.h)
-        if (__builtin_amdgcn_ballot_w64(hit)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0, 0)) {   // cold: keep it out of the straight-line loop body
             const uint64_t h = murmur21_finish(F1, F2);
-            hit = hit && h <= thr && st.lim21 <= b && inword == 0;
+            hit = hit && h <= thr && (!slow || (st.lim21 <= b && inword == 0));
             const unsigned long long m = __ballot(hit);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (hit) {
                 const uint32_t at = cand_n + rank;
-                if (at < CAND_WAVE_CAP) cand_lds[wave][at] = h;
+                if (__builtin_expect(at < CAND_WAVE_CAP, 1)) cand_lds[wave][at] = h;
                 else {  // wave buffer full (thresholds far above the default): straight to the global list
                     uint32_t idx = atomicAdd(&cand_count[slot], 1u);
                     if (idx < ccap) cand[cstart + idx] = h;
@@ -231,8 +230,9 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     // instead of two 64-bit shift/or/and chains per byte.  SLOW: some lane of the wave holds a non-ACGT byte in this word
     // (wave-uniform, rare): only then are the per-byte bad-byte masks evaluated; otherwise a window is clean iff
     // lim <= b, tested for the ~1/2000 hash survivors and the ~1/125 seed candidates only.
-    auto word_impl = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto slow_tag, const bool seed_gate, const bool have_pend) __attribute__((always_inline)) {
+    auto word_impl = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto slow_tag, auto widx_tag, const bool seed_gate, const bool have_pend) __attribute__((always_inline)) {
         constexpr bool HASH = decltype(hash_tag)::value;
+        constexpr int WIDX = decltype(widx_tag)::value;   // index of the word in its group of four (-1: a warm-up word)
         constexpr bool SEED_HERE = SEEDS && decltype(seed_tag)::value;
         constexpr bool SLOW = decltype(slow_tag)::value;
         const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;   // A0 C1 G2 T3 per byte
@@ -253,20 +253,31 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
             const uint32_t flo = fs ? __builtin_amdgcn_alignbit(st.whi, st.wlo, fs) : st.wlo;
             const uint32_t rlo = rs ? __builtin_amdgcn_alignbit(st.rhi, st.rlo, rs) : st.rlo;
             if constexpr (SEED_HERE) {
-                // so.k-mer ending here: forward big-endian code = complement of rc's low bits; reverse
-                // complement = complement of the top so.k bases of the forward little-endian code
-                const uint32_t f15 = ~rlo & amask;
-                const uint32_t r15 = ~(uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift)) & amask;
-                const uint32_t c15 = min(f15, r15);
-                const bool pass = seed_gate && ghip_seed::seed_mix(c15) < so.thr;
-                if (pass) {  // ~1/125 of the lanes: validity only here
-                    const bool ok = st.lim15 <= b && inword == 0;
-#ifdef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
-                    sb.n_lane += ok;
+                // so.k-mer ending here: the low 2 so.k bits of rlo hold the COMPLEMENT of its forward big-endian code, those
+                // of W >> (fs + ashift) the complement of its reverse complement's; their sum is the selection key
+                // (seed_common.h) -- no masks, no min: add, multiply, compare
+                const uint32_t wsh = (uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift));
+                const bool pass = seed_gate && (rlo + wsh) * so.mul < so.thr;
+#if defined(GHIP_DBG_SEEDNOBRANCH)   // timing experiments only (scripts/sketch_variants.sh)
+                sb.slot += pass ? 4u : 0u;
+#elif defined(GHIP_DBG_SEEDTRIVIAL)
+                if (pass) sb.slot += 4u;
 #else
-                    ghip_seed::seed_append(sl, so, sb, ok, c15, toff + (uint32_t)(b - (ak - 1)), r15 < f15 ? 1u : 0u);
+                if (pass) {  // ~1/125 of the lanes; only the raw forward code is stored, seed_canon() finishes it in the flush
+                    // validity only in the SLOW variant: the fast one runs when no lane of the wave saw a bad byte in
+                    // this word or the six before it
+                    if (!SLOW || (st.lim15 <= b && inword == 0)) {
+#ifndef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
+                        if constexpr (WIDX >= 0) ghip_seed::seed_mark(sl, sb, rlo, 4 * WIDX + j);
+                        else {  // warm-up words (first lane of a genome): positions before the lane's 64
+                            uint32_t canon, strand;
+                            ghip_seed::seed_canon<true>(rlo, so.k, canon, strand);
+                            ghip_seed::seed_emit_global(so, sb, canon, strand, toff + (uint32_t)(b - (ak - 1)));
+                        }
 #endif
+                    }
                 }
+#endif
             }
             if constexpr (HASH) {
                 // software pipeline: issue this position's five table reads, then hash the PREVIOUS position
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
 #endif
                 // the previous position is byte j-1 of this word, or byte 3 of the word before (whose bad
                 // bytes are already folded into lim21)
-                if (j > 0 || have_pend) finish(pend, b - 1, (SLOW && j > 0) ? (bad4 & (0xffffffffu >> (8 * (4 - j)))) : 0u);
+                if (j > 0 || have_pend) finish(pend, b - 1, (SLOW && j > 0) ? (bad4 & (0xffffffffu >> (8 * (4 - j)))) : 0u, SLOW);
                 pend = cur;
             }
         }
@@ -298,10 +309,18 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, const bool seed_gate, const bool have_pend) __attribute__((always_inline)) {
-        if (__builtin_amdgcn_ballot_w64((w & 0x08080808u) != 0)) word_impl(w, b0, hash_tag, seed_tag, T_{}, seed_gate, have_pend);
-        else word_impl(w, b0, hash_tag, seed_tag, F_{}, seed_gate, have_pend);
+    // The careful variant runs for a word in which some lane of the wave holds a bad byte AND for the five words after
+    // it (a 21-mer reaches 20 bytes back, and the pending hash of a word's first position belongs to the word before):
+    // the fast variant never looks at lim21 / lim15.  The warm-up words are always careful (lim starts at k - 1).
+    uint32_t slow_left = 0;  // wave-uniform
+    auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto widx_tag, const bool seed_gate, const bool have_pend, const bool careful) __attribute__((always_inline)) {
+        if (__builtin_amdgcn_ballot_w64((w & 0x08080808u) != 0)) slow_left = 7;
+        if (careful || slow_left) {
+            slow_left = slow_left ? slow_left - 1 : 0;
+            word_impl(w, b0, hash_tag, seed_tag, T_{}, widx_tag, seed_gate, have_pend);
+        } else word_impl(w, b0, hash_tag, seed_tag, F_{}, widx_tag, seed_gate, have_pend);
     };
+    using W_ = std::integral_constant<int, -1>;
     // warm-up: bytes 0..19 only fill the windows -- except in the first wave of a genome, whose lane 0
     // owns the seeds that end before byte 20
     const uint32_t warm[5] = {q0.x, q0.y, q0.z, q0.w, q1.x};
@@ -310,26 +329,27 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             // bytes b < ak-1 cannot end a seed: lim15 = ak - 1 says so
-            word(warm[i], 4 * i, F_{}, T_{}, first, false);
+            word(warm[i], 4 * i, F_{}, T_{}, W_{}, first, false, true);
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 5; i++) word(warm[i], 4 * i, F_{}, F_{}, false, false);
+        for (int i = 0; i < 5; i++) word(warm[i], 4 * i, F_{}, F_{}, W_{}, false, false, true);
     }
     uint32_t w0 = q1.y, w1 = q1.z, w2 = q1.w, w3 = q2.x;
 #pragma unroll 1
     for (int v = 0; v < 4; v++) {
         const int b0 = 20 + 16 * v;
-        word(w0, b0, T_{}, std::integral_constant<bool, SEEDS>{}, true, v > 0);
-        word(w1, b0 + 4, T_{}, std::integral_constant<bool, SEEDS>{}, true, true);
-        word(w2, b0 + 8, T_{}, std::integral_constant<bool, SEEDS>{}, true, true);
-        word(w3, b0 + 12, T_{}, std::integral_constant<bool, SEEDS>{}, true, true);
+        word(w0, b0, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 0>{}, true, v > 0, false);
+        word(w1, b0 + 4, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 1>{}, true, true, false);
+        word(w2, b0 + 8, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 2>{}, true, true, false);
+        word(w3, b0 + 12, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 3>{}, true, true, false);
+        if constexpr (SEEDS) ghip_seed::seed_group_end(sb, (uint32_t)v);
         w0 = q2.y; w1 = q2.z; w2 = q2.w; w3 = q3.x;
         q2 = q3; q3 = q4; q4.x = q5x;
     }
-    finish(pend, 83, 0u);  // the last position (ends at byte 83)
+    finish(pend, 83, 0u, true);  // the last position (ends at byte 83)
     flush_candidates();
-    if constexpr (SEEDS) ghip_seed::seed_block_flush(sl, so, sb);
+    if constexpr (SEEDS) ghip_seed::seed_block_flush<true>(sl, so, sb, toff + (uint32_t)(K - ak), bytes + starts[g] + blk0);
 }
 
 // Generic-k fallback (k in [1,32], not 21): same algorithm, runtime k.
@@ -613,6 +633,12 @@ void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes /* m
     hipLaunchKernelGGL(sanitize_bases_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(d_bytes), n16);
 }
 
+// timing experiment only (scripts/sketch_variants.sh): unused dynamic LDS caps the workgroups per CU
+static unsigned dbg_extra_lds() {
+    static const unsigned v = [] { const char *e = getenv("GHIP_DBG_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    return v;
+}
+
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,
                               const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
@@ -622,7 +648,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
     if (n_work == 0) return;
     ghip_seed::SeedOut so{};
     if (seeds)
-        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, seeds->chunk, seeds->d_seed_code, seeds->d_seed_loc,
+        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, ghip_seed::seed_mul(seeds->k), seeds->chunk, seeds->d_seed_code, seeds->d_seed_loc,
                                 seeds->d_seed_start, seeds->d_seed_count, seeds->d_chunk_total, seeds->d_chunk_start};
     const KmerLuts *luts = nullptr;
     if (k == 21) {
@@ -638,7 +664,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
         const unsigned grid = (unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID);
         if (k == 21) {  // seeds != nullptr: fused MinHash + ANI seeding pass (first pass over all genomes only)
 #define GHIP_LAUNCH21(SEEDS, SEED0)                                                                                  \
-    hipLaunchKernelGGL((sketch_kmers21_kernel<SEEDS, SEED0>), dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, \
+    hipLaunchKernelGGL((sketch_kmers21_kernel<SEEDS, SEED0>), dim3(grid), dim3(GHIP_SKETCH_THREADS), dbg_extra_lds(), ctx->stream, \
                        d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start, d_slot_cand_cap,     \
                        d_work + off, seed, d_cand, d_cand_count, so, luts)
             if (seeds && seed == 0) GHIP_LAUNCH21(true, true);

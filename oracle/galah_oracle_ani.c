@@ -17,7 +17,10 @@
  *   stream G  = for each FASTA record: normalised bytes, then one 'N'          (length L)
  *   seed at p = window G[p..p+k) all ACGT (k <= 16); fwd / rev = 2-bit codes of the k-mer and of its reverse
  *               complement (A0 C1 G2 T3, first base most significant); code = min(fwd, rev), strand = (rev < fwd);
- *               kept iff (u32)(code * 0x85EBCA6B) < (2^32-1) / c  (a bijective multiplicative mix: equal hash <=> equal code)
+ *               kept iff (u32)((0 - 2 - fwd - rev) * (0x85EBCA6B << (32 - 2k))) < (2^32-1) / c  -- the selection key
+ *               fwd + rev mod 4^k is the same on both strands, like the canonical code, and costs the device one add
+ *               where min() of two masked fields cost four instructions on every base; the shifted odd multiplier is a
+ *               bijective mix of the key's 2k bits (and ignores whatever a register holds above them)
  *   chunk(p)  = p / chunk_len  (chunk_len <= 32768)
  *   anchor    = (seed a of q, seed b of r) with equal codes; orientation o = strand_a ^ strand_b;
  *               band = o ? ((pos_b + pos_a) >> 12 & 7) | 8 : ((2 (pos_b - pos_a) + 1 + 4096) >> 13) & 7   (mod 2^32)
@@ -87,7 +90,7 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
     s->chunk_id = (uint32_t *)malloc(cap * sizeof(uint32_t));
     s->pos = (uint32_t *)malloc(cap * sizeof(uint32_t));
     s->strand = (uint8_t *)malloc(cap);
-    const uint32_t thr = UINT32_MAX / c;
+    const uint32_t thr = UINT32_MAX / c, mix = 0x85EBCA6Bu << (32 - 2 * k);   /* k <= 16 */
     const uint64_t mask = (k < 32) ? ((1ULL << (2 * k)) - 1) : UINT64_MAX;
     uint64_t fwd = 0, rev = 0;
     size_t good = 0;
@@ -99,7 +102,7 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
         rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k - 1)));
         if (++good < k) continue;
         const uint32_t code = (uint32_t)(fwd < rev ? fwd : rev);
-        if ((uint32_t)(code * 0x85EBCA6Bu) >= thr) continue;
+        if ((uint32_t)((0u - 2u - (uint32_t)fwd - (uint32_t)rev) * mix) >= thr) continue;
         if (s->n == cap) {
             cap *= 2;
             s->h = (uint64_t *)realloc(s->h, cap * sizeof(uint64_t));
