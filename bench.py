@@ -375,6 +375,24 @@ def pmc_live(dom_kernel: str):
         f_b, w_b = out["FETCH_SIZE_KB_per_launch"] * 1024, out["WRITE_SIZE_KB_per_launch"] * 1024
         out["fetch_x2"] = wide
         out["hbm_bytes_per_launch"] = (2 * f_b if wide else f_b) + w_b
+        # third pass: how many VALU instructions the kernel issues (it is instruction-issue bound: DESIGN.md section 4)
+        try:
+            cmd = [exe, "--pmc", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, "SQ"),
+                   "-o", "SQ", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            acc = {"SQ_INSTS_VALU": [0.0, 0], "GRBM_GUI_ACTIVE": [0.0, 0]}
+            for f in glob.glob(os.path.join(d, "SQ", "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if re.search(label, row["Kernel_Name"]) and row["Counter_Name"] in acc:
+                        acc[row["Counter_Name"]][0] += float(row["Counter_Value"])
+                        acc[row["Counter_Name"]][1] += 1
+            if r.returncode == 0 and acc["SQ_INSTS_VALU"][1]:
+                valu = acc["SQ_INSTS_VALU"][0] / acc["SQ_INSTS_VALU"][1]
+                out["valu_insts_per_launch"] = valu
+                if acc["GRBM_GUI_ACTIVE"][1]:   # summed over the 8 XCDs; 1024 SIMDs
+                    out["simd_cycles_per_valu_inst"] = 1024.0 * (acc["GRBM_GUI_ACTIVE"][0] / acc["GRBM_GUI_ACTIVE"][1]) / 8.0 / valu
+        except Exception:  # noqa: BLE001
+            pass
         return out
     except Exception as e:  # noqa: BLE001 -- a counter pass must never cost the headline
         return {"error": repr(e)}
@@ -601,6 +619,10 @@ def main():
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_unit"] = ("bytes/launch, measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                        "(separate passes, kernel-trace only; FETCH x2 for 16 B/lane streams on gfx950)")
+                if t and "valu_insts_per_launch" in t:  # likewise the VALU instruction count
+                    out["roofline"]["valu"] = {"valu_insts_per_launch": t["valu_insts_per_launch"],
+                                               "simd_cycles_per_valu_inst": t.get("simd_cycles_per_valu_inst"),
+                                               "source": "measured by this run (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE)"}
                 return t if t is not None else "rocprofv3 not on PATH: roofline.traffic is the recorded figure"
 
             for name, fn in (("north_star_10k", lambda: north_star_10k(args, ctx, rates, min_ani, ani_thr, min_af)),

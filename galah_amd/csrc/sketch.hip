@@ -258,11 +258,6 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 // (seed_common.h) -- no masks, no min: add, multiply, compare
                 const uint32_t wsh = (uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift));
                 const bool pass = seed_gate && (rlo + wsh) * so.mul < so.thr;
-#if defined(GHIP_DBG_SEEDNOBRANCH)   // timing experiments only (scripts/sketch_variants.sh)
-                sb.slot += pass ? 4u : 0u;
-#elif defined(GHIP_DBG_SEEDTRIVIAL)
-                if (pass) sb.slot += 4u;
-#else
                 if (pass) {  // ~1/125 of the lanes; only the raw forward code is stored, seed_canon() finishes it in the flush
                     // validity only in the SLOW variant: the fast one runs when no lane of the wave saw a bad byte in
                     // this word or the six before it
@@ -277,7 +272,6 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
 #endif
                     }
                 }
-#endif
             }
             if constexpr (HASH) {
                 // software pipeline: issue this position's five table reads, then hash the PREVIOUS position
@@ -315,7 +309,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     uint32_t slow_left = 0;  // wave-uniform
     auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto widx_tag, const bool seed_gate, const bool have_pend, const bool careful) __attribute__((always_inline)) {
         if (__builtin_amdgcn_ballot_w64((w & 0x08080808u) != 0)) slow_left = 7;
-        if (careful || slow_left) {
+        if (__builtin_expect(careful || slow_left, 0)) {   // the fast variant is the fall-through
             slow_left = slow_left ? slow_left - 1 : 0;
             word_impl(w, b0, hash_tag, seed_tag, T_{}, widx_tag, seed_gate, have_pend);
         } else word_impl(w, b0, hash_tag, seed_tag, F_{}, widx_tag, seed_gate, have_pend);

@@ -2,11 +2,11 @@
 # the product library and times each with scripts/sketch_bench.py.  Run the build part here (`build`), the timing on the
 # GPU box.  `old` = the kernel sources of the last commit, for an A/B on the same box.
 cd "$(dirname "$0")/../galah_amd/csrc"
-VARIANTS="${VARIANTS:-old base noappend sumseed sumseed_noappend nohash nolds}"
+VARIANTS="${VARIANTS:-old base ifcvt noappend nohash nolds}"
 for V in $VARIANTS; do
   D=build/dbg_$V; mkdir -p $D
   FLAGS=""; case $V in nohash) FLAGS="-DGHIP_DBG_NOHASH";; nolds) FLAGS="-DGHIP_DBG_NOLDS";; nohash_nolds) FLAGS="-DGHIP_DBG_NOHASH -DGHIP_DBG_NOLDS";; noappend) FLAGS="-DGHIP_DBG_NOAPPEND";;
-     sumseed) FLAGS="-DGHIP_DBG_SUMSEED";; sumseed_noappend) FLAGS="-DGHIP_DBG_SUMSEED -DGHIP_DBG_NOAPPEND";; nobranch) FLAGS="-DGHIP_DBG_SEEDNOBRANCH";; ifcvt) FLAGS="-DGHIP_DBG_IFCVT";; clamp) FLAGS="-DGHIP_DBG_CLAMP";; sum_clamp) FLAGS="-DGHIP_DBG_CLAMP -DGHIP_DBG_SUMSEED";; trivial) FLAGS="-DGHIP_DBG_SEEDTRIVIAL";; sum_nobranch) FLAGS="-DGHIP_DBG_SUMSEED -DGHIP_DBG_SEEDNOBRANCH";; sum_trivial) FLAGS="-DGHIP_DBG_SUMSEED -DGHIP_DBG_SEEDTRIVIAL";; esac
+     ifcvt) FLAGS="-DGHIP_DBG_IFCVT";; esac
   if [ "$1" = build ]; then
     SRC=.
     if [ $V = old ]; then
