@@ -8,6 +8,7 @@
 //   tests/test_cmdline.rs:161-181, 417-440     representative list order; github issue 7
 //   src/clusterer.rs:14,267-296,375-399        `C: Sync`: calculate_ani called from many threads at once
 //   src/finch.rs:14-15,40, src/clusterer.rs:38-44   refusals (panics -> std::runtime_error with the same text)
+#include <cstdlib>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -65,8 +66,13 @@ int main(int argc, char **argv) {
         auto clusters = sorted(galah::cluster(abisko, pre, cl));
         CHECK((clusters == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(pre.last_edges.size() == 6);
-        // the HIP clusterer is asked lazily: genome 0 is the representative, only its 3 edges are ever looked at
+        // a list this short is asked for whole, in one batch; with that shortcut off the HIP clusterer is asked lazily:
+        // genome 0 is the representative, only its 3 edges are ever looked at
+        CHECK(galah::last_ani_pairs_requested() == 6);
+        setenv("GHIP_LAZY_ALL_BELOW", "0", 1);
+        CHECK((sorted(galah::cluster(abisko, pre, cl)) == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(galah::last_ani_pairs_requested() == 3);
+        unsetenv("GHIP_LAZY_ALL_BELOW");
     }
     {   // src/clusterer.rs:661-690: at 99 -> [[0,1,3],[2]]
         galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);

@@ -229,9 +229,13 @@ def test_ani_callback_exception_propagates():
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_lazy_batched_clusterer_equals_full(seed):
+def test_lazy_batched_clusterer_equals_full(seed, monkeypatch):
     """ghip_cluster_lazy asks only for precluster pairs that touch a representative, in rounds -- and returns the
-    clusters of the oracle's run of the reference's greedy algorithm with every ANI known."""
+    clusters of the oracle's run of the reference's greedy algorithm with every ANI known.  (Short edge lists are asked
+    for whole in one round -- a round costs the GPU callee a launch's latency: GHIP_LAZY_ALL_BELOW, default 8192 edges;
+    every second case here runs with that shortcut off.)"""
+    all_at_once = seed % 2 == 1
+    monkeypatch.setenv("GHIP_LAZY_ALL_BELOW", "1000000" if all_at_once else "0")
     rng = np.random.default_rng(100 + seed)
     n = int(rng.integers(5, 160))
     pairs = _random_graph(rng, n, rng.uniform(0.2, 0.95), int(rng.integers(1, 9)))
@@ -252,7 +256,9 @@ def test_lazy_batched_clusterer_equals_full(seed):
     assert asked == sum(rounds) <= len(pairs)
     assert got == cluster_pairs(n, pairs, thr, np.array([vals[p["i"], p["j"]] for p in pairs], dtype=np.float32))
     n_reps = len(want)
-    if len(pairs) > 30 and n_reps < n // 3:
+    if all_at_once:
+        assert rounds == [len(pairs)] or len(pairs) == 0
+    elif len(pairs) > 30 and n_reps < n // 3:
         assert asked < len(pairs)            # and it really is lazy when few genomes are representatives
 
 
