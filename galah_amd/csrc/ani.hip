@@ -77,32 +77,57 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     seed_block_flush<false>(sl, so, sb, toff, bytes + starts[g] + blk0);
 }
 
-__device__ __forceinline__ uint32_t code_bin(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - GHIP_ANI_BIN_BITS); }
 
 constexpr uint32_t BIN_COUNT = GHIP_ANI_BIN_COUNT, BIN_THREADS = 1024;
+constexpr uint32_t SEG_BINS = BIN_COUNT / SEGMENTS;          // bins of one segment
+constexpr uint32_t BIN_WINDOW = 8192;                        // seeds sorted inside LDS at a time (64 KiB)
+constexpr uint32_t BIN_PER_THREAD = BIN_WINDOW / BIN_THREADS;
+constexpr size_t BIN_LDS = SEG_BINS * sizeof(uint32_t) + (size_t)BIN_WINDOW * 8;
 
-// Counting sort in LDS; the order inside a bin is arbitrary.  bin_start[g][b] is relative to the
+// Counting sort of ONE SEGMENT of one genome's seed list (seed_common.h: the seeding pass files every seed under the
+// top bits of its bin) by the remaining bin bits, in LDS; the order inside a bin is arbitrary.  A segment of a genome up
+// to ~8 Mb at c = 125 fits the window: it is read once (the seeds wait in registers between the histogram and the
+// placement) and written once, contiguously.  Longer segments take the windowed form (destination slots to a scratch
+// array, every window re-reads them).  The segments' outputs are concatenated: bin_start[g][b] is relative to the
 // genome's first seed slot, so shards can be concatenated.
 __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     const uint32_t *__restrict__ in_code, const uint32_t *__restrict__ in_loc,
     uint32_t *__restrict__ out_code, uint32_t *__restrict__ out_loc,
-    const uint64_t *__restrict__ seed_start, const uint32_t *__restrict__ seed_count,
+    const uint64_t *__restrict__ seed_start, const uint32_t *__restrict__ seg_count,
     uint32_t *__restrict__ bin_start, uint32_t *__restrict__ pos_tmp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);  // BIN_COUNT counters
-    constexpr uint32_t BIN_WINDOW = 8192;  // 64 KiB / 8 B per seed
-    static_assert(BIN_WINDOW * 8 <= BIN_COUNT * 4, "the output window reuses the histogram's LDS");
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);               // SEG_BINS counters, then cursors
+    uint32_t *w_code = hist + SEG_BINS, *w_loc = w_code + BIN_WINDOW;      // the output window
     __shared__ uint32_t wave_tot[BIN_THREADS / 64];
-    const uint32_t g = blockIdx.x;
+    const uint32_t g = blockIdx.x / SEGMENTS, seg = blockIdx.x % SEGMENTS;
     const uint64_t s0 = seed_start[g];
-    const uint32_t n = min(seed_count[g], (uint32_t)(seed_start[g + 1] - s0));
-    uint32_t *bstart = bin_start + (uint64_t)g * (BIN_COUNT + 1);
-    for (uint32_t i = threadIdx.x; i < BIN_COUNT; i += BIN_THREADS) hist[i] = 0;
+    const uint32_t segcap = (uint32_t)(seed_start[g + 1] - s0) / SEGMENTS;
+    uint32_t out_base = 0, total = 0, n = 0;
+    for (uint32_t s = 0; s < SEGMENTS; s++) {
+        const uint32_t c = min(seg_count[(uint64_t)g * SEGMENTS + s], segcap);
+        if (s < seg) out_base += c;
+        if (s == seg) n = c;
+        total += c;
+    }
+    const uint64_t in0 = s0 + (uint64_t)seg * segcap, out0 = s0 + out_base;
+    uint32_t *bstart = bin_start + (uint64_t)g * (BIN_COUNT + 1) + seg * SEG_BINS;
+    const bool one_window = n <= BIN_WINDOW;
+    for (uint32_t i = threadIdx.x; i < SEG_BINS; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) atomicAdd(&hist[code_bin(in_code[s0 + i])], 1u);
+    uint32_t code_r[BIN_PER_THREAD], loc_r[BIN_PER_THREAD];
+    if (one_window) {
+#pragma unroll
+        for (uint32_t k = 0; k < BIN_PER_THREAD; k++) {
+            const uint32_t i = threadIdx.x + k * BIN_THREADS;
+            code_r[k] = 0; loc_r[k] = 0;
+            if (i < n) { code_r[k] = in_code[in0 + i]; loc_r[k] = in_loc[in0 + i]; atomicAdd(&hist[code_bin(code_r[k]) & (SEG_BINS - 1)], 1u); }
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) atomicAdd(&hist[code_bin(in_code[in0 + i]) & (SEG_BINS - 1)], 1u);
+    }
     __syncthreads();
-    // exclusive scan of hist: 16 consecutive bins per thread
-    constexpr uint32_t PER = BIN_COUNT / BIN_THREADS;
+    // exclusive scan of hist: consecutive bins per thread
+    constexpr uint32_t PER = SEG_BINS / BIN_THREADS;
     uint32_t local[PER], sum = 0;
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) { local[j] = hist[threadIdx.x * PER + j]; sum += local[j]; }
@@ -121,34 +146,39 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
         hist[threadIdx.x * PER + j] = run;
-        bstart[threadIdx.x * PER + j] = run;
+        bstart[threadIdx.x * PER + j] = out_base + run;
         run += local[j];
     }
-    if (threadIdx.x == BIN_THREADS - 1) bstart[BIN_COUNT] = run;  // == n
+    if (seg == SEGMENTS - 1 && threadIdx.x == BIN_THREADS - 1) bstart[SEG_BINS] = total;  // bin_start[g][BIN_COUNT] == n
     __syncthreads();
-    // destination slot of every seed (one LDS atomic each), kept in a scratch array -- as 16-bit values when the
-    // genome has fewer than 65 536 seeds (it is re-read once per window)
-    const bool narrow = n <= 0xffffu;
-    uint16_t *pos16 = reinterpret_cast<uint16_t *>(pos_tmp + s0);
-    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
-        const uint32_t p = atomicAdd(&hist[code_bin(in_code[s0 + i])], 1u);
-        if (narrow) pos16[i] = (uint16_t)p; else pos_tmp[s0 + i] = p;
+    if (one_window) {
+#pragma unroll
+        for (uint32_t k = 0; k < BIN_PER_THREAD; k++) {
+            const uint32_t i = threadIdx.x + k * BIN_THREADS;
+            if (i < n) {
+                const uint32_t p = atomicAdd(&hist[code_bin(code_r[k]) & (SEG_BINS - 1)], 1u);
+                w_code[p] = code_r[k]; w_loc[p] = loc_r[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += BIN_THREADS) { out_code[out0 + k] = w_code[k]; out_loc[out0 + k] = w_loc[k]; }
+        return;
     }
+    // destination slot of every seed (one LDS atomic each), kept in a scratch array (re-read once per window)
+    for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) pos_tmp[in0 + i] = atomicAdd(&hist[code_bin(in_code[in0 + i]) & (SEG_BINS - 1)], 1u);
     __syncthreads();
-    // Scatter through an LDS window and write each window out contiguously: scattering 4-byte
+    // Scatter through the LDS window and write each window out contiguously: scattering 4-byte
     // stores straight to HBM costs a whole sector per seed (PMC: 3.3 GB written for 0.27 GB).
-    uint32_t *w_code = hist;                                               // BIN_WINDOW x 4 B (the histogram is dead)
-    uint32_t *w_loc = hist + BIN_WINDOW;                                   // BIN_WINDOW x 4 B
     for (uint32_t w0 = 0; w0 < n; w0 += BIN_WINDOW) {
         for (uint32_t i = threadIdx.x; i < n; i += BIN_THREADS) {
-            const uint32_t p = (narrow ? (uint32_t)pos16[i] : pos_tmp[s0 + i]) - w0;
-            if (p < BIN_WINDOW) { w_code[p] = in_code[s0 + i]; w_loc[p] = in_loc[s0 + i]; }
+            const uint32_t p = pos_tmp[in0 + i] - w0;
+            if (p < BIN_WINDOW) { w_code[p] = in_code[in0 + i]; w_loc[p] = in_loc[in0 + i]; }
         }
         __syncthreads();
         const uint32_t m = min(BIN_WINDOW, n - w0);
         for (uint32_t k = threadIdx.x; k < m; k += BIN_THREADS) {
-            out_code[s0 + w0 + k] = w_code[k];
-            out_loc[s0 + w0 + k] = w_loc[k];
+            out_code[out0 + w0 + k] = w_code[k];
+            out_loc[out0 + w0 + k] = w_loc[k];
         }
         __syncthreads();
     }
@@ -423,10 +453,10 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
                            uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
-                           uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
+                           uint32_t *d_seg_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    ghip_seed::SeedOut so{k, ~0u / c, ghip_seed::seed_mul(k), chunk, d_seed_code, d_seed_loc, d_seed_start, d_seed_count, d_chunk_total, d_chunk_start};
+    ghip_seed::SeedOut so{k, ~0u / c, ghip_seed::seed_mul(k), chunk, d_seed_code, d_seed_loc, d_seed_start, d_seg_count, d_chunk_total, d_chunk_start};
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),
@@ -435,7 +465,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
 }
 
 void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint32_t *in_loc, uint32_t *out_code,
-                         uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
+                         uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seg_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp) {
     if (n == 0) return;
     static bool attr_set = false;
@@ -444,8 +474,12 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
         attr_set = true;
     }
     ghip_prof_begin(ctx, "ani_bin");
-    hipLaunchKernelGGL(ani_bin_kernel, dim3((unsigned)n), dim3(BIN_THREADS), BIN_COUNT * sizeof(uint32_t), ctx->stream,
-                       in_code, in_loc, out_code, out_loc, d_seed_start, d_seed_count, d_bin_start, d_pos_tmp);
+    for (size_t off = 0; off < n; off += GHIP_MAX_GRID / ghip_seed::SEGMENTS) {   // one block per genome and segment
+        const size_t m = std::min<size_t>(n - off, GHIP_MAX_GRID / ghip_seed::SEGMENTS);
+        hipLaunchKernelGGL(ani_bin_kernel, dim3((unsigned)(m * ghip_seed::SEGMENTS)), dim3(BIN_THREADS), BIN_LDS, ctx->stream,
+                           in_code, in_loc, out_code, out_loc, d_seed_start + off, d_seg_count + off * ghip_seed::SEGMENTS,
+                           d_bin_start + off * (size_t)(BIN_COUNT + 1), d_pos_tmp);
+    }
     ghip_prof_end(ctx);
 }
 

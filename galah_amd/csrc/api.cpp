@@ -182,7 +182,8 @@ int d2h(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
 }
 
 // Deterministic ANI index layout (shards must agree): Poisson(L/c) seeds, +10 % + 256 slack.
-uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) { return len / c + len / (10ull * c) + 256; }
+// a multiple of the segment count: the unordered list is GHIP_ANI_SEGMENTS equal parts (seed_common.h)
+uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) { return (len / c + len / (10ull * c) + 256 + GHIP_ANI_SEGMENTS - 1) / GHIP_ANI_SEGMENTS * GHIP_ANI_SEGMENTS; }
 
 // fn(begin, end) over [0, n) on up to max_threads threads of at least min_per_thread items each (the caller's thread
 // takes the last range); spawning costs ~30 us per thread, so short loops stay serial (callers pass min_per_thread = 10 000)
@@ -1164,10 +1165,10 @@ static void free_index_arrays_locked(ghip_ani_index *idx) {
         ghip_pool_free(ctx, idx->d_seed_code); ghip_pool_free(ctx, idx->d_seed_loc);
         ghip_pool_free(ctx, idx->d_bin_start); ghip_pool_free(ctx, idx->d_chunk_total);
     }
-    ghip_pool_free(ctx, idx->d_seed_start); ghip_pool_free(ctx, idx->d_seed_count);
+    ghip_pool_free(ctx, idx->d_seed_start); ghip_pool_free(ctx, idx->d_seed_count); ghip_pool_free(ctx, idx->d_seg_count);
     ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen);
     idx->d_seed_code = nullptr; idx->d_seed_loc = nullptr; idx->d_bin_start = nullptr; idx->d_chunk_total = nullptr;
-    idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_chunk_start = nullptr;
+    idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_seg_count = nullptr; idx->d_chunk_start = nullptr;
     idx->d_glen = nullptr;
 }
 
@@ -1228,31 +1229,40 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
     if ((rc = dmalloc(ctx, &idx->d_seed_loc, idx->seed_start[n]))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_seed_start, n + 1))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_seed_count, n))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_seg_count, n * GHIP_ANI_SEGMENTS))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_chunk_start, n + 1))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_glen, n))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seed_count, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seg_count, 0, std::max<size_t>(n, 1) * GHIP_ANI_SEGMENTS * sizeof(uint32_t), ctx->stream));
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream));
     return stream_sync(ctx);  // the index's host vectors may be rewritten by a retry
 }
 
 static ghip_seed_args index_seed_args(const ghip_ani_index *idx) {
     return ghip_seed_args{idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
-                          idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start};
+                          idx->d_seg_count, idx->d_chunk_total, idx->d_chunk_start};
 }
 
-// reads the per-genome seed counts; *overflow = some list was too small (cap raised to the exact count)
+// reads the per-segment seed counts; *overflow = some segment was too small (the genome's capacity is raised to
+// GHIP_ANI_SEGMENTS x its fullest segment's exact count)
 static int index_check_seeds(ghip_ctx *ctx, ghip_ani_index *idx, std::vector<uint64_t> &cap, bool *overflow) {
     const size_t n = idx->n;
+    std::vector<uint32_t> seg(n * GHIP_ANI_SEGMENTS);
     idx->seed_count.assign(n, 0);
-    int rc = d2h(ctx, idx->seed_count.data(), idx->d_seed_count, n);
+    int rc = d2h(ctx, seg.data(), idx->d_seg_count, n * GHIP_ANI_SEGMENTS);
     if (rc) return rc;
     *overflow = false;
-    for (size_t i = 0; i < n; i++) if (idx->seed_count[i] > cap[i]) { *overflow = true; cap[i] = idx->seed_count[i]; }
-    return GHIP_OK;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t tot = 0, mx = 0;
+        for (size_t s = 0; s < GHIP_ANI_SEGMENTS; s++) { tot += seg[i * GHIP_ANI_SEGMENTS + s]; mx = std::max<uint64_t>(mx, seg[i * GHIP_ANI_SEGMENTS + s]); }
+        idx->seed_count[i] = (uint32_t)tot;
+        if (mx * GHIP_ANI_SEGMENTS > cap[i]) { *overflow = true; cap[i] = mx * GHIP_ANI_SEGMENTS; }
+    }
+    if (!*overflow) rc = h2d_nosync(ctx, idx->d_seed_count, idx->seed_count.data(), n);   // (the host vector lives as long as the index)
+    return rc;
 }
 
 // standalone seeding with retry on overflow
@@ -1261,7 +1271,7 @@ static int index_seed_standalone(ghip_ctx *ctx, const ghip_genomes *g, ghip_ani_
         int rc = index_alloc_seeds(ctx, idx, cap);
         if (rc) return rc;
         ghip_launch_ani_seeds(ctx, g, idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
-                              idx->d_seed_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
+                              idx->d_seg_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
         bool overflow = false;
         if ((rc = index_check_seeds(ctx, idx, cap, &overflow))) return rc;
         if (!overflow) return GHIP_OK;
@@ -1278,13 +1288,15 @@ static int index_finish(ghip_ctx *ctx, ghip_ani_index *idx) {
         !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n])) &&
         !(rc = dmalloc(ctx, &d_pos, idx->seed_start[n]))) {
         ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_loc, d_code2, d_chunk2, idx->d_seed_start,
-                            idx->d_seed_count, idx->d_bin_start, d_pos);
+                            idx->d_seg_count, idx->d_bin_start, d_pos);
         std::swap(idx->d_seed_code, d_code2);
         std::swap(idx->d_seed_loc, d_chunk2);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
             rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
     }
     ghip_pool_free(ctx, d_code2); ghip_pool_free(ctx, d_chunk2); ghip_pool_free(ctx, d_pos);  // the unordered lists
+    ghip_pool_free(ctx, idx->d_seg_count);
+    idx->d_seg_count = nullptr;
     return rc;
 }
 

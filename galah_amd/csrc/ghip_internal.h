@@ -138,6 +138,7 @@ struct ghip_ani_index {
     uint32_t *d_seed_loc = nullptr;    // concatenated: chunk << 16 | strand << 15 | offset in chunk
     uint64_t *d_seed_start = nullptr;  // [n+1] offsets into seed arrays (capacity layout)
     uint32_t *d_seed_count = nullptr;  // [n]
+    uint32_t *d_seg_count = nullptr;   // [n][GHIP_ANI_SEGMENTS] while the index is being built (seed_common.h), then freed
     uint32_t *d_bin_start = nullptr;   // [n][GHIP_ANI_BIN_COUNT+1] CSR offsets of the binned seed list
     uint32_t *d_chunk_total = nullptr; // concatenated per-chunk seed totals T_c
     uint64_t *d_chunk_start = nullptr; // [n+1]
@@ -150,6 +151,7 @@ struct ghip_ani_index {
 
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
+#define GHIP_ANI_SEGMENTS 8u   // the seeding pass files a genome's seeds under the top 3 bits of their bin (seed_common.h)
 #define GHIP_ANI_MAX_CHUNKS 1450u  // per genome: band votes + repeat counter (36 B) + aligned-chunk list (8 B) of both genomes + the 28 KiB seed stage fit the 160 KiB LDS
 #define GHIP_ANI_MAX_CHUNK_LEN 32768u  // a seed's offset in its chunk is a 15-bit field
 
@@ -176,7 +178,7 @@ struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the 
     uint32_t *d_seed_code;
     uint32_t *d_seed_loc;
     const uint64_t *d_seed_start;
-    uint32_t *d_seed_count;
+    uint32_t *d_seg_count;   // [n][GHIP_ANI_SEGMENTS]
     uint32_t *d_chunk_total;
     const uint64_t *d_chunk_start;
 };
@@ -219,10 +221,10 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
                            uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
-                           uint32_t *d_seed_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
+                           uint32_t *d_seg_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work);
 void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint32_t *in_loc, uint32_t *out_code,
-                         uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seed_count,
+                         uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seg_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp);
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out /* [n_pairs][2][3] = M, T, aligned bases */);

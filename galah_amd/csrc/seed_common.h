@@ -14,6 +14,15 @@ namespace ghip_seed {
 __host__ __device__ __forceinline__ uint32_t seed_mul(uint32_t k) { return 0x85EBCA6Bu << (32u - 2u * k); }
 __device__ __forceinline__ bool seed_selected(uint32_t fwd, uint32_t rev, uint32_t mul, uint32_t thr) { return (0u - 2u - fwd - rev) * mul < thr; }
 
+// Bin of a code in the per-genome join index (ani_bin / ani_pairs): the top bits of a second multiplicative hash.  The
+// seeding pass already files every seed under the top SEG_BITS of its bin -- the genome's unordered list is SEGMENTS
+// lists, each of capacity (genome capacity / SEGMENTS) -- so that ani_bin sorts a whole segment inside LDS in one
+// read and one write (a genome's 40 000 seeds x 8 B do not fit; the one-list form re-read them once per output window).
+__device__ __forceinline__ uint32_t code_bin(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - GHIP_ANI_BIN_BITS); }
+constexpr uint32_t SEG_BITS = 3, SEGMENTS = 1u << SEG_BITS;
+static_assert(SEGMENTS == GHIP_ANI_SEGMENTS, "host and device agree on the segment count");
+__device__ __forceinline__ uint32_t code_segment(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - SEG_BITS); }
+
 // packed location of a seed: chunk << 16 | strand << 15 | offset within the chunk (chunk length <= 32768)
 __device__ __forceinline__ uint32_t seed_loc(uint32_t chunk_id, uint32_t strand, uint32_t off) { return (chunk_id << 16) | (strand << 15) | off; }
 
@@ -32,8 +41,8 @@ struct SeedOut {  // where a block's seeds go (kernel argument, by value)
     uint32_t k, thr, mul, chunk;   // mul = seed_mul(k)
     uint32_t *seed_code;
     uint32_t *seed_loc;   // chunk << 16 | strand << 15 | offset in chunk
-    const uint64_t *seed_start;
-    uint32_t *seed_count;
+    const uint64_t *seed_start;   // [n + 1], capacity layout; a genome's capacity is a multiple of SEGMENTS
+    uint32_t *seg_count;          // [n][SEGMENTS] seeds filed under each segment (may exceed the capacity: overflow)
     uint32_t *chunk_total;
     const uint64_t *chunk_start;
 };
@@ -41,7 +50,7 @@ struct SeedOut {  // where a block's seeds go (kernel argument, by value)
 struct SeedLds {  // per-block LDS state; slot-major so that the 64 lanes of a wave write consecutive words
     uint32_t raw[SEED_LANE_CAP][GHIP_SKETCH_THREADS];   // forward code as the pass holds it (see seed_canon)
     uint32_t ctot[SEED_LDS_CHUNKS];
-    uint32_t wave_n[SEED_WAVES], wave_base[SEED_WAVES];
+    uint32_t seg_n[SEGMENTS], seg_base[SEGMENTS];
 };
 
 // Per-thread view of one block's seeding state.  A lane owns 64 consecutive positions; WHICH of them hold a seed is a
@@ -82,13 +91,14 @@ __device__ __forceinline__ SeedBlock seed_block_begin(SeedLds &sl, const SeedOut
     sb.ch_first = (uint32_t)(blk0 / so.chunk);
     sb.rem_first = (uint32_t)(blk0 - (uint64_t)sb.ch_first * so.chunk);
     sb.sstart = so.seed_start[g];
-    sb.scap = (uint32_t)(so.seed_start[g + 1] - sb.sstart);
+    sb.scap = (uint32_t)(so.seed_start[g + 1] - sb.sstart) / SEGMENTS;   // capacity of ONE segment
     sb.ctot = so.chunk_total + so.chunk_start[g];
     sb.slot = 4 * threadIdx.x;
     sb.slot_last = 4 * ((SEED_LANE_CAP - 1) * GHIP_SKETCH_THREADS + threadIdx.x);
     sb.m16 = 0;
     sb.mask = 0;
     if (threadIdx.x < SEED_LDS_CHUNKS) sl.ctot[threadIdx.x] = 0;
+    if (threadIdx.x < SEGMENTS) sl.seg_n[threadIdx.x] = 0;
     __syncthreads();
     return sb;
 }
@@ -120,9 +130,13 @@ __device__ __forceinline__ void seed_group_end(SeedBlock &sb, uint32_t v) {
 // A seed outside the lane's 64 positions (the fused pass: the few seeds of a genome that end before byte 20) goes
 // straight to the global list.
 __device__ __forceinline__ void seed_emit_global(const SeedOut &so, SeedBlock &sb, uint32_t canon, uint32_t strand, uint32_t rel) {
-    const uint32_t at = sb.rem_first + rel, ch = at / so.chunk;
-    const uint32_t idx = atomicAdd(&so.seed_count[sb.g], 1u);
-    if (idx < sb.scap) { so.seed_code[sb.sstart + idx] = canon; so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + ch, strand, at - ch * so.chunk); }
+    const uint32_t at = sb.rem_first + rel, ch = at / so.chunk, seg = code_segment(canon);
+    const uint32_t idx = atomicAdd(&so.seg_count[(uint64_t)sb.g * SEGMENTS + seg], 1u);
+    if (idx < sb.scap) {
+        const uint64_t o = sb.sstart + (uint64_t)seg * sb.scap + idx;
+        so.seed_code[o] = canon;
+        so.seed_loc[o] = seed_loc(sb.ch_first + ch, strand, at - ch * so.chunk);
+    }
     atomicAdd(&sb.ctot[sb.ch_first + ch], 1u);
 }
 
@@ -130,43 +144,55 @@ __device__ __forceinline__ void seed_emit_global(const SeedOut &so, SeedBlock &s
 // of the lane's first seed position (bit 0 of its mask); block_bases = the block's first base in the genome's stream.
 template <bool COMPLEMENTED>
 __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so, SeedBlock &sb, uint32_t rel0, const uint8_t *block_bases) {
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    uint64_t mask = sb.mask;
-    const uint32_t mine = (uint32_t)__popcll(mask);
-    uint32_t incl = mine;  // inclusive scan over the wave
+    const uint32_t mine = (uint32_t)__popcll(sb.mask);
+    // seeds with a row of their own in SeedLds::raw (the clamped stores of a lane with more than SEED_LANE_CAP seeds
+    // overwrote its last row): they are filed through the block's segment runs; the others, rare, one by one
+    const uint32_t rowed = mine <= SEED_LANE_CAP ? mine : SEED_LANE_CAP - 1;
+    // pass 1: canonical code, strand, segment, and the rank in the block's run of that segment (one LDS counter per segment)
+    uint32_t canon_r[SEED_LANE_CAP], place_r[SEED_LANE_CAP];   // place = segment << 28 | strand << 27 | rank
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= (uint32_t)off) incl += v;
-    }
-    if (lane == 63) sl.wave_n[w] = incl;
-    __syncthreads();
-    // one global atomic per block reserves room for all waves' seeds
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t i = 0; i < SEED_WAVES; i++) { sl.wave_base[i] = tot; tot += sl.wave_n[i]; }
-        const uint32_t base = tot ? atomicAdd(&so.seed_count[sb.g], tot) : 0u;
-        for (uint32_t i = 0; i < SEED_WAVES; i++) sl.wave_base[i] += base;
+    for (uint32_t i = 0; i < SEED_LANE_CAP; i++) {
+        canon_r[i] = 0; place_r[i] = 0;
+        if (i < rowed) {
+            uint32_t canon, strand;
+            seed_canon<COMPLEMENTED>(sl.raw[i][threadIdx.x], so.k, canon, strand);
+            const uint32_t seg = code_segment(canon);
+            canon_r[i] = canon;
+            place_r[i] = (seg << 28) | (strand << 27) | atomicAdd(&sl.seg_n[seg], 1u);
+        }
     }
     __syncthreads();
-    uint32_t idx = sl.wave_base[w] + incl - mine;
-    for (uint32_t i = 0; i < mine; i++, idx++) {
+    // one global atomic per segment and block reserves the block's run in the genome's segment
+    if (threadIdx.x < SEGMENTS) {
+        const uint32_t c = sl.seg_n[threadIdx.x];
+        sl.seg_base[threadIdx.x] = c ? atomicAdd(&so.seg_count[(uint64_t)sb.g * SEGMENTS + threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    // pass 2: positions come off the lane's mask in the order the codes were stored
+    uint64_t mask = sb.mask;
+#pragma unroll
+    for (uint32_t i = 0; i < SEED_LANE_CAP; i++) {
+        if (i < rowed) {
+            const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t at = sb.rem_first + rel, chrel = at / so.chunk;
+            const uint32_t seg = place_r[i] >> 28, idx = sl.seg_base[seg] + (place_r[i] & 0x07ffffffu);
+            if (idx < sb.scap) {
+                const uint64_t o = sb.sstart + (uint64_t)seg * sb.scap + idx;
+                so.seed_code[o] = canon_r[i];
+                so.seed_loc[o] = seed_loc(sb.ch_first + chrel, (place_r[i] >> 27) & 1u, at - chrel * so.chunk);
+            }
+            if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
+            else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
+        }
+    }
+    for (uint32_t i = rowed; i < mine; i++) {   // the code again, from the bases
         const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
         mask &= mask - 1;
-        const uint32_t at = sb.rem_first + rel, chrel = at / so.chunk;
-        if (idx < sb.scap) {
-            uint32_t canon, strand;
-            if (i + 1 < SEED_LANE_CAP || mine <= SEED_LANE_CAP) seed_canon<COMPLEMENTED>(sl.raw[i][threadIdx.x], so.k, canon, strand);
-            else {  // no row of its own (the clamped stores overwrote the last one): the code again, from the bases
-                uint32_t f = 0;
-                for (uint32_t j = 0; j < so.k; j++) f = (f << 2) | (base_code(block_bases[rel + j]) & 3u);
-                seed_canon<false>(f, so.k, canon, strand);
-            }
-            so.seed_code[sb.sstart + idx] = canon;
-            so.seed_loc[sb.sstart + idx] = seed_loc(sb.ch_first + chrel, strand, at - chrel * so.chunk);
-        }
-        if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
-        else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
+        uint32_t f = 0, canon, strand;
+        for (uint32_t j = 0; j < so.k; j++) f = (f << 2) | (base_code(block_bases[rel + j]) & 3u);
+        seed_canon<false>(f, so.k, canon, strand);
+        seed_emit_global(so, sb, canon, strand, rel);
     }
     __syncthreads();
     if (threadIdx.x < SEED_LDS_CHUNKS && sl.ctot[threadIdx.x]) atomicAdd(&sb.ctot[sb.ch_first + threadIdx.x], sl.ctot[threadIdx.x]);

@@ -107,13 +107,23 @@ class Comm:
 
         def _init():
             result["rc"] = L.ghip_comm_init_rank(ctx._h, rank, world, uid, C.byref(h))
+            if result["rc"] == 0:
+                # a first, tiny collective under the same watchdog: a communicator that initialises but whose
+                # all-gather fails or hangs (no usable link between two ranks) is found out here, where the caller
+                # can still fall back to the host transport on every rank
+                probe = np.array([rank * 7 + 1], dtype=np.int64)
+                got = np.empty((world, 1), dtype=np.int64)
+                result["probe_rc"] = L.ghip_comm_allgather_host(h, probe.ctypes.data, probe.nbytes, got.ctypes.data)
+                result["probe_ok"] = result["probe_rc"] == 0 and got[:, 0].tolist() == [r * 7 + 1 for r in range(world)]
 
         t = threading.Thread(target=_init, daemon=True)
         t.start()
         t.join(timeout_s)
         if t.is_alive():
-            raise TimeoutError(f"ncclCommInitRank did not return within {timeout_s:.0f} s")
+            raise TimeoutError(f"RCCL communicator set-up (ncclCommInitRank + a first all-gather) did not finish within {timeout_s:.0f} s")
         check(result["rc"], ctx._h)
+        if not result.get("probe_ok"):
+            raise GalahHipError(5, "the first RCCL all-gather failed: " + L.ghip_comm_last_error(h).decode())
         return cls(h, ctx)
 
     # ---- queries
