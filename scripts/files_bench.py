@@ -13,7 +13,7 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 gz = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 ctx = galah_amd.Context(0)
-d = tempfile.mkdtemp(prefix="ghip_files_", dir="/tmp")
+d = tempfile.mkdtemp(prefix="ghip_files_", dir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
 g = ctx.genomes_synthetic(42, n // 10, 10, L, 0.0253)
 
 def write(i):
@@ -33,7 +33,10 @@ paths = [write(i) for i in range(n)]   # to_host goes through the one context: k
 print(f"wrote {n} files ({n * L / 1e9:.2f} GB{' gz' if gz else ''}) in {time.perf_counter() - t0:.1f}s")
 del g
 
-for rep in range(2):
+for rep in range(int(os.environ.get("GHIP_FILES_BENCH_REPS", "2"))):
+    if os.environ.get("GHIP_FILES_BENCH_ALTERNATE"):   # A/B of the batch pipeline inside one process
+        os.environ["GHIP_PIPELINE"] = "1" if rep % 2 == 0 else "0"
+        print("GHIP_PIPELINE =", os.environ["GHIP_PIPELINE"], end="  ")
     t0 = time.perf_counter()
     gg = ctx.genomes_from_files(paths, T)
     t_ingest = time.perf_counter() - t0
