@@ -340,8 +340,12 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                 // no bound check: an entry past the bin is a seed of ANOTHER bin (this round's next bin, or a stale one of
                 // an earlier round, or the never-a-code fill) -- a code determines its bin, so it cannot equal c
                 uint32_t mm = 0;
+#ifdef GHIP_DBG_ANI_NOCOMPARE   // timing experiment only: wrong results
+                mm = (j0 ^ c) == 0x12345u ? 1u : 0u;
+#else
 #pragma unroll
                 for (uint32_t u = 0; u < 8; u++) mm |= (uint32_t)(sr[j0 + u] == c) << u;
+#endif
                 bool any = mm != 0;
                 for (uint32_t j = j0 + 8; j < jz; j++) any |= (sr[j] == c);
                 if (any) {   // ~half of the seeds of related genomes
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifndef GHIP_DBG_ANI_NORVOTES   // timing experiment only: wrong results
             for (uint32_t w = lane; w < (nr + 1) / 2; w += 64) {
                 const uint32_t m2 = rm[w];
                 if (m2) {
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
                     if (m2 >> 16) cast_vote(vr, lr[2 * w + 1] >> 16, m2 >> 16);
                 }
             }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
         } else {  // a run longer than the stage: lane-per-bin walk in global memory
@@ -412,21 +418,45 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     // (m, t) of the group is reported.
     constexpr uint32_t KEY_CAP = sizeof(st_code) / sizeof(double);
     if (n <= KEY_CAP) {
+        // (key, entry) pairs sorted in LDS by an ascending-only bitonic network (positions >= n act as +infinity without
+        // being stored: pairs_join.hip has the same network) -- ~45 block-wide exchange steps for the ~500 aligned chunks
+        // of two 5 Mb genomes, where counting every entry's rank against every other took 500 steps per thread and a
+        // quarter of the kernel's instructions.  Ties: equal keys <=> equal fractions; the order inside a tie group is
+        // by entry, so the group's first element is its smallest (m, t).
         double *keys = reinterpret_cast<double *>(&st_code[0][0][0]);
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
             const unsigned long long me = list[e];
             keys[e] = (double)(uint32_t)(me >> 32) / (double)(uint32_t)me;
         }
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-            const double me = keys[e];
-            uint32_t lt = 0, le = 0;
-            for (uint32_t j = 0; j < n; j++) {
-                const double o = keys[j];
-                lt += o < me ? 1u : 0u;
-                le += o <= me ? 1u : 0u;
+        uint32_t P = 2;
+        while (P < n) P <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t x) {
+            if (x >= n) return;
+            const double ka = keys[i], kb = keys[x];
+            if (ka < kb) return;
+            const unsigned long long ma = list[i], mb = list[x];
+            if (ka > kb || ma > mb) { keys[i] = kb; keys[x] = ka; list[i] = mb; list[x] = ma; }
+        };
+        for (uint32_t kk = 2; kk <= P && n > 1; kk <<= 1) {
+            __syncthreads();
+            const uint32_t half = kk >> 1;
+            for (uint32_t t = threadIdx.x; t < P / 2; t += blockDim.x) {
+                const uint32_t i = kk * (t / half) + (t % half);
+                exchange(i, i ^ (kk - 1));
             }
-            if (lt <= target && target < le) atomicMin(&red[4], list[e]);
+            for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < P / 2; t += blockDim.x) {
+                    const uint32_t i = 2 * j * (t / j) + (t % j);
+                    exchange(i, i + j);
+                }
+            }
+        }
+        __syncthreads();
+        if (n) {
+            const double km = keys[target];
+            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x)
+                if (keys[e] == km && (e == 0 || keys[e - 1] != km)) red[4] = list[e];   // exactly one thread
         }
     } else {
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
