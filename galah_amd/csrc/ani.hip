@@ -184,6 +184,12 @@ __global__ __launch_bounds__(BIN_THREADS) void ani_bin_kernel(
     }
 }
 
+#ifdef GHIP_DBG_ANI_PHASES   // timing experiment only: cycles per phase of wave 0 of pair 0
+__device__ unsigned long long g_ani_phase[16];
+#define PH(i) do { if (pair == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_ani_phase[i] += t_ - ph_t; ph_t = t_; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
 constexpr uint32_t ANI_PAIR_THREADS = 512;
 constexpr uint32_t ANI_PAIR_WAVES = ANI_PAIR_THREADS / 64;
 constexpr uint32_t ANI_STAGE = 192;  // seeds of one round's consecutive bins staged per wave and genome (rounds are sized for ~150)
@@ -263,6 +269,9 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
     const uint32_t pair = ((slot_in_xcd >> 5) * 8u + xcd) * 32u + (slot_in_xcd & 31u);
     if (pair >= n_pairs) return;
+#ifdef GHIP_DBG_ANI_PHASES
+    unsigned long long ph_t = __builtin_readcyclecounter();
+#endif
     const uint32_t q = pairs[2 * pair], r = pairs[2 * pair + 1];
     const uint32_t nchq = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
     const uint32_t nchr = (uint32_t)(chunk_start[r + 1] - chunk_start[r]);
@@ -298,6 +307,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     }
     // the bounds of the next round are fetched while this round is joined
     uint32_t n_rs = rb[min(wave * rbins + lane, BIN_COUNT)], n_qlo = qb[wave * rbins], n_qhi = qb[wave * rbins + rbins], n_rhi = rb[wave * rbins + rbins];
+    PH(0);   // prologue
     for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * rbins) {
         const uint32_t rs = n_rs, q_lo = n_qlo, q_hi = n_qhi, r_hi = n_rhi;
         const uint32_t r_lo = __shfl(rs, 0, 64);
@@ -307,6 +317,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
         }
         if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
         const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
+        PH(1);   // bounds
         if (staged) {
             {   // both runs in one loop: the four loads of an iteration are in flight together
                 const uint32_t nqs = q_hi - q_lo, nrs = r_hi - r_lo;
@@ -320,6 +331,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            PH(2);   // staging
             // Flattened join: q seeds are dealt to the lanes one each (not one BIN per lane, whose cost is the
             // largest bin of the wave squared); a seed's bin, hence its short r range, follows from its code.
             // Every anchor sets its band in the q seed's mask (a register) and in the r seed's mask (LDS); the
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             if (lane == 63) ro[rbins] = (uint16_t)nr;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            PH(3);   // offsets
             for (uint32_t i = lane; i < nq; i += 64) {
                 const uint32_t c = sq[i];
                 const uint32_t x = code_bin(c) - b0;
@@ -369,6 +382,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            PH(4);   // join
 #ifndef GHIP_DBG_ANI_NORVOTES   // timing experiment only: wrong results
             for (uint32_t w = lane; w < (nr + 1) / 2; w += 64) {
                 const uint32_t m2 = rm[w];
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
+            PH(5);   // r votes
         } else {  // a run longer than the stage: lane-per-bin walk in global memory
             for (uint32_t u = lane; u < rbins; u += 64) {
                 const uint32_t qs = qb[b0 + u], qe = qb[b0 + u + 1], rs_ = rb[b0 + u], re = rb[b0 + u + 1];
@@ -402,6 +417,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
         }
     }
     __syncthreads();
+    PH(6);   // waiting for the other waves
     // (M_c, T_c) of the aligned chunks of both directions, then the LOWER MEDIAN containment M_c/T_c
     // by rank selection (exact: fractions compared by cross-multiplication)
     const unsigned long long bq = collect_aligned(vq, chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
@@ -409,6 +425,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[2], bq); atomicAdd(&red[5], br); }
     __syncthreads();
     const uint32_t n = n_al;
+    PH(7);   // collect
     if (threadIdx.x == 0) { red[3] = n; red[4] = ~0ull; }
     const uint32_t target = n ? (n - 1) / 2 : 0;
     // Exact order of the fractions M_c/T_c through f64 keys: the quotient is correctly rounded, hence monotone, and
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
     if (threadIdx.x == 0) red[4] = 0;
     __syncthreads();
     if (threadIdx.x < 6) out[(uint64_t)pair * 6 + threadIdx.x] = red[threadIdx.x];
+    PH(8);   // median + output
 }
 
 }  // namespace
@@ -535,4 +553,15 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
                        idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
                        idx->d_chunk_start, idx->d_glen, idx->chunk, ro_cap, d_out);
     ghip_prof_end(ctx);
+#ifdef GHIP_DBG_ANI_PHASES
+    {
+        unsigned long long h[16];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ani_phase), sizeof h);
+        static const char *nm[9] = {"prologue", "bounds", "staging", "offsets", "join", "r-votes", "wait-waves", "collect", "median+out"};
+        fprintf(stderr, "[ani_pairs phases, wave 0 of pair 0, cumulative cycles]");
+        for (int i = 0; i < 9; i++) fprintf(stderr, " %s %llu", nm[i], h[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
 }

@@ -8,10 +8,13 @@ g = ctx.genomes_synthetic(42, 100, 10, 5_000_000, 0.0253)
 sk, idx = ctx.sketch_and_index(g, 21, 1000, 0)
 pairs = ctx.precluster(sk, np.float32(0.9))
 pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32)
-ctx.ani_pairs(idx, pi, 0.15)
-ctx.profile(True); ctx.profile_reset()
-for _ in range(5):
-    ctx.ani_pairs(idx, pi, 0.15)
-ctx.profile(False)
-nl, ms = ctx.kernel_stats()["ani_pairs"]
-print("ani_pairs %d pairs: %.3f ms per launch" % (len(pi), ms / nl))
+out = []
+for m in (len(pi), 1536, 384, 96, 8):
+    ctx.ani_pairs(idx, pi[:m], 0.15)
+    ctx.profile(True); ctx.profile_reset()
+    for _ in range(5):
+        ctx.ani_pairs(idx, pi[:m], 0.15)
+    ctx.profile(False)
+    nl, ms = ctx.kernel_stats()["ani_pairs"]
+    out.append("%d pairs: %.3f ms" % (m, ms / nl))
+print("ani_pairs " + "   ".join(out))
