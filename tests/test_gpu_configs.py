@@ -212,6 +212,36 @@ def test_ani_large_genomes_narrow_rounds(ctx):
     g.free()
 
 
+def test_ani_tandem_repeats_skewed_segments(ctx):
+    """Genomes that are mostly ONE short unit repeated: a handful of distinct seed codes, hundreds of copies each.  The
+    seeding pass files seeds under 8 segments of the bin hash with equal capacities -- here nearly all land in two or
+    three, the segment overflows and the index is rebuilt with exact capacities; a bin then holds hundreds of seeds, so a
+    round's run exceeds the LDS stage and ani_pairs walks it in global memory.  Fused and standalone passes, dense and
+    sparse seeds, against the oracle."""
+    rng = np.random.default_rng(11)
+    unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1500)
+    flank = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=400_000)
+    def variant(rate):
+        g = np.concatenate([flank[:200_000]] + [unit] * 300 + [flank[200_000:]])
+        m = rng.random(len(g)) < rate
+        g[m] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(m.sum()))
+        return g
+    seqs = [variant(0.0), variant(0.01), variant(0.03), rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=400_000),
+            np.concatenate([unit] * 300)]   # the last one: nothing but the repeat
+    g = ctx.genomes_from_host(seqs)
+    pairs = np.array([(a, b) for a in range(5) for b in range(5) if a != b], dtype=np.uint32)
+    for c in (125, 9):
+        osk = [oracle.AniSketch.from_bytes(s, 15, c, 20000) for s in seqs]
+        want = np.float32([oracle.ani_pair(osk[a], osk[b], 0.15)[0] for a, b in pairs])
+        sk, fused = ctx.sketch_and_index(g, 21, 1000, 0, 15, c, 20000)
+        alone = ctx.ani_index_build(g, 15, c, 20000)
+        for idx in (fused, alone):
+            assert np.array_equal(ctx.ani_pairs(idx, pairs, 0.15), want), c
+            idx.free()
+        sk.free()
+    assert want[0] > 95 and want[2] == 0   # the variants are related (their unique flanks align), the random genome is not
+
+
 def test_config4_full_size_100k_contig_sketches(ctx):
     """configs[3] at its stated size: 100 000 contigs, small sketches (s' = 256): 5e9 pairs through the join form; the
     expected list from the planted families (the oracle's pair loop per family); every 9th contig ragged."""
