@@ -504,7 +504,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uin
                            uint32_t *d_seg_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    ghip_seed::SeedOut so{k, ~0u / c, ghip_seed::seed_mul(k), chunk, d_seed_code, d_seed_loc, d_seed_start, d_seg_count, d_chunk_total, d_chunk_start};
+    ghip_seed::SeedOut so{k, ~0u / c, ghip_seed::seed_mul(k), chunk, ghip_seed::seed_chunk_magic(chunk), d_seed_code, d_seed_loc, d_seed_start, d_seg_count, d_chunk_total, d_chunk_start};
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),

@@ -23,6 +23,13 @@ constexpr uint32_t SEG_BITS = 3, SEGMENTS = 1u << SEG_BITS;
 static_assert(SEGMENTS == GHIP_ANI_SEGMENTS, "host and device agree on the segment count");
 __device__ __forceinline__ uint32_t code_segment(uint32_t code) { return (code * 0x9E3779B1u) >> (32 - SEG_BITS); }
 
+// A block-relative position `at` (< 2^16: at most one chunk length plus one block) divided by the chunk length, exactly,
+// by one v_mul_hi: M = ceil(2^32 / chunk) overestimates 2^32 / chunk by e / chunk with e < chunk <= 2^15, so at * M / 2^32
+// exceeds at / chunk by less than at * e / (chunk * 2^32) < 1 / chunk -- never enough to reach the next integer.  (The
+// compiler's division by a run-time value is ~15 instructions, once per seed and pass of the flush.)
+__host__ __device__ __forceinline__ uint32_t seed_chunk_magic(uint32_t chunk) { return chunk <= 1 ? 0u : (uint32_t)(((1ull << 32) + chunk - 1) / chunk); }
+__device__ __forceinline__ uint32_t seed_chunk_of(uint32_t at, uint32_t magic) { return magic ? __umulhi(at, magic) : at; }
+
 // packed location of a seed: chunk << 16 | strand << 15 | offset within the chunk (chunk length <= 32768)
 __device__ __forceinline__ uint32_t seed_loc(uint32_t chunk_id, uint32_t strand, uint32_t off) { return (chunk_id << 16) | (strand << 15) | off; }
 
@@ -39,6 +46,7 @@ constexpr uint32_t SEED_WAVES = GHIP_SKETCH_THREADS / 64;
 
 struct SeedOut {  // where a block's seeds go (kernel argument, by value)
     uint32_t k, thr, mul, chunk;   // mul = seed_mul(k)
+    uint32_t chunk_magic;          // seed_chunk_magic(chunk): positions -> chunks by one multiply
     uint32_t *seed_code;
     uint32_t *seed_loc;   // chunk << 16 | strand << 15 | offset in chunk
     const uint64_t *seed_start;   // [n + 1], capacity layout; a genome's capacity is a multiple of SEGMENTS
@@ -130,7 +138,7 @@ __device__ __forceinline__ void seed_group_end(SeedBlock &sb, uint32_t v) {
 // A seed outside the lane's 64 positions (the fused pass: the few seeds of a genome that end before byte 20) goes
 // straight to the global list.
 __device__ __forceinline__ void seed_emit_global(const SeedOut &so, SeedBlock &sb, uint32_t canon, uint32_t strand, uint32_t rel) {
-    const uint32_t at = sb.rem_first + rel, ch = at / so.chunk, seg = code_segment(canon);
+    const uint32_t at = sb.rem_first + rel, ch = seed_chunk_of(at, so.chunk_magic), seg = code_segment(canon);
     const uint32_t idx = atomicAdd(&so.seg_count[(uint64_t)sb.g * SEGMENTS + seg], 1u);
     if (idx < sb.scap) {
         const uint64_t o = sb.sstart + (uint64_t)seg * sb.scap + idx;
@@ -175,7 +183,7 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
         if (i < rowed) {
             const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
             mask &= mask - 1;
-            const uint32_t at = sb.rem_first + rel, chrel = at / so.chunk;
+            const uint32_t at = sb.rem_first + rel, chrel = seed_chunk_of(at, so.chunk_magic);
             const uint32_t seg = place_r[i] >> 28, idx = sl.seg_base[seg] + (place_r[i] & 0x07ffffffu);
             if (idx < sb.scap) {
                 const uint64_t o = sb.sstart + (uint64_t)seg * sb.scap + idx;

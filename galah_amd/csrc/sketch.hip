@@ -642,7 +642,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
     if (n_work == 0) return;
     ghip_seed::SeedOut so{};
     if (seeds)
-        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, ghip_seed::seed_mul(seeds->k), seeds->chunk, seeds->d_seed_code, seeds->d_seed_loc,
+        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, ghip_seed::seed_mul(seeds->k), seeds->chunk, ghip_seed::seed_chunk_magic(seeds->chunk), seeds->d_seed_code, seeds->d_seed_loc,
                                 seeds->d_seed_start, seeds->d_seg_count, seeds->d_chunk_total, seeds->d_chunk_start};
     const KmerLuts *luts = nullptr;
     if (k == 21) {
