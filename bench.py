@@ -142,6 +142,17 @@ class CpuRates:
         sub = gpu_pairs[(gpu_pairs["i"] < self.m) & (gpu_pairs["j"] < self.m)]
         assert sub.tobytes() == self.serial_pairs.tobytes(), "GPU precluster pairs differ from the CPU oracle"
 
+    @staticmethod
+    def cpu_quota():
+        """CPUs' worth of time the container may use per period (cgroup v2 cpu.max), or None when unlimited / unknown: the
+        boxes this ran on expose 256 logical CPUs under a quota of 16 -- the timed legs of the CPU baseline (and the gzip
+        ingest) are bound by it, the per-pair ANI term is divided by the THREAD count, which flatters the CPU."""
+        try:
+            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            return None if q == "max" else float(q) / float(period)
+        except Exception:  # noqa: BLE001
+            return None
+
     def baseline(self, n: int, n_pairs_total: int, n_cand_total: int):
         cores = self.cores
         scale = n / self.sample
@@ -157,6 +168,7 @@ class CpuRates:
                        f"{self.t_pairs_serial:.2f}s / parallel {self.t_pairs_par:.2f}s; "
                        f"{self.n_ani_timed} ANI pairs at {self.t_ani_pair * 1e3:.2f} ms each x {n_cand_total} candidates / {cores} cores; "
                        f"value = B2 (all stages parallel)"),
+            "host_cgroup_cpu_quota": self.cpu_quota(),   # CPUs' worth of time the container gets (None = unlimited)
             "b1_faithful_serial_pair_loop_value": n_pairs_total / t_b1,
             "pair_stage_only_pairs_per_s": {"serial": self.p_sample / self.t_pairs_serial, "parallel": self.p_sample / self.t_pairs_par},
         }
