@@ -13,7 +13,27 @@ int main() {
         uint32_t *m = nullptr; uint64_t *o = nullptr; size_t nc = 0;
         int skip = rng() % 3 == 0;
         int rc = ghip_cluster(n, pairs.data(), pairs.size(), skip ? nullptr : ani.data(), skip, skip ? 0.95f : 95.0f, nullptr, nullptr, &m, &o, &nc);
-        if (rc == 0) { size_t tot = o[nc]; if (tot != n) { printf("BAD total %zu != %zu\n", tot, n); return 1; } ghip_free(m); ghip_free(o); }
+        if (rc == 0) { size_t tot = o[nc]; if (tot != n) { printf("BAD total %zu != %zu\n", tot, n); return 1; } }
+        if (!skip) {   // the lazy, batched form: same clusters, asked in rounds (with and without the short-list shortcut)
+            struct St { const std::vector<float> *ani; size_t rounds; } st{&ani, 0};
+            auto cb = [](void *u, const uint32_t *e, size_t k, float *out) -> int {
+                St *s = static_cast<St *>(u);
+                s->rounds++;
+                for (size_t x = 0; x < k; x++) out[x] = (*s->ani)[e[x]];
+                return 0;
+            };
+            setenv("GHIP_LAZY_ALL_BELOW", rep % 2 ? "0" : "100000", 1);
+            uint32_t *m2 = nullptr; uint64_t *o2 = nullptr; size_t nc2 = 0; uint64_t asked = 0;
+            const int rc2 = ghip_cluster_lazy(n, pairs.data(), pairs.size(), 95.0f, cb, &st, &m2, &o2, &nc2, &asked);
+            if (rc2 != rc) { printf("BAD lazy rc %d != %d\n", rc2, rc); return 1; }
+            if (rc2 == 0) {
+                if (nc2 != nc || asked > pairs.size()) { printf("BAD lazy clusters %zu != %zu\n", nc2, nc); return 1; }
+                for (size_t x = 0; x < n; x++) if (m2[x] != m[x]) { printf("BAD lazy member at %zu\n", x); return 1; }
+                for (size_t c = 0; c <= nc; c++) if (o2[c] != o[c]) { printf("BAD lazy offset\n"); return 1; }
+                ghip_free(m2); ghip_free(o2);
+            }
+        }
+        if (rc == 0) { ghip_free(m); ghip_free(o); }
     }
     printf("cluster asan ok\n");
 }
