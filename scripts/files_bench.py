@@ -33,7 +33,9 @@ paths = [write(i) for i in range(n)]   # to_host goes through the one context: k
 print(f"wrote {n} files ({n * L / 1e9:.2f} GB{' gz' if gz else ''}) in {time.perf_counter() - t0:.1f}s")
 del g
 
-for rep in range(int(os.environ.get("GHIP_FILES_BENCH_REPS", "2"))):
+thread_list = [int(x) for x in os.environ.get("GHIP_FILES_BENCH_THREADS", str(T)).split(",")]
+for rep in range(int(os.environ.get("GHIP_FILES_BENCH_REPS", "2")) * len(thread_list)):
+    T = thread_list[rep % len(thread_list)]
     if os.environ.get("GHIP_FILES_BENCH_ALTERNATE"):   # A/B of the batch pipeline inside one process
         os.environ["GHIP_PIPELINE"] = "1" if rep % 2 == 0 else "0"
         print("GHIP_PIPELINE =", os.environ["GHIP_PIPELINE"], end="  ")
