@@ -965,7 +965,7 @@ static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t 
         if ((rc = h2d_nosync(ctx, d_cstart, cand_start.data(), ns))) break;
         if ((rc = h2d_nosync(ctx, d_cap, slot_cap.data(), ns))) break;
         if (hipMemsetAsync(d_count, 0, ns * sizeof(uint32_t), ctx->stream) != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed"); break; }
-        if ((rc = stream_sync(ctx))) break;  // the three host vectors are rebuilt below
+        // (no synchronisation here: the three host vectors stay as they are until the one after the kernels)
         ghip_launch_sketch_kmers(ctx, g->d_bytes, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
                                  d_work, n_work, k, (uint32_t)seed, d_cand, d_count, first ? seeds : nullptr);
         ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, s, sk->d_hashes,
@@ -1264,7 +1264,7 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
     if ((rc = h2d_nosync(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seg_count, 0, std::max<size_t>(n, 1) * GHIP_ANI_SEGMENTS * sizeof(uint32_t), ctx->stream));
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream));
-    return stream_sync(ctx);  // the index's host vectors may be rewritten by a retry
+    return GHIP_OK;  // (the host vectors just queued for upload are only rewritten by a retry, i.e. after index_check_seeds has synchronised)
 }
 
 static ghip_seed_args index_seed_args(const ghip_ani_index *idx) {
