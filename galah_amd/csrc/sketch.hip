@@ -327,7 +327,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 5; i++) word(warm[i], 4 * i, F_{}, F_{}, W_{}, false, false, true);
+        for (int i = 0; i < 5; i++) word(warm[i], 4 * i, F_{}, F_{}, W_{}, false, false, false);   // (windows only: the fast variant unless a bad byte shows up)
     }
     uint32_t w0 = q1.y, w1 = q1.z, w2 = q1.w, w3 = q2.x;
 #pragma unroll 1
