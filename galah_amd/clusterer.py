@@ -1,8 +1,9 @@
 """clusterer::cluster mirror (reference src/clusterer.rs:14-152).
 
 Same argument list and the same panics (raised as RuntimeError); the O(N^2) host loops run in
-the C++ host clusterer behind ghip_cluster, and the clusterer's ANI is requested in ONE batch
-for all precluster pairs when the back-end offers `calculate_ani_indices`.
+the C++ host clusterer behind ghip_cluster, and a back-end that offers `calculate_ani_indices` is
+asked for the clusterer's ANI lazily, in batched rounds (ghip_cluster_lazy: only the precluster
+pairs that touch a representative; short lists in one round).
 Returns Vec<Vec<usize>> with the representative first in each inner list.
 """
 from __future__ import annotations
