@@ -1,3 +1,4 @@
+# Full GPU regression in one gpurun call: the parity suite, two fuzzers, the C++ host mirror, the headline bench at 1 000 and 10 000 genomes.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -5

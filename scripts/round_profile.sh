@@ -1,3 +1,4 @@
+# One round's evidence in one gpurun call: parity suite, rocprofv3 kernel trace + PMC passes + bench (gpu_profile.sh), the 8-rank functional bench, the join shard table.
 export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -4
 bash scripts/gpu_profile.sh r02f
