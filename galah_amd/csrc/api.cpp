@@ -200,7 +200,14 @@ double ghip_cpu_quota() {
 }
 
 // a multiple of the segment count: the unordered list is GHIP_ANI_SEGMENTS equal parts (seed_common.h)
-uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) { return (len / c + len / (10ull * c) + 256 + GHIP_ANI_SEGMENTS - 1) / GHIP_ANI_SEGMENTS * GHIP_ANI_SEGMENTS; }
+// Room for the expected seeds of each segment (m = len / (SEGMENTS c), about Poisson), six standard deviations, 5 % for
+// repeats and a constant: with 4 sigma (the first form) a run of 50 000 genomes of 1 Mb overflowed a handful of its
+// 400 000 segments every time, and an overflow re-seeds the whole batch with exact capacities (33 ms there).
+uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) {
+    const double m = (double)len / ((double)GHIP_ANI_SEGMENTS * (double)c);
+    const uint64_t segcap = (uint64_t)(m + 6.0 * std::sqrt(m) + m / 20.0) + 24;
+    return segcap * GHIP_ANI_SEGMENTS;
+}
 
 // fn(begin, end) over [0, n) on up to max_threads threads of at least min_per_thread items each (the caller's thread
 // takes the last range); spawning costs ~30 us per thread, so short loops stay serial (callers pass min_per_thread = 10 000)
