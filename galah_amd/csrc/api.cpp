@@ -200,12 +200,15 @@ double ghip_cpu_quota() {
 }
 
 // a multiple of the segment count: the unordered list is GHIP_ANI_SEGMENTS equal parts (seed_common.h)
-// Room for the expected seeds of each segment (m = len / (SEGMENTS c), about Poisson), six standard deviations, 5 % for
-// repeats and a constant: with 4 sigma (the first form) a run of 50 000 genomes of 1 Mb overflowed a handful of its
-// 400 000 segments every time, and an overflow re-seeds the whole batch with exact capacities (33 ms there).
+// Room for the expected seeds of each segment (m = len / (SEGMENTS c), about Poisson), six standard deviations, a quarter
+// more for repeats -- all copies of a repeated k-mer land in ONE segment: an insertion-sequence family of 300 copies adds
+// a few hundred seeds to two or three segments of a 5 Mb genome -- and a constant.  The list is 8 B per seed, ~6 % of the
+// bases it indexes, so room is cheap; an overflow is not: it re-seeds the whole batch with exact capacities (with four
+// standard deviations and 10 %, the first form, 50 000 genomes of 1 Mb overflowed a handful of their 400 000 segments
+// every time: +33 ms).
 uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) {
     const double m = (double)len / ((double)GHIP_ANI_SEGMENTS * (double)c);
-    const uint64_t segcap = (uint64_t)(m + 6.0 * std::sqrt(m) + m / 20.0) + 24;
+    const uint64_t segcap = (uint64_t)(m + 6.0 * std::sqrt(m) + m / 4.0) + 24;
     return segcap * GHIP_ANI_SEGMENTS;
 }
 
