@@ -316,3 +316,39 @@ def test_config2_1000_full_length_genomes_sketch_stage_sampled(ctx):
     assert [int(cnt[r]) for r in rows[:8]] == seeds
     for h in (sk, idx, g):
         h.free()
+
+
+def test_bench_line_contract():
+    """The driver's contract for `bench.py`: exactly ONE line on stdout, a JSON object with the agreed keys, the roofline
+    and CPU-baseline objects of the hot-path tier -- on a small workload (the default one is the driver's to run), once as
+    a plain invocation and once self-launched with two ranks on the one GPU (host transport)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--species", "6", "--members", "4", "--length", "300000", "--steps", "2", "--warmup", "1", "--no-extras",
+             "--cpu-sample-genomes", "4", "--cpu-pair-sample", "24"]
+    for extra, env in (([], {}), (["--gpus", "2"], {"GHIP_BENCH_BACKEND": "gloo"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small + extra, capture_output=True, text=True,
+                           timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout[:2000]
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["metric"].startswith("genome-pairs/sec") and d["unit"] == "genome-pairs/s" and d["higher_is_better"] is True
+        assert d["n_gpus"] == (2 if extra else 1) and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+        assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
+        rf = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in rf, k
+        assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+        if not extra:
+            cb = d["cpu_baseline"]
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in cb, k
+            assert cb["kind"] in ("port", "reference") and cb["value"] > 0
+        else:
+            assert len(d["per_rank"]) == 2 and d["config"]["transport"] == "host-callback"
