@@ -120,17 +120,12 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
         std::vector<uint8_t> requested(n_pairs, 0);
         std::vector<float> answers;
         // A round costs the callee one launch's latency however few edges it holds (ani_pairs: ~0.25 ms for anything up
-        // to ~800 pairs, 1.2 ms for 4 500), so a SHORT edge list is asked for whole, in one round: five rounds of a few
-        // hundred pairs took as long as the one launch (measured at 1 000 genomes), plus their fixed costs.
-        size_t all_below = 8192, flush_below = 512;
-        if (const char *e = getenv("GHIP_LAZY_ALL_BELOW")) all_below = (size_t)strtoull(e, nullptr, 10);
+        // to ~800 pairs), so a SHORT round is topped up (below): a short edge list is thereby asked for whole in its
+        // first round, and the tail of a long one is one round instead of several tiny ones.
+        size_t flush_below = 512;
         if (const char *e = getenv("GHIP_LAZY_FLUSH_BELOW")) flush_below = (size_t)strtoull(e, nullptr, 10);
-        bool first_round = true;
         for (;;) {
             req.clear();
-            if (first_round && n_pairs <= all_below)
-                for (size_t e = 0; e < n_pairs; e++) if (ani_state[e] == 0) { requested[e] = 1; req.push_back((uint32_t)e); }
-            first_round = false;
             for (size_t s = 0; s < nsets; s++) {
                 const uint32_t *orig = members.data() + set_start[s];
                 const uint32_t m = set_size[s];
@@ -155,10 +150,11 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
                 }
             }
             if (req.empty()) break;
-            // The tail: once a round asks for fewer than `flush_below` edges, only a few preclusters with long chains of
-            // representatives are still open, and every further round costs the callee a launch's latency for a handful
-            // of pairs (10 000 genomes: rounds of 468, 85, 12 and 3 pairs after the first three).  Ask for everything
-            // those preclusters still lack, once -- they then finish without another round.
+            // Once a round asks for fewer than `flush_below` edges -- a small input's first round, or the tail of a large one,
+            // where only a few preclusters with long chains of representatives are still open (10 000 genomes: rounds of
+            // 468, 85, 12 and 3 pairs after the first three) -- every further round would cost a launch's latency for a
+            // handful of pairs.  Ask for everything the open preclusters still lack, once: they finish without another round.
+            // (1 000 genomes, 4 500 edges: rounds of 900, 520 and 476 = 1.3 ms; everything in one round 1.6 ms.)
             if (req.size() < flush_below)
                 for (size_t s = 0; s < nsets; s++) {
                     const uint32_t *orig = members.data() + set_start[s];

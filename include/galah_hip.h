@@ -280,10 +280,9 @@ int ghip_cluster(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, const
  * answers every request: edge_index[x] = index into `pairs`, out_ani[x] = ANI in the clusterer's unit (NaN = None);
  * return 0, or non-zero to abort (GHIP_ECALLBACK).  Rounds = (most representatives in one precluster) + 1.  Same
  * clusters as ghip_cluster with pair_ani for every pair.  *out_pairs_requested (nullable) = pairs asked in total.
- * A pair list of at most 8192 entries (environment GHIP_LAZY_ALL_BELOW) is asked for whole in ONE round: a round costs a
- * GPU callee one launch's latency however few pairs it holds, which is more than the skipped pairs are worth there.  For
- * the same reason a round of fewer than 512 requests (GHIP_LAZY_FLUSH_BELOW) also asks for everything the still-open
- * preclusters lack, so that the tail of the computation is one round instead of several tiny ones. */
+ * A round costs a GPU callee one launch's latency however few pairs it holds, so a round of fewer than 512 requests
+ * (environment GHIP_LAZY_FLUSH_BELOW) also asks for everything the still-open preclusters lack: a small input is asked for
+ * whole in its first round, the tail of a large one is one round instead of several tiny ones. */
 typedef int (*ghip_ani_batch_callback)(void *user, const uint32_t *edge_index, size_t n, float *out_ani);
 int ghip_cluster_lazy(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, float ani_threshold,
                       ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members, uint64_t **out_offsets,

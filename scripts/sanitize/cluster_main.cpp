@@ -22,8 +22,7 @@ int main() {
                 for (size_t x = 0; x < k; x++) out[x] = (*s->ani)[e[x]];
                 return 0;
             };
-            setenv("GHIP_LAZY_ALL_BELOW", rep % 2 ? "0" : "100000", 1);
-            setenv("GHIP_LAZY_FLUSH_BELOW", rep % 3 ? "512" : "0", 1);
+            setenv("GHIP_LAZY_FLUSH_BELOW", rep % 3 == 0 ? "0" : (rep % 3 == 1 ? "16" : "100000"), 1);
             uint32_t *m2 = nullptr; uint64_t *o2 = nullptr; size_t nc2 = 0; uint64_t asked = 0;
             const int rc2 = ghip_cluster_lazy(n, pairs.data(), pairs.size(), 95.0f, cb, &st, &m2, &o2, &nc2, &asked);
             if (rc2 != rc) { printf("BAD lazy rc %d != %d\n", rc2, rc); return 1; }

@@ -66,14 +66,12 @@ int main(int argc, char **argv) {
         auto clusters = sorted(galah::cluster(abisko, pre, cl));
         CHECK((clusters == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(pre.last_edges.size() == 6);
-        // a list this short is asked for whole, in one batch; with that shortcut off the HIP clusterer is asked lazily:
+        // a round this short is topped up with every edge still open (one batch); with that off the HIP clusterer is asked lazily:
         // genome 0 is the representative, only its 3 edges are ever looked at
         CHECK(galah::last_ani_pairs_requested() == 6);
-        setenv("GHIP_LAZY_ALL_BELOW", "0", 1);
         setenv("GHIP_LAZY_FLUSH_BELOW", "0", 1);
         CHECK((sorted(galah::cluster(abisko, pre, cl)) == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(galah::last_ani_pairs_requested() == 3);
-        unsetenv("GHIP_LAZY_ALL_BELOW");
         unsetenv("GHIP_LAZY_FLUSH_BELOW");
     }
     {   // src/clusterer.rs:661-690: at 99 -> [[0,1,3],[2]]

@@ -231,12 +231,11 @@ def test_ani_callback_exception_propagates():
 @pytest.mark.parametrize("seed", range(8))
 def test_lazy_batched_clusterer_equals_full(seed, monkeypatch):
     """ghip_cluster_lazy asks only for precluster pairs that touch a representative, in rounds -- and returns the
-    clusters of the oracle's run of the reference's greedy algorithm with every ANI known.  (Short edge lists are asked
-    for whole in one round -- a round costs the GPU callee a launch's latency: GHIP_LAZY_ALL_BELOW, default 8192 edges;
-    every second case here runs with that shortcut off.)"""
+    clusters of the oracle's run of the reference's greedy algorithm with every ANI known.  (A round of fewer than
+    GHIP_LAZY_FLUSH_BELOW = 512 requests is topped up with everything the open preclusters lack -- a round costs the GPU
+    callee a launch's latency; here: off, default, and so large that the first round asks for everything.)"""
     all_at_once = seed % 2 == 1
-    monkeypatch.setenv("GHIP_LAZY_ALL_BELOW", "1000000" if all_at_once else "0")
-    monkeypatch.setenv("GHIP_LAZY_FLUSH_BELOW", "0" if seed % 4 == 0 else "512")   # the tail flush: on for most cases
+    monkeypatch.setenv("GHIP_LAZY_FLUSH_BELOW", "1000000" if all_at_once else ("0" if seed % 4 == 0 else "12"))
     rng = np.random.default_rng(100 + seed)
     n = int(rng.integers(5, 160))
     pairs = _random_graph(rng, n, rng.uniform(0.2, 0.95), int(rng.integers(1, 9)))

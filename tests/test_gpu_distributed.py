@@ -88,8 +88,7 @@ def test_lazy_ani_on_one_rank_equals_all_pairs(ctx, monkeypatch):
     """One rank asks the clusterer's ANI lazily and in batches (ghip_cluster_lazy: only pairs touching a representative,
     the reference's laziness): same clusters as computing every precluster pair's ANI, with fewer pairs asked."""
     from galah_amd.distributed import DereplicationJob
-    monkeypatch.setenv("GHIP_LAZY_ALL_BELOW", "0")   # lists this short are otherwise asked for whole, in one round
-    monkeypatch.setenv("GHIP_LAZY_FLUSH_BELOW", "0")  # ... and short rounds topped up with everything still open
+    monkeypatch.setenv("GHIP_LAZY_FLUSH_BELOW", "0")  # (short rounds are otherwise topped up with everything still open)
     for n, members, length, min_ani in ((N, MEMBERS, LENGTH, 0.9), (120, 8, 60_000, 0.9), (40, 3, 40_000, 0.0)):
         out = []
         for lazy in (False, True):
