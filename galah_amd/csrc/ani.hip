@@ -190,8 +190,7 @@ __device__ unsigned long long g_ani_phase[16];
 #else
 #define PH(i) do {} while (0)
 #endif
-constexpr uint32_t ANI_PAIR_THREADS = 512;
-constexpr uint32_t ANI_PAIR_WAVES = ANI_PAIR_THREADS / 64;
+constexpr uint32_t ANI_PAIR_WAVES_WIDE = 8, ANI_PAIR_WAVES_TALL = 16;   // waves per pair: 8 for long pair lists, 16 for short ones
 constexpr uint32_t ANI_STAGE = 192;  // seeds of one round's consecutive bins staged per wave and genome (rounds are sized for ~150)
 constexpr uint32_t ANI_BAND_SHIFT = 12, ANI_MIN_COLINEAR = 3;   // 4 kb diagonal bands; >= 3 seeds of a chunk must agree (oracle: GO_ANI_*)
 constexpr uint32_t ANI_VOTE_WORDS = 9;                          // per chunk: 16 bands x u16, then the repeat-seed counter
@@ -250,7 +249,11 @@ __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *vo
 // lane then joins its own seeds out of LDS.  (Walking the bins straight from global memory chained
 // ~25 dependent L2 round trips per lane and bin.)  A round whose run exceeds the stage -- a
 // pathologically repetitive or a very large genome -- falls back to the global-memory walk for that round only.
-__global__ __launch_bounds__(ANI_PAIR_THREADS) void ani_pairs_kernel(
+// WAVES wavefronts share a pair, each a slice of the bins.  Long pair lists run 8 (three workgroups per CU: throughput); a
+// list the chip holds at once anyway runs 16 -- half the rounds per wave, i.e. about half a pair's latency, which is all
+// a short launch costs (the lazy clusterer's rounds, a single calculate_ani).
+template <uint32_t ANI_PAIR_WAVES>
+__global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
     const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ seed_code,
     const uint32_t *__restrict__ seed_loc, const uint64_t *__restrict__ seed_start,
     const uint32_t *__restrict__ bin_start, const uint32_t *__restrict__ chunk_total,
@@ -531,6 +534,33 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
     ghip_prof_end(ctx);
 }
 
+namespace {
+// dynamic LDS of a launch with WAVES waves per pair, 0 if it does not fit next to the kernel's static arrays
+template <uint32_t WAVES>
+size_t ani_pairs_lds(uint32_t max_chunks, uint32_t &ro_cap) {
+    constexpr size_t STATIC_LDS = (size_t)WAVES * (2 * (ANI_STAGE + 8) + 2 * ANI_STAGE + ANI_STAGE / 2) * 4 + 256;   // seed stage + band masks
+    const size_t per_chunk = ANI_VOTE_WORDS * sizeof(uint32_t) + sizeof(uint64_t);   // votes + aligned-chunk list entry
+    const size_t fixed = (size_t)2 * max_chunks * per_chunk + 24;
+    if (fixed + (size_t)WAVES * ro_cap * sizeof(uint16_t) > 160 * 1024 - STATIC_LDS) ro_cap = 66;   // no room for the wide rounds' offset table
+    const size_t lds = fixed + (size_t)WAVES * ro_cap * sizeof(uint16_t);   // + r-bin offsets of a round
+    return lds > 160 * 1024 - STATIC_LDS ? 0 : lds;
+}
+
+template <uint32_t WAVES>
+void ani_pairs_launch(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs, size_t lds,
+                      uint32_t ro_cap, uint64_t *d_out) {
+    static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand
+    if (lds > attr_lds) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
+    hipLaunchKernelGGL(ani_pairs_kernel<WAVES>, dim3(grid), dim3(WAVES * 64), lds, ctx->stream, d_pairs, (uint32_t)n_pairs,
+                       idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
+                       idx->d_chunk_start, idx->d_glen, idx->chunk, ro_cap, d_out);
+}
+}  // namespace
+
 void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
                            uint32_t max_chunks, uint64_t *d_out) {
     if (n_pairs == 0) return;
@@ -538,20 +568,17 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
     // costs 16 KiB of LDS per workgroup, which large-genome runs keep for a third resident workgroup per CU
     uint32_t ro_cap = 66;
     for (uint32_t c : idx->seed_count) if (c <= 12000) { ro_cap = 1026; break; }
-    constexpr size_t STATIC_LDS = 30 * 1024;   // seed stage (code + loc, both genomes) + band masks, rounded up
-    const size_t per_chunk = ANI_VOTE_WORDS * sizeof(uint32_t) + sizeof(uint64_t);   // votes + aligned-chunk list entry
-    if ((size_t)2 * max_chunks * per_chunk + 24 + (size_t)ANI_PAIR_WAVES * 1026 * 2 > 160 * 1024 - STATIC_LDS) ro_cap = 66;
-    const size_t lds = (size_t)2 * max_chunks * per_chunk + 24 + (size_t)ANI_PAIR_WAVES * ro_cap * sizeof(uint16_t);   // + r-bin offsets of a round
-    static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand
-    if (lds > attr_lds) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    // 16 waves per pair while there are fewer pairs than CUs (GHIP_ANI_TALL_BELOW; 0 = never).  Measured, 8 -> 16 waves:
+    // 8 pairs 0.133 -> 0.095 ms, 96 pairs 0.168 -> 0.122, but 384 pairs 0.192 -> 0.235 and 1 536 pairs 0.44 -> 0.64.
+    static const size_t tall_below = [] { const char *e = getenv("GHIP_ANI_TALL_BELOW"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)200; }();
     ghip_prof_begin(ctx, "ani_pairs");
-    const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
-    hipLaunchKernelGGL(ani_pairs_kernel, dim3(grid), dim3(ANI_PAIR_THREADS), lds, ctx->stream, d_pairs, (uint32_t)n_pairs,
-                       idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
-                       idx->d_chunk_start, idx->d_glen, idx->chunk, ro_cap, d_out);
+    uint32_t ro_tall = ro_cap;
+    const size_t lds_tall = n_pairs < tall_below ? ani_pairs_lds<ANI_PAIR_WAVES_TALL>(max_chunks, ro_tall) : 0;
+    if (lds_tall) ani_pairs_launch<ANI_PAIR_WAVES_TALL>(ctx, idx, d_pairs, n_pairs, lds_tall, ro_tall, d_out);
+    else {
+        const size_t lds = ani_pairs_lds<ANI_PAIR_WAVES_WIDE>(max_chunks, ro_cap);   // (always fits: GHIP_ANI_MAX_CHUNKS)
+        ani_pairs_launch<ANI_PAIR_WAVES_WIDE>(ctx, idx, d_pairs, n_pairs, lds, ro_cap, d_out);
+    }
     ghip_prof_end(ctx);
 #ifdef GHIP_DBG_ANI_PHASES
     {
