@@ -570,7 +570,8 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
     for (uint32_t c : idx->seed_count) if (c <= 12000) { ro_cap = 1026; break; }
     // 16 waves per pair while there are fewer pairs than CUs (GHIP_ANI_TALL_BELOW; 0 = never).  Measured, 8 -> 16 waves:
     // 8 pairs 0.133 -> 0.095 ms, 96 pairs 0.168 -> 0.122, but 384 pairs 0.192 -> 0.235 and 1 536 pairs 0.44 -> 0.64.
-    static const size_t tall_below = [] { const char *e = getenv("GHIP_ANI_TALL_BELOW"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)200; }();
+    const char *tb = getenv("GHIP_ANI_TALL_BELOW");   // (read per launch: the tests switch it)
+    const size_t tall_below = tb ? (size_t)strtoull(tb, nullptr, 10) : (size_t)200;
     ghip_prof_begin(ctx, "ani_pairs");
     uint32_t ro_tall = ro_cap;
     const size_t lds_tall = n_pairs < tall_below ? ani_pairs_lds<ANI_PAIR_WAVES_TALL>(max_chunks, ro_tall) : 0;

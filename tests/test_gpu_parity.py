@@ -163,6 +163,27 @@ def test_ani_pairs_vs_oracle(ctx):
     assert all(v == 0.0 for v in diff)                # unrelated genomes fail the aligned-fraction gate
 
 
+def test_ani_pairs_both_workgroup_shapes(ctx, monkeypatch):
+    """Short pair lists run 16 waves per pair, long ones 8 (ani.hip): the same values either way -- on genomes of very
+    different sizes (rounds of 64 bins and of 1024), with sparse and dense seeds."""
+    g = ctx.genomes_synthetic(4, 3, 4, 700_000, 0.03)
+    small = ctx.genomes_synthetic(5, 4, 3, 9_000, 0.02)
+    for genomes, c in ((g, 125), (g, 7), (small, 30)):
+        n = len(genomes)
+        idx = ctx.ani_index_build(genomes, 15, c, 20000)
+        pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.uint32)
+        monkeypatch.setenv("GHIP_ANI_TALL_BELOW", "0")
+        want, want_af = ctx.ani_pairs(idx, pairs, 0.15, want_af=True)
+        assert (want > 90).sum() >= n
+        monkeypatch.setenv("GHIP_ANI_TALL_BELOW", "1000000")
+        got, got_af = ctx.ani_pairs(idx, pairs, 0.15, want_af=True)
+        assert np.array_equal(got, want) and np.array_equal(got_af, want_af), c
+        monkeypatch.delenv("GHIP_ANI_TALL_BELOW")
+        for m in (1, 3, 90, len(pairs)):
+            assert np.array_equal(ctx.ani_pairs(idx, pairs[:m], 0.15), want[:m]), m
+        idx.free()
+
+
 def test_ani_on_fixture_files_vs_oracle(ctx):
     names = ["abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13", "antonio_MAG52"]
     cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=4)
