@@ -58,6 +58,7 @@ void ghip_io_pool::run(int n, std::function<void(int)> fn) {
     while ((int)threads.size() < n) {
         const int id = (int)threads.size();
         raw.emplace_back();
+        ascii.emplace_back();
         threads.emplace_back([this, id] {
             uint64_t seen = 0;
             for (;;) {
@@ -89,6 +90,7 @@ void ghip_io_pool::shutdown() {
     for (auto &t : threads) t.join();
     threads.clear();
     raw.clear();
+    ascii.clear();
 }
 
 static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
@@ -101,7 +103,7 @@ static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     hipSetDevice(ctx->device);
     ctx->io.shutdown();
     for (auto &b : ctx->pool) hipFree(b.p);
-    for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+    for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); if (sl.d) hipFree(sl.d); }
     for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -582,7 +584,13 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         // caller offers is used, up to ~1.5x the CPUs the process may actually use (below).
         {
             const char *mt = getenv("GHIP_INGEST_THREADS_PLAIN");
-            const int plain_cap = mt ? std::max(1, atoi(mt)) : 12;
+            // (the ASCII form is PCIe-bound: a dozen readers; the packed form ships a quarter of the bytes and is bound
+            // by the CPUs the process may use -- 1 000 x 5 Mb on the 16-CPU-quota boxes: 127 / 90 / 78 / 74 / 86 / 94 ms
+            // with 8 / 12 / 16 / 20 / 24 / 32 readers)
+            const char *form = getenv("GHIP_INGEST");
+            const bool ascii_form = form && (!strcmp(form, "ascii") || !strcmp(form, "pageable"));
+            const double q = ghip_cpu_quota();
+            const int plain_cap = mt ? std::max(1, atoi(mt)) : (ascii_form ? 12 : (q > 0 ? std::max(8, (int)(q * 1.25 + 0.5)) : 16));
             if (n_gz == 0) threads = std::min(threads, plain_cap);
             else {
                 // ... of the CPUs the process may actually use: under a cgroup quota (the GPU boxes: 256 logical CPUs, 16
@@ -622,6 +630,12 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         bool use_pinned = !(ing && !strcmp(ing, "pageable"));
         for (int x = 0; x < ctx->n_copy_streams; x++) use_pinned = use_pinned && ctx->copy_stream[x];
         const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, GHIP_PINNED_SLOT_MAX);
+        // Packed form (the default; GHIP_INGEST=ascii turns it off): the stream crosses PCIe as 2-bit codes plus the runs
+        // of its other bytes -- a quarter of the bytes, and PCIe is what bounds files -> clusters (5 GB: 88 ms) -- into a
+        // device staging area that belongs to the slot, and is expanded there into the resident one-byte-per-base stream
+        // by a kernel queued behind the copy on the same copy stream (sketch.hip: unpack_bases_kernel).
+        const bool packed_mode = use_pinned && !(ing && !strcmp(ing, "ascii"));
+        const size_t stage_bytes = (slot_bytes / 4 + (64u << 10) + 4095) / 4096 * 4096;   // + room for ~5 000 runs
         size_t n_slots = 0;
         if (use_pinned) {
             const size_t want = std::min<size_t>(GHIP_PINNED_SLOTS, (size_t)2 * threads);
@@ -635,11 +649,18 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                     else { sl.p = nullptr; (void)hipGetLastError(); }
                 }
                 if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) sl.ev = nullptr;
+                if (packed_mode && x < want && sl.dbytes < stage_bytes) {
+                    if (sl.d) hipFree(sl.d);
+                    sl.d = nullptr; sl.dbytes = 0;
+                    if (hipMalloc((void **)&sl.d, stage_bytes) == hipSuccess) sl.dbytes = stage_bytes;
+                    else { sl.d = nullptr; (void)hipGetLastError(); }
+                }
                 sl.state = 0;
             }
             // usable slots first
-            std::stable_partition(ctx->ingest_slots.begin(), ctx->ingest_slots.end(), [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= slot_bytes; });
-            for (auto &sl : ctx->ingest_slots) if (sl.p && sl.ev && sl.bytes >= slot_bytes) n_slots++;
+            auto usable = [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= slot_bytes && (!packed_mode || sl.dbytes >= stage_bytes); };
+            std::stable_partition(ctx->ingest_slots.begin(), ctx->ingest_slots.end(), usable);
+            for (auto &sl : ctx->ingest_slots) if (usable(sl)) n_slots++;
             n_slots = std::min(n_slots, want);
         }
         const double w_pin = since(w0) - w_hint - w_alloc;
@@ -683,12 +704,15 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 const auto t1 = std::chrono::steady_clock::now();
                 size_t len = 0;
                 std::string e;
-                ghip_ctx::pinned_slot *slot = (n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
+                const bool pack_this = packed_mode && n_slots && cap[i] + 64 <= slot_bytes;
+                // packed: parse into the worker's own buffer, take a slot only for the (short) packing step
+                ghip_ctx::pinned_slot *slot = (!pack_this && n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
                 uint8_t *stream_buf;
                 if (slot) stream_buf = slot->p;
                 else {
-                    if (heap_buf.size() < (size_t)cap[i] + 64) heap_buf.resize((size_t)cap[i] + 64);
-                    stream_buf = heap_buf.data();
+                    std::vector<uint8_t> &hb = pack_this ? ctx->io.ascii[me] : heap_buf;
+                    if (hb.size() < (size_t)cap[i] + 64) hb.resize((size_t)cap[i] + 64);
+                    stream_buf = hb.data();
                 }
                 const auto t1b = std::chrono::steady_clock::now();
                 const int r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf, (size_t)cap[i], &len, g->stats[i], e);
@@ -701,7 +725,27 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 else {
                     g->lens[i] = len;
                     hipError_t ce = hipSuccess;
-                    if (len && slot) {
+                    bool shipped = false;
+                    if (len && pack_this) {
+                        slot = take_slot();
+                        size_t used = 0, runs_off = 0;
+                        uint32_t n_runs = 0;
+                        if (ghip_pack_stream(stream_buf, len, slot->p, std::min(slot->bytes, slot->dbytes), &used, &runs_off, &n_runs)) {
+                            ce = hipMemcpyAsync(slot->d, slot->p, used, hipMemcpyHostToDevice, cs);
+                            if (ce == hipSuccess) {
+                                ghip_launch_unpack_bases(cs, slot->d, reinterpret_cast<const uint32_t *>(slot->d + runs_off), n_runs,
+                                                         g->d_bytes + g->starts[i], len);
+                                ce = hipEventRecord(slot->ev, cs);
+                                inflight = true;
+                            }
+                            shipped = true;
+                        } else {   // more runs than the staging area holds (or a stream of 4 GB): this one goes as it is
+                            give_slot(slot, 0);
+                            slot = nullptr;
+                        }
+                    }
+                    if (shipped) {
+                    } else if (len && slot) {
                         ce = hipMemcpyAsync(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice, cs);
                         if (ce == hipSuccess) { ce = hipEventRecord(slot->ev, cs); inflight = true; }
                     } else if (len) ce = hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice);

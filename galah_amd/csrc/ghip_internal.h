@@ -45,6 +45,7 @@ struct ghip_cmin_cache {  // device filter table of ghip_precluster, keyed by (m
 struct ghip_io_pool {
     std::vector<std::thread> threads;
     std::vector<std::vector<uint8_t>> raw;   // one read / inflate buffer per worker, kept mapped
+    std::vector<std::vector<uint8_t>> ascii; // one parse buffer per worker (packed ingest: parse here, pack into the pinned slot)
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::function<void(int)> job;
@@ -74,7 +75,8 @@ struct ghip_ctx {
     uint64_t *d_kmer_luts = nullptr;  // MurmurHash3 first-stage tables of sketch_kmers21 (12 KiB, built once; pool-owned)
     // ingest staging (ghip_genomes_from_files): pinned double buffers of the worker threads and two copy streams, kept
     // for the life of the context (hipHostMalloc costs ~0.16 ms/MB, hipStreamCreate ~3 ms)
-    struct pinned_slot { uint8_t *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; int state = 0; uint64_t seq = 0; };   // state: 0 free, 1 owned by a thread, 2 copy in flight (seq = issue order)
+    struct pinned_slot { uint8_t *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; int state = 0; uint64_t seq = 0;
+                         uint8_t *d = nullptr; size_t dbytes = 0; };   // d: device staging of the packed form (same life as p)   // state: 0 free, 1 owned by a thread, 2 copy in flight (seq = issue order)
     std::vector<pinned_slot> ingest_slots;
     ghip_io_pool io;
     std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
@@ -184,6 +186,11 @@ struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the 
 };
 
 void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes);
+// packed ingest (sketch.hip / ingest.cpp): 2-bit codes + runs of the bytes that are not A/C/G/T -> the one-byte-per-base stream
+void ghip_launch_unpack_bases(hipStream_t stream, const uint8_t *d_packed, const uint32_t *d_runs, uint32_t n_runs, uint8_t *d_out, uint64_t len);
+// packs stream[0, len) into dst: ceil(len / 4) bytes rounded up to 16, then the run table (3 x u32 each) -- false if
+// dst_bytes is too small or len >= 2^32.  *used = bytes written, *runs_off = offset of the table, *n_runs its entries
+bool ghip_pack_stream(const uint8_t *stream, size_t len, uint8_t *dst, size_t dst_bytes, size_t *used, size_t *runs_off, uint32_t *n_runs);
 int ghip_launch_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *ms);
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,

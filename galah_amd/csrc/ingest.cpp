@@ -235,6 +235,69 @@ int ghip_parse_fasta(const uint8_t *buf, size_t n, const char *path, uint8_t *ou
     return GHIP_OK;
 }
 
+// 2-bit packing of a device-format stream for the trip over PCIe (sketch.hip: unpack_bases_kernel has the layout).  The
+// fast path turns 32 A/C/G/T bytes into 8 packed bytes with a dozen AVX2 instructions; a block holding anything else
+// (the 'N' after a record, ambiguity codes, gaps) goes byte by byte and extends the run table.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) static size_t pack_acgt_avx2(const uint8_t *src, size_t len, uint8_t *dst) {
+    const __m256i A = _mm256_set1_epi8('A'), C = _mm256_set1_epi8('C'), G = _mm256_set1_epi8('G'), T = _mm256_set1_epi8('T');
+    const __m256i three = _mm256_set1_epi8(3), m14 = _mm256_set1_epi16(0x0401), m116 = _mm256_set1_epi32(0x00100001);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                          0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    size_t q = 0;
+    for (; q + 32 <= len; q += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(src + q));
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, A), _mm256_cmpeq_epi8(v, C)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(v, G), _mm256_cmpeq_epi8(v, T)));
+        if (_mm256_movemask_epi8(ok) != -1) break;
+        const __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
+        const __m256i p2 = _mm256_maddubs_epi16(code, m14);          // c0 + 4 c1 per 16-bit lane
+        const __m256i p4 = _mm256_madd_epi16(p2, m116);              // + 16 (c2 + 4 c3) per 32-bit lane: one packed byte
+        const __m256i b = _mm256_shuffle_epi8(p4, pick);             // the four packed bytes of each half in its low dword
+        const uint32_t lo = (uint32_t)_mm256_cvtsi256_si32(b), hi = (uint32_t)_mm256_extract_epi32(b, 4);
+        memcpy(dst + q / 4, &lo, 4);
+        memcpy(dst + q / 4 + 4, &hi, 4);
+    }
+    return q;   // bases packed (a multiple of 32)
+}
+#else
+static size_t pack_acgt_avx2(const uint8_t *, size_t, uint8_t *) { return 0; }
+#endif
+
+bool ghip_pack_stream(const uint8_t *stream, size_t len, uint8_t *dst, size_t dst_bytes, size_t *used, size_t *runs_off, uint32_t *n_runs) {
+    if (len >= (1ull << 32)) return false;
+    const size_t packed_bytes = ((len + 3) / 4 + 15) / 16 * 16;
+    if (packed_bytes + 12 > dst_bytes) return false;
+    uint32_t *runs = reinterpret_cast<uint32_t *>(dst + packed_bytes);
+    const size_t max_runs = (dst_bytes - packed_bytes) / 12;
+    size_t nr = 0;
+    memset(dst + (len / 4), 0, packed_bytes - len / 4);   // the partly filled byte and the padding
+    size_t p = 0;
+    while (p < len) {
+        if (kHaveAvx2 && (p & 3) == 0) p += pack_acgt_avx2(stream + p, len - p, dst + p / 4);
+        // up to the next multiple of 32 (or the end) byte by byte
+        const size_t stop = std::min(len, (p & ~(size_t)31) + 32);
+        for (; p < stop; p++) {
+            const uint8_t c = stream[p];
+            uint32_t code = 0;
+            if (c == 'A' || c == 'C' || c == 'G' || c == 'T') code = ((c >> 1) ^ (c >> 2)) & 3u;
+            else if (nr && runs[3 * (nr - 1) + 2] == c && (size_t)runs[3 * (nr - 1)] + runs[3 * (nr - 1) + 1] == p) runs[3 * (nr - 1) + 1]++;
+            else {
+                if (nr == max_runs) return false;
+                runs[3 * nr] = (uint32_t)p; runs[3 * nr + 1] = 1; runs[3 * nr + 2] = c;
+                nr++;
+            }
+            const size_t bit = 2 * (p & 3);
+            if (bit == 0) dst[p / 4] = (uint8_t)code;
+            else dst[p / 4] |= (uint8_t)(code << bit);
+        }
+    }
+    *used = packed_bytes + 12 * nr;
+    *runs_off = packed_bytes;
+    *n_runs = (uint32_t)nr;
+    return true;
+}
+
 // Reads a whole file (plain or gzip) into `buf`.
 bool ghip_slurp(const char *path, std::vector<uint8_t> &buf) { return slurp(path, buf); }
 

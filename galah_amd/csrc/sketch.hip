@@ -620,6 +620,43 @@ void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts
     ghip_prof_end(ctx);
 }
 
+// ---- packed ingest: files cross PCIe as 2-bit codes (a quarter of the bytes), the resident stream stays one byte per
+// base.  packed[i / 4] holds base i in bits 2 (i % 4) .. +1 (A0 C1 G2 T3, what ingest.cpp: ghip_pack_stream writes);
+// every stream byte that is not A/C/G/T (the 'N' after each record, ambiguity codes, gaps) travels as a run
+// (start, length, byte) and is patched in afterwards.  Bytes from `len` to the end of the last 16-byte group get 'N',
+// which is what the whole buffer was filled with.
+__global__ __launch_bounds__(256) void unpack_bases_kernel(const uint32_t *__restrict__ packed, uint4 *__restrict__ out, uint64_t len) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 16 bases per thread
+    if (16 * t >= len) return;
+    const uint32_t w = packed[t];
+    uint32_t a[4] = {ascii4(w & 0xffu), ascii4((w >> 8) & 0xffu), ascii4((w >> 16) & 0xffu), ascii4(w >> 24)};
+    const uint64_t left = len - 16 * t;
+    if (left < 16) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int have = (int)left - 4 * q;   // valid bytes of word q
+            if (have <= 0) a[q] = 0x4e4e4e4eu;
+            else if (have < 4) a[q] = (a[q] & (0xffffffffu >> (8 * (4 - have)))) | (0x4e4e4e4eu << (8 * have));
+        }
+    }
+    out[t] = make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+__global__ __launch_bounds__(64) void patch_runs_kernel(const uint32_t *__restrict__ runs /* start, len, byte */, uint8_t *__restrict__ out) {
+    const uint32_t start = runs[3 * blockIdx.x], n = runs[3 * blockIdx.x + 1];
+    const uint8_t b = (uint8_t)runs[3 * blockIdx.x + 2];
+    for (uint32_t k = threadIdx.x; k < n; k += 64) out[(uint64_t)start + k] = b;
+}
+
+// both on `stream`, in this order, after the copy that brought `d_packed` and `d_runs`
+void ghip_launch_unpack_bases(hipStream_t stream, const uint8_t *d_packed, const uint32_t *d_runs, uint32_t n_runs, uint8_t *d_out, uint64_t len) {
+    if (len == 0) return;
+    const uint64_t groups = (len + 15) / 16;
+    hipLaunchKernelGGL(unpack_bases_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(d_packed), reinterpret_cast<uint4 *>(d_out), len);
+    if (n_runs) hipLaunchKernelGGL(patch_runs_kernel, dim3(n_runs), dim3(64), 0, stream, d_runs, d_out);
+}
+
 void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes /* multiple of 16 */) {
     const uint64_t n16 = n_bytes / 16;
     if (n16 == 0) return;

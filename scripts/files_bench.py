@@ -36,6 +36,10 @@ del g
 thread_list = [int(x) for x in os.environ.get("GHIP_FILES_BENCH_THREADS", str(T)).split(",")]
 for rep in range(int(os.environ.get("GHIP_FILES_BENCH_REPS", "2")) * len(thread_list)):
     T = thread_list[rep % len(thread_list)]
+    if os.environ.get("GHIP_FILES_BENCH_PLAIN_CAPS"):   # sweep the reader cap for plain files
+        caps = os.environ["GHIP_FILES_BENCH_PLAIN_CAPS"].split(",")
+        os.environ["GHIP_INGEST_THREADS_PLAIN"] = caps[rep % len(caps)]
+        print("plain cap", os.environ["GHIP_INGEST_THREADS_PLAIN"], end="  ")
     if os.environ.get("GHIP_FILES_BENCH_ALTERNATE"):   # A/B of the batch pipeline inside one process
         os.environ["GHIP_PIPELINE"] = "1" if rep % 2 == 0 else "0"
         print("GHIP_PIPELINE =", os.environ["GHIP_PIPELINE"], end="  ")

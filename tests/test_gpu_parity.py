@@ -668,13 +668,20 @@ def test_ingest_forms_agree(ctx, tmp_path, monkeypatch):
     want_st = [oracle.genome_stats(p) for p in paths]
     for p in paths[1:5]:
         assert np.array_equal(oracle.sketch_file(p), want_sk[0])   # all forms hold the same records
-    for form in ("pipelined", "two-phase"):
+    streams = {}
+    for form in ("pipelined", "ascii", "two-phase"):   # pipelined = 2-bit packed over PCIe, expanded on the device
         monkeypatch.setenv("GHIP_INGEST", form)
         g = ctx.genomes_from_files(paths, 3)
         hashes, lens = ctx.sketch_genomes(g, 21, 1000, 0).to_host()
         for i, p in enumerate(paths):
             assert lens[i] == len(want_sk[i]) and np.array_equal(hashes[i, : lens[i]], want_sk[i]), (form, p)
             assert g.stats(i) == want_st[i], (form, p)
+        streams[form] = [g.to_host(i).tobytes() for i in range(len(paths))]
+    # the resident streams are the same bytes whichever way they travelled (IUPAC codes, gaps, the 'N' after a record)
+    assert streams["pipelined"] == streams["ascii"] == streams["two-phase"]
+    assert b"-" in streams["pipelined"][0] and streams["pipelined"][0].count(b"N") > 100
+    for i, p in enumerate(paths):   # ... and the host parser's (ghip_fasta_stream, no GPU involved)
+        assert streams["pipelined"][i] == galah_amd.fasta_stream(p)[0].tobytes(), p
     with pytest.raises(galah_amd.GalahHipError):
         ctx.genomes_from_files([str(tmp_path / "missing.fna")], 1)
     bad = tmp_path / "notfasta.fna"
