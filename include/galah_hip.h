@@ -78,7 +78,9 @@ int ghip_selftest_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *out
 /* ---------------------------------------------------------------- genome ingest
  * Device format of one genome: stream G = for each FASTA record, needletail-normalised bytes
  * followed by one 'N' (k-mers never span records, src/finch.rs:69 -> finch sketch_stream).
- * Any byte other than A,C,G,T breaks k-mers. */
+ * Any byte other than A,C,G,T breaks k-mers.  (From files the stream crosses PCIe as 2-bit codes plus the runs of its
+ * other bytes and is expanded on the device -- the resident form is the one described here; GHIP_INGEST=ascii ships it
+ * as it is.) */
 int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
                             ghip_genomes **out);
 /* Host-only (no GPU, no context): the device-format stream of one FASTA file and its assembly statistics
