@@ -636,16 +636,17 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         // by a kernel queued behind the copy on the same copy stream (sketch.hip: unpack_bases_kernel).
         const bool packed_mode = use_pinned && !(ing && !strcmp(ing, "ascii"));
         const size_t stage_bytes = (slot_bytes / 4 + (64u << 10) + 4095) / 4096 * 4096;   // + room for ~5 000 runs
+        const size_t host_slot_bytes = packed_mode ? stage_bytes : slot_bytes;   // what a pinned slot has to hold
         size_t n_slots = 0;
         if (use_pinned) {
             const size_t want = std::min<size_t>(GHIP_PINNED_SLOTS, (size_t)2 * threads);
             if (ctx->ingest_slots.size() < want) ctx->ingest_slots.resize(want);
             for (size_t x = 0; x < ctx->ingest_slots.size(); x++) {
                 ghip_ctx::pinned_slot &sl = ctx->ingest_slots[x];
-                if (x < want && sl.bytes < slot_bytes) {
+                if (x < want && sl.bytes < host_slot_bytes) {
                     if (sl.p) hipHostFree(sl.p);
                     sl.p = nullptr; sl.bytes = 0;
-                    if (hipHostMalloc((void **)&sl.p, slot_bytes, hipHostMallocDefault) == hipSuccess) sl.bytes = slot_bytes;
+                    if (hipHostMalloc((void **)&sl.p, host_slot_bytes, hipHostMallocDefault) == hipSuccess) sl.bytes = host_slot_bytes;
                     else { sl.p = nullptr; (void)hipGetLastError(); }
                 }
                 if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) sl.ev = nullptr;
@@ -658,7 +659,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 sl.state = 0;
             }
             // usable slots first
-            auto usable = [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= slot_bytes && (!packed_mode || sl.dbytes >= stage_bytes); };
+            auto usable = [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= host_slot_bytes && (!packed_mode || sl.dbytes >= stage_bytes); };
             std::stable_partition(ctx->ingest_slots.begin(), ctx->ingest_slots.end(), usable);
             for (auto &sl : ctx->ingest_slots) if (usable(sl)) n_slots++;
             n_slots = std::min(n_slots, want);
@@ -706,7 +707,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 std::string e;
                 const bool pack_this = packed_mode && n_slots && cap[i] + 64 <= slot_bytes;
                 // packed: parse into the worker's own buffer, take a slot only for the (short) packing step
-                ghip_ctx::pinned_slot *slot = (!pack_this && n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
+                ghip_ctx::pinned_slot *slot = (!packed_mode && n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
                 uint8_t *stream_buf;
                 if (slot) stream_buf = slot->p;
                 else {
