@@ -736,7 +736,8 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                             if (ce == hipSuccess) {
                                 ghip_launch_unpack_bases(cs, slot->d, reinterpret_cast<const uint32_t *>(slot->d + runs_off), n_runs,
                                                          g->d_bytes + g->starts[i], len);
-                                ce = hipEventRecord(slot->ev, cs);
+                                ce = hipGetLastError();   // (per thread: the two launches just made)
+                                if (ce == hipSuccess) ce = hipEventRecord(slot->ev, cs);
                                 inflight = true;
                             }
                             shipped = true;
