@@ -706,32 +706,28 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 size_t len = 0;
                 std::string e;
                 const bool pack_this = packed_mode && n_slots && cap[i] + 64 <= slot_bytes;
-                // packed: parse into the worker's own buffer, take a slot only for the (short) packing step
-                ghip_ctx::pinned_slot *slot = (!packed_mode && n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
-                uint8_t *stream_buf;
-                if (slot) stream_buf = slot->p;
-                else {
-                    std::vector<uint8_t> &hb = pack_this ? ctx->io.ascii[me] : heap_buf;
-                    if (hb.size() < (size_t)cap[i] + 64) hb.resize((size_t)cap[i] + 64);
-                    stream_buf = hb.data();
-                }
-                const auto t1b = std::chrono::steady_clock::now();
-                const int r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf, (size_t)cap[i], &len, g->stats[i], e);
-                const auto t2 = std::chrono::steady_clock::now();
-                t_read += std::chrono::duration<double>(t1 - t0).count();
-                t_parse += std::chrono::duration<double>(t2 - t1b).count();
                 bool stop = false, inflight = false;
-                if (r != GHIP_OK) { fail(r, e); stop = true; }
-                else if (len > cap[i]) { over = true; stop = true; }  // capacity hint too small (multi-member gzip): two-phase form
-                else {
-                    g->lens[i] = len;
-                    hipError_t ce = hipSuccess;
-                    bool shipped = false;
-                    if (len && pack_this) {
-                        slot = take_slot();
-                        size_t used = 0, runs_off = 0;
-                        uint32_t n_runs = 0;
-                        if (ghip_pack_stream(stream_buf, len, slot->p, std::min(slot->bytes, slot->dbytes), &used, &runs_off, &n_runs)) {
+                int r = GHIP_OK;
+                ghip_ctx::pinned_slot *slot = nullptr;
+                std::chrono::steady_clock::time_point t1b = t1, t2 = t1;
+                bool done = false;   // this file has been shipped (or failed) by the packed path
+                if (pack_this) {
+                    // Parse and pack in one pass, straight into a pinned slot (ingest.cpp: ghip_parse_fasta_packed): the
+                    // normalised bytes never leave the L1.  A stream that outgrows its hint or the slot's run table comes
+                    // back "does not fit" and takes the plain path below.
+                    slot = take_slot();
+                    t1b = std::chrono::steady_clock::now();
+                    size_t used = 0, runs_off = 0;
+                    uint32_t n_runs = 0;
+                    bool fit = false;
+                    r = ghip_parse_fasta_packed(raw.data(), raw.size(), paths[i], slot->p, std::min(slot->bytes, slot->dbytes), (size_t)cap[i],
+                                                &len, g->stats[i], e, &used, &runs_off, &n_runs, &fit);
+                    t2 = std::chrono::steady_clock::now();
+                    if (r != GHIP_OK) { fail(r, e); stop = true; done = true; }
+                    else if (fit) {
+                        g->lens[i] = len;
+                        hipError_t ce = hipSuccess;
+                        if (len) {
                             ce = hipMemcpyAsync(slot->d, slot->p, used, hipMemcpyHostToDevice, cs);
                             if (ce == hipSuccess) {
                                 ghip_launch_unpack_bases(cs, slot->d, reinterpret_cast<const uint32_t *>(slot->d + runs_off), n_runs,
@@ -740,19 +736,40 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                                 if (ce == hipSuccess) ce = hipEventRecord(slot->ev, cs);
                                 inflight = true;
                             }
-                            shipped = true;
-                        } else {   // more runs than the staging area holds (or a stream of 4 GB): this one goes as it is
-                            give_slot(slot, 0);
-                            slot = nullptr;
                         }
+                        if (ce != hipSuccess) { fail(GHIP_EHIP, "ingest copy failed"); stop = true; }
+                        done = true;
+                    } else {   // goes as it is
+                        give_slot(slot, 0);
+                        slot = nullptr;
                     }
-                    if (shipped) {
-                    } else if (len && slot) {
-                        ce = hipMemcpyAsync(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice, cs);
-                        if (ce == hipSuccess) { ce = hipEventRecord(slot->ev, cs); inflight = true; }
-                    } else if (len) ce = hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice);
-                    if (ce != hipSuccess) { fail(GHIP_EHIP, "ingest copy failed"); stop = true; }
                 }
+                if (!done) {
+                    slot = (!packed_mode && n_slots && cap[i] + 64 <= slot_bytes) ? take_slot() : nullptr;
+                    uint8_t *stream_buf;
+                    if (slot) stream_buf = slot->p;
+                    else {
+                        std::vector<uint8_t> &hb = packed_mode ? ctx->io.ascii[me] : heap_buf;
+                        if (hb.size() < (size_t)cap[i] + 64) hb.resize((size_t)cap[i] + 64);
+                        stream_buf = hb.data();
+                    }
+                    t1b = std::chrono::steady_clock::now();
+                    r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf, (size_t)cap[i], &len, g->stats[i], e);
+                    t2 = std::chrono::steady_clock::now();
+                    if (r != GHIP_OK) { fail(r, e); stop = true; }
+                    else if (len > cap[i]) { over = true; stop = true; }  // capacity hint too small (multi-member gzip): two-phase form
+                    else {
+                        g->lens[i] = len;
+                        hipError_t ce = hipSuccess;
+                        if (len && slot) {
+                            ce = hipMemcpyAsync(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice, cs);
+                            if (ce == hipSuccess) { ce = hipEventRecord(slot->ev, cs); inflight = true; }
+                        } else if (len) ce = hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice);
+                        if (ce != hipSuccess) { fail(GHIP_EHIP, "ingest copy failed"); stop = true; }
+                    }
+                }
+                t_read += std::chrono::duration<double>(t1 - t0).count();
+                t_parse += std::chrono::duration<double>(t2 - t1b).count();
                 if (slot) give_slot(slot, inflight ? 2 : 0);
                 if (stop) break;
                 t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() + std::chrono::duration<double>(t1b - t1).count();

@@ -191,6 +191,11 @@ void ghip_launch_unpack_bases(hipStream_t stream, const uint8_t *d_packed, const
 // packs stream[0, len) into dst: ceil(len / 4) bytes rounded up to 16, then the run table (3 x u32 each) -- false if
 // dst_bytes is too small or len >= 2^32.  *used = bytes written, *runs_off = offset of the table, *n_runs its entries
 bool ghip_pack_stream(const uint8_t *stream, size_t len, uint8_t *dst, size_t dst_bytes, size_t *used, size_t *runs_off, uint32_t *n_runs);
+// ghip_parse_fasta and ghip_pack_stream in one pass over the file image (the table behind room for cap_hint bases); *fit =
+// false: the stream does not fit that layout, nothing usable was written
+int ghip_parse_fasta_packed(const uint8_t *buf, size_t n, const char *path, uint8_t *dst, size_t dst_bytes, size_t cap_hint,
+                            size_t *out_len, ghip_genome_stats &st, std::string &err, size_t *used, size_t *runs_off,
+                            uint32_t *n_runs, bool *fit);
 int ghip_launch_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *ms);
 void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,

@@ -264,38 +264,141 @@ __attribute__((target("avx2"))) static size_t pack_acgt_avx2(const uint8_t *src,
 static size_t pack_acgt_avx2(const uint8_t *, size_t, uint8_t *) { return 0; }
 #endif
 
+namespace {
+struct RunTable {   // (start, length, byte) of the stream bytes that are not A/C/G/T, in stream order
+    uint32_t *runs = nullptr;
+    size_t n = 0, cap = 0;
+    bool add(size_t pos, uint8_t c) {
+        if (n && runs[3 * (n - 1) + 2] == c && (size_t)runs[3 * (n - 1)] + runs[3 * (n - 1) + 1] == pos) { runs[3 * (n - 1) + 1]++; return true; }
+        if (n == cap) return false;
+        runs[3 * n] = (uint32_t)pos; runs[3 * n + 1] = 1; runs[3 * n + 2] = c;
+        n++;
+        return true;
+    }
+};
+
+// packs src[0, count) = stream[pos0, pos0 + count) into dst (pos0 a multiple of 4; the bytes of dst it touches are overwritten)
+bool pack_range(const uint8_t *src, size_t count, size_t pos0, uint8_t *dst, RunTable &rt) {
+    size_t p = 0;
+    while (p < count) {
+        if (kHaveAvx2 && ((pos0 + p) & 3) == 0) p += pack_acgt_avx2(src + p, count - p, dst + (pos0 + p) / 4);
+        const size_t stop = std::min(count, (p & ~(size_t)31) + 32);   // up to the next multiple of 32 (or the end) byte by byte
+        for (; p < stop; p++) {
+            const uint8_t c = src[p];
+            uint32_t code = 0;
+            if (c == 'A' || c == 'C' || c == 'G' || c == 'T') code = ((c >> 1) ^ (c >> 2)) & 3u;
+            else if (!rt.add(pos0 + p, c)) return false;
+            const size_t q = pos0 + p, bit = 2 * (q & 3);
+            if (bit == 0) dst[q / 4] = (uint8_t)code;
+            else dst[q / 4] |= (uint8_t)(code << bit);
+        }
+    }
+    return true;
+}
+}  // namespace
+
 bool ghip_pack_stream(const uint8_t *stream, size_t len, uint8_t *dst, size_t dst_bytes, size_t *used, size_t *runs_off, uint32_t *n_runs) {
     if (len >= (1ull << 32)) return false;
     const size_t packed_bytes = ((len + 3) / 4 + 15) / 16 * 16;
     if (packed_bytes + 12 > dst_bytes) return false;
-    uint32_t *runs = reinterpret_cast<uint32_t *>(dst + packed_bytes);
-    const size_t max_runs = (dst_bytes - packed_bytes) / 12;
-    size_t nr = 0;
+    RunTable rt{reinterpret_cast<uint32_t *>(dst + packed_bytes), 0, (dst_bytes - packed_bytes) / 12};
     memset(dst + (len / 4), 0, packed_bytes - len / 4);   // the partly filled byte and the padding
-    size_t p = 0;
-    while (p < len) {
-        if (kHaveAvx2 && (p & 3) == 0) p += pack_acgt_avx2(stream + p, len - p, dst + p / 4);
-        // up to the next multiple of 32 (or the end) byte by byte
-        const size_t stop = std::min(len, (p & ~(size_t)31) + 32);
-        for (; p < stop; p++) {
-            const uint8_t c = stream[p];
-            uint32_t code = 0;
-            if (c == 'A' || c == 'C' || c == 'G' || c == 'T') code = ((c >> 1) ^ (c >> 2)) & 3u;
-            else if (nr && runs[3 * (nr - 1) + 2] == c && (size_t)runs[3 * (nr - 1)] + runs[3 * (nr - 1) + 1] == p) runs[3 * (nr - 1) + 1]++;
-            else {
-                if (nr == max_runs) return false;
-                runs[3 * nr] = (uint32_t)p; runs[3 * nr + 1] = 1; runs[3 * nr + 2] = c;
-                nr++;
-            }
-            const size_t bit = 2 * (p & 3);
-            if (bit == 0) dst[p / 4] = (uint8_t)code;
-            else dst[p / 4] |= (uint8_t)(code << bit);
-        }
-    }
-    *used = packed_bytes + 12 * nr;
+    if (!pack_range(stream, len, 0, dst, rt)) return false;
+    *used = packed_bytes + 12 * rt.n;
     *runs_off = packed_bytes;
-    *n_runs = (uint32_t)nr;
+    *n_runs = (uint32_t)rt.n;
     return true;
+}
+
+// The parser of ghip_parse_fasta and the packer in ONE pass: the normalised bytes only ever live in an 8 KiB buffer (L1)
+// before they are packed, instead of being written out whole and read back (a tenth of the ingest's CPU time per file,
+// which is what bounds files -> clusters once the bases cross PCIe packed).  The run table starts behind room for
+// `cap_hint` bases; *fit = false (nothing usable in dst) when the stream outgrows the hint, the table its room, or 4 GB.
+int ghip_parse_fasta_packed(const uint8_t *buf, size_t n, const char *path, uint8_t *dst, size_t dst_bytes, size_t cap_hint,
+                            size_t *out_len, ghip_genome_stats &st, std::string &err, size_t *used, size_t *runs_off,
+                            uint32_t *n_runs, bool *fit) {
+    st = ghip_genome_stats();
+    *out_len = 0; *used = 0; *runs_off = 0; *n_runs = 0;
+    *fit = false;
+    const size_t table_at = ((cap_hint + 3) / 4 + 15) / 16 * 16;
+    if (cap_hint >= (1ull << 32) || table_at + 12 > dst_bytes) return GHIP_OK;
+    RunTable rt{reinterpret_cast<uint32_t *>(dst + table_at), 0, (dst_bytes - table_at) / 12};
+    constexpr size_t BLOCK = 8192;                      // packed whenever the buffer holds this much (a multiple of 32)
+    uint8_t tmp[BLOCK + 4096 + 64];
+    size_t tc = 0, tpos = 0;                            // bytes waiting in tmp; stream position of tmp[0] (a multiple of BLOCK)
+    bool ok = true;
+    auto drain = [&](bool all) {
+        while (ok && (tc >= BLOCK || (all && tc))) {
+            const size_t take = tc >= BLOCK ? BLOCK : tc;
+            if (tpos + take > cap_hint) { ok = false; break; }
+            ok = pack_range(tmp, take, tpos, dst, rt);
+            tc -= take; tpos += take;
+            if (tc) memmove(tmp, tmp + take, tc);
+        }
+    };
+    std::vector<uint64_t> contig_lengths;
+    size_t p = 0;
+    while (p < n && (buf[p] == '\n' || buf[p] == '\r')) p++;
+    if (p == n) { *fit = true; *runs_off = table_at; return GHIP_OK; }  // empty file: empty stream
+    if (buf[p] != '>') { err = std::string("Not a FASTA file (no '>' header): ") + path; return GHIP_EIO; }
+    uint64_t amb = 0;
+    while (p < n && ok) {
+        const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', n - p);  // header line
+        p = nl ? (size_t)(nl - buf) + 1 : n;
+        uint64_t bases = 0;
+        while (p < n && buf[p] != '>' && ok) {  // sequence lines up to the next line that starts with '>'
+            nl = (const uint8_t *)memchr(buf + p, '\n', n - p);
+            const size_t e = nl ? (size_t)(nl - buf) : n;
+            uint64_t cr = 0;
+            for (size_t q = p; q < e && ok;) {       // the line in pieces the buffer has room for
+                const size_t len = std::min<size_t>(e - q, 4096);
+                const size_t crlf = (q + len == e && buf[e - 1] == '\r') ? 1 : 0;   // a CRLF line: the fast path takes the part before the '\r'
+                if (len - crlf >= 32 && kHaveAvx2 && line_acgt_avx2(buf + q, len - crlf, tmp + tc)) {
+                    tc += len - crlf;
+                    cr += crlf;
+                } else {
+                    uint8_t *o = tmp + tc;
+                    size_t w = 0;
+                    for (size_t x = q; x < q + len; x++) {
+                        const uint8_t c = buf[x];
+                        const uint8_t t = kNorm.t[c];
+                        o[w] = t;
+                        w += (t != 0);
+                        amb += (c == 'N') | (c == 'n');
+                        cr += (c == '\r');
+                    }
+                    tc += w;
+                }
+                q += len;
+                drain(false);
+            }
+            bases += (e - p) - cr;
+            p = nl ? e + 1 : n;
+        }
+        tmp[tc++] = 'N';
+        drain(false);
+        st.num_contigs++;
+        contig_lengths.push_back(bases);
+    }
+    drain(true);
+    if (!ok) return GHIP_OK;   // (*fit stays false: the caller takes the two-step path)
+    const size_t m = tpos;
+    if (m % 4) { /* the last, partly filled byte is complete: pack_range wrote it with = for its first base */ }
+    memset(dst + (m + 3) / 4, 0, table_at - (m + 3) / 4);   // padding up to the table (shipped with it)
+    st.num_ambiguous_bases = amb;
+    *out_len = m;
+    std::sort(contig_lengths.begin(), contig_lengths.end());   // genome_stats.rs:33-45: ascending lengths, first running sum >= total/2
+    uint64_t total = 0, run = 0;
+    for (uint64_t l : contig_lengths) total += l;
+    for (uint64_t l : contig_lengths) {
+        run += l;
+        if (run >= total / 2) { st.n50 = l; break; }
+    }
+    *used = table_at + 12 * rt.n;
+    *runs_off = table_at;
+    *n_runs = (uint32_t)rt.n;
+    *fit = true;
+    return GHIP_OK;
 }
 
 // Reads a whole file (plain or gzip) into `buf`.
