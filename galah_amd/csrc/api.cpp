@@ -103,7 +103,8 @@ static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     hipSetDevice(ctx->device);
     ctx->io.shutdown();
     for (auto &b : ctx->pool) hipFree(b.p);
-    for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); if (sl.d) hipFree(sl.d); }
+    for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+    if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
     for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -650,19 +651,28 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                     else { sl.p = nullptr; (void)hipGetLastError(); }
                 }
                 if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) sl.ev = nullptr;
-                if (packed_mode && x < want && sl.dbytes < stage_bytes) {
-                    if (sl.d) hipFree(sl.d);
-                    sl.d = nullptr; sl.dbytes = 0;
-                    if (hipMalloc((void **)&sl.d, stage_bytes) == hipSuccess) sl.dbytes = stage_bytes;
-                    else { sl.d = nullptr; (void)hipGetLastError(); }
-                }
                 sl.state = 0;
             }
+            if (packed_mode) {   // one device allocation for all the staging areas (32 hipMalloc calls cost ~20 ms of a first call)
+                const size_t need = want * stage_bytes;
+                if (ctx->ingest_stage_bytes < need) {
+                    if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
+                    ctx->ingest_stage = nullptr; ctx->ingest_stage_bytes = 0;
+                    if (hipMalloc((void **)&ctx->ingest_stage, need) == hipSuccess) ctx->ingest_stage_bytes = need;
+                    else { ctx->ingest_stage = nullptr; (void)hipGetLastError(); }
+                    for (auto &sl : ctx->ingest_slots) { sl.d = nullptr; sl.dbytes = 0; }
+                }
+                // (slots are re-ordered below: areas are handed out afresh every call, nothing is in flight between calls)
+            }
             // usable slots first
-            auto usable = [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= host_slot_bytes && (!packed_mode || sl.dbytes >= stage_bytes); };
+            auto usable = [&](const ghip_ctx::pinned_slot &sl) { return sl.p && sl.ev && sl.bytes >= host_slot_bytes; };
             std::stable_partition(ctx->ingest_slots.begin(), ctx->ingest_slots.end(), usable);
             for (auto &sl : ctx->ingest_slots) if (usable(sl)) n_slots++;
             n_slots = std::min(n_slots, want);
+            if (packed_mode) {
+                if (!ctx->ingest_stage) n_slots = 0;   // no staging memory: every file takes the plain blocking path
+                for (size_t x = 0; x < n_slots; x++) { ctx->ingest_slots[x].d = ctx->ingest_stage + x * stage_bytes; ctx->ingest_slots[x].dbytes = stage_bytes; }
+            }
         }
         const double w_pin = since(w0) - w_hint - w_alloc;
         std::mutex smu;

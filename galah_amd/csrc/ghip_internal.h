@@ -78,6 +78,8 @@ struct ghip_ctx {
     struct pinned_slot { uint8_t *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; int state = 0; uint64_t seq = 0;
                          uint8_t *d = nullptr; size_t dbytes = 0; };   // d: device staging of the packed form (same life as p)   // state: 0 free, 1 owned by a thread, 2 copy in flight (seq = issue order)
     std::vector<pinned_slot> ingest_slots;
+    uint8_t *ingest_stage = nullptr;   // one device allocation behind all the slots' staging areas (pinned_slot::d point into it)
+    size_t ingest_stage_bytes = 0;
     ghip_io_pool io;
     std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
     hipStream_t copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};
