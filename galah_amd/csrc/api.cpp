@@ -630,12 +630,14 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         const char *ing = getenv("GHIP_INGEST");
         bool use_pinned = !(ing && !strcmp(ing, "pageable"));
         for (int x = 0; x < ctx->n_copy_streams; x++) use_pinned = use_pinned && ctx->copy_stream[x];
-        const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, GHIP_PINNED_SLOT_MAX);
+        // (the packed form stages a quarter of the bytes: streams of up to four times the size go through the slots)
+        const bool packed_wanted = use_pinned && !(ing && !strcmp(ing, "ascii"));
+        const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, packed_wanted ? 4 * GHIP_PINNED_SLOT_MAX : GHIP_PINNED_SLOT_MAX);
         // Packed form (the default; GHIP_INGEST=ascii turns it off): the stream crosses PCIe as 2-bit codes plus the runs
         // of its other bytes -- a quarter of the bytes, and PCIe is what bounds files -> clusters (5 GB: 88 ms) -- into a
         // device staging area that belongs to the slot, and is expanded there into the resident one-byte-per-base stream
         // by a kernel queued behind the copy on the same copy stream (sketch.hip: unpack_bases_kernel).
-        const bool packed_mode = use_pinned && !(ing && !strcmp(ing, "ascii"));
+        const bool packed_mode = packed_wanted;
         const size_t stage_bytes = (slot_bytes / 4 + (64u << 10) + 4095) / 4096 * 4096;   // + room for ~5 000 runs
         const size_t host_slot_bytes = packed_mode ? stage_bytes : slot_bytes;   // what a pinned slot has to hold
         size_t n_slots = 0;

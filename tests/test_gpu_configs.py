@@ -352,3 +352,27 @@ def test_bench_line_contract():
             assert cb["kind"] in ("port", "reference") and cb["value"] > 0
         else:
             assert len(d["per_rank"]) == 2 and d["config"]["transport"] == "host-callback"
+
+
+def test_ingest_of_a_large_file_in_every_form(ctx, tmp_path, monkeypatch):
+    """A 30 Mb genome (above the 24 MB an ASCII staging slot holds, inside what a packed one does) next to a small one:
+    the resident stream is the same whichever way it travelled -- packed through a slot, as it is through a slot or a
+    blocking copy, or by the two-phase form."""
+    rng = np.random.default_rng(3)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=30_000_000)]
+    big[1_000_000:1_000_300] = ord("N")
+    small = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=50_000)]
+    paths = []
+    for name, seq in (("big.fna", big), ("small.fna", small)):
+        p = tmp_path / name
+        body = seq.reshape(-1, 100)
+        lines = np.concatenate([body, np.full((body.shape[0], 1), 10, np.uint8)], axis=1).tobytes()
+        p.write_bytes(b">contig1 x\n" + lines[: len(lines) // 2] + b">contig2\n" + lines[len(lines) // 2:])
+        paths.append(str(p))
+    want = [galah_amd.fasta_stream(p)[0].tobytes() for p in paths]
+    for form in ("pipelined", "ascii", "pageable", "two-phase"):
+        monkeypatch.setenv("GHIP_INGEST", form)
+        g = ctx.genomes_from_files(paths, 4)
+        for i in range(2):
+            assert g.to_host(i).tobytes() == want[i], (form, i)
+        g.free()
