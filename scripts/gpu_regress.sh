@@ -5,6 +5,7 @@ timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^\[W\|amdgpu.id
 python tests/fuzz_ani.py 120 3 2>&1 | tail -1
 GHIP_ANI_TALL_BELOW=0 python tests/fuzz_ani.py 120 4 2>&1 | tail -1
 python tests/fuzz_sketch.py 40 3 2>&1 | tail -1
+python tests/fuzz_ingest.py 60 3 2>&1 | tail -1
 galah_amd/csrc/build/test_host_mirror tests/golden/fasta 2>&1 | tail -2
 python bench.py --no-extras 2>/dev/null | tee gpurun_out/bench_check5.json | python -c "
 import json,sys

@@ -709,6 +709,7 @@ def test_randomised_differential_runs():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for script, args in (("fuzz_pairs.py", ["45", "4"]), ("fuzz_sketch.py", ["12", "21"]), ("fuzz_ani.py", ["25", "3"])):
+    for script, args in (("fuzz_pairs.py", ["45", "4"]), ("fuzz_sketch.py", ["12", "21"]), ("fuzz_ani.py", ["25", "3"]),
+                         ("fuzz_ingest.py", ["25", "2"])):   # random FASTA files through every ingest form
         r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
