@@ -303,6 +303,7 @@ def wall_clock(args, ctx):
                     "ingest_only_s": t_ingest, "ingest_GBps": out["plain_bytes"] / t_ingest / 1e9,
                     # the ingest ships 2-bit codes (a quarter of the bases' bytes; GHIP_INGEST=ascii ships them whole):
                     # the floor of what actually crosses PCIe, and -- for reference -- of the file bytes
+                    "pcie_form": "2-bit codes + runs of the other bytes, expanded on the device (GHIP_INGEST=ascii: one byte per base)",
                     "h2d_pinned_GBps": h2d, "pcie_bytes_shipped": n * args.length // 4,
                     "pcie_floor_s": (n * args.length / 4) / (h2d * 1e9),
                     "pcie_floor_if_ascii_s": out["plain_bytes"] / (h2d * 1e9),
