@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--min-aligned-fraction", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the north_star_10k / wall_clock / skani legs")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: every logical CPU)")
     ap.add_argument("--cpu-sample-genomes", type=int, default=32)
     ap.add_argument("--cpu-pair-sample", type=int, default=2000, help="genomes whose all-vs-all pair loop the CPU baseline times")
     return ap.parse_args()
@@ -102,7 +103,11 @@ class CpuRates:
 
         import oracle
 
-        self.cores = cores = os.cpu_count() or 1
+        # threads: every logical CPU -- or, under a cgroup CPU quota, four per granted CPU: on the GPU boxes (256 logical
+        # CPUs, 16 granted) the port runs 20 % FASTER with 64 threads than with 256, and the strongest CPU figure is the fair one
+        quota = self.cpu_quota()
+        ncpu = os.cpu_count() or 1
+        self.cores = cores = args.cpu_threads or (max(1, min(ncpu, int(4 * quota))) if quota else ncpu)
         n = hashes.shape[0]
         self.sample = sample = min(max(args.cpu_sample_genomes, cores), n)
         genomes = [oracle.synth_genome(args.seed, g // args.members, g % args.members, args.length, args.sub_rate)
