@@ -76,6 +76,7 @@ SIGNATURES = {
     "ghip_fasta_stream": (_int, [C.c_char_p, _pp, C.POINTER(_sz), _vp]),
     "ghip_sketch_and_index_files": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _u32, _u32, _u32, _int, _u64, _pp, _vp, _vp]),
     "ghip_ani_pairs": (_int, [_vp, _vp, _vp, _sz, _f32, _vp, _vp]),
+    "ghip_ani_pairs_detail": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "ghip_ani_index_free": (None, [_vp]),
     "ghip_ani_index_layout": (_int, [_vp, _vp]),
     "ghip_ani_index_meta": (_int, [_vp, _vp, _vp, _vp]),

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint64_t blk0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK;
     const uint32_t toff = threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
     const uint64_t p0 = blk0 + toff;
-    const uint32_t K = so.k;
+    const uint32_t K = so.k, sthr = so.seed_thr[g];
     SeedBlock sb = seed_block_begin(sl, so, g, blk0);
     {
         // every base is fetched once: own 64 bytes from memory, the K-1 overlap bytes from the next
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
                 fwd = ((fwd << 2) | code) & mask;
                 rev = (rev >> 2) | ((3u - code) << top);
                 good = valid ? good + 1 : 0;
-                const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_selected(fwd, rev, so.mul, so.thr);
+                const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_selected(fwd, rev, so.mul, sthr);
                 if (pass) seed_mark_at(sl, sb, fwd, (uint32_t)(b - ((int)K - 1)));
             }
         }
@@ -252,48 +252,79 @@ __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *vo
 // WAVES wavefronts share a pair, each a slice of the bins.  Long pair lists run 8 (three workgroups per CU: throughput); a
 // list the chip holds at once anyway runs 16 -- half the rounds per wave, i.e. about half a pair's latency, which is all
 // a short launch costs (the lazy clusterer's rounds, a single calculate_ani).
-template <uint32_t ANI_PAIR_WAVES>
+// GENERAL = false: both genomes at the same seed density and their per-chunk state in LDS (every pair of genome-sized
+// inputs).  GENERAL = true: the per-chunk state lives in a global scratch region of the pair (genomes of any length: a
+// 100 Mb eukaryotic bin has 5 000 chunks) and the pair may be MIXED -- its genomes seeded at different densities
+// (ghip_ani_density): it is evaluated at the sparser one, the denser genome's seeds are filtered by their selection hash
+// and its per-chunk totals recounted.  `sel` (nullable) = the indices of the pairs this launch handles.
+template <uint32_t ANI_PAIR_WAVES, bool GENERAL>
 __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
-    const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ seed_code,
+    const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ seed_code,
     const uint32_t *__restrict__ seed_loc, const uint64_t *__restrict__ seed_start,
     const uint32_t *__restrict__ bin_start, const uint32_t *__restrict__ chunk_total,
-    const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, uint32_t chunk,
-    uint32_t ro_cap, uint64_t *__restrict__ out) {
+    const uint64_t *__restrict__ chunk_start, const uint64_t *__restrict__ glen, const uint32_t *__restrict__ seed_thr,
+    uint32_t seed_k, uint32_t chunk, uint32_t ro_cap, uint32_t *__restrict__ scratch, const uint64_t *__restrict__ scratch_off,
+    uint64_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned long long red[6];
     __shared__ uint32_t n_al;
     __shared__ uint32_t st_code[ANI_PAIR_WAVES][2][ANI_STAGE + 8];   // + 8: the branch-free compares read up to 8 entries past a bin
     __shared__ uint32_t st_loc[ANI_PAIR_WAVES][2][ANI_STAGE];
     __shared__ uint32_t st_mask[ANI_PAIR_WAVES][ANI_STAGE / 2];  // band mask (16 bits) of every staged r seed, two per word
-    uint32_t *vq = reinterpret_cast<uint32_t *>(smem_raw);
 
     // physical block b runs on XCD b % 8: give each XCD runs of 32 consecutive pairs (one precluster's
     // genomes are then re-read from that XCD's L2)
     const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
-    const uint32_t pair = ((slot_in_xcd >> 5) * 8u + xcd) * 32u + (slot_in_xcd & 31u);
-    if (pair >= n_pairs) return;
+    const uint32_t slot = ((slot_in_xcd >> 5) * 8u + xcd) * 32u + (slot_in_xcd & 31u);
+    if (slot >= n_pairs) return;
+    const uint32_t pair = sel ? sel[slot] : slot;
 #ifdef GHIP_DBG_ANI_PHASES
     unsigned long long ph_t = __builtin_readcyclecounter();
 #endif
     const uint32_t q = pairs[2 * pair], r = pairs[2 * pair + 1];
     const uint32_t nchq = (uint32_t)(chunk_start[q + 1] - chunk_start[q]);
     const uint32_t nchr = (uint32_t)(chunk_start[r + 1] - chunk_start[r]);
+    // per-chunk state: votes of q, votes of r, [GENERAL: recounted totals of q, of r], the aligned-chunk list
+    uint32_t *vq;
+    unsigned long long *list;
+    uint16_t *ro_base;
+    if constexpr (GENERAL) {
+        vq = scratch + scratch_off[slot];   // zeroed by the launcher
+        ro_base = reinterpret_cast<uint16_t *>(smem_raw);
+    } else {
+        vq = reinterpret_cast<uint32_t *>(smem_raw);
+    }
     uint32_t *vr = vq + (size_t)nchq * ANI_VOTE_WORDS;
-    unsigned long long *list = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)(nchq + nchr) * ANI_VOTE_WORDS * 4 + 7) & ~(size_t)7));
-    for (uint32_t i = threadIdx.x; i < (nchq + nchr) * ANI_VOTE_WORDS; i += blockDim.x) vq[i] = 0;
+    uint32_t *tq_re = vr + (size_t)nchr * ANI_VOTE_WORDS, *tr_re = tq_re + nchq;   // GENERAL only
+    if constexpr (GENERAL) {
+        list = reinterpret_cast<unsigned long long *>(scratch + ((scratch_off[slot] + (size_t)(nchq + nchr) * (ANI_VOTE_WORDS + 1) + 1) & ~(uint64_t)1));
+    } else {
+        list = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)(nchq + nchr) * ANI_VOTE_WORDS * 4 + 7) & ~(size_t)7));
+        ro_base = reinterpret_cast<uint16_t *>(list + (nchq + nchr));
+        for (uint32_t i = threadIdx.x; i < (nchq + nchr) * ANI_VOTE_WORDS; i += blockDim.x) vq[i] = 0;
+    }
     if (threadIdx.x < 6) red[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_al = 0;
     __syncthreads();
 
+    // the pair's density is the sparser of its genomes': a genome seeded denser than that is filtered by the selection
+    // hash of its codes (recomputed from the canonical code: fwd + rev is symmetric) and its totals are recounted
+    const uint32_t thr_q = seed_thr[q], thr_r = seed_thr[r], thr_pair = min(thr_q, thr_r), smul = seed_mul(seed_k);
+    const bool filt_q = GENERAL && thr_q != thr_pair, filt_r = GENERAL && thr_r != thr_pair;
+    auto at_pair_density = [&](uint32_t code) { return (0u - 2u - code - revcomp_code(code, seed_k)) * smul < thr_pair; };
     const uint32_t *qb = bin_start + (uint64_t)q * (BIN_COUNT + 1), *rb = bin_start + (uint64_t)r * (BIN_COUNT + 1);
     const uint32_t *qc = seed_code + seed_start[q], *rc = seed_code + seed_start[r];
     const uint32_t *ql = seed_loc + seed_start[q], *rl = seed_loc + seed_start[r];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if constexpr (GENERAL) {
+        if (filt_q) for (uint32_t i = threadIdx.x; i < qb[BIN_COUNT]; i += blockDim.x) if (at_pair_density(qc[i])) atomicAdd(&tq_re[ql[i] >> 16], 1u);
+        if (filt_r) for (uint32_t i = threadIdx.x; i < rb[BIN_COUNT]; i += blockDim.x) if (at_pair_density(rc[i])) atomicAdd(&tr_re[rl[i] >> 16], 1u);
+    }
     uint32_t *sq = st_code[wave][0], *sr = st_code[wave][1];
     uint32_t *lq = st_loc[wave][0], *lr = st_loc[wave][1];
     uint32_t *rm = st_mask[wave];
-    // stage offsets of the round's r bins: dynamic LDS behind the aligned-chunk list, ro_cap entries per wave
-    uint16_t *ro = reinterpret_cast<uint16_t *>(list + (nchq + nchr)) + (size_t)wave * ro_cap;
+    // stage offsets of the round's r bins: dynamic LDS (behind the aligned-chunk list), ro_cap entries per wave
+    uint16_t *ro = ro_base + (size_t)wave * ro_cap;
     for (uint32_t k = lane; k < ANI_STAGE / 2; k += 64) rm[k] = 0;
     // 2^32 - 1 is never a canonical code (its reverse complement, 0, is smaller): entries of the r stage that no round of
     // this workgroup has written yet can never compare equal to a seed
@@ -305,7 +336,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
     uint32_t rbins = 64;
     {
         const uint32_t tmax = max(qb[BIN_COUNT], rb[BIN_COUNT]);  // total seeds of the larger genome
-        if (tmax > 41000) rbins = tmax > 164000 ? 8u : (tmax > 82000 ? 16u : 32u);
+        if (tmax > 41000) rbins = tmax > 1312000 ? 1u : tmax > 656000 ? 2u : tmax > 328000 ? 4u : tmax > 164000 ? 8u : (tmax > 82000 ? 16u : 32u);
         else if (ro_cap > 1024) rbins = tmax <= 3000 ? 1024u : (tmax <= 12000 ? 256u : 64u);
     }
     // the bounds of the next round are fetched while this round is joined
@@ -328,6 +359,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
                     uint32_t c1 = 0, c2 = 0, h1 = 0, h2 = 0;
                     if (k < nqs) { c1 = qc[q_lo + k]; h1 = ql[q_lo + k]; }
                     if (k < nrs) { c2 = rc[r_lo + k]; h2 = rl[r_lo + k]; }
+                    if constexpr (GENERAL) { if (filt_r && k < nrs && !at_pair_density(c2)) c2 = 0xffffffffu; }   // never a code: matches nothing
                     if (k < nqs) { sq[k] = c1; lq[k] = h1; }
                     if (k < nrs) { sr[k] = c2; lr[k] = h2; }
                 }
@@ -348,6 +380,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
             PH(3);   // offsets
             for (uint32_t i = lane; i < nq; i += 64) {
                 const uint32_t c = sq[i];
+                if constexpr (GENERAL) { if (filt_q && !at_pair_density(c)) continue; }
                 const uint32_t x = code_bin(c) - b0;
                 const uint32_t j0 = ro[x], jz = ro[x + 1];
                 // the first 8 seeds of the bin branch-free (a bin holds ~2.4 seeds, more than 8 with P ~ 5e-4): an
@@ -405,6 +438,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
                 for (uint32_t i = qs; i < qe; i++) {
                     const uint32_t c = qc[i], qloc = ql[i], qpos = loc_pos(qloc, chunk);
                     uint32_t qmask = 0;
+                    if constexpr (GENERAL) { if ((filt_q || filt_r) && !at_pair_density(c)) continue; }
                     for (uint32_t j = rs_; j < re; j++)
                         if (rc[j] == c) qmask |= 1u << anchor_band(qloc, qpos, rl[j], chunk);
                     if (qmask) cast_vote(vq, qloc >> 16, qmask);
@@ -412,6 +446,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
                 for (uint32_t j = rs_; j < re; j++) {
                     const uint32_t c = rc[j], rloc = rl[j];
                     uint32_t rmask = 0;
+                    if constexpr (GENERAL) { if ((filt_q || filt_r) && !at_pair_density(c)) continue; }
                     for (uint32_t i = qs; i < qe; i++)
                         if (qc[i] == c) { const uint32_t qloc = ql[i]; rmask |= 1u << anchor_band(qloc, loc_pos(qloc, chunk), rloc, chunk); }
                     if (rmask) cast_vote(vr, rloc >> 16, rmask);
@@ -423,8 +458,8 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
     PH(6);   // waiting for the other waves
     // (M_c, T_c) of the aligned chunks of both directions, then the LOWER MEDIAN containment M_c/T_c
     // by rank selection (exact: fractions compared by cross-multiplication)
-    const unsigned long long bq = collect_aligned(vq, chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
-    const unsigned long long br = collect_aligned(vr, chunk_total + chunk_start[r], nchr, glen[r], chunk, list, &n_al);
+    const unsigned long long bq = collect_aligned(vq, filt_q ? tq_re : chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
+    const unsigned long long br = collect_aligned(vr, filt_r ? tr_re : chunk_total + chunk_start[r], nchr, glen[r], chunk, list, &n_al);
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[2], bq); atomicAdd(&red[5], br); }
     __syncthreads();
     const uint32_t n = n_al;
@@ -502,12 +537,12 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
 
 }  // namespace
 
-void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
+void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, const uint32_t *d_seed_thr, uint32_t chunk,
                            uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
                            uint32_t *d_seg_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work) {
     if (n_work == 0) return;
-    ghip_seed::SeedOut so{k, ~0u / c, ghip_seed::seed_mul(k), chunk, ghip_seed::seed_chunk_magic(chunk), d_seed_code, d_seed_loc, d_seed_start, d_seg_count, d_chunk_total, d_chunk_start};
+    ghip_seed::SeedOut so{k, ghip_seed::seed_mul(k), chunk, d_seed_thr, ghip_seed::seed_chunk_magic(chunk), d_seed_code, d_seed_loc, d_seed_start, d_seg_count, d_chunk_total, d_chunk_start};
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),
@@ -519,11 +554,7 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
                          uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seg_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp) {
     if (n == 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(ani_bin_kernel), 96 * 1024);
     ghip_prof_begin(ctx, "ani_bin");
     for (size_t off = 0; off < n; off += GHIP_MAX_GRID / ghip_seed::SEGMENTS) {   // one block per genome and segment
         const size_t m = std::min<size_t>(n - off, GHIP_MAX_GRID / ghip_seed::SEGMENTS);
@@ -535,50 +566,119 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
 }
 
 namespace {
-// dynamic LDS of a launch with WAVES waves per pair, 0 if it does not fit next to the kernel's static arrays
+struct DeviceFree_ {   // pool blocks handed back at scope exit (the caller synchronises the stream before they are reused)
+    ghip_ctx *ctx;
+    std::vector<void *> ptrs;
+    ~DeviceFree_() { for (void *p : ptrs) ghip_pool_free(ctx, p); }
+};
+constexpr size_t ANI_PER_CHUNK_LDS = ANI_VOTE_WORDS * sizeof(uint32_t) + sizeof(uint64_t);   // votes + aligned-chunk list entry
 template <uint32_t WAVES>
-size_t ani_pairs_lds(uint32_t max_chunks, uint32_t &ro_cap) {
-    constexpr size_t STATIC_LDS = (size_t)WAVES * (2 * (ANI_STAGE + 8) + 2 * ANI_STAGE + ANI_STAGE / 2) * 4 + 256;   // seed stage + band masks
-    const size_t per_chunk = ANI_VOTE_WORDS * sizeof(uint32_t) + sizeof(uint64_t);   // votes + aligned-chunk list entry
-    const size_t fixed = (size_t)2 * max_chunks * per_chunk + 24;
-    if (fixed + (size_t)WAVES * ro_cap * sizeof(uint16_t) > 160 * 1024 - STATIC_LDS) ro_cap = 66;   // no room for the wide rounds' offset table
+constexpr size_t ani_static_lds() { return (size_t)WAVES * (2 * (ANI_STAGE + 8) + 2 * ANI_STAGE + ANI_STAGE / 2) * 4 + 256; }   // seed stage + band masks
+
+// dynamic LDS of an LDS-form launch with WAVES waves per pair whose largest pair holds pair_chunks chunks (both genomes), 0
+// if it does not fit next to the kernel's static arrays; ro_cap falls back to the narrow rounds when the wide rounds'
+// offset table has no room
+template <uint32_t WAVES>
+size_t ani_pairs_lds(uint32_t pair_chunks, uint32_t &ro_cap) {
+    const size_t fixed = (size_t)pair_chunks * ANI_PER_CHUNK_LDS + 24, room = 160 * 1024 - ani_static_lds<WAVES>();
+    if (fixed + (size_t)WAVES * ro_cap * sizeof(uint16_t) > room) ro_cap = 66;
     const size_t lds = fixed + (size_t)WAVES * ro_cap * sizeof(uint16_t);   // + r-bin offsets of a round
-    return lds > 160 * 1024 - STATIC_LDS ? 0 : lds;
+    return lds > room ? 0 : lds;
 }
 
-template <uint32_t WAVES>
-void ani_pairs_launch(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs, size_t lds,
-                      uint32_t ro_cap, uint64_t *d_out) {
-    static size_t attr_lds = 48 * 1024;  // default dynamic-LDS allowance; raised on demand
-    if (lds > attr_lds) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(ani_pairs_kernel<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
-    const uint32_t grid = ((uint32_t)n_pairs + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
-    hipLaunchKernelGGL(ani_pairs_kernel<WAVES>, dim3(grid), dim3(WAVES * 64), lds, ctx->stream, d_pairs, (uint32_t)n_pairs,
+template <uint32_t WAVES, bool GENERAL>
+void ani_pairs_launch(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, const uint32_t *d_sel, size_t n_launch, size_t lds,
+                      uint32_t ro_cap, uint32_t *d_scratch, const uint64_t *d_scratch_off, uint64_t *d_out) {
+    if (lds > 48 * 1024) ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(ani_pairs_kernel<WAVES, GENERAL>), lds);   // (48 KiB is the default allowance)
+    const uint32_t grid = ((uint32_t)n_launch + 255u) / 256u * 256u;  // whole runs of 32 pairs on each of 8 XCDs
+    hipLaunchKernelGGL((ani_pairs_kernel<WAVES, GENERAL>), dim3(grid), dim3(WAVES * 64), lds, ctx->stream, d_pairs, (uint32_t)n_launch, d_sel,
                        idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start, idx->d_bin_start, idx->d_chunk_total,
-                       idx->d_chunk_start, idx->d_glen, idx->chunk, ro_cap, d_out);
+                       idx->d_chunk_start, idx->d_glen, idx->d_seed_thr, idx->k, idx->chunk, ro_cap, d_scratch, d_scratch_off, d_out);
 }
 }  // namespace
 
-void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
-                           uint32_t max_chunks, uint64_t *d_out) {
-    if (n_pairs == 0) return;
-    // wide rounds (256 / 1024 bins) only exist when some genome is small enough to use them: their offset table
-    // costs 16 KiB of LDS per workgroup, which large-genome runs keep for a third resident workgroup per CU
-    uint32_t ro_cap = 66;
-    for (uint32_t c : idx->seed_count) if (c <= 12000) { ro_cap = 1026; break; }
+// Two kernel forms (see ani_pairs_kernel): a pair whose genomes share a seed density and whose per-chunk state fits the
+// LDS -- every pair of genome-sized inputs -- takes the LDS form; a MIXED pair (densities differ: one genome short
+// enough for a denser tier, ghip_ani_density) or a pair of very long genomes (above GHIP_ANI_LDS_PAIR_CHUNKS chunks together:
+// 58 Mb at the default chunk) takes the general form, its per-chunk state in a zeroed global scratch region.
+int ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, const uint32_t *d_pairs, size_t n_pairs,
+                          uint64_t *d_out) {
+    if (n_pairs == 0) return GHIP_OK;
+    auto nch_of = [&](uint32_t g) { return (uint32_t)(idx->chunk_start[g + 1] - idx->chunk_start[g]); };
+    std::vector<uint32_t> sel_fast, sel_gen;
+    uint32_t fast_chunks = 1;
+    bool small_fast = false, small_gen = false;   // some genome small enough for the wide rounds (their offset table costs LDS)
+    size_t n_gen = 0;
+    for (size_t p = 0; p < n_pairs; p++) {
+        const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1], nch = nch_of(q) + nch_of(r);
+        n_gen += (idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) ? 1 : 0;
+    }
+    for (size_t p = 0; p < n_pairs; p++) {
+        const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1], nch = nch_of(q) + nch_of(r);
+        const bool small = idx->seed_count[q] <= 12000 || idx->seed_count[r] <= 12000;
+        if (idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) { sel_gen.push_back((uint32_t)p); small_gen |= small; }
+        else { if (n_gen) sel_fast.push_back((uint32_t)p); fast_chunks = std::max(fast_chunks, nch); small_fast |= small; }
+    }
+    const size_t n_fast = n_pairs - n_gen;
     // 16 waves per pair while there are fewer pairs than CUs (GHIP_ANI_TALL_BELOW; 0 = never).  Measured, 8 -> 16 waves:
     // 8 pairs 0.133 -> 0.095 ms, 96 pairs 0.168 -> 0.122, but 384 pairs 0.192 -> 0.235 and 1 536 pairs 0.44 -> 0.64.
     const char *tb = getenv("GHIP_ANI_TALL_BELOW");   // (read per launch: the tests switch it)
     const size_t tall_below = tb ? (size_t)strtoull(tb, nullptr, 10) : (size_t)200;
+    DeviceFree_ tmp{ctx, {}};
+    uint32_t *d_sel = nullptr;
+    if (n_gen) {   // the two selections, one upload: [fast..., general...]
+        std::vector<uint32_t> both(sel_fast);
+        both.insert(both.end(), sel_gen.begin(), sel_gen.end());
+        d_sel = (uint32_t *)ghip_pool_alloc(ctx, both.size() * sizeof(uint32_t));
+        if (!d_sel) return GHIP_EHIP;
+        tmp.ptrs.push_back(d_sel);
+        if (hipMemcpyAsync(d_sel, both.data(), both.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return ghip_set_error(ctx, GHIP_EHIP, "ani_pairs: selection upload failed");
+    }
     ghip_prof_begin(ctx, "ani_pairs");
-    uint32_t ro_tall = ro_cap;
-    const size_t lds_tall = n_pairs < tall_below ? ani_pairs_lds<ANI_PAIR_WAVES_TALL>(max_chunks, ro_tall) : 0;
-    if (lds_tall) ani_pairs_launch<ANI_PAIR_WAVES_TALL>(ctx, idx, d_pairs, n_pairs, lds_tall, ro_tall, d_out);
-    else {
-        const size_t lds = ani_pairs_lds<ANI_PAIR_WAVES_WIDE>(max_chunks, ro_cap);   // (always fits: GHIP_ANI_MAX_CHUNKS)
-        ani_pairs_launch<ANI_PAIR_WAVES_WIDE>(ctx, idx, d_pairs, n_pairs, lds, ro_cap, d_out);
+    if (n_fast) {
+        // wide rounds (256 / 1024 bins) only exist when some genome is small enough to use them: their offset table
+        // costs 16 KiB of LDS per workgroup, which large-genome runs keep for a third resident workgroup per CU
+        uint32_t ro_cap = small_fast ? 1026 : 66, ro_tall = ro_cap;
+        const size_t lds_tall = n_fast < tall_below ? ani_pairs_lds<ANI_PAIR_WAVES_TALL>(fast_chunks, ro_tall) : 0;
+        if (lds_tall) ani_pairs_launch<ANI_PAIR_WAVES_TALL, false>(ctx, idx, d_pairs, n_gen ? d_sel : nullptr, n_fast, lds_tall, ro_tall, nullptr, nullptr, d_out);
+        else {
+            const size_t lds = ani_pairs_lds<ANI_PAIR_WAVES_WIDE>(fast_chunks, ro_cap);   // (always fits: GHIP_ANI_LDS_PAIR_CHUNKS)
+            ani_pairs_launch<ANI_PAIR_WAVES_WIDE, false>(ctx, idx, d_pairs, n_gen ? d_sel : nullptr, n_fast, lds, ro_cap, nullptr, nullptr, d_out);
+        }
+    }
+    int rc = GHIP_OK;
+    if (n_gen) {
+        // scratch region of a pair, in 32-bit words: votes (9 per chunk) + recounted totals (1 per chunk), padded to an even
+        // count, then the aligned-chunk list (one u64 per chunk); launches are cut so that a launch's scratch stays below 1 GiB
+        const uint32_t ro_cap = small_gen ? 1026 : 66;
+        const size_t lds = (size_t)ANI_PAIR_WAVES_WIDE * ro_cap * sizeof(uint16_t);
+        constexpr uint64_t SCRATCH_WORDS_MAX = (1ull << 30) / 4;
+        size_t at = 0;
+        while (at < n_gen && rc == GHIP_OK) {
+            std::vector<uint64_t> off;
+            uint64_t words = 0;
+            size_t m = 0;
+            while (at + m < n_gen) {
+                const uint32_t p = sel_gen[at + m], nch = nch_of(pairs[2 * p]) + nch_of(pairs[2 * p + 1]);
+                const uint64_t w = (((uint64_t)nch * (ANI_VOTE_WORDS + 1) + 1) & ~1ull) + 2ull * nch;
+                if (m && words + w > SCRATCH_WORDS_MAX) break;
+                off.push_back(words);
+                words += w;
+                m++;
+            }
+            uint32_t *d_scratch = (uint32_t *)ghip_pool_alloc(ctx, std::max<uint64_t>(words, 2) * sizeof(uint32_t));
+            uint64_t *d_off = (uint64_t *)ghip_pool_alloc(ctx, m * sizeof(uint64_t));
+            if (!d_scratch || !d_off) { ghip_pool_free(ctx, d_scratch); ghip_pool_free(ctx, d_off); rc = GHIP_EHIP; break; }
+            if (hipMemsetAsync(d_scratch, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_off, off.data(), m * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = ghip_set_error(ctx, GHIP_EHIP, "ani_pairs: scratch set-up failed");
+            else ani_pairs_launch<ANI_PAIR_WAVES_WIDE, true>(ctx, idx, d_pairs, d_sel + sel_fast.size() + at, m, lds, ro_cap, d_scratch, d_off, d_out);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "ani_pairs (general form) failed");   // `off` and the scratch are reused
+            ghip_pool_free(ctx, d_scratch); ghip_pool_free(ctx, d_off);
+            at += m;
+        }
     }
     ghip_prof_end(ctx);
 #ifdef GHIP_DBG_ANI_PHASES
@@ -592,4 +692,5 @@ void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint3
         fprintf(stderr, "\n");
     }
 #endif
+    return rc;
 }

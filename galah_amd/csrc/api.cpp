@@ -22,8 +22,17 @@ uint64_t ghip_stream_capacity_hint(const char *path);
 static thread_local std::string g_init_error;
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg) {
-    if (ctx) ctx->err = msg; else g_init_error = msg;
+    if (ctx) { std::lock_guard<std::mutex> l(ctx->err_mu); ctx->err = msg; } else g_init_error = msg;
     return code;
+}
+
+void ghip_ensure_dyn_lds(ghip_ctx *ctx, const void *kernel, size_t bytes) {
+    std::lock_guard<std::mutex> l(ctx->dyn_lds_mu);
+    size_t &have = ctx->dyn_lds[kernel];
+    if (bytes <= have) return;
+    hipSetDevice(ctx->device);
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) have = bytes;
+    else (void)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ memory pool
@@ -209,6 +218,17 @@ double ghip_cpu_quota() {
 // bases it indexes, so room is cheap; an overflow is not: it re-seeds the whole batch with exact capacities (with four
 // standard deviations and 10 %, the first form, 50 000 genomes of 1 Mb overflowed a handful of their 400 000 segments
 // every time: +33 ms).
+}  // namespace
+// Seed density of a genome (oracle: go_ani_density): the base density c while the genome holds ~8192 seeds at it, else four
+// times denser, and so on down to every k-mer (125 -> 31 -> 7 -> 1): a 200 kb plasmid or a 5 kb contig carries as many
+// seeds as a genome does, and its ANI is as little noisy (skani's own remedy is --small-genomes = -c 30, chosen by the
+// user for the whole run: src/skani.rs:152-153).
+uint32_t ghip_ani_density(uint64_t len, uint32_t c) {
+    uint32_t t = c ? c : 1;
+    while (t > 1 && len < (uint64_t)GHIP_ANI_SEEDS_WANTED * t) t = t / 4 ? t / 4 : 1;
+    return t;
+}
+namespace {
 uint64_t ghip_ani_seed_capacity(uint64_t len, uint32_t c) {
     const double m = (double)len / ((double)GHIP_ANI_SEGMENTS * (double)c);
     const uint64_t segcap = (uint64_t)(m + 6.0 * std::sqrt(m) + m / 4.0) + 24;
@@ -367,7 +387,15 @@ extern "C" void ghip_destroy(ghip_ctx *ctx) {
     ctx_release(ctx);  // deferred until the last genomes/sketches/index handle is freed
 }
 
-extern "C" const char *ghip_last_error(const ghip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+// the text is copied out under the error lock into a per-thread buffer: another thread of the same context (the ingest
+// producer) may be writing a new message meanwhile
+extern "C" const char *ghip_last_error(const ghip_ctx *ctx) {
+    if (!ctx) return g_init_error.c_str();
+    static thread_local std::string copy;
+    ghip_ctx *c = const_cast<ghip_ctx *>(ctx);
+    { std::lock_guard<std::mutex> l(c->err_mu); copy = c->err; }
+    return copy.c_str();
+}
 
 extern "C" int ghip_set_stream(ghip_ctx *ctx, void *hip_stream) {
     if (!ctx) return GHIP_EINVAL;
@@ -1277,7 +1305,8 @@ static void free_index_arrays_locked(ghip_ani_index *idx) {
         ghip_pool_free(ctx, idx->d_bin_start); ghip_pool_free(ctx, idx->d_chunk_total);
     }
     ghip_pool_free(ctx, idx->d_seed_start); ghip_pool_free(ctx, idx->d_seed_count); ghip_pool_free(ctx, idx->d_seg_count);
-    ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen);
+    ghip_pool_free(ctx, idx->d_chunk_start); ghip_pool_free(ctx, idx->d_glen); ghip_pool_free(ctx, idx->d_seed_thr);
+    idx->d_seed_thr = nullptr;
     idx->d_seed_code = nullptr; idx->d_seed_loc = nullptr; idx->d_bin_start = nullptr; idx->d_chunk_total = nullptr;
     idx->d_seed_start = nullptr; idx->d_seed_count = nullptr; idx->d_seg_count = nullptr; idx->d_chunk_start = nullptr;
     idx->d_glen = nullptr;
@@ -1320,10 +1349,15 @@ static int index_new(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t 
     }
     if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) {
         free_index_locked(idx);
-        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters (at most 1450 chunks per genome: 29 Mb at the default 20 kb chunk, 47 Mb at 32768)");
+        return ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI index (a seed's chunk is a 16-bit field: at most 65535 chunks per genome, 1.3 Gb at the default 20 kb chunk)");
     }
     cap.resize(n);
-    for (size_t i = 0; i < n; i++) cap[i] = ghip_ani_seed_capacity(g->lens[i], c);
+    idx->seed_thr.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t cg = ghip_ani_density(g->lens[i], c);
+        idx->seed_thr[i] = ~0u / cg;
+        cap[i] = ghip_ani_seed_capacity(g->lens[i], cg);
+    }
     *out = idx;
     return GHIP_OK;
 }
@@ -1344,6 +1378,8 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
     if ((rc = dmalloc(ctx, &idx->d_chunk_total, idx->chunk_start[n]))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_chunk_start, n + 1))) return rc;
     if ((rc = dmalloc(ctx, &idx->d_glen, n))) return rc;
+    if ((rc = dmalloc(ctx, &idx->d_seed_thr, n))) return rc;
+    if ((rc = h2d_nosync(ctx, idx->d_seed_thr, idx->seed_thr.data(), n))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
@@ -1353,7 +1389,7 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
 }
 
 static ghip_seed_args index_seed_args(const ghip_ani_index *idx) {
-    return ghip_seed_args{idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
+    return ghip_seed_args{idx->k, idx->chunk, idx->d_seed_thr, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
                           idx->d_seg_count, idx->d_chunk_total, idx->d_chunk_start};
 }
 
@@ -1381,7 +1417,7 @@ static int index_seed_standalone(ghip_ctx *ctx, const ghip_genomes *g, ghip_ani_
     for (int attempt = 0; attempt < 2; attempt++) {
         int rc = index_alloc_seeds(ctx, idx, cap);
         if (rc) return rc;
-        ghip_launch_ani_seeds(ctx, g, idx->k, idx->c, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
+        ghip_launch_ani_seeds(ctx, g, idx->k, idx->d_seed_thr, idx->chunk, idx->d_seed_code, idx->d_seed_loc, idx->d_seed_start,
                               idx->d_seg_count, idx->d_chunk_total, idx->d_chunk_start, g->d_work, g->n_work);
         bool overflow = false;
         if ((rc = index_check_seeds(ctx, idx, cap, &overflow))) return rc;
@@ -1606,6 +1642,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
             idx->max_chunks = std::max(idx->max_chunks, b->max_chunks);
             idx->glen.insert(idx->glen.end(), b->glen.begin(), b->glen.end());
             idx->seed_count.insert(idx->seed_count.end(), b->seed_count.begin(), b->seed_count.end());
+            idx->seed_thr.insert(idx->seed_thr.end(), b->seed_thr.begin(), b->seed_thr.end());
             for (size_t i = 0; i < b->n; i++) {
                 idx->seed_start.push_back(idx->seed_start.back() + (b->seed_start[i + 1] - b->seed_start[i]));
                 idx->chunk_start.push_back(idx->chunk_start.back() + (b->chunk_start[i + 1] - b->chunk_start[i]));
@@ -1616,6 +1653,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
             !(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) && !(rc = dmalloc(ctx, &idx->d_chunk_total, n_chunk)) &&
             !(rc = dmalloc(ctx, &idx->d_seed_start, n + 1)) && !(rc = dmalloc(ctx, &idx->d_seed_count, n)) &&
             !(rc = dmalloc(ctx, &idx->d_chunk_start, n + 1)) && !(rc = dmalloc(ctx, &idx->d_glen, n)) &&
+            !(rc = dmalloc(ctx, &idx->d_seed_thr, n)) && !(rc = h2d(ctx, idx->d_seed_thr, idx->seed_thr.data(), n)) &&
             !(rc = h2d(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1)) && !(rc = h2d(ctx, idx->d_seed_count, idx->seed_count.data(), n)) &&
             !(rc = h2d(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1)) && !(rc = h2d(ctx, idx->d_glen, idx->glen.data(), n))) {
             uint64_t at_seed = 0, at_chunk = 0;
@@ -1641,31 +1679,53 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
     return GHIP_OK;
 }
 
+// device part of ghip_ani_pairs: res[6 p ..] = M and T of the median-containment chunk, aligned bases of q, aligned chunks,
+// (unused), aligned bases of r
+static int ani_pairs_device(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, size_t n, uint64_t *res) {
+    // the context is held for the device part only: the host finish runs next to other callers' launches
+    // (calculate_ani arrives from many rayon workers at once, src/clusterer.rs:267-296)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DeviceFree tmp(ctx);
+    uint32_t *d_pairs = nullptr;
+    uint64_t *d_out = nullptr;
+    int rc;
+    if ((rc = dmalloc(ctx, &d_pairs, 2 * n))) return rc;
+    tmp.add(d_pairs);
+    if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
+    tmp.add(d_out);
+    if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
+    const size_t batch = (size_t)1 << 22;  // 512 threads per pair: keep each dispatch below 2^32 work-items
+    for (size_t off = 0; off < n; off += batch)
+        if ((rc = ghip_launch_ani_pairs(ctx, idx, pairs + 2 * off, d_pairs + 2 * off, std::min(batch, n - off), d_out + 6 * off))) return rc;
+    if ((rc = d2h(ctx, res, d_out, 6 * n))) return rc;
+    { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
+    return GHIP_OK;
+}
+
+extern "C" int ghip_ani_pairs_detail(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, size_t n, uint64_t *out) {
+    if (!ctx || !idx || !out || (n && !pairs)) return GHIP_EINVAL;
+    for (size_t i = 0; i < 2 * n; i++) if (pairs[i] >= idx->n) return ghip_set_error(ctx, GHIP_EINVAL, "genome index out of range");
+    if (n == 0) return GHIP_OK;
+    std::vector<uint64_t> res(6 * n);
+    int rc = ani_pairs_device(ctx, idx, pairs, n, res.data());
+    if (rc) return rc;
+    for (size_t p = 0; p < n; p++) {
+        const uint32_t tq = idx->seed_thr[pairs[2 * p]], tr = idx->seed_thr[pairs[2 * p + 1]];
+        out[6 * p] = res[6 * p]; out[6 * p + 1] = res[6 * p + 1]; out[6 * p + 2] = res[6 * p + 3];
+        out[6 * p + 3] = res[6 * p + 2]; out[6 * p + 4] = res[6 * p + 5];
+        out[6 * p + 5] = ~0u / std::min(tq, tr);   // thr = (2^32 - 1) / c exactly inverts for c <= 65535
+    }
+    return GHIP_OK;
+}
+
 extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, size_t n,
                               float min_af, float *out_ani, float *out_af) {
     if (!ctx || !idx || !out_ani || (n && !pairs)) return GHIP_EINVAL;
     for (size_t i = 0; i < 2 * n; i++) if (pairs[i] >= idx->n) return ghip_set_error(ctx, GHIP_EINVAL, "genome index out of range");
     if (n == 0) return GHIP_OK;
     std::vector<uint64_t> res(6 * n);
-    {   // the context is held for the device part only: the host finish below runs next to other callers' launches
-        // (calculate_ani arrives from many rayon workers at once, src/clusterer.rs:267-296)
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        DeviceFree tmp(ctx);
-        uint32_t *d_pairs = nullptr;
-        uint64_t *d_out = nullptr;
-        int rc;
-        if ((rc = dmalloc(ctx, &d_pairs, 2 * n))) return rc;
-        tmp.add(d_pairs);
-        if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
-        tmp.add(d_out);
-        if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
-        const size_t batch = (size_t)1 << 22;  // 512 threads per pair: keep each dispatch below 2^32 work-items
-        for (size_t off = 0; off < n; off += batch)
-            ghip_launch_ani_pairs(ctx, idx, d_pairs + 2 * off, std::min(batch, n - off), std::max<uint32_t>(idx->max_chunks, 1), d_out + 6 * off);
-        if ((rc = d2h(ctx, res.data(), d_out, 6 * n))) return rc;
-        { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
-    }
+    { const int rc = ani_pairs_device(ctx, idx, pairs, n, res.data()); if (rc) return rc; }
     // the f64 pow and the two-decimal rounding stay on the host (glibc's pow is what the oracle's parity is defined
     // by): ~70 ns per pair, spread over threads from 20 000 pairs on (below that spawning costs more than it saves)
     auto finish_range = [&](size_t p0, size_t p1) {
@@ -1732,6 +1792,8 @@ extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, u
     idx->glen.assign(genome_len, genome_len + n);
     idx->seed_count.assign(seed_count, seed_count + n);
     idx->seed_start.assign(n + 1, 0); idx->chunk_start.assign(n + 1, 0);
+    idx->seed_thr.resize(n);
+    for (size_t i = 0; i < n; i++) idx->seed_thr[i] = ~0u / ghip_ani_density(genome_len[i], c);   // the density follows from the length
     for (size_t i = 0; i < n; i++) {
         if (seed_count[i] > seed_cap[i]) { free_index_locked(idx); return ghip_set_error(ctx, GHIP_EINVAL, "inconsistent ANI index metadata"); }
         uint64_t nch = (genome_len[i] + chunk - 1) / chunk;
@@ -1742,7 +1804,9 @@ extern "C" int ghip_ani_index_wrap_device(ghip_ctx *ctx, size_t n, uint32_t k, u
     idx->d_seed_code = (uint32_t *)d_seed_code; idx->d_seed_loc = (uint32_t *)d_seed_loc;
     idx->d_bin_start = (uint32_t *)d_bin_start; idx->d_chunk_total = (uint32_t *)d_chunk_total;
     int rc = GHIP_OK;
-    if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI chunk counters");
+    if (idx->max_chunks > GHIP_ANI_MAX_CHUNKS) rc = ghip_set_error(ctx, GHIP_EINVAL, "genome too long for the ANI index (at most 65535 chunks per genome)");
+    if (!rc) rc = dmalloc(ctx, &idx->d_seed_thr, n);
+    if (!rc) rc = h2d(ctx, idx->d_seed_thr, idx->seed_thr.data(), n);
     if (!rc) rc = dmalloc(ctx, &idx->d_seed_start, n + 1);
     if (!rc) rc = dmalloc(ctx, &idx->d_seed_count, n);
     if (!rc) rc = dmalloc(ctx, &idx->d_chunk_start, n + 1);

@@ -61,7 +61,12 @@ struct ghip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
+    std::mutex err_mu;  // `err` alone: the file ingest runs on a producer thread next to the consumer's kernels, both may fail
     std::mutex mu;  // serialises API calls on this ctx (ghip_ani_pairs is called from rayon workers)
+    // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: what this context's device has been told so far, per kernel
+    // (a process-wide flag left devices 1..7 of a one-process multi-GPU run without the allowance)
+    std::unordered_map<const void *, size_t> dyn_lds;
+    std::mutex dyn_lds_mu;
     bool profile = false;
     std::unordered_map<std::string, ghip_kstat> stats;
     std::vector<ghip_pending_event> pending;
@@ -142,6 +147,8 @@ struct ghip_ani_index {
     uint32_t *d_seed_loc = nullptr;    // concatenated: chunk << 16 | strand << 15 | offset in chunk
     uint64_t *d_seed_start = nullptr;  // [n+1] offsets into seed arrays (capacity layout)
     uint32_t *d_seed_count = nullptr;  // [n]
+    uint32_t *d_seed_thr = nullptr;    // [n] selection threshold (2^32 - 1) / c_g of every genome
+    std::vector<uint32_t> seed_thr;    // the same on the host; c_g = ghip_ani_density(glen[g], c)
     uint32_t *d_seg_count = nullptr;   // [n][GHIP_ANI_SEGMENTS] while the index is being built (seed_common.h), then freed
     uint32_t *d_bin_start = nullptr;   // [n][GHIP_ANI_BIN_COUNT+1] CSR offsets of the binned seed list
     uint32_t *d_chunk_total = nullptr; // concatenated per-chunk seed totals T_c
@@ -156,10 +163,15 @@ struct ghip_ani_index {
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
 #define GHIP_ANI_SEGMENTS 8u   // the seeding pass files a genome's seeds under the top 3 bits of their bin (seed_common.h)
-#define GHIP_ANI_MAX_CHUNKS 1450u  // per genome: band votes + repeat counter (36 B) + aligned-chunk list (8 B) of both genomes + the 28 KiB seed stage fit the 160 KiB LDS
+#define GHIP_ANI_LDS_PAIR_CHUNKS 2900u  // chunks of BOTH genomes of a pair whose band votes + repeat counter (36 B) + aligned-chunk list (8 B) fit the
+                                       // 160 KiB LDS next to the 28 KiB seed stage; a pair above it takes the kernel form with its votes in global memory
+#define GHIP_ANI_MAX_CHUNKS 65535u     // per genome: a seed's chunk is a 16-bit field (1.3 Gb at the default 20 kb chunk)
+#define GHIP_ANI_SEEDS_WANTED 8192u    // ghip_ani_density: a genome shorter than this many seeds' worth of bases is seeded four times denser
 #define GHIP_ANI_MAX_CHUNK_LEN 32768u  // a seed's offset in its chunk is a 15-bit field
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);
+// raises the dynamic-LDS allowance of `kernel` on the context's device to at least `bytes` (no-op once it is that large)
+void ghip_ensure_dyn_lds(ghip_ctx *ctx, const void *kernel, size_t bytes);
 
 #define GHIP_HIP_CHECK(ctx, expr)                                                          \
     do {                                                                                   \
@@ -178,7 +190,8 @@ void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts
                        uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr);
 
 struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the ANI seeds
-    uint32_t k, c, chunk;
+    uint32_t k, chunk;
+    const uint32_t *d_seed_thr;   // [n] per-genome selection threshold
     uint32_t *d_seed_code;
     uint32_t *d_seed_loc;
     const uint64_t *d_seed_start;
@@ -233,15 +246,18 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, ghip_pair *d_out,
                              unsigned long long *d_count, uint64_t cap);
 
-void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c, uint32_t chunk,
+void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, const uint32_t *d_seed_thr, uint32_t chunk,
                            uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
                            uint32_t *d_seg_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work);
 void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint32_t *in_loc, uint32_t *out_code,
                          uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seg_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp);
-void ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *d_pairs, size_t n_pairs,
-                           uint32_t max_chunks, uint64_t *d_out /* [n_pairs][2][3] = M, T, aligned bases */);
+// the density a genome of `len` stream bytes is seeded at, given the base density c (oracle: go_ani_density)
+uint32_t ghip_ani_density(uint64_t len, uint32_t c);
+// pairs = the host copy of d_pairs (the launcher sorts the pairs into the LDS form and the general form by their genomes)
+int ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, const uint32_t *d_pairs, size_t n_pairs,
+                          uint64_t *d_out /* [n_pairs][6] = M, T, aligned bases of q, aligned chunks, -, aligned bases of r */);
 
 constexpr uint32_t GHIP_SKETCH_POS_PER_THREAD = 64;
 constexpr uint32_t GHIP_SKETCH_THREADS = 256;

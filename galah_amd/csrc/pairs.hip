@@ -222,12 +222,7 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
     }
     if (my_tiles == 0) return;
     const size_t lds_bytes = (size_t)2 * pt * sp * sizeof(uint64_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(pair_intersect_tile_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_intersect_tile_kernel), 160 * 1024);
     ghip_prof_begin(ctx, "pair_intersect_tile");
     const unsigned grid = (unsigned)std::min<uint64_t>(my_tiles, 1u << 21);  // x 1024 threads < 2^32 work-items
     hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3(grid), dim3(PAIR_THREADS), lds_bytes,

@@ -238,12 +238,8 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     if (mine == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
     const size_t lds = (size_t)PROBE_TA * buckets * 16 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(pair_probe_tile_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(pair_probe_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<16>), 160 * 1024);
+    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<4>), 160 * 1024);
     const unsigned grid = (unsigned)std::min<uint64_t>(mine, GHIP_MAX_GRID);
     ghip_prof_begin(ctx, "pair_intersect_tile");
     if (s <= 256)

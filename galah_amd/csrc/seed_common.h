@@ -45,7 +45,9 @@ constexpr uint32_t SEED_LDS_CHUNKS = 64;   // per-block chunk counters
 constexpr uint32_t SEED_WAVES = GHIP_SKETCH_THREADS / 64;
 
 struct SeedOut {  // where a block's seeds go (kernel argument, by value)
-    uint32_t k, thr, mul, chunk;   // mul = seed_mul(k)
+    uint32_t k, mul, chunk;        // mul = seed_mul(k)
+    const uint32_t *seed_thr;      // [n] selection threshold of every genome, (2^32 - 1) / c_g: the density is per genome
+                                   // (ghip_ani_density: short genomes are seeded 4x, 16x ... denser)
     uint32_t chunk_magic;          // seed_chunk_magic(chunk): positions -> chunks by one multiply
     uint32_t *seed_code;
     uint32_t *seed_loc;   // chunk << 16 | strand << 15 | offset in chunk

@@ -145,9 +145,10 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     const uint64_t p0 = blk0 + toff;
     const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's bytes
     ghip_seed::SeedBlock sb;
-    uint32_t ashift = 0;
+    uint32_t ashift = 0, sthr = 0;
     int ak = 1;
     if constexpr (SEEDS) {
+        sthr = so.seed_thr[g];   // this genome's density
         sb = ghip_seed::seed_block_begin(sl, so, g, blk0);
         ashift = 2 * (K - so.k);  // the newest so.k bases of the 21-mer
         ak = (int)so.k;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 // of W >> (fs + ashift) the complement of its reverse complement's; their sum is the selection key
                 // (seed_common.h) -- no masks, no min: add, multiply, compare
                 const uint32_t wsh = (uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift));
-                const bool pass = seed_gate && (rlo + wsh) * so.mul < so.thr;
+                const bool pass = seed_gate && (rlo + wsh) * so.mul < sthr;
                 if (pass) {  // ~1/125 of the lanes; only the raw forward code is stored, seed_canon() finishes it in the flush
                     // validity only in the SLOW variant: the fast one runs when no lane of the wave saw a bad byte in
                     // this word or the six before it
@@ -679,7 +680,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
     if (n_work == 0) return;
     ghip_seed::SeedOut so{};
     if (seeds)
-        so = ghip_seed::SeedOut{seeds->k, ~0u / seeds->c, ghip_seed::seed_mul(seeds->k), seeds->chunk, ghip_seed::seed_chunk_magic(seeds->chunk), seeds->d_seed_code, seeds->d_seed_loc,
+        so = ghip_seed::SeedOut{seeds->k, ghip_seed::seed_mul(seeds->k), seeds->chunk, seeds->d_seed_thr, ghip_seed::seed_chunk_magic(seeds->chunk), seeds->d_seed_code, seeds->d_seed_loc,
                                 seeds->d_seed_start, seeds->d_seg_count, seeds->d_chunk_total, seeds->d_chunk_start};
     const KmerLuts *luts = nullptr;
     if (k == 21) {

@@ -316,6 +316,13 @@ class Context:
                                         af.ctypes.data if want_af else None), self._h)
         return (out, af) if want_af else out
 
+    def ani_pairs_detail(self, idx: AniIndex, pairs: np.ndarray) -> np.ndarray:
+        """u64[n][6] = M, T of the lower-median chunk, aligned chunks, aligned bases of q, of r, c_pair (ghip_ani_pairs_detail)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros((pairs.shape[0], 6), dtype=np.uint64)
+        check(_lib.lib().ghip_ani_pairs_detail(self._h, idx._h, pairs.ctypes.data, pairs.shape[0], out.ctypes.data), self._h)
+        return out
+
 
 def cluster_pairs(n_genomes: int, pairs: np.ndarray, ani_threshold: float, pair_ani: Optional[np.ndarray] = None,
                   skip_clusterer: bool = False, ani_callback=None) -> List[List[int]]:

@@ -161,8 +161,10 @@ uint64_t ghip_last_pairs_compared(const ghip_ctx *ctx);
  * batched.  Returns PERCENT, 0.0 when below the aligned-fraction gate (skani prints no row).
  * Build-defined estimator (FracMinHash seeds, matches colinear within a chunk), skani parity unpinned: see DESIGN.md
  * "ANI" and oracle/galah_oracle_ani.c.  Symmetric in the pair.  Thread-safe. */
-/* Limits: k <= 16; chunk <= 32768; at most 1450 chunks per genome (29 Mb at the default 20 kb chunk, 47 Mb at 32768 --
- * galah's inputs are prokaryotic genomes; a longer genome is refused with GHIP_EINVAL). */
+/* Seed density is PER GENOME: the base density c (125; 30 = skani's --small-genomes, src/skani.rs:152-153) for a genome long
+ * enough to hold ~8192 seeds at it, else four times denser, and so on (125 -> 31 -> 7 -> 1): c_g = c; while (c_g > 1 &&
+ * len < 8192 c_g) c_g = max(1, c_g / 4).  A pair is evaluated at the sparser of its two densities (FracMinHash samples nest).
+ * Limits: k <= 16; chunk <= 32768; at most 65535 chunks per genome (1.3 Gb at the default 20 kb chunk). */
 int ghip_ani_index_build(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t c,
                          uint32_t chunk, ghip_ani_index **out);
 /* MinHash sketches and ANI index from ONE pass over the bases (fused kernel for k = 21; otherwise the
@@ -182,6 +184,11 @@ int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *paths, size_t 
 int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */,
                    size_t n, float min_aligned_fraction, float *out_ani_percent,
                    float *out_af /* nullable, [n][2] */);
+/* The integers behind ghip_ani_pairs' values (what the device hands back before the host's pow):
+ * out[6 p ..] = M, T of the lower-median chunk, aligned chunks of both directions, aligned bases of q, of r, c_pair.
+ * tests/golden/ani_golden.json freezes them for the reference's fixture genomes. */
+int ghip_ani_pairs_detail(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */, size_t n,
+                          uint64_t *out /* [n][6] */);
 void ghip_ani_index_free(ghip_ani_index *idx);
 /* Exchange of an ANI index between GPUs (RCCL all-gather of the flat arrays): genome g owns
  * seed slots [sum seed_cap[<g], +seed_cap[g]), bin slots [g*16385, +16385) (offsets relative to its

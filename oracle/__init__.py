@@ -106,6 +106,12 @@ def lib():
     L.go_ani_sketch_strands.argtypes = [C.c_void_p]
     L.go_ani_sketch_length.restype = C.c_uint64
     L.go_ani_sketch_length.argtypes = [C.c_void_p]
+    L.go_ani_density.restype = C.c_uint32
+    L.go_ani_density.argtypes = [C.c_uint64, C.c_uint32]
+    L.go_ani_sketch_density.restype = C.c_uint32
+    L.go_ani_sketch_density.argtypes = [C.c_void_p]
+    L.go_ani_pair_detail.restype = C.c_float
+    L.go_ani_pair_detail.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.go_ani_pair.restype = C.c_float
     L.go_ani_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = L
@@ -311,6 +317,11 @@ class AniSketch:
     def length(self) -> int:
         return lib().go_ani_sketch_length(self._h)
 
+    @property
+    def density(self) -> int:
+        """The FracMinHash density c_g this genome was seeded at (ani_density of its length and the base c)."""
+        return lib().go_ani_sketch_density(self._h)
+
     def seeds(self) -> np.ndarray:
         n = self.nseeds
         return np.ctypeslib.as_array(lib().go_ani_sketch_seeds(self._h), shape=(n,)).copy() if n else np.empty(0, np.uint64)
@@ -332,6 +343,18 @@ class AniSketch:
         """The device's packed seed location: chunk << 16 | strand << 15 | offset within the chunk."""
         p = self.positions().astype(np.uint64)
         return ((p // chunk) << np.uint64(16) | (self.strands().astype(np.uint64) << np.uint64(15)) | (p % chunk)).astype(np.uint32)
+
+
+def ani_density(length: int, c: int = 125) -> int:
+    return lib().go_ani_density(length, c)
+
+
+def ani_pair_detail(q: AniSketch, r: AniSketch, min_af: float = 0.15):
+    """(ANI percent, AF_q, AF_r, [M, T, aligned chunks, aligned bases of q, aligned bases of r, c_pair])."""
+    afq, afr = C.c_float(0), C.c_float(0)
+    d = (C.c_uint64 * 6)()
+    ani = lib().go_ani_pair_detail(q._h, r._h, np.float32(min_af), C.byref(afq), C.byref(afr), d)
+    return float(ani), float(afq.value), float(afr.value), [int(x) for x in d]
 
 
 def ani_pair(q: AniSketch, r: AniSketch, min_af: float = 0.15) -> Tuple[float, float, float]:

@@ -107,9 +107,16 @@ const uint32_t *go_ani_sketch_chunks(const go_ani_sketch *s);
 const uint32_t *go_ani_sketch_positions(const go_ani_sketch *s);   /* start position of every seed */
 const uint8_t *go_ani_sketch_strands(const go_ani_sketch *s);      /* 1: canonical code = reverse complement */
 uint64_t go_ani_sketch_length(const go_ani_sketch *s);
+/* per-genome seed density: c_g = c; while (c_g > 1 && len < 8192 * c_g) c_g = max(1, c_g / 4) */
+uint32_t go_ani_density(uint64_t len, uint32_t c);
+uint32_t go_ani_sketch_density(const go_ani_sketch *s);
 /* returns ANI in PERCENT (skani's unit, src/skani.rs:203-209), 0.0 when AF < min_af */
 float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction,
                   float *af_q, float *af_r);
+/* the same, plus the integers behind the value: detail = {M, T of the median chunk, aligned chunks, aligned bases of q,
+ * aligned bases of r, c_pair} (what the device hands back before the host's pow; tests/golden/ani_golden.json) */
+float go_ani_pair_detail(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r,
+                         uint64_t detail[6]);
 
 #ifdef __cplusplus
 }

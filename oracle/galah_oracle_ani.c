@@ -21,7 +21,15 @@
  *               fwd + rev mod 4^k is the same on both strands, like the canonical code, and costs the device one add
  *               where min() of two masked fields cost four instructions on every base; the shifted odd multiplier is a
  *               bijective mix of the key's 2k bits (and ignores whatever a register holds above them)
- *   chunk(p)  = p / chunk_len  (chunk_len <= 32768)
+ *   density   : the `c` above is PER GENOME.  A genome gets the base density c (125; 30 with --small-genomes) when it is
+ *               long enough to hold ~8192 seeds at it, else a four times denser one, and so on down to every k-mer:
+ *                   c_g = c;  while (c_g > 1 && L < 8192 * c_g) c_g = max(1, c_g / 4)        (125 -> 31 -> 7 -> 1)
+ *               (skani's `--small-genomes` = `-c 30` is the reference's own remedy for the same noise,
+ *               src/skani.rs:152-153; here it is chosen per genome -- a 200 kb plasmid or a 5 kb contig carries as many
+ *               seeds as a genome does).  FracMinHash samples are nested (hash < 2^32/c), so a PAIR is evaluated at the
+ *               sparser of its two densities, c_pair = max(c_q, c_r): seeds of the denser genome whose selection hash is
+ *               not below (2^32-1)/c_pair are ignored, and its T_c counts only the seeds that remain
+ *   chunk(p)  = p / chunk_len  (chunk_len <= 32768; at most 65535 chunks per genome)
  *   anchor    = (seed a of q, seed b of r) with equal codes; orientation o = strand_a ^ strand_b;
  *               band = o ? ((pos_b + pos_a) >> 12 & 7) | 8 : ((2 (pos_b - pos_a) + 1 + 4096) >> 13) & 7   (mod 2^32)
  *               -- anchors of one alignment share the orientation and, up to indels, the diagonal: 4 kb bands,
@@ -58,11 +66,13 @@
 #define GO_ANI_SLOTS 17   /* per chunk: 16 band counters + the seeds whose anchors fall into more than one band */
 #define GO_ANI_BAND_SHIFT 12
 #define GO_ANI_MIN_COLINEAR 3
+#define GO_ANI_SEEDS_WANTED 8192   /* a genome shorter than this many seeds' worth of bases is seeded four times denser */
 
 typedef struct { uint32_t code, idx; } code_ref;
 
 struct go_ani_sketch {
-    uint32_t k, c, chunk;
+    uint32_t k, c, chunk;   /* c: the density THIS genome was seeded at (go_ani_density of its length and the base c) */
+    uint32_t *sel;       /* selection hash per seed (< (2^32-1)/c): what a sparser partner's threshold is applied to */
     uint64_t length;     /* L */
     size_t n;            /* seeds in position order */
     uint64_t *h;         /* code per seed (position order; u64 for the accessor's sake) */
@@ -80,8 +90,16 @@ static int cmp_code_ref(const void *a, const void *b) {
     return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
+/* the density a genome of `len` stream bytes is seeded at, given the base density c */
+uint32_t go_ani_density(uint64_t len, uint32_t c) {
+    uint32_t t = c ? c : 1;
+    while (t > 1 && len < (uint64_t)GO_ANI_SEEDS_WANTED * t) t = t / 4 ? t / 4 : 1;
+    return t;
+}
+
 go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint32_t c, uint32_t chunk) {
     go_ani_sketch *s = (go_ani_sketch *)calloc(1, sizeof(*s));
+    c = go_ani_density(n, c);
     s->k = k; s->c = c; s->chunk = chunk; s->length = n;
     s->n_chunks = (uint32_t)((n + chunk - 1) / chunk);
     s->chunk_total = (uint32_t *)calloc((size_t)s->n_chunks + 1, sizeof(uint32_t));
@@ -90,6 +108,7 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
     s->chunk_id = (uint32_t *)malloc(cap * sizeof(uint32_t));
     s->pos = (uint32_t *)malloc(cap * sizeof(uint32_t));
     s->strand = (uint8_t *)malloc(cap);
+    s->sel = (uint32_t *)malloc(cap * sizeof(uint32_t));
     const uint32_t thr = UINT32_MAX / c, mix = 0x85EBCA6Bu << (32 - 2 * k);   /* k <= 16 */
     const uint64_t mask = (k < 32) ? ((1ULL << (2 * k)) - 1) : UINT64_MAX;
     uint64_t fwd = 0, rev = 0;
@@ -102,9 +121,11 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
         rev = (rev >> 2) | ((uint64_t)(3 - b) << (2 * (k - 1)));
         if (++good < k) continue;
         const uint32_t code = (uint32_t)(fwd < rev ? fwd : rev);
-        if ((uint32_t)((0u - 2u - (uint32_t)fwd - (uint32_t)rev) * mix) >= thr) continue;
+        const uint32_t sel = (uint32_t)((0u - 2u - (uint32_t)fwd - (uint32_t)rev) * mix);
+        if (sel >= thr) continue;
         if (s->n == cap) {
             cap *= 2;
+            s->sel = (uint32_t *)realloc(s->sel, cap * sizeof(uint32_t));
             s->h = (uint64_t *)realloc(s->h, cap * sizeof(uint64_t));
             s->chunk_id = (uint32_t *)realloc(s->chunk_id, cap * sizeof(uint32_t));
             s->pos = (uint32_t *)realloc(s->pos, cap * sizeof(uint32_t));
@@ -112,6 +133,7 @@ go_ani_sketch *go_ani_sketch_bytes(const uint8_t *g, size_t n, uint32_t k, uint3
         }
         const size_t start = p + 1 - k;
         s->h[s->n] = code;
+        s->sel[s->n] = sel;
         s->pos[s->n] = (uint32_t)start;
         s->strand[s->n] = rev < fwd;
         s->chunk_id[s->n] = (uint32_t)(start / chunk);
@@ -160,7 +182,7 @@ int go_ani_sketch_file(const char *path, uint32_t k, uint32_t c, uint32_t chunk,
 
 void go_ani_sketch_free(go_ani_sketch *s) {
     if (!s) return;
-    free(s->h); free(s->chunk_id); free(s->pos); free(s->strand); free(s->sorted); free(s->chunk_total); free(s);
+    free(s->h); free(s->chunk_id); free(s->pos); free(s->strand); free(s->sel); free(s->sorted); free(s->chunk_total); free(s);
 }
 size_t go_ani_sketch_nseeds(const go_ani_sketch *s) { return s->n; }
 const uint64_t *go_ani_sketch_seeds(const go_ani_sketch *s) { return s->h; }
@@ -168,6 +190,7 @@ const uint32_t *go_ani_sketch_chunks(const go_ani_sketch *s) { return s->chunk_i
 const uint32_t *go_ani_sketch_positions(const go_ani_sketch *s) { return s->pos; }
 const uint8_t *go_ani_sketch_strands(const go_ani_sketch *s) { return s->strand; }
 uint64_t go_ani_sketch_length(const go_ani_sketch *s) { return s->length; }
+uint32_t go_ani_sketch_density(const go_ani_sketch *s) { return s->c; }
 
 typedef struct { uint64_t m, t; } chunk_frac;
 
@@ -185,11 +208,12 @@ static size_t lower_bound_code(const code_ref *a, size_t n, uint32_t code) {
 }
 
 /* band votes of both genomes: vq[chunk][band], vr[chunk][band] */
-static void ani_votes(const go_ani_sketch *q, const go_ani_sketch *r, uint32_t *vq, uint32_t *vr) {
+static void ani_votes(const go_ani_sketch *q, const go_ani_sketch *r, uint32_t thr, uint32_t *vq, uint32_t *vr) {
     uint16_t *rmask = (uint16_t *)calloc(r->n + 1, sizeof(uint16_t));
     for (size_t a = 0; a < q->n; a++) {
         const uint32_t code = (uint32_t)q->h[a];
         uint32_t qmask = 0;
+        if (q->sel[a] >= thr) continue;   /* not a seed at the pair's density (equal codes have equal hashes: the r side agrees) */
         for (size_t x = lower_bound_code(r->sorted, r->n, code); x < r->n && r->sorted[x].code == code; x++) {
             const uint32_t b = r->sorted[x].idx;
             const uint32_t o = (uint32_t)(q->strand[a] ^ r->strand[b]);
@@ -210,9 +234,9 @@ static void ani_votes(const go_ani_sketch *q, const go_ani_sketch *r, uint32_t *
 }
 
 /* appends (M_c, T_c) of every aligned chunk of x and adds its aligned bases */
-static void ani_collect(const go_ani_sketch *x, const uint32_t *votes, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
+static void ani_collect(const go_ani_sketch *x, const uint32_t *totals, const uint32_t *votes, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
     for (uint32_t c = 0; c < x->n_chunks; c++) {
-        const uint64_t tc = x->chunk_total[c];
+        const uint64_t tc = totals[c];
         if (tc < 1) continue;
         const uint32_t *v = votes + (size_t)c * GO_ANI_SLOTS;
         uint64_t mc = 0;
@@ -228,29 +252,50 @@ static void ani_collect(const go_ani_sketch *x, const uint32_t *votes, chunk_fra
     }
 }
 
-float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r) {
+/* T_c of x at the pair's density: its own totals when that is its own density, else a recount of the seeds that remain */
+static uint32_t *ani_totals(const go_ani_sketch *x, uint32_t thr) {
+    uint32_t *t = (uint32_t *)calloc((size_t)x->n_chunks + 1, sizeof(uint32_t));
+    if (UINT32_MAX / x->c == thr) memcpy(t, x->chunk_total, (size_t)x->n_chunks * sizeof(uint32_t));
+    else for (size_t a = 0; a < x->n; a++) if (x->sel[a] < thr) t[x->chunk_id[a]]++;
+    return t;
+}
+
+/* detail (nullable): M, T of the median chunk, number of aligned chunks, aligned bases of q, aligned bases of r, c_pair */
+float go_ani_pair_detail(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r,
+                         uint64_t detail[6]) {
     uint64_t bq = 0, br = 0;
     size_t n = 0;
+    const uint32_t c_pair = q->c > r->c ? q->c : r->c, thr = UINT32_MAX / c_pair;
     chunk_frac *fr = (chunk_frac *)malloc(((size_t)q->n_chunks + r->n_chunks + 1) * sizeof(chunk_frac));
     uint32_t *vq = (uint32_t *)calloc(((size_t)q->n_chunks + 1) * GO_ANI_SLOTS, sizeof(uint32_t));
     uint32_t *vr = (uint32_t *)calloc(((size_t)r->n_chunks + 1) * GO_ANI_SLOTS, sizeof(uint32_t));
-    ani_votes(q, r, vq, vr);
-    ani_collect(q, vq, fr, &n, &bq);
-    ani_collect(r, vr, fr, &n, &br);
-    free(vq); free(vr);
+    uint32_t *tq = ani_totals(q, thr), *tr = ani_totals(r, thr);
+    ani_votes(q, r, thr, vq, vr);
+    ani_collect(q, tq, vq, fr, &n, &bq);
+    ani_collect(r, tr, vr, fr, &n, &br);
+    free(vq); free(vr); free(tq); free(tr);
     double afq = q->length ? (double)bq / (double)q->length : 0.0;
     double afr = r->length ? (double)br / (double)r->length : 0.0;
     if (af_q) *af_q = (float)afq;
     if (af_r) *af_r = (float)afr;
+    if (detail) { detail[0] = detail[1] = 0; detail[2] = n; detail[3] = bq; detail[4] = br; detail[5] = c_pair; }
     if (n == 0) { free(fr); return 0.0f; }
     /* lower median of the per-chunk containments over the aligned chunks of both directions */
     qsort(fr, n, sizeof(chunk_frac), cmp_frac);
-    const chunk_frac med = fr[(n - 1) / 2];
+    chunk_frac med = fr[(n - 1) / 2];
+    /* every member of the median's tie group holds the same fraction: the smallest (m, t) of the group is reported */
+    for (size_t e = 0; e < n; e++)
+        if (fr[e].m * med.t == med.m * fr[e].t && (fr[e].m < med.m || (fr[e].m == med.m && fr[e].t < med.t))) med = fr[e];
     free(fr);
+    if (detail) { detail[0] = med.m; detail[1] = med.t; }
     if (afq < (double)min_af_fraction && afr < (double)min_af_fraction) return 0.0f;
     const double c = (double)med.m / (double)med.t;
     double ani = 100.0 * pow(c, 1.0 / (double)q->k);
     char txt[64];
     snprintf(txt, sizeof txt, "%.2f", ani);
     return strtof(txt, NULL);
+}
+
+float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r) {
+    return go_ani_pair_detail(q, r, min_af_fraction, af_q, af_r, NULL);
 }

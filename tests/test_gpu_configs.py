@@ -203,13 +203,40 @@ def test_ani_large_genomes_narrow_rounds(ctx):
         assert 90.0 < ani[0] < 99.0
         idx.free()
         g.free()
-    # beyond the chunk counters the index is refused with a clear message, not computed wrongly
-    g = ctx.genomes_synthetic(78, 1, 1, 31_000_000, 0.0)
-    with pytest.raises(galah_amd.GalahHipError, match="too long"):
-        ctx.ani_index_build(g)
-    idx = ctx.ani_index_build(g, 15, 125, 32768)   # a proportionally longer chunk takes it
-    idx.free()
-    g.free()
+
+
+def test_ani_genomes_beyond_the_lds_votes_area(ctx):
+    """A pair whose chunks (both genomes together) do not fit the LDS votes area -- above 58 Mb at the default 20 kb chunk --
+    takes the general form of ani_pairs (per-chunk state in a global scratch region) instead of being refused: the
+    reference hands any FASTA to skani (src/skani.rs:730-744).  31 Mb against 31 Mb (3 100 chunks), 62 Mb against 62 Mb
+    and against a 4 Mb part of itself, both orders, against the oracle; short pair lists and long ones mix the two forms."""
+    g = ctx.genomes_synthetic(78, 1, 2, 31_000_000, 0.03)
+    idx = ctx.ani_index_build(g)
+    sks = [oracle.AniSketch.from_bytes(g.to_host(i)) for i in range(2)]
+    want = oracle.ani_pair_detail(sks[0], sks[1], 0.15)
+    ani, af = ctx.ani_pairs(idx, np.array([[0, 1], [1, 0]], dtype=np.uint32), 0.15, want_af=True)
+    assert ani[0] == np.float32(want[0]) and ani[1] == ani[0] and 90.0 < ani[0] < 99.0
+    assert af[0, 0] == np.float32(want[1]) and af[0, 1] == np.float32(want[2])
+    assert ctx.ani_pairs_detail(idx, np.array([[0, 1]], dtype=np.uint32))[0].tolist() == want[3]
+    idx.free(); g.free()
+    big = ctx.genomes_synthetic(79, 1, 2, 62_000_000, 0.02)
+    a, b = big.to_host(0), big.to_host(1)
+    part = b[30_000_000:34_000_000].copy()
+    big.free()
+    seqs = [a, b, part, oracle.synth_genome(80, 0, 0, 4_000_000, 0.0), oracle.synth_genome(80, 0, 1, 4_000_000, 0.01)]
+    g = ctx.genomes_from_host(seqs)
+    sk, idx = ctx.sketch_and_index(g, 21, 1000, 0, 15, 125, 20000)   # the fused pass seeds them too
+    sks = [oracle.AniSketch.from_bytes(s) for s in seqs]
+    pairs = np.array([(0, 1), (1, 0), (0, 2), (2, 1), (3, 4), (2, 3), (4, 3)], dtype=np.uint32)
+    want = [oracle.ani_pair_detail(sks[x], sks[y], 0.15) for x, y in pairs]
+    ani, af = ctx.ani_pairs(idx, pairs, 0.15, want_af=True)
+    assert [float(v) for v in ani] == [float(np.float32(w[0])) for w in want], (ani, [w[0] for w in want])
+    assert np.array_equal(af, np.float32([[w[1], w[2]] for w in want]))
+    assert ctx.ani_pairs_detail(idx, pairs).tolist() == [w[3] for w in want]
+    assert 95.5 < ani[0] < 96.7 and 95.0 < ani[2] < 97.0 and ani[4] > 98.5 and ani[5] == 0   # two copies at 2 % each: ~96 %
+    many = np.concatenate([pairs] * 40)   # long list: the LDS form runs 8 waves per pair, the general form beside it
+    assert np.array_equal(ctx.ani_pairs(idx, many, 0.15), np.concatenate([ani] * 40))
+    sk.free(); idx.free(); g.free()
 
 
 def test_ani_tandem_repeats_skewed_segments(ctx):

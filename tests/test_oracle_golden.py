@@ -107,10 +107,11 @@ def test_reference_cli_min_aligned_fraction():
 CONTIG_CLUSTERS = [[0, 1, 2, 3, 4, 5], [6], [7], [8]]
 
 
-def test_reference_contig_expectation_needs_dense_seeds():
-    """On 1 kb contigs the FracMinHash ANI keeps ~35 seeds at c = 30 (skani's --small-genomes density): the estimate's
-    standard error (~1.5 ANI points) cannot be relied on to separate 96 % from 94 % at the 95 % threshold.  With every
-    15-mer as a seed (c = 1) the build-defined estimator reproduces the reference's expected contig clusters."""
+def test_reference_contig_expectation_with_automatic_density():
+    """On 1 kb contigs a FracMinHash ANI at skani's --small-genomes density (c = 30) keeps ~35 seeds: the estimate's
+    standard error (~1.5 ANI points) cannot be relied on to separate 96 % from 94 % at the 95 % threshold.  The seed density
+    is chosen per genome (go_ani_density): a contig this short is seeded with every 15-mer, whatever base density the
+    caller names, and the build-defined estimator reproduces the reference's expected contig clusters."""
     from conftest import fasta_records
     names, seqs = fasta_records("contigs_specific")
     assert names[5].startswith("96ANI") and names[6].startswith("94ANI") and len(names) == 9
@@ -123,14 +124,59 @@ def test_reference_contig_expectation_needs_dense_seeds():
             ani = oracle.mash_ani(c, t, 21)
             if ani >= float(np.float32(0.9)):
                 cache.insert((i, j), np.float32(ani))
-    dense = [oracle.AniSketch.from_bytes(s, 15, 1, 20000) for s in seqs]
-    got = oracle.cluster(n, cache, 95.0, lambda a, b: oracle.ani_pair(dense[a], dense[b], 0.15)[0])
-    assert got == CONTIG_CLUSTERS
-    assert oracle.ani_pair(dense[0], dense[5], 0.15)[0] >= 95.0 > oracle.ani_pair(dense[0], dense[6], 0.15)[0]
-    # at c = 30 a 1 kb contig keeps ~35 seeds: one seed more or less moves the estimate by ~0.2 ANI points at 95 %, the
-    # binomial standard error is ~1.5 -- which side of 95 % the 96 % variant lands on is luck of the seed hash
-    sparse = [oracle.AniSketch.from_bytes(s, 15, 30, 20000) for s in seqs]
-    assert all(25 <= sparse[i].nseeds <= 45 for i in range(7))
+    for base_c in (125, 30, 1):
+        dense = [oracle.AniSketch.from_bytes(s, 15, base_c, 20000) for s in seqs]
+        assert all(d.density == 1 and d.nseeds >= 0.95 * len(s) for d, s in zip(dense, seqs))
+        got = oracle.cluster(n, cache, 95.0, lambda a, b: oracle.ani_pair(dense[a], dense[b], 0.15)[0])
+        assert got == CONTIG_CLUSTERS
+        assert oracle.ani_pair(dense[0], dense[5], 0.15)[0] >= 95.0 > oracle.ani_pair(dense[0], dense[6], 0.15)[0]
+
+
+def test_ani_density_tiers():
+    """c_g = c; while (c_g > 1 and L < 8192 c_g) c_g = max(1, c_g // 4): 125 -> 31 -> 7 -> 1."""
+    assert [oracle.ani_density(L) for L in (0, 1000, 57343, 57344, 253951, 253952, 1023999, 1024000, 5_000_000)] == [1, 1, 1, 7, 7, 31, 31, 125, 125]
+    assert [oracle.ani_density(L, 30) for L in (1000, 57343, 57344, 245759, 245760, 5_000_000)] == [1, 1, 7, 7, 30, 30]
+    assert oracle.ani_density(10, 1) == 1 and oracle.ani_density(10**9, 1) == 1
+
+
+def test_ani_mixed_density_pair_is_evaluated_at_the_sparser_density():
+    """A 300 kb replicon (density 31) against a 2 Mb genome that contains a 97 % copy of it (density 125): the pair uses the
+    seeds both samples hold -- those below the sparser threshold -- and is symmetric."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    small = rng.choice(acgt, size=300_000)
+    big = rng.choice(acgt, size=2_000_000)
+    cp = small.copy()
+    hit = rng.random(len(cp)) < 0.03
+    cp[hit] = acgt[(np.searchsorted(acgt, cp[hit]) + rng.integers(1, 4, size=int(hit.sum()))) % 4]
+    big[500_000:800_000] = cp
+    a, b = oracle.AniSketch.from_bytes(small), oracle.AniSketch.from_bytes(big)
+    assert (a.density, b.density) == (31, 125)
+    ani, afq, afr, d = oracle.ani_pair_detail(a, b, 0.15)
+    ani2, afq2, afr2, d2 = oracle.ani_pair_detail(b, a, 0.15)
+    assert d[5] == 125 and ani == ani2 and (afq, afr) == (afr2, afq2) and d[:3] == d2[:3]
+    true = 100.0 * float(np.mean(small == cp))
+    assert afq > 0.9 and afr < 0.2 and abs(ani - true) < 0.5, (ani, true, afq, afr)
+    # the same replicon against itself stays at its own density
+    assert oracle.ani_pair_detail(a, oracle.AniSketch.from_bytes(cp), 0.15)[3][5] == 31
+
+
+def test_ani_golden_file_is_what_the_oracle_computes():
+    """tests/golden/ani_golden.json freezes the build-defined estimator on the reference's fixture genomes: a change of
+    its definition has to change that file (tests/golden/make_ani_golden.py), in a diff a reviewer sees."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_ani_golden
+    with open(os.path.join(here, "golden", "ani_golden.json")) as f:
+        want = json.load(f)
+    got = make_ani_golden.build()
+    assert got["genomes"] == want["genomes"] and got["contigs"] == want["contigs"]
+    assert got["genome_pairs"] == want["genome_pairs"]
+    assert got["contig_pairs"] == want["contig_pairs"]
+    assert len(want["genome_pairs"]) == 91 and len(want["contig_pairs"]) == 36
 
 
 def _finch_plus_ani(names, thr, min_af):
