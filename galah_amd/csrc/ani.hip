@@ -18,8 +18,8 @@
 //               seeds with an anchor there are counted in LDS (u16 votes); M_c = the votes of the
 //               bands that hold >= 3 seeds (colinear matches only), capped at T_c; a chunk is
 //               aligned iff M_c*10000 >= 510*T_c; emits the (M_c, T_c) of the lower-median containment
-//               over the aligned chunks of both directions (rank selection, exact), their number,
-//               and the aligned bases per direction.
+//               over the aligned chunks of the shorter genome (of both at equal length; rank selection, exact),
+//               their number, and the aligned bases per direction.
 #include "ghip_internal.h"
 #include "seed_common.h"
 
@@ -27,9 +27,10 @@ namespace {
 
 using namespace ghip_seed;
 
-// Standalone seeding pass (the fused form lives in sketch.hip: sketch_kmers<K, true>).
+// Standalone seeding pass (the fused form lives in sketch.hip: sketch_kmers<K, true>) over the resident bases (2-bit
+// codes + validity bitmap, ghip_internal.h).
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
-    const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ valid, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const ghip_sketch_work *__restrict__ work, SeedOut so) {
     __shared__ SeedLds sl;
     const ghip_sketch_work wk = work[blockIdx.x];
@@ -41,40 +42,34 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void ani_seeds_kernel(
     const uint32_t K = so.k, sthr = so.seed_thr[g];
     SeedBlock sb = seed_block_begin(sl, so, g, blk0);
     {
-        // every base is fetched once: own 64 bytes from memory, the K-1 overlap bytes from the next
-        // lane's registers (lane 63: from memory); lanes past the stream end hold 'N'
+        // every base is fetched once: own 64 bases (one 16-byte vector, 8 bytes of validity) from memory, the K-1 <= 15
+        // overlap bases from the next lane's registers (lane 63: from memory); lanes past the stream end hold invalid positions
         const bool live = p0 < L;
-        const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);
-        const uint4 NNNN = make_uint4(0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu);
-        uint4 q0 = live ? src[0] : NNNN, q1 = live ? src[1] : NNNN, q2 = live ? src[2] : NNNN, q3 = live ? src[3] : NNNN;
-        uint4 q4;
-        q4.x = __shfl_down(q0.x, 1, 64); q4.y = __shfl_down(q0.y, 1, 64); q4.z = __shfl_down(q0.z, 1, 64); q4.w = __shfl_down(q0.w, 1, 64);
-        if ((threadIdx.x & 63u) == 63u) q4 = live ? src[4] : NNNN;
+        const uint64_t base0 = starts[g] + p0;
+        const uint32_t *pw = packed + (base0 >> 4), *vw = valid + (base0 >> 5);
+        uint4 q = make_uint4(0, 0, 0, 0);
+        uint2 vb = make_uint2(0, 0);
+        if (live) { q = *reinterpret_cast<const uint4 *>(pw); vb = *reinterpret_cast<const uint2 *>(vw); }
+        uint32_t o0 = __shfl_down(q.x, 1, 64), v2 = __shfl_down(vb.x, 1, 64);
+        if ((threadIdx.x & 63u) == 63u) { o0 = live ? pw[4] : 0u; v2 = live ? vw[2] : 0u; }
+        const uint32_t words[5] = {q.x, q.y, q.z, q.w, o0}, vbits[3] = {vb.x, vb.y, v2};
         const uint32_t mask = (K < 16) ? ((1u << (2 * K)) - 1) : ~0u;  // K <= 16: codes fit 32 bits
         const uint32_t top = 2 * (K - 1);
         uint32_t fwd = 0, rev = 0;
         uint32_t good = 0;
-        const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;  // K <= 16 -> at most 79 bytes = 5 vectors
-        const int NV = (NB + 15) / 16;
-        for (int v = 0; v < NV; v++) {
-            const uint4 cur = q0;
-            q0 = q1; q1 = q2; q2 = q3; q3 = q4;
-            uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+        const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;  // K <= 16 -> at most 79 bases = 5 words
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int b = v * 16 + j;
-                uint32_t code = base_code((words[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                const bool valid = code <= 3u;
-                code &= 3u;
-                fwd = ((fwd << 2) | code) & mask;
-                rev = (rev >> 2) | ((3u - code) << top);
-                good = valid ? good + 1 : 0;
-                const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_selected(fwd, rev, so.mul, sthr);
-                if (pass) seed_mark_at(sl, sb, fwd, (uint32_t)(b - ((int)K - 1)));
-            }
+        for (int b = 0; b < 80; b++) {
+            uint32_t code = (words[b >> 4] >> (2 * (b & 15))) & 3u;
+            const bool ok = (vbits[b >> 5] >> (b & 31)) & 1u;
+            fwd = ((fwd << 2) | code) & mask;
+            rev = (rev >> 2) | ((3u - code) << top);
+            good = ok ? good + 1 : 0;
+            const bool pass = b < NB && b >= (int)K - 1 && good >= K && seed_selected(fwd, rev, so.mul, sthr);
+            if (pass) seed_mark_at(sl, sb, fwd, (uint32_t)(b - ((int)K - 1)));
         }
     }
-    seed_block_flush<false>(sl, so, sb, toff, bytes + starts[g] + blk0);
+    seed_block_flush<false>(sl, so, sb, toff, packed + ((starts[g] + blk0) >> 4));
 }
 
 
@@ -219,7 +214,7 @@ __device__ __forceinline__ void cast_vote(uint32_t *votes, uint32_t c, uint32_t 
 // thread's share of the aligned bases.  M_c = votes of the bands holding >= ANI_MIN_COLINEAR seeds, plus the repeat seeds
 // of a chunk that has such a band, capped at T_c.
 __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *votes, const uint32_t *tc, uint32_t nch, uint64_t L,
-                                                              uint32_t chunk, unsigned long long *list, uint32_t *n_al) {
+                                                              uint32_t chunk, bool listed, unsigned long long *list, uint32_t *n_al) {
     unsigned long long bases = 0;
     for (uint32_t c = threadIdx.x; c < nch; c += blockDim.x) {
         const unsigned long long t = tc[c];
@@ -232,7 +227,7 @@ __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *vo
         if (m) m += votes[c * ANI_VOTE_WORDS + 8];
         if (m > t) m = t;
         if (t >= 1 && m * 10000ull >= 510ull * t) {
-            list[atomicAdd(n_al, 1u)] = (m << 32) | t;
+            if (listed) list[atomicAdd(n_al, 1u)] = (m << 32) | t;
             const uint64_t lo = (uint64_t)c * chunk;
             uint64_t hi = lo + chunk;
             if (hi > L) hi = L;
@@ -456,10 +451,13 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
     }
     __syncthreads();
     PH(6);   // waiting for the other waves
-    // (M_c, T_c) of the aligned chunks of both directions, then the LOWER MEDIAN containment M_c/T_c
+    // (M_c, T_c) of the aligned chunks, then the LOWER MEDIAN containment M_c/T_c
     // by rank selection (exact: fractions compared by cross-multiplication)
-    const unsigned long long bq = collect_aligned(vq, filt_q ? tq_re : chunk_total + chunk_start[q], nchq, glen[q], chunk, list, &n_al);
-    const unsigned long long br = collect_aligned(vr, filt_r ? tr_re : chunk_total + chunk_start[r], nchr, glen[r], chunk, list, &n_al);
+    // the median is taken over the chunks of the SHORTER genome (both at equal length): a chunk of the longer one is diluted
+    // wherever the shorter one ends inside it (oracle/galah_oracle_ani.c)
+    const uint64_t Lq = glen[q], Lr = glen[r];
+    const unsigned long long bq = collect_aligned(vq, filt_q ? tq_re : chunk_total + chunk_start[q], nchq, Lq, chunk, Lq <= Lr, list, &n_al);
+    const unsigned long long br = collect_aligned(vr, filt_r ? tr_re : chunk_total + chunk_start[r], nchr, Lr, chunk, Lr <= Lq, list, &n_al);
     if ((threadIdx.x & 63u) == 0) { atomicAdd(&red[2], bq); atomicAdd(&red[5], br); }
     __syncthreads();
     const uint32_t n = n_al;
@@ -546,7 +544,7 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, con
     ghip_prof_begin(ctx, "ani_seeds");
     for (size_t off = 0; off < n_work; off += GHIP_MAX_GRID)  // one AQL dispatch holds < 2^32 work-items
         hipLaunchKernelGGL(ani_seeds_kernel, dim3((unsigned)std::min<size_t>(n_work - off, GHIP_MAX_GRID)),
-                           dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, g->d_bytes, g->d_starts, g->d_lens, d_work + off, so);
+                           dim3(GHIP_SKETCH_THREADS), 0, ctx->stream, g->d_packed, g->d_valid, g->d_starts, g->d_lens, d_work + off, so);
     ghip_prof_end(ctx);
 }
 

@@ -321,7 +321,22 @@ int build_work(ghip_ctx *ctx, ghip_genomes *g, hipStream_t st = nullptr) {
     return h2d_on(ctx, st, g->d_identity, ident.data(), g->n);
 }
 
-// lays genomes out with 16-B aligned starts and GHIP_TAIL_PAD bytes of 'N' after each
+// base offset of the genome after one of `len` bases that starts at `off`: room for the bases and GHIP_TAIL_PAD invalid
+// positions, rounded up to the alignment of a genome's first base
+inline uint64_t next_genome_offset(uint64_t off, uint64_t len) { return off + (len + GHIP_TAIL_PAD + GHIP_BASE_ALIGN - 1) / GHIP_BASE_ALIGN * GHIP_BASE_ALIGN; }
+
+// allocates the resident arrays for g->total_alloc base positions, all invalid (the validity bitmap is zero-filled; the
+// 2-bit codes of invalid positions are never looked at)
+int alloc_bases(ghip_ctx *ctx, ghip_genomes *g, hipStream_t st) {
+    int rc = dmalloc(ctx, &g->d_packed, g->total_alloc / 16);
+    if (rc) return rc;
+    if ((rc = dmalloc(ctx, &g->d_valid, g->total_alloc / 32))) return rc;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(g->d_valid, 0, g->total_alloc / 32 * sizeof(uint32_t), st));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(g->d_packed, 0, g->total_alloc / 16 * sizeof(uint32_t), st));   // (tidy: keeps saved / compared images deterministic)
+    return GHIP_OK;
+}
+
+// lays genomes out (first base at a multiple of GHIP_BASE_ALIGN, GHIP_TAIL_PAD invalid positions after each)
 int layout_genomes(ghip_ctx *ctx, ghip_genomes *g, const std::vector<uint64_t> &lens) {
     g->n = lens.size();
     g->lens = lens;
@@ -330,18 +345,37 @@ int layout_genomes(ghip_ctx *ctx, ghip_genomes *g, const std::vector<uint64_t> &
     g->total_bases = 0;
     for (size_t i = 0; i < g->n; i++) {
         g->starts[i] = off;
-        off += (lens[i] + GHIP_TAIL_PAD + 15) / 16 * 16;
+        off = next_genome_offset(off, lens[i]);
         g->total_bases += lens[i];
     }
     g->total_alloc = off + 256;
-    int rc = dmalloc(ctx, &g->d_bytes, g->total_alloc);
+    int rc = alloc_bases(ctx, g, ctx->stream);
     if (rc) return rc;
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(g->d_bytes, 'N', g->total_alloc, ctx->stream));
     if ((rc = dmalloc(ctx, &g->d_starts, g->n))) return rc;
     if ((rc = dmalloc(ctx, &g->d_lens, g->n))) return rc;
     if ((rc = h2d(ctx, g->d_starts, g->starts.data(), g->n))) return rc;
     if ((rc = h2d(ctx, g->d_lens, g->lens.data(), g->n))) return rc;
     return build_work(ctx, g);
+}
+
+// Stream bytes on the host -> the resident form, genome by genome through ONE device staging buffer (the copies and the
+// pack kernels are ordered by `st`; pageable sources are staged by the runtime, so the host buffers are free on return).
+int upload_streams(ghip_ctx *ctx, ghip_genomes *g, hipStream_t st, const std::function<const uint8_t *(size_t)> &bytes_of) {
+    uint64_t longest = 0;
+    for (uint64_t l : g->lens) longest = std::max(longest, l);
+    if (longest == 0) return GHIP_OK;
+    uint8_t *d_stage = nullptr;
+    int rc = dmalloc(ctx, &d_stage, longest + 64);
+    if (rc) return rc;
+    for (size_t i = 0; i < g->n && rc == GHIP_OK; i++) {
+        if (!g->lens[i]) continue;
+        if (hipMemcpyAsync(d_stage, bytes_of(i), g->lens[i], hipMemcpyHostToDevice, st) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "base upload failed");
+        else ghip_launch_pack_bases(st, d_stage, g->lens[i], g->starts[i], g->d_packed, g->d_valid);
+    }
+    if (rc == GHIP_OK && (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)) rc = ghip_set_error(ctx, GHIP_EHIP, "base upload failed");
+    else if (rc != GHIP_OK) hipStreamSynchronize(st);
+    ghip_pool_free(ctx, d_stage);
+    return rc;
 }
 
 }  // namespace
@@ -457,7 +491,7 @@ extern "C" void ghip_free(void *p) { free(p); }
 // ------------------------------------------------------------------------------------ genomes
 static void free_genomes_locked(ghip_genomes *g) {  // ctx->mu held
     ghip_ctx *ctx = g->ctx;
-    ghip_pool_free(ctx, g->d_bytes); ghip_pool_free(ctx, g->d_starts); ghip_pool_free(ctx, g->d_lens);
+    ghip_pool_free(ctx, g->d_packed); ghip_pool_free(ctx, g->d_valid); ghip_pool_free(ctx, g->d_starts); ghip_pool_free(ctx, g->d_lens);
     ghip_pool_free(ctx, g->d_work); ghip_pool_free(ctx, g->d_identity);
     ctx->live_handles--;
     delete g;
@@ -488,14 +522,8 @@ extern "C" int ghip_genomes_from_host(ghip_ctx *ctx, const uint8_t *bytes, const
     g->ctx = ctx;
     ctx->live_handles++;
     int rc = layout_genomes(ctx, g, lens);
-    for (size_t i = 0; i < n && rc == GHIP_OK; i++)
-        if (lens[i]) {
-            hipError_t e = hipMemcpyAsync(g->d_bytes + g->starts[i], bytes + offsets[i], lens[i], hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
-        }
-    // caller-supplied bytes are arbitrary: anything but A,C,G,T becomes 'N' (the k-mer kernels' alphabet invariant)
-    if (rc == GHIP_OK) ghip_launch_sanitize(ctx, g->d_bytes, g->total_alloc / 16 * 16);
-    if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
+    // caller-supplied bytes are arbitrary: anything but A,C,G,T becomes an invalid position ('N' when read back)
+    if (rc == GHIP_OK) rc = upload_streams(ctx, g, ctx->stream, [&](size_t i) { return bytes + offsets[i]; });
     if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
     *out = g;
     return GHIP_OK;
@@ -536,12 +564,7 @@ static int genomes_from_files_two_phase(ghip_ctx *ctx, const char *const *paths,
     g->stats = stats;
     ctx->live_handles++;
     rc = layout_genomes(ctx, g, lens);
-    for (size_t i = 0; i < n && rc == GHIP_OK; i++)
-        if (lens[i]) {
-            hipError_t e = hipMemcpyAsync(g->d_bytes + g->starts[i], streams[i].data(), lens[i], hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, hipGetErrorString(e));
-        }
-    if (rc == GHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
+    if (rc == GHIP_OK) rc = upload_streams(ctx, g, ctx->stream, [&](size_t i) { return (const uint8_t *)streams[i].data(); });
     if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
     *out = g;
     return GHIP_OK;
@@ -596,10 +619,9 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         g->starts.resize(n);
         ctx->live_handles++;
         uint64_t off = 0;
-        for (size_t i = 0; i < n; i++) { g->starts[i] = off; off += (cap[i] + GHIP_TAIL_PAD + 15) / 16 * 16; }
+        for (size_t i = 0; i < n; i++) { g->starts[i] = off; off = next_genome_offset(off, cap[i]); }
         g->total_alloc = off + 256;
-        int rc = dmalloc(ctx, &g->d_bytes, g->total_alloc);
-        if (rc == GHIP_OK && hipMemsetAsync(g->d_bytes, 'N', g->total_alloc, fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed");
+        int rc = alloc_bases(ctx, g, fill_stream);
         if (rc == GHIP_OK && hipStreamSynchronize(fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sync failed");
         if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
         const double w_alloc = since(w0) - w_hint;
@@ -662,12 +684,15 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         const bool packed_wanted = use_pinned && !(ing && !strcmp(ing, "ascii"));
         const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, packed_wanted ? 4 * GHIP_PINNED_SLOT_MAX : GHIP_PINNED_SLOT_MAX);
         // Packed form (the default; GHIP_INGEST=ascii turns it off): the stream crosses PCIe as 2-bit codes plus the runs
-        // of its other bytes -- a quarter of the bytes, and PCIe is what bounds files -> clusters (5 GB: 88 ms) -- into a
-        // device staging area that belongs to the slot, and is expanded there into the resident one-byte-per-base stream
-        // by a kernel queued behind the copy on the same copy stream (sketch.hip: unpack_bases_kernel).
+        // of its other bytes -- a quarter of the bytes, and PCIe is what bounds files -> clusters (5 GB: 88 ms).  The
+        // codes ARE the resident form: they are copied straight to their place; the run table goes to a small device
+        // staging area that belongs to the slot, and a kernel queued behind the copy on the same copy stream turns it
+        // into the genome's validity bits (sketch.hip: ghip_launch_valid_from_runs).  The ASCII forms stage the stream
+        // bytes on the device and pack them there (ghip_launch_pack_bases).
         const bool packed_mode = packed_wanted;
-        const size_t stage_bytes = (slot_bytes / 4 + (64u << 10) + 4095) / 4096 * 4096;   // + room for ~5 000 runs
-        const size_t host_slot_bytes = packed_mode ? stage_bytes : slot_bytes;   // what a pinned slot has to hold
+        const size_t packed_slot_bytes = (slot_bytes / 4 + (64u << 10) + 4095) / 4096 * 4096;   // codes + room for ~5 000 runs
+        const size_t host_slot_bytes = packed_mode ? packed_slot_bytes : slot_bytes;   // what a pinned slot has to hold
+        const size_t stage_bytes = packed_mode ? (64u << 10) + 4096 : slot_bytes;      // ... and its device staging area: the runs / the stream bytes
         size_t n_slots = 0;
         if (use_pinned) {
             const size_t want = std::min<size_t>(GHIP_PINNED_SLOTS, (size_t)2 * threads);
@@ -683,7 +708,7 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) sl.ev = nullptr;
                 sl.state = 0;
             }
-            if (packed_mode) {   // one device allocation for all the staging areas (32 hipMalloc calls cost ~20 ms of a first call)
+            {   // one device allocation for all the staging areas (32 hipMalloc calls cost ~20 ms of a first call)
                 const size_t need = want * stage_bytes;
                 if (ctx->ingest_stage_bytes < need) {
                     if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
@@ -699,10 +724,8 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
             std::stable_partition(ctx->ingest_slots.begin(), ctx->ingest_slots.end(), usable);
             for (auto &sl : ctx->ingest_slots) if (usable(sl)) n_slots++;
             n_slots = std::min(n_slots, want);
-            if (packed_mode) {
-                if (!ctx->ingest_stage) n_slots = 0;   // no staging memory: every file takes the plain blocking path
-                for (size_t x = 0; x < n_slots; x++) { ctx->ingest_slots[x].d = ctx->ingest_stage + x * stage_bytes; ctx->ingest_slots[x].dbytes = stage_bytes; }
-            }
+            if (!ctx->ingest_stage) n_slots = 0;   // no staging memory: every file takes the plain blocking path
+            for (size_t x = 0; x < n_slots; x++) { ctx->ingest_slots[x].d = ctx->ingest_stage + x * stage_bytes; ctx->ingest_slots[x].dbytes = stage_bytes; }
         }
         const double w_pin = since(w0) - w_hint - w_alloc;
         std::mutex smu;
@@ -760,7 +783,9 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                     size_t used = 0, runs_off = 0;
                     uint32_t n_runs = 0;
                     bool fit = false;
-                    r = ghip_parse_fasta_packed(raw.data(), raw.size(), paths[i], slot->p, std::min(slot->bytes, slot->dbytes), (size_t)cap[i],
+                    // (the run table is bounded by the slot's device staging area: a stream with more runs "does not fit")
+                    const size_t table_at = (((size_t)cap[i] + 3) / 4 + 15) / 16 * 16;
+                    r = ghip_parse_fasta_packed(raw.data(), raw.size(), paths[i], slot->p, std::min(slot->bytes, table_at + slot->dbytes), (size_t)cap[i],
                                                 &len, g->stats[i], e, &used, &runs_off, &n_runs, &fit);
                     t2 = std::chrono::steady_clock::now();
                     if (r != GHIP_OK) { fail(r, e); stop = true; done = true; }
@@ -768,10 +793,11 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                         g->lens[i] = len;
                         hipError_t ce = hipSuccess;
                         if (len) {
-                            ce = hipMemcpyAsync(slot->d, slot->p, used, hipMemcpyHostToDevice, cs);
+                            // the codes to their place (whole 16-byte groups: the slot is zero-padded, the genome's room is longer)
+                            ce = hipMemcpyAsync(reinterpret_cast<uint8_t *>(g->d_packed) + g->starts[i] / 4, slot->p, ((len + 3) / 4 + 15) / 16 * 16, hipMemcpyHostToDevice, cs);
+                            if (ce == hipSuccess && n_runs) ce = hipMemcpyAsync(slot->d, slot->p + runs_off, (size_t)12 * n_runs, hipMemcpyHostToDevice, cs);
                             if (ce == hipSuccess) {
-                                ghip_launch_unpack_bases(cs, slot->d, reinterpret_cast<const uint32_t *>(slot->d + runs_off), n_runs,
-                                                         g->d_bytes + g->starts[i], len);
+                                ghip_launch_valid_from_runs(cs, reinterpret_cast<const uint32_t *>(slot->d), n_runs, g->d_valid + g->starts[i] / 32, len);
                                 ce = hipGetLastError();   // (per thread: the two launches just made)
                                 if (ce == hipSuccess) ce = hipEventRecord(slot->ev, cs);
                                 inflight = true;
@@ -801,10 +827,26 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                     else {
                         g->lens[i] = len;
                         hipError_t ce = hipSuccess;
-                        if (len && slot) {
-                            ce = hipMemcpyAsync(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice, cs);
-                            if (ce == hipSuccess) { ce = hipEventRecord(slot->ev, cs); inflight = true; }
-                        } else if (len) ce = hipMemcpy(g->d_bytes + g->starts[i], stream_buf, len, hipMemcpyHostToDevice);
+                        if (len && slot) {   // stream bytes to the slot's device staging area, packed into place behind the copy
+                            ce = hipMemcpyAsync(slot->d, stream_buf, len, hipMemcpyHostToDevice, cs);
+                            if (ce == hipSuccess) {
+                                ghip_launch_pack_bases(cs, slot->d, len, g->starts[i], g->d_packed, g->d_valid);
+                                ce = hipGetLastError();
+                                if (ce == hipSuccess) ce = hipEventRecord(slot->ev, cs);
+                                inflight = true;
+                            }
+                        } else if (len) {    // no slot (a file larger than the slots, or no pinned memory): a staging block of its own
+                            uint8_t *d_tmp = (uint8_t *)ghip_pool_alloc(ctx, len + 64);
+                            if (!d_tmp) ce = hipErrorOutOfMemory;
+                            else {
+                                ce = hipMemcpy(d_tmp, stream_buf, len, hipMemcpyHostToDevice);
+                                if (ce == hipSuccess) {
+                                    ghip_launch_pack_bases(cs, d_tmp, len, g->starts[i], g->d_packed, g->d_valid);
+                                    ce = hipStreamSynchronize(cs);
+                                }
+                                ghip_pool_free(ctx, d_tmp);
+                            }
+                        }
                         if (ce != hipSuccess) { fail(GHIP_EHIP, "ingest copy failed"); stop = true; }
                     }
                 }
@@ -861,7 +903,7 @@ extern "C" int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32
     ctx->live_handles++;
     int rc = layout_genomes(ctx, g, lens);
     if (rc != GHIP_OK) { free_genomes_locked(g); return rc; }
-    if (count) ghip_launch_synth(ctx, g->d_bytes, g->d_starts, length, (uint32_t)first, (uint32_t)count, members, seed, (uint32_t)(sub_rate * 4294967296.0));
+    if (count) ghip_launch_synth(ctx, g->d_packed, g->d_valid, g->d_starts, length, (uint32_t)first, (uint32_t)count, members, seed, (uint32_t)(sub_rate * 4294967296.0));
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_genomes_locked(g); return ghip_set_error(ctx, GHIP_EHIP, "synth_genomes failed"); }
     *out = g;
     return GHIP_OK;
@@ -885,7 +927,15 @@ extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t
     if (!ctx || !g || idx >= g->n || !outp) return GHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    return d2h(ctx, outp, g->d_bytes + g->starts[idx], g->lens[idx]);
+    const uint64_t len = g->lens[idx];
+    if (len == 0) return GHIP_OK;
+    uint8_t *d_tmp = nullptr;   // the stream as bytes ('N' at every invalid position)
+    int rc = dmalloc(ctx, &d_tmp, (len + 15) / 16 * 16);
+    if (rc) return rc;
+    ghip_launch_unpack_bases(ctx->stream, g->d_packed, g->d_valid, g->starts[idx], d_tmp, len);
+    rc = d2h(ctx, outp, d_tmp, len);
+    ghip_pool_free(ctx, d_tmp);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------ sketches
@@ -1079,7 +1129,7 @@ static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t 
         if ((rc = h2d_nosync(ctx, d_cap, slot_cap.data(), ns))) break;
         if (hipMemsetAsync(d_count, 0, ns * sizeof(uint32_t), ctx->stream) != hipSuccess) { rc = ghip_set_error(ctx, GHIP_EHIP, "memset failed"); break; }
         // (no synchronisation here: the three host vectors stay as they are until the one after the kernels)
-        ghip_launch_sketch_kmers(ctx, g->d_bytes, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
+        ghip_launch_sketch_kmers(ctx, g->d_packed, g->d_valid, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
                                  d_work, n_work, k, (uint32_t)seed, d_cand, d_count, first ? seeds : nullptr);
         ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, s, sk->d_hashes,
                                   sk->d_lens, d_status);
@@ -1518,18 +1568,19 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
     // concatenation, so 8 pieces gave back what they hid), ingested by a producer thread one piece ahead.
     std::vector<uint64_t> caps(n);
     parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b0, size_t e0) {
-        for (size_t i = b0; i < e0; i++) caps[i] = ghip_stream_capacity_hint(paths[i]) + GHIP_TAIL_PAD + 16;
+        for (size_t i = b0; i < e0; i++) caps[i] = ghip_stream_capacity_hint(paths[i]) + GHIP_TAIL_PAD + GHIP_BASE_ALIGN;   // base positions
     });
     uint64_t total_bytes = 0;
     for (uint64_t c : caps) total_bytes += c;
-    uint64_t piece = batch_bytes;
+    const uint64_t batch_bases = batch_bytes / 3 * 8;   // the resident form takes 3 bits per base (2-bit code + validity bit)
+    uint64_t piece = batch_bases;
     {
         // (gzip input is inflate-bound on the host: cutting it into pieces only adds eight load-imbalanced tails)
         size_t n_gz = 0;
         for (size_t i = 0; i < n; i++) { const size_t l = strlen(paths[i]); n_gz += (l > 3 && !strcmp(paths[i] + l - 3, ".gz")) ? 1 : 0; }
         const char *pl = getenv("GHIP_PIPELINE");
         if (!(pl && !strcmp(pl, "0")) && n_gz == 0 && total_bytes > (1ull << 30))
-            piece = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 4 + 1, 512ull << 20));
+            piece = std::min<uint64_t>(batch_bases, std::max<uint64_t>(total_bytes / 4 + 1, 512ull << 20));
     }
     std::vector<std::pair<size_t, size_t>> ranges;
     for (size_t first = 0; first < n || ranges.empty();) {  // at least one (possibly empty) batch, so that n == 0 yields empty handles

@@ -108,8 +108,12 @@ struct ghip_genome_stats {  // reference src/genome_stats.rs:5-9
 struct ghip_genomes {
     ghip_ctx *ctx = nullptr;
     size_t n = 0;
-    uint8_t *d_bytes = nullptr;        // all streams; each genome starts 16-B aligned, 'N' padded
-    uint64_t *d_starts = nullptr;      // [n] byte offset of genome g
+    // resident bases: 2-bit codes (base i in bits 2 (i % 16).. of word i / 16; A0 C1 G2 T3) and a validity bitmap (bit i % 32
+    // of word i / 32: the stream byte is A/C/G/T); every genome starts at a base offset that is a multiple of 64 and is
+    // followed by >= GHIP_TAIL_PAD invalid positions
+    uint32_t *d_packed = nullptr;      // [total_alloc / 16]
+    uint32_t *d_valid = nullptr;       // [total_alloc / 32]
+    uint64_t *d_starts = nullptr;      // [n] base offset of genome g
     uint64_t *d_lens = nullptr;        // [n] stream length L_g
     std::vector<uint64_t> starts, lens;
     std::vector<ghip_genome_stats> stats;  // filled by ghip_genomes_from_files
@@ -186,7 +190,7 @@ void ghip_prof_begin(ghip_ctx *ctx, const char *name);
 void ghip_prof_end(ghip_ctx *ctx);
 
 // ---- launchers (defined in the .hip files) ----
-void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
+void ghip_launch_synth(ghip_ctx *ctx, uint32_t *d_packed, uint32_t *d_valid, const uint64_t *d_starts, uint64_t length,
                        uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr);
 
 struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the ANI seeds
@@ -200,9 +204,10 @@ struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the 
     const uint64_t *d_chunk_start;
 };
 
-void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes);
-// packed ingest (sketch.hip / ingest.cpp): 2-bit codes + runs of the bytes that are not A/C/G/T -> the one-byte-per-base stream
-void ghip_launch_unpack_bases(hipStream_t stream, const uint8_t *d_packed, const uint32_t *d_runs, uint32_t n_runs, uint8_t *d_out, uint64_t len);
+// resident base format <-> stream bytes, and the validity bits of a genome that arrived as 2-bit codes + runs (sketch.hip)
+void ghip_launch_pack_bases(hipStream_t stream, const uint8_t *d_src, uint64_t n, uint64_t gbase_plus_pos0, uint32_t *d_packed, uint32_t *d_valid);
+void ghip_launch_unpack_bases(hipStream_t stream, const uint32_t *d_packed, const uint32_t *d_valid, uint64_t gbase, uint8_t *d_out, uint64_t len);
+void ghip_launch_valid_from_runs(hipStream_t stream, const uint32_t *d_runs, uint32_t n_runs, uint32_t *d_valid_genome, uint64_t len);
 // packs stream[0, len) into dst: ceil(len / 4) bytes rounded up to 16, then the run table (3 x u32 each) -- false if
 // dst_bytes is too small or len >= 2^32.  *used = bytes written, *runs_off = offset of the table, *n_runs its entries
 bool ghip_pack_stream(const uint8_t *stream, size_t len, uint8_t *dst, size_t dst_bytes, size_t *used, size_t *runs_off, uint32_t *n_runs);
@@ -212,7 +217,7 @@ int ghip_parse_fasta_packed(const uint8_t *buf, size_t n, const char *path, uint
                             size_t *out_len, ghip_genome_stats &st, std::string &err, size_t *used, size_t *runs_off,
                             uint32_t *n_runs, bool *fit);
 int ghip_launch_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *ms);
-void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
+void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_valid, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,
                               const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
                               const uint32_t *d_slot_cand_cap, const ghip_sketch_work *d_work,
@@ -263,4 +268,5 @@ constexpr uint32_t GHIP_SKETCH_POS_PER_THREAD = 64;
 constexpr uint32_t GHIP_SKETCH_THREADS = 256;
 constexpr uint32_t GHIP_SKETCH_CHUNK = GHIP_SKETCH_POS_PER_THREAD * GHIP_SKETCH_THREADS;  // positions per block
 constexpr size_t GHIP_MAX_GRID = 1u << 21;  // workgroups per dispatch (x <= 1024 threads stays below 2^32 work-items)
-constexpr uint32_t GHIP_TAIL_PAD = 128;  // 'N' bytes after every genome (vector loads may over-read)
+constexpr uint32_t GHIP_TAIL_PAD = 128;  // invalid positions after every genome (vector loads may over-read)
+constexpr uint32_t GHIP_BASE_ALIGN = 64; // a genome's first base sits at a multiple of this many bases

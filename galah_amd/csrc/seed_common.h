@@ -151,9 +151,10 @@ __device__ __forceinline__ void seed_emit_global(const SeedOut &so, SeedBlock &s
 }
 
 // call after the position loop by every thread of the block (contains __syncthreads).  rel0 = block-relative position
-// of the lane's first seed position (bit 0 of its mask); block_bases = the block's first base in the genome's stream.
+// of the lane's first seed position (bit 0 of its mask); block_packed = the packed word holding the block's first base
+// (a block starts at a multiple of 16 bases).
 template <bool COMPLEMENTED>
-__device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so, SeedBlock &sb, uint32_t rel0, const uint8_t *block_bases) {
+__device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so, SeedBlock &sb, uint32_t rel0, const uint32_t *block_packed) {
     const uint32_t mine = (uint32_t)__popcll(sb.mask);
     // seeds with a row of their own in SeedLds::raw (the clamped stores of a lane with more than SEED_LANE_CAP seeds
     // overwrote its last row): they are filed through the block's segment runs; the others, rare, one by one
@@ -200,7 +201,7 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
         const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
         mask &= mask - 1;
         uint32_t f = 0, canon, strand;
-        for (uint32_t j = 0; j < so.k; j++) f = (f << 2) | (base_code(block_bases[rel + j]) & 3u);
+        for (uint32_t j = 0; j < so.k; j++) f = (f << 2) | ((block_packed[(rel + j) >> 4] >> (2u * ((rel + j) & 15u))) & 3u);
         seed_canon<false>(f, so.k, canon, strand);
         seed_emit_global(so, sb, canon, strand, rel);
     }

@@ -1,11 +1,11 @@
 // MinHash sketching on gfx950: replaces finch::sketch_files (reference src/finch.rs:55-69).
 //
-//   sketch_kmers  : one pass over the normalised base stream (k = 21: sketch_kmers21_kernel, below; any other k:
-//                   sketch_kmers_kernel_rt).  Each lane owns 64 consecutive k-mer starts, rolls the 2-bit
-//                   codes of both strands, hashes the canonical k-mer with MurmurHash3_x64_128 (seed, first
-//                   u64) and keeps hashes <= a per-genome threshold as candidates; with SEEDS the same pass
-//                   emits the FracMinHash seeds of the ANI index.  VALU-issue bound (~98 instructions per
-//                   base in the fused form), not HBM bound.
+//   sketch_kmers  : one pass over the resident bases -- 2-bit codes + a validity bitmap, 3 bits per base (k = 21:
+//                   sketch_kmers21_kernel, below; any other k: sketch_kmers_kernel_rt).  Each lane owns 64 consecutive
+//                   k-mer starts; the codes of both strands are bit fields of the packed words, the canonical k-mer is
+//                   hashed with MurmurHash3_x64_128 (seed, first u64) and hashes <= a per-genome threshold are kept as
+//                   candidates; with SEEDS the same pass emits the FracMinHash seeds of the ANI index.  VALU-issue
+//                   bound (MurmurHash3 alone is 47 instructions per base), not HBM bound.
 //   sketch_select : per genome, sort the candidates (bitonic, LDS), drop duplicates, write the
 //                   s smallest into the packed u64[n][s] matrix.  Exact: the host re-runs a
 //                   genome with a wider threshold / larger list if fewer than s distinct
@@ -110,21 +110,38 @@ __device__ __forceinline__ void load_kmer_luts(KmerLuts &L, const KmerLuts *__re
     for (uint32_t i = threadIdx.x; i < sizeof(KmerLuts) / 16; i += blockDim.x) dst[i] = src[i];
 }
 
-struct Win21 {  // per-lane window state, refreshed once per 4-byte word
-    uint32_t wlo, whi;  // W (48 bits): forward 2-bit codes of the last 24 bases, the oldest in bits 1:0
-    uint32_t rlo, rhi;  // R: complement codes of the same bases, the NEWEST in bits 1:0 (bits >= 48 hold stale bases)
-    int32_t lim21;      // last bad byte + 21: the 21-mer ending at byte b is clean iff lim21 <= b (and no bad byte of b's own word precedes it)
-    int32_t lim15;      // last bad byte + seed k
-};
+// ---- resident base format (ghip_genomes) ------------------------------------------------------
+// packed[i / 16] holds base i in bits 2 (i % 16) .. +1 (A0 C1 G2 T3: the form the files cross PCIe in, ingest.cpp);
+// valid[i / 32] bit i % 32 says whether stream byte i is one of A/C/G/T (the 'N' after a record, ambiguity codes, gaps and
+// everything past the genome's length are 0).  3 bits per base instead of 8: 50 000 x 5 Mb = 94 GB resident on one GPU.
+// A genome starts at a base offset that is a multiple of 64 (16-byte packed words, 8-byte bitmap words) and is followed
+// by at least 128 invalid positions (vector loads over-read).
+__device__ __forceinline__ uint32_t packed_base(const uint32_t *__restrict__ packed, uint64_t i) { return (packed[i >> 4] >> (2u * ((uint32_t)i & 15u))) & 3u; }
+__device__ __forceinline__ bool valid_base(const uint32_t *__restrict__ valid, uint64_t i) { return (valid[i >> 5] >> ((uint32_t)i & 31u)) & 1u; }
+
+// the 16 bases of a packed word complemented and in reverse order (base 15 in bits 1:0)
+__device__ __forceinline__ uint32_t revcomp16(uint32_t w) {
+    const uint32_t x = __brev(~w);   // bases reversed, the two bits of each base swapped
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
 
 // SEEDS = true: the same pass also emits the FracMinHash seeds of the ANI index (ani.hip), whose
-// k <= 16 rolling codes are bit fields of the 21-mer codes already in registers -- one read of the
-// bases, one byte decode, for both sketches.  A lane owns the 21-mers STARTING at its 64 bytes, i.e.
-// ending at bytes 20..83; in the fused pass it owns the seeds ending at the same bytes (starts
-// 21-k .. 84-k of its range), and the first lane of a genome adds the seeds ending at bytes k-1..19.
+// k <= 16 codes are bit fields of the packed words already in registers -- one read of the bases for both sketches.
+// A lane owns the 21-mers STARTING at its 64 bases, i.e. ending at bases 20..83; in the fused pass it owns the seeds
+// ending at the same bases (starts 21-k .. 84-k of its range), and the first lane of a genome adds the seeds that end
+// at bases k-1..19.
+//
+// The stream is consumed as it is stored: a lane loads ITS 64 bases as one 16-byte vector (and 8 bytes of validity);
+// the 20 bases that run into the next lane's range come from that lane's registers.  The forward strand's little-endian
+// code of the 21-mer starting at base p IS the packed stream shifted right by 2p; the reverse complement's is the
+// word-wise reversed complement of the stream (revcomp16, once per 16 bases) shifted likewise -- one v_alignbit per
+// strand and position for the low 32 bits, one v_bfe (v_alignbit + v_and in four of sixteen positions) for the 10 bits
+// above them; no per-base decode, no rolling state, no warm-up.  Validity is per 16 positions: when some lane of the
+// wave holds an invalid position among the 36 bases an iteration touches, the iteration runs the careful variant
+// (per-position window tests); otherwise the fast one, which contains no validity test at all.
 template <bool SEEDS, bool SEED0>
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
-    const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ valid, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
     const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
     const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
@@ -143,34 +160,33 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     const uint64_t blk0 = (uint64_t)wk.chunk * GHIP_SKETCH_CHUNK;
     const uint32_t toff = threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;
     const uint64_t p0 = blk0 + toff;
-    const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's bytes
+    const bool live = p0 < L;  // no early exit: the neighbour lane shuffles this lane's words
     ghip_seed::SeedBlock sb;
     uint32_t ashift = 0, sthr = 0;
     int ak = 1;
     if constexpr (SEEDS) {
         sthr = so.seed_thr[g];   // this genome's density
         sb = ghip_seed::seed_block_begin(sl, so, g, blk0);
-        ashift = 2 * (K - so.k);  // the newest so.k bases of the 21-mer
+        ashift = 2 * (K - so.k);  // the seed is the newest so.k bases of the 21-mer
         ak = (int)so.k;
     }
     const uint64_t thr = slot_thr[slot];
     const uint32_t thr_bound = murmur21_filter_bound(thr);
     const uint64_t cstart = slot_cand_start[slot];
     const uint32_t ccap = slot_cand_cap[slot];
-    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + starts[g] + p0);  // 16-B aligned
+    const uint64_t base0 = starts[g] + p0;   // a multiple of 64
+    const uint32_t *pw = packed + (base0 >> 4), *vw = valid + (base0 >> 5);
 
-    // Every base is fetched from HBM once: a lane loads only its own 64 bytes; the 20 bytes that run
-    // into the next lane's range come from that lane's registers (wave shuffle), and only lane 63
-    // reads them from memory.  Lanes past the stream end hold 'N'.
-    const uint4 NNNN = make_uint4(0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu);
-    uint4 q0 = NNNN, q1 = NNNN, q2 = NNNN, q3 = NNNN;
-    if (live) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
-    uint4 q4;
-    q4.x = __shfl_down(q0.x, 1, 64); q4.y = __shfl_down(q0.y, 1, 64); q4.z = __shfl_down(q0.z, 1, 64); q4.w = __shfl_down(q0.w, 1, 64);
-    uint32_t q5x = __shfl_down(q1.x, 1, 64);
-    if ((threadIdx.x & 63u) == 63u) {  // next wave's bytes (or the 'N' tail padding of the genome)
-        q4 = NNNN; q5x = NNNN.x;
-        if (live) { q4 = src[4]; q5x = src[5].x; }
+    // Every base is fetched from HBM once: a lane loads only its own 64 bases; the 20 that run into the next lane's
+    // range come from that lane's registers (wave shuffle), and only lane 63 reads them from memory.  Lanes past the
+    // stream end hold invalid positions.
+    uint4 q = make_uint4(0, 0, 0, 0);
+    uint2 vb = make_uint2(0, 0);
+    if (live) { q = *reinterpret_cast<const uint4 *>(pw); vb = *reinterpret_cast<const uint2 *>(vw); }
+    uint32_t o0 = __shfl_down(q.x, 1, 64), o1 = __shfl_down(q.y, 1, 64), v2 = __shfl_down(vb.x, 1, 64);
+    if ((threadIdx.x & 63u) == 63u) {  // next wave's bases (or the invalid tail of the genome)
+        o0 = o1 = v2 = 0;
+        if (live) { o0 = pw[4]; o1 = pw[5]; v2 = vw[2]; }
     }
 
     constexpr uint32_t CAND_WAVE_CAP = 64;  // expected 64*64*2.5*s/L ~ 2 per wave at the default threshold
@@ -178,11 +194,11 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
     __shared__ uint32_t cand_wave_n[GHIP_SKETCH_THREADS / 64], cand_base;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t cand_n = 0;  // wave-uniform
-    Win21 st{0, 0, 0, 0, K - 1, ak - 1};   // "last bad byte" = -1
     struct Pend { uint64_t A, B, T; uint32_t ax, bx; } pend{};  // table terms of the position whose hash is pending
+    bool pend_ok = true;   // ... and whether its window holds only valid bases (maintained by the careful variant)
     // hash one position from its table terms and append it to the genome's candidate list if it is under the
-    // threshold and its window holds no bad byte (b = the byte it ends at, inword = bad bytes of its own word up to b)
-    auto finish = [&](const Pend &p, const int b, const uint32_t inword, const bool slow) __attribute__((always_inline)) {
+    // threshold and its window is clean
+    auto finish = [&](const Pend &p, const bool ok) __attribute__((always_inline)) {
         const uint32_t a1 = (uint32_t)(p.A >> 32) + p.ax, b1 = (uint32_t)(p.B >> 32) + p.bx;
         uint64_t F1, F2;  // the two halves of the hash short of their last multiply (murmur21_asm.h)
 #ifdef GHIP_DBG_NOHASH  // timing experiment only: wrong results
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         bool hit = s1 <= thr_bound;  // necessary for h <= thr (murmur21_asm.h)
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0, 0)) {   // cold: keep it out of the straight-line loop body
             const uint64_t h = murmur21_finish(F1, F2);
-            hit = hit && h <= thr && (!slow || (st.lim21 <= b && inword == 0));
+            hit = hit && h <= thr && ok;
             const unsigned long long m = __ballot(hit);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (hit) {
@@ -224,60 +240,55 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
         for (uint32_t i = threadIdx.x & 63u; i < mine; i += 64)
             if (base + i < ccap) cand[cstart + base + i] = cand_lds[wave][i];
     };
-    // One 4-byte word.  The four codes are decoded together (SWAR) and packed by two multiplies -- (t * 0x01041040) >> 24 =
-    // c0 | c1<<2 | c2<<4 | c3<<6 and ((t ^ 3333) * 0x40100401) >> 24 = the complements in reverse order; the partial
-    // products fall into distinct 2-bit fields, so nothing carries -- and shifted into the two 24-base windows ONCE; the
-    // four 21-mers ending in this word are bit fields of the windows (one v_alignbit + one v_bfe per strand and position),
-    // instead of two 64-bit shift/or/and chains per byte.  SLOW: some lane of the wave holds a non-ACGT byte in this word
-    // (wave-uniform, rare): only then are the per-byte bad-byte masks evaluated; otherwise a window is clean iff
-    // lim <= b, tested for the ~1/2000 hash survivors and the ~1/125 seed candidates only.
-    auto word_impl = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto slow_tag, auto widx_tag, const bool seed_gate, const bool have_pend) __attribute__((always_inline)) {
-        constexpr bool HASH = decltype(hash_tag)::value;
-        constexpr int WIDX = decltype(widx_tag)::value;   // index of the word in its group of four (-1: a warm-up word)
-        constexpr bool SEED_HERE = SEEDS && decltype(seed_tag)::value;
+    // Sixteen positions: the 21-mers starting at bases 16 v + j of the lane, j = 0..15.  W0..W2 = the packed words holding
+    // bases 16 v .. 16 v + 47, R0..R2 their reversed complements, vlo/vhi = the validity bits of bases 16 v .. 16 v + 63.
+    auto body16 = [&](const uint32_t W0, const uint32_t W1, const uint32_t W2, const uint32_t R0, const uint32_t R1, const uint32_t R2,
+                      const uint32_t vlo, const uint32_t vhi, auto slow_tag, const bool have_pend) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
-        const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;   // A0 C1 G2 T3 per byte
-        const uint32_t fm = t * 0x01041040u, rm = (t ^ 0x03030303u) * 0x40100401u;
-        [[maybe_unused]] const uint32_t bad4 = w & 0x08080808u;    // bit 3: not one of A,C,G,T
-        {   // W = (W >> 8) | (fpack << 40);  R = (R << 8) | rpack
-            const uint32_t nwlo = __builtin_amdgcn_alignbit(st.whi, st.wlo, 8);
-            const uint32_t nwhi = __builtin_amdgcn_perm(fm, st.whi, 0x0c0c0701u);   // byte 0 = whi.byte1, byte 1 = fm.byte3
-            const uint32_t nrhi = __builtin_amdgcn_alignbit(st.rhi, st.rlo, 24);
-            const uint32_t nrlo = __builtin_amdgcn_alignbit(st.rlo, rm, 24);
-            st.wlo = nwlo; st.whi = nwhi; st.rlo = nrlo; st.rhi = nrhi;
+        // the forward stream from the seed's first base on: {W2, W1, W0} >> ashift (run-time seed length, uniform)
+        [[maybe_unused]] uint32_t S0 = 0, S1 = 0;
+        if constexpr (SEEDS) {
+            const uint32_t bs = ashift & 31u;
+            if (ashift < 32) { S0 = __builtin_amdgcn_alignbit(W1, W0, bs); S1 = __builtin_amdgcn_alignbit(W2, W1, bs); }
+            else { S0 = __builtin_amdgcn_alignbit(W2, W1, bs); S1 = W2 >> bs; }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int b = b0 + j;
-            [[maybe_unused]] const uint32_t inword = SLOW ? (bad4 & (0xffffffffu >> (8 * (3 - j)))) : 0u;  // bad bytes 0..j of this word
-            const int fs = 2 * j, rs = 6 - 2 * j;
-            const uint32_t flo = fs ? __builtin_amdgcn_alignbit(st.whi, st.wlo, fs) : st.wlo;
-            const uint32_t rlo = rs ? __builtin_amdgcn_alignbit(st.rhi, st.rlo, rs) : st.rlo;
-            if constexpr (SEED_HERE) {
+        for (int j = 0; j < 16; j++) {
+            const uint32_t flo = j ? __builtin_amdgcn_alignbit(W1, W0, 2 * j) : W0;
+            uint32_t rlo;
+            if (j < 11) rlo = __builtin_amdgcn_alignbit(R0, R1, 2 * (11 - j));
+            else if (j == 11) rlo = R1;
+            else rlo = __builtin_amdgcn_alignbit(R1, R2, 2 * (27 - j));
+            [[maybe_unused]] bool ok21 = true;
+            if constexpr (SLOW) {   // bases j .. j + 20 of the window all valid
+                const uint32_t vv = j ? __builtin_amdgcn_alignbit(vhi, vlo, j) : vlo;
+                ok21 = (vv & 0x1fffffu) == 0x1fffffu;
+            }
+            if constexpr (SEEDS) {
                 // so.k-mer ending here: the low 2 so.k bits of rlo hold the COMPLEMENT of its forward big-endian code, those
-                // of W >> (fs + ashift) the complement of its reverse complement's; their sum is the selection key
-                // (seed_common.h) -- no masks, no min: add, multiply, compare
-                const uint32_t wsh = (uint32_t)((((uint64_t)st.whi << 32) | st.wlo) >> (fs + ashift));
-                const bool pass = seed_gate && (rlo + wsh) * so.mul < sthr;
+                // of the forward stream from its first base on the complement of its reverse complement's; their sum is the
+                // selection key (seed_common.h) -- no masks, no min: add, multiply, compare
+                const uint32_t wsh = j ? __builtin_amdgcn_alignbit(S1, S0, 2 * j) : S0;
+                const bool pass = (rlo + wsh) * so.mul < sthr;
                 if (pass) {  // ~1/125 of the lanes; only the raw forward code is stored, seed_canon() finishes it in the flush
-                    // validity only in the SLOW variant: the fast one runs when no lane of the wave saw a bad byte in
-                    // this word or the six before it
-                    if (!SLOW || (st.lim15 <= b && inword == 0)) {
-#ifndef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
-                        if constexpr (WIDX >= 0) ghip_seed::seed_mark(sl, sb, rlo, 4 * WIDX + j);
-                        else {  // warm-up words (first lane of a genome): positions before the lane's 64
-                            uint32_t canon, strand;
-                            ghip_seed::seed_canon<true>(rlo, so.k, canon, strand);
-                            ghip_seed::seed_emit_global(so, sb, canon, strand, toff + (uint32_t)(b - (ak - 1)));
-                        }
-#endif
+                    bool okk = true;
+                    if constexpr (SLOW) {   // bases j + 21 - k .. j + 20
+                        const uint32_t sh = (uint32_t)(j + K - ak);
+                        const uint64_t vv = ((((uint64_t)vhi << 32) | vlo) >> sh);
+                        const uint32_t mk = ak >= 32 ? ~0u : ((1u << ak) - 1u);
+                        okk = ((uint32_t)vv & mk) == mk;
                     }
+#ifndef GHIP_DBG_NOAPPEND   // timing experiment only: no seeds come out
+                    if (okk) ghip_seed::seed_mark(sl, sb, rlo, j);
+#endif
                 }
             }
-            if constexpr (HASH) {
+            {
                 // software pipeline: issue this position's five table reads, then hash the PREVIOUS position
                 // (its reads were issued one step ago), so LDS latency hides behind ~240 cycles of hashing
-                const uint32_t fhi = __builtin_amdgcn_ubfe(st.whi, fs, 10), rhi = __builtin_amdgcn_ubfe(st.rhi, rs, 10);
+                uint32_t fhi, rhi;
+                if (j <= 11) { fhi = __builtin_amdgcn_ubfe(W1, 2 * j, 10); rhi = __builtin_amdgcn_ubfe(R0, 2 * (11 - j), 10); }
+                else { fhi = __builtin_amdgcn_alignbit(W2, W1, 2 * j) & 0x3ffu; rhi = __builtin_amdgcn_alignbit(R0, R1, 2 * (27 - j)) & 0x3ffu; }
                 const bool use_rc = (((uint64_t)rhi << 32) | rlo) < (((uint64_t)fhi << 32) | flo);
                 const uint32_t lo = use_rc ? rlo : flo, hi = use_rc ? rhi : fhi;
                 Pend cur;
@@ -288,63 +299,43 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers21_kernel(
                 cur.ax = reinterpret_cast<const uint32_t *>(luts.c1)[2 * ((lo >> 8) & 0xffu)];  // low words only
                 cur.bx = reinterpret_cast<const uint32_t *>(luts.c2)[2 * (lo >> 24)];
 #endif
-                // the previous position is byte j-1 of this word, or byte 3 of the word before (whose bad
-                // bytes are already folded into lim21)
-                if (j > 0 || have_pend) finish(pend, b - 1, (SLOW && j > 0) ? (bad4 & (0xffffffffu >> (8 * (4 - j)))) : 0u, SLOW);
+                if (j > 0 || have_pend) finish(pend, pend_ok);
                 pend = cur;
-            }
-        }
-        if constexpr (SLOW) {
-            if (bad4) {
-                const int lastbad = b0 + 3 - (int)(__builtin_clz(bad4) >> 3);
-                st.lim21 = lastbad + K;
-                st.lim15 = lastbad + ak;
+                pend_ok = SLOW ? ok21 : true;
             }
         }
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    // The careful variant runs for a word in which some lane of the wave holds a bad byte AND for the five words after
-    // it (a 21-mer reaches 20 bytes back, and the pending hash of a word's first position belongs to the word before):
-    // the fast variant never looks at lim21 / lim15.  The warm-up words are always careful (lim starts at k - 1).
-    uint32_t slow_left = 0;  // wave-uniform
-    auto word = [&](const uint32_t w, const int b0, auto hash_tag, auto seed_tag, auto widx_tag, const bool seed_gate, const bool have_pend, const bool careful) __attribute__((always_inline)) {
-        if (__builtin_amdgcn_ballot_w64((w & 0x08080808u) != 0)) slow_left = 7;
-        if (__builtin_expect(careful || slow_left, 0)) {   // the fast variant is the fall-through
-            slow_left = slow_left ? slow_left - 1 : 0;
-            word_impl(w, b0, hash_tag, seed_tag, T_{}, widx_tag, seed_gate, have_pend);
-        } else word_impl(w, b0, hash_tag, seed_tag, F_{}, widx_tag, seed_gate, have_pend);
-    };
-    using W_ = std::integral_constant<int, -1>;
-    // warm-up: bytes 0..19 only fill the windows -- except in the first wave of a genome, whose lane 0
-    // owns the seeds that end before byte 20
-    const uint32_t warm[5] = {q0.x, q0.y, q0.z, q0.w, q1.x};
-    if (SEEDS && wk.chunk == 0 && threadIdx.x < 64) {
-        const bool first = threadIdx.x == 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            // bytes b < ak-1 cannot end a seed: lim15 = ak - 1 says so
-            word(warm[i], 4 * i, F_{}, T_{}, W_{}, first, false, true);
+    if (SEEDS && wk.chunk == 0 && threadIdx.x == 0) {
+        // the seeds of a genome that end before base 20 belong to no lane's 64 positions: its first lane emits them (cold)
+        const uint64_t gb = starts[g];
+        for (int e = ak - 1; e < K - 1 && (uint64_t)e < L; e++) {
+            uint32_t f = 0;
+            bool okk = true;
+            for (int i = e - ak + 1; i <= e; i++) { f = (f << 2) | packed_base(packed, gb + (uint64_t)i); okk = okk && valid_base(valid, gb + (uint64_t)i); }
+            if (!okk) continue;
+            const uint32_t r = ghip_seed::revcomp_code(f, so.k);
+            if (ghip_seed::seed_selected(f, r, so.mul, sthr)) ghip_seed::seed_emit_global(so, sb, min(f, r), r < f ? 1u : 0u, (uint32_t)(e - ak + 1));
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 5; i++) word(warm[i], 4 * i, F_{}, F_{}, W_{}, false, false, false);   // (windows only: the fast variant unless a bad byte shows up)
     }
-    uint32_t w0 = q1.y, w1 = q1.z, w2 = q1.w, w3 = q2.x;
+    uint32_t W0 = q.x, W1 = q.y, W2 = q.z, n0 = q.w, n1 = o0, n2 = o1;
+    uint32_t R0 = revcomp16(W0), R1 = revcomp16(W1), R2 = revcomp16(W2);
+    uint32_t va = vb.x, vbb = vb.y, vc = v2;   // validity of bases 16 v .. 16 v + 95 (shifted down 16 bits per iteration)
 #pragma unroll 1
     for (int v = 0; v < 4; v++) {
-        const int b0 = 20 + 16 * v;
-        word(w0, b0, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 0>{}, true, v > 0, false);
-        word(w1, b0 + 4, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 1>{}, true, true, false);
-        word(w2, b0 + 8, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 2>{}, true, true, false);
-        word(w3, b0 + 12, T_{}, std::integral_constant<bool, SEEDS>{}, std::integral_constant<int, 3>{}, true, true, false);
+        // clean = the 36 bases this iteration touches are all valid, in every lane of the wave
+        const bool dirty = va != 0xffffffffu || (vbb & 0xfu) != 0xfu;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(dirty) != 0, 0)) body16(W0, W1, W2, R0, R1, R2, va, vbb, T_{}, v > 0);   // the fast variant is the fall-through
+        else body16(W0, W1, W2, R0, R1, R2, va, vbb, F_{}, v > 0);
         if constexpr (SEEDS) ghip_seed::seed_group_end(sb, (uint32_t)v);
-        w0 = q2.y; w1 = q2.z; w2 = q2.w; w3 = q3.x;
-        q2 = q3; q3 = q4; q4.x = q5x;
+        W0 = W1; W1 = W2; W2 = n0; n0 = n1; n1 = n2;
+        R0 = R1; R1 = R2; R2 = revcomp16(W2);
+        va = __builtin_amdgcn_alignbit(vbb, va, 16); vbb = __builtin_amdgcn_alignbit(vc, vbb, 16); vc >>= 16;
     }
-    finish(pend, 83, 0u, true);  // the last position (ends at byte 83)
+    finish(pend, pend_ok);  // the last position (ends at base 83)
     flush_candidates();
-    if constexpr (SEEDS) ghip_seed::seed_block_flush<true>(sl, so, sb, toff + (uint32_t)(K - ak), bytes + starts[g] + blk0);
+    if constexpr (SEEDS) ghip_seed::seed_block_flush<true>(sl, so, sb, toff + (uint32_t)(K - ak), packed + ((starts[g] + blk0) >> 4));
 }
 
 // Generic-k fallback (k in [1,32], not 21): same algorithm, runtime k.
@@ -376,7 +367,7 @@ __device__ __forceinline__ uint64_t murmur3_h1_rt(const uint64_t (&w)[4], int K,
 }
 
 __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel_rt(
-    const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ starts,
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ valid, const uint64_t *__restrict__ starts,
     const uint64_t *__restrict__ lens, const uint32_t *__restrict__ slot_genome,
     const uint64_t *__restrict__ slot_thr, const uint64_t *__restrict__ slot_cand_start,
     const uint32_t *__restrict__ slot_cand_cap, const ghip_sketch_work *__restrict__ work,
@@ -390,19 +381,18 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel_rt(
     const uint64_t thr = slot_thr[slot];
     const uint64_t cstart = slot_cand_start[slot];
     const uint32_t ccap = slot_cand_cap[slot];
-    const uint8_t *src = bytes + starts[g] + p0;
+    const uint64_t base0 = starts[g] + p0;
     const uint64_t mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
     uint64_t fwd_be = 0, fwd_le = 0;
     uint32_t good = 0;
     const int NB = GHIP_SKETCH_POS_PER_THREAD + K - 1;
     for (int b = 0; b < NB; b++) {
-        uint32_t code = base_code(src[b]);
-        if (code > 3u) { good = 0; continue; }
+        if (!valid_base(valid, base0 + (uint64_t)b)) { good = 0; continue; }   // (positions past the genome's length are invalid)
+        const uint32_t code = packed_base(packed, base0 + (uint64_t)b);
         fwd_be = ((fwd_be << 2) | code) & mask;
         fwd_le = (fwd_le >> 2) | ((uint64_t)code << (2 * (K - 1)));
         good++;
         if (b < K - 1 || good < (uint32_t)K) continue;
-        if (p0 + (uint64_t)(b - (K - 1)) + K > L) continue;
         uint64_t rc_be = (~fwd_le) & mask;
         uint64_t canon_le = (rc_be < fwd_be) ? ((~fwd_be) & mask) : fwd_le;
         uint64_t w[4] = {0, 0, 0, 0};
@@ -527,50 +517,90 @@ __device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint32_t species, u
     return splitmix64(splitmix64(seed ^ ((uint64_t)species << 20)) ^ ((uint64_t)stream * 0xd1b54a32d192ed03ULL));
 }
 
-// each thread writes 16 bases (one 16-B store)
-__global__ __launch_bounds__(256) void synth_genomes_kernel(uint8_t *__restrict__ bytes,
+// each thread writes 32 bases: two packed words and one validity word (positions past `length` are invalid)
+__global__ __launch_bounds__(256) void synth_genomes_kernel(uint32_t *__restrict__ packed, uint32_t *__restrict__ valid,
                                                             const uint64_t *__restrict__ starts,
                                                             uint64_t length, uint32_t first,
                                                             uint32_t members, uint64_t seed,
                                                             uint32_t sub_thr) {
     const uint32_t g = blockIdx.y;  // local index; the series index is first + g
     const uint32_t species = (first + g) / members, member = (first + g) % members;
-    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 32;
     if (p0 >= length) return;
     const uint64_t ka = synth_key(seed, species, 0), km = synth_key(seed, species, member + 1);
     const uint64_t w = splitmix64(ka + (p0 >> 5));
-    uint32_t out[4] = {0, 0, 0, 0};
+    uint32_t out[2] = {0, 0};
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < 32; j++) {
         uint64_t p = p0 + j;
         uint32_t base = (uint32_t)(w >> (2 * (p & 31))) & 3u;
         uint64_t u = splitmix64(km + p);
         if ((uint32_t)(u >> 32) < sub_thr) base = (base + 1 + (uint32_t)((u >> 8) % 3)) & 3u;
-        uint32_t ch = (0x54474341u >> (8 * base)) & 0xffu;
-        if (p >= length) ch = 'N';
-        out[j >> 2] |= ch << (8 * (j & 3));
+        out[j >> 4] |= base << (2 * (j & 15));
     }
-    *reinterpret_cast<uint4 *>(bytes + starts[g] + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+    const uint64_t at = starts[g] + p0;   // a multiple of 32
+    packed[at >> 4] = out[0];
+    packed[(at >> 4) + 1] = out[1];
+    const uint64_t left = length - p0;
+    valid[at >> 5] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
 }
 
-// Device base streams hold A,C,G,T or a byte with bit 3 set (what sketch_kmers21 tests): caller-supplied
-// streams (ghip_genomes_from_host) are rewritten in place, every other byte becomes 'N'.  16 bytes per thread.
-__global__ __launch_bounds__(256) void sanitize_bases_kernel(uint4 *__restrict__ bytes, uint64_t n16) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint4 v = bytes[i];
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+// ASCII stream bytes -> the resident form: `src` holds stream bytes [pos0, pos0 + n) of a genome whose first base sits at
+// base offset `gbase` (a multiple of 64); pos0 is a multiple of 32.  Every byte other than A,C,G,T becomes an invalid
+// position.  32 bases per thread.
+__global__ __launch_bounds__(256) void pack_bases_kernel(const uint8_t *__restrict__ src, uint64_t n, uint64_t gbase_plus_pos0,
+                                                         uint32_t *__restrict__ packed, uint32_t *__restrict__ valid) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; 32 * t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t out[2] = {0, 0}, ok = 0;
+        const uint64_t b0 = 32 * t;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t out = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t c = (w[k] >> (8 * j)) & 0xffu;
-                const bool ok = c == 'A' || c == 'C' || c == 'G' || c == 'T';
-                out |= (ok ? c : (uint32_t)'N') << (8 * j);
-            }
-            w[k] = out;
+        for (int j = 0; j < 32; j++) {
+            const uint32_t c = b0 + j < n ? src[b0 + j] : 0u;
+            const bool good = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+            out[j >> 4] |= (good ? (((c >> 1) ^ (c >> 2)) & 3u) : 0u) << (2 * (j & 15));
+            ok |= (good ? 1u : 0u) << j;
         }
-        bytes[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        const uint64_t at = gbase_plus_pos0 + b0;
+        packed[at >> 4] = out[0];
+        packed[(at >> 4) + 1] = out[1];
+        valid[at >> 5] = ok;
+    }
+}
+
+// the resident form -> stream bytes ('N' at every invalid position): ghip_genomes_to_host.  16 bases per thread.
+__global__ __launch_bounds__(256) void unpack_bases_kernel(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ valid,
+                                                           uint64_t gbase, uint4 *__restrict__ out, uint64_t len) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 16 bases per thread
+    if (16 * t >= len) return;
+    const uint64_t at = gbase + 16 * t;
+    const uint32_t w = packed[at >> 4], ok = (valid[at >> 5] >> ((uint32_t)at & 16u)) & 0xffffu;
+    uint32_t a[4] = {ascii4(w & 0xffu), ascii4((w >> 8) & 0xffu), ascii4((w >> 16) & 0xffu), ascii4(w >> 24)};
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        const uint32_t m4 = (ok >> (4 * qd)) & 0xfu;
+        // spread the four validity bits to byte masks; invalid bytes become 'N'
+        const uint32_t bm = ((m4 & 1u) ? 0xffu : 0u) | ((m4 & 2u) ? 0xff00u : 0u) | ((m4 & 4u) ? 0xff0000u : 0u) | ((m4 & 8u) ? 0xff000000u : 0u);
+        a[qd] = (a[qd] & bm) | (0x4e4e4e4eu & ~bm);
+    }
+    out[t] = make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+// validity bitmap of a genome that arrived as 2-bit codes + runs (the packed ingest): bits [0, len) set, the rest of its
+// words clear (the allocation is zero-filled), then the runs cleared.
+__global__ __launch_bounds__(256) void valid_fill_kernel(uint32_t *__restrict__ vw /* the genome's first bitmap word */, uint64_t len) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (32 * t >= len) return;
+    const uint64_t left = len - 32 * t;
+    vw[t] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+}
+__global__ __launch_bounds__(64) void valid_clear_runs_kernel(const uint32_t *__restrict__ runs /* start, len, byte */, uint32_t *__restrict__ vw) {
+    const uint32_t start = runs[3 * blockIdx.x], n = runs[3 * blockIdx.x + 1];
+    // word-wise: the first and last word of the run by atomicAnd (a neighbouring run may share them), the words between by stores
+    const uint32_t w0 = start >> 5, w1 = (start + n - 1) >> 5;
+    for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 64) {
+        const uint32_t lo = w == w0 ? (start & 31u) : 0u, hi = w == w1 ? ((start + n - 1) & 31u) : 31u;
+        const uint32_t m = (hi == 31u ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        atomicAnd(&vw[w], ~m);
     }
 }
 
@@ -612,57 +642,40 @@ int ghip_launch_hash_floor(ghip_ctx *ctx, uint64_t wave_positions, double *ms) {
     return GHIP_OK;
 }
 
-void ghip_launch_synth(ghip_ctx *ctx, uint8_t *d_bytes, const uint64_t *d_starts, uint64_t length,
+void ghip_launch_synth(ghip_ctx *ctx, uint32_t *d_packed, uint32_t *d_valid, const uint64_t *d_starts, uint64_t length,
                        uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr) {
-    uint64_t threads = (length + 15) / 16;
+    uint64_t threads = (length + 31) / 32;
     dim3 grid((unsigned)((threads + 255) / 256), count);
     ghip_prof_begin(ctx, "synth_genomes");
-    hipLaunchKernelGGL(synth_genomes_kernel, grid, dim3(256), 0, ctx->stream, d_bytes, d_starts, length, first, members, seed, sub_thr);
+    hipLaunchKernelGGL(synth_genomes_kernel, grid, dim3(256), 0, ctx->stream, d_packed, d_valid, d_starts, length, first, members, seed, sub_thr);
     ghip_prof_end(ctx);
 }
 
-// ---- packed ingest: files cross PCIe as 2-bit codes (a quarter of the bytes), the resident stream stays one byte per
-// base.  packed[i / 4] holds base i in bits 2 (i % 4) .. +1 (A0 C1 G2 T3, what ingest.cpp: ghip_pack_stream writes);
-// every stream byte that is not A/C/G/T (the 'N' after each record, ambiguity codes, gaps) travels as a run
-// (start, length, byte) and is patched in afterwards.  Bytes from `len` to the end of the last 16-byte group get 'N',
-// which is what the whole buffer was filled with.
-__global__ __launch_bounds__(256) void unpack_bases_kernel(const uint32_t *__restrict__ packed, uint4 *__restrict__ out, uint64_t len) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 16 bases per thread
-    if (16 * t >= len) return;
-    const uint32_t w = packed[t];
-    uint32_t a[4] = {ascii4(w & 0xffu), ascii4((w >> 8) & 0xffu), ascii4((w >> 16) & 0xffu), ascii4(w >> 24)};
-    const uint64_t left = len - 16 * t;
-    if (left < 16) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int have = (int)left - 4 * q;   // valid bytes of word q
-            if (have <= 0) a[q] = 0x4e4e4e4eu;
-            else if (have < 4) a[q] = (a[q] & (0xffffffffu >> (8 * (4 - have)))) | (0x4e4e4e4eu << (8 * have));
-        }
-    }
-    out[t] = make_uint4(a[0], a[1], a[2], a[3]);
+// stream bytes [pos0, pos0 + n) of the genome at base offset gbase (device memory `d_src`) -> the resident form
+void ghip_launch_pack_bases(hipStream_t stream, const uint8_t *d_src, uint64_t n, uint64_t gbase_plus_pos0, uint32_t *d_packed, uint32_t *d_valid) {
+    if (n == 0) return;
+    const uint64_t threads = (n + 31) / 32;
+    hipLaunchKernelGGL(pack_bases_kernel, dim3((unsigned)std::min<uint64_t>((threads + 255) / 256, 1u << 20)), dim3(256), 0, stream, d_src, n,
+                       gbase_plus_pos0, d_packed, d_valid);
 }
 
-__global__ __launch_bounds__(64) void patch_runs_kernel(const uint32_t *__restrict__ runs /* start, len, byte */, uint8_t *__restrict__ out) {
-    const uint32_t start = runs[3 * blockIdx.x], n = runs[3 * blockIdx.x + 1];
-    const uint8_t b = (uint8_t)runs[3 * blockIdx.x + 2];
-    for (uint32_t k = threadIdx.x; k < n; k += 64) out[(uint64_t)start + k] = b;
-}
-
-// both on `stream`, in this order, after the copy that brought `d_packed` and `d_runs`
-void ghip_launch_unpack_bases(hipStream_t stream, const uint8_t *d_packed, const uint32_t *d_runs, uint32_t n_runs, uint8_t *d_out, uint64_t len) {
+// the resident form of bases [0, len) of the genome at base offset gbase -> stream bytes (d_out 16-byte aligned, room for
+// len rounded up to 16)
+void ghip_launch_unpack_bases(hipStream_t stream, const uint32_t *d_packed, const uint32_t *d_valid, uint64_t gbase, uint8_t *d_out, uint64_t len) {
     if (len == 0) return;
     const uint64_t groups = (len + 15) / 16;
-    hipLaunchKernelGGL(unpack_bases_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const uint32_t *>(d_packed), reinterpret_cast<uint4 *>(d_out), len);
-    if (n_runs) hipLaunchKernelGGL(patch_runs_kernel, dim3(n_runs), dim3(64), 0, stream, d_runs, d_out);
+    hipLaunchKernelGGL(unpack_bases_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, d_packed, d_valid, gbase,
+                       reinterpret_cast<uint4 *>(d_out), len);
 }
 
-void ghip_launch_sanitize(ghip_ctx *ctx, uint8_t *d_bytes, uint64_t n_bytes /* multiple of 16 */) {
-    const uint64_t n16 = n_bytes / 16;
-    if (n16 == 0) return;
-    const unsigned grid = (unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(sanitize_bases_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(d_bytes), n16);
+// The packed ingest: the 2-bit codes are copied straight to their place; this builds the genome's validity bits from the
+// run table that travelled with them (both kernels on `stream`, after the copy that brought `d_runs`; the bitmap
+// allocation is zero-filled, so the words past the genome's length stay clear).
+void ghip_launch_valid_from_runs(hipStream_t stream, const uint32_t *d_runs, uint32_t n_runs, uint32_t *d_valid_genome, uint64_t len) {
+    if (len == 0) return;
+    const uint64_t words = (len + 31) / 32;
+    hipLaunchKernelGGL(valid_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_valid_genome, len);
+    if (n_runs) hipLaunchKernelGGL(valid_clear_runs_kernel, dim3(n_runs), dim3(64), 0, stream, d_runs, d_valid_genome);
 }
 
 // timing experiment only (scripts/sketch_variants.sh): unused dynamic LDS caps the workgroups per CU
@@ -671,7 +684,7 @@ static unsigned dbg_extra_lds() {
     return v;
 }
 
-void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint64_t *d_starts,
+void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_valid, const uint64_t *d_starts,
                               const uint64_t *d_lens, const uint32_t *d_slot_genome,
                               const uint64_t *d_slot_thr, const uint64_t *d_slot_cand_start,
                               const uint32_t *d_slot_cand_cap, const ghip_sketch_work *d_work,
@@ -697,7 +710,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
         if (k == 21) {  // seeds != nullptr: fused MinHash + ANI seeding pass (first pass over all genomes only)
 #define GHIP_LAUNCH21(SEEDS, SEED0)                                                                                  \
     hipLaunchKernelGGL((sketch_kmers21_kernel<SEEDS, SEED0>), dim3(grid), dim3(GHIP_SKETCH_THREADS), dbg_extra_lds(), ctx->stream, \
-                       d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start, d_slot_cand_cap,     \
+                       d_packed, d_valid, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start, d_slot_cand_cap, \
                        d_work + off, seed, d_cand, d_cand_count, so, luts)
             if (seeds && seed == 0) GHIP_LAUNCH21(true, true);
             else if (seeds) GHIP_LAUNCH21(true, false);
@@ -706,7 +719,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint8_t *d_bytes, const uint6
 #undef GHIP_LAUNCH21
         } else {
             hipLaunchKernelGGL(sketch_kmers_kernel_rt, dim3(grid), dim3(GHIP_SKETCH_THREADS), 0, ctx->stream,
-                               d_bytes, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
+                               d_packed, d_valid, d_starts, d_lens, d_slot_genome, d_slot_thr, d_slot_cand_start,
                                d_slot_cand_cap, d_work + off, (int)k, seed, d_cand, d_cand_count);
         }
     }

@@ -185,7 +185,7 @@ int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pai
                    size_t n, float min_aligned_fraction, float *out_ani_percent,
                    float *out_af /* nullable, [n][2] */);
 /* The integers behind ghip_ani_pairs' values (what the device hands back before the host's pow):
- * out[6 p ..] = M, T of the lower-median chunk, aligned chunks of both directions, aligned bases of q, of r, c_pair.
+ * out[6 p ..] = M, T of the lower-median chunk, chunks the median was taken over, aligned bases of q, of r, c_pair.
  * tests/golden/ani_golden.json freezes them for the reference's fixture genomes. */
 int ghip_ani_pairs_detail(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */, size_t n,
                           uint64_t *out /* [n][6] */);

@@ -43,10 +43,14 @@
  *               rearrangement two); M_c = min(T_c, S_c + (S_c > 0 ? A_c : 0)) -- a repeat seed is a match, once, where
  *               the chunk aligns anyway, and cannot align a chunk on its own;
  *               chunk aligned iff T_c >= 1 and M_c * 10000 >= 510 * T_c   (0.82^15 ~ 0.0510)
- *   M,T       = the (M_c, T_c) of the LOWER MEDIAN containment M_c/T_c over the aligned chunks of BOTH
- *               directions (exact order by cross-multiplication; skani likewise reports a robust
- *               per-chunk statistic rather than a pooled count, and with this choice the reference's
- *               own membership tests src/clusterer.rs:631-690 are reproduced, see tests)
+ *   M,T       = the (M_c, T_c) of the LOWER MEDIAN containment M_c/T_c over the aligned chunks of the SHORTER genome
+ *               (smaller L; both genomes' chunks when the lengths are equal -- so the value is symmetric in the pair).
+ *               A chunk of the longer genome is diluted wherever the shorter one ends inside it: a 4 kb contig inside a
+ *               50 kb one fills a fifth of the one chunk it touches, and the median over both directions came out at
+ *               86 % for a 96 % pair; the shorter genome's chunks are covered whole wherever it aligns at all (skani
+ *               likewise computes ANI over the chunks of the query).  Exact order by cross-multiplication; a robust
+ *               per-chunk statistic rather than a pooled count, and with this choice the reference's own membership
+ *               tests src/clusterer.rs:631-690 are reproduced, see tests
  *   AF_x      = (bases in aligned chunks of x) / L_x
  *   ANI%      = 100 * (M/T)^(1/k); 0 if no chunk aligned or (AF_q < min_af and AF_r < min_af)
  *               (a chance match of a mutated seed elsewhere in the other genome only counts if it falls into a band
@@ -234,7 +238,7 @@ static void ani_votes(const go_ani_sketch *q, const go_ani_sketch *r, uint32_t t
 }
 
 /* appends (M_c, T_c) of every aligned chunk of x and adds its aligned bases */
-static void ani_collect(const go_ani_sketch *x, const uint32_t *totals, const uint32_t *votes, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
+static void ani_collect(const go_ani_sketch *x, const uint32_t *totals, const uint32_t *votes, int listed, chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
     for (uint32_t c = 0; c < x->n_chunks; c++) {
         const uint64_t tc = totals[c];
         if (tc < 1) continue;
@@ -244,7 +248,7 @@ static void ani_collect(const go_ani_sketch *x, const uint32_t *totals, const ui
         if (mc) mc += v[GO_ANI_BANDS];   /* repeats: matched once, and only in a chunk that aligns by its single-copy seeds */
         if (mc > tc) mc = tc;
         if (mc * 10000 >= 510 * tc) {
-            out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++;
+            if (listed) { out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++; }
             uint64_t lo = (uint64_t)c * x->chunk, hi = lo + x->chunk;
             if (hi > x->length) hi = x->length;
             *aligned_bases += hi - lo;
@@ -271,8 +275,8 @@ float go_ani_pair_detail(const go_ani_sketch *q, const go_ani_sketch *r, float m
     uint32_t *vr = (uint32_t *)calloc(((size_t)r->n_chunks + 1) * GO_ANI_SLOTS, sizeof(uint32_t));
     uint32_t *tq = ani_totals(q, thr), *tr = ani_totals(r, thr);
     ani_votes(q, r, thr, vq, vr);
-    ani_collect(q, tq, vq, fr, &n, &bq);
-    ani_collect(r, tr, vr, fr, &n, &br);
+    ani_collect(q, tq, vq, q->length <= r->length, fr, &n, &bq);   /* the shorter genome's chunks (both at equal length) */
+    ani_collect(r, tr, vr, r->length <= q->length, fr, &n, &br);
     free(vq); free(vr); free(tq); free(tr);
     double afq = q->length ? (double)bq / (double)q->length : 0.0;
     double afr = r->length ? (double)br / (double)r->length : 0.0;
@@ -280,7 +284,7 @@ float go_ani_pair_detail(const go_ani_sketch *q, const go_ani_sketch *r, float m
     if (af_r) *af_r = (float)afr;
     if (detail) { detail[0] = detail[1] = 0; detail[2] = n; detail[3] = bq; detail[4] = br; detail[5] = c_pair; }
     if (n == 0) { free(fr); return 0.0f; }
-    /* lower median of the per-chunk containments over the aligned chunks of both directions */
+    /* lower median of the per-chunk containments over the listed chunks */
     qsort(fr, n, sizeof(chunk_frac), cmp_frac);
     chunk_frac med = fr[(n - 1) / 2];
     /* every member of the median's tie group holds the same fraction: the smallest (m, t) of the group is reported */

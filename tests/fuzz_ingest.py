@@ -52,7 +52,9 @@ for rnd in range(rounds):
         g = ctx.genomes_from_files(paths, int(rng.integers(1, 9)))
         for i, p in enumerate(paths):
             got = g.to_host(i).tobytes()
-            assert got == want[i][0].tobytes(), (rnd, form, p, len(got), len(want[i][0]))
+            # the resident form keeps "is it A/C/G/T" per position (2-bit codes + validity bits): every other stream byte
+            # -- 'N', needletail's '-' for gaps -- reads back as 'N'
+            assert got == want[i][0].tobytes().replace(b"-", b"N"), (rnd, form, p, len(got), len(want[i][0]))
             assert g.stats(i) == tuple(int(x) for x in want[i][1]) == oracle.genome_stats(p), (rnd, form, p)
             checked += 1
         g.free()

@@ -215,5 +215,6 @@ def test_mixed_density_pairs_equal_the_oracle(ctx):
         assert np.array_equal(af, np.float32([[w[1], w[2]] for w in want]))
         assert ctx.ani_pairs_detail(idx, pairs).tolist() == [w[3] for w in want]
         idx.free()
-    assert all(94.5 < w[0] < 97.5 for w in want), [w[0] for w in want]   # two copies at 2 % each: ~96 %
+    # two copies at 2 % each: ~96 % (the 4 kb contig against a genome at density 125 keeps ~30 seeds: +-1.5)
+    assert all(95.4 < w[0] < 96.8 for w, (a, b) in zip(want, pairs) if a < 8 and b < 8) and all(94.0 < w[0] < 98.5 for w in want), [w[0] for w in want]
     sk.free(); g.free()
