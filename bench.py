@@ -2,12 +2,13 @@
 """bench.py -- genome-pairs/sec of the galah finch-precluster + ANI hot path on MI355X.
 
 One "step" = one full pass of the hot path over one batch of synthetic genomes already resident
-in HBM: MinHash sketch (k=21, s=1000) -> all-vs-all precluster pairs at 90 % -> ANI index +
+in HBM (2-bit codes + validity bits): MinHash sketch (k=21, s=1000) -> all-vs-all precluster pairs at 90 % -> ANI index +
 ANI on the surviving pairs -> host greedy clustering at 95 %.  value = genome pairs / second
 (all N(N-1)/2 pairs of the workload divided by the whole-step wall time, max over ranks).
 
 Workloads (BASELINE.json):
-  --gpus 1            configs[1]: 1 000 synthetic ~5 Mb genomes (100 species x 10 members at ~95 % identity), s = 1000.
+  --gpus 1            the configuration BASELINE's north_star quotes the metric on: 10 000 synthetic ~5 Mb genomes
+                      (1 000 species x 10 members at ~95 % identity), s = 1000, on ONE MI355X (configs[2]'s size).
   --gpus N (N > 1)    1 250 genomes per GPU, i.e. configs[2] -- 10 000 genomes -- on 8 GPUs (weak scaling: per-GPU
                       sketch/ANI work is fixed, the all-vs-all pair count grows as N^2, so `value` grows faster than N;
                       `genomes_per_s` is the linear figure).  --total-genomes T pins the total instead (strong scaling).
@@ -18,16 +19,20 @@ Launch: the driver starts N > 1 as `python -m torch.distributed.run --nproc-per-
 `python bench.py --gpus N` re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous).
 GHIP_BENCH_BACKEND=gloo lets the ranks share the GPUs of a smaller box (functional check, not a measurement).
 
-At N = 1 the same process then also reports (skipped with --no-extras):
-  north_star_10k   10 000 x 5 Mb on the ONE GPU with its own CPU baseline and the >= 10x check (BASELINE north_star)
-  wall_clock       BASELINE metric 2: FASTA files in -> clusters out (1 000 genomes written to /dev/shm, plain and gzip)
-  skani            run-time probe for a `skani` binary (ANI parity is unpinned without one)
+At N = 1 the same process then also reports every other BASELINE configuration (skipped with --no-extras):
+  configs1_1k                 configs[1]: 1 000 x 5 Mb, with the WHOLE, unscaled CPU baseline and full-size parity asserts
+  configs4_50k_quality_order  configs[4]: 50 000 x 5 Mb (94 GB resident), CheckM2-style qualities, Parks2020_reduced order
+  configs3_contigs            configs[3]: 100 000 contigs of 2-20 kb, FASTA files in -> clusters out (small sketches)
+  wall_clock                  BASELINE metric 2: 1 000 genome FASTA files in -> clusters out (plain and gzip)
+  skani                       run-time probe for a `skani` binary (GHIP_SKANI_BIN or PATH; ANI parity is unpinned without one)
+  pmc_live                    HBM bytes / VALU instructions per launch of the dominant kernels, measured by child runs
 
 Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline legs and the parity asserts.
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import shutil
@@ -41,8 +46,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-GENOMES_PER_GPU_1 = 1000     # configs[1]
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+LDS_ROOF_PAIRS_PER_S = 9.4e9  # ~150 TB/s aggregate LDS bandwidth / 16 000 algorithmic bytes per pair (s = 1000)
+GENOMES_1GPU = 10_000        # north_star: 10k x 5 Mb on one MI355X
 GENOMES_PER_GPU_N = 1250     # configs[2] = 10 000 genomes on 8 GPUs
 
 
@@ -51,7 +57,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--species", type=int, default=None, help="species per GPU (default 100 at --gpus 1, 125 per GPU above)")
+    ap.add_argument("--species", type=int, default=None, help="species per GPU (default 1 000 at --gpus 1, 125 per GPU above)")
     ap.add_argument("--total-genomes", type=int, default=None, help="total genomes sharded over the ranks (strong scaling)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --species is the total, sharded over the ranks")
     ap.add_argument("--members", type=int, default=10)
@@ -64,10 +70,10 @@ def parse():
     ap.add_argument("--ani", type=float, default=95.0)
     ap.add_argument("--min-aligned-fraction", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the north_star_10k / wall_clock / skani legs")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: every logical CPU)")
-    ap.add_argument("--cpu-sample-genomes", type=int, default=32)
-    ap.add_argument("--cpu-pair-sample", type=int, default=2000, help="genomes whose all-vs-all pair loop the CPU baseline times")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no other configs, wall clock, probes)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: 4 per CPU of the cgroup quota)")
+    ap.add_argument("--contigs", type=int, default=100_000, help="contigs of the configs[3] leg")
+    ap.add_argument("--big-species", type=int, default=5000, help="species (x members genomes) of the configs[4] leg")
     return ap.parse_args()
 
 
@@ -79,148 +85,231 @@ def parse_percentage(x: float) -> np.float32:
     return p
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (scripts/gpu_pmc.sh +
-    scripts/pmc_summary.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 x2 read correction for
-    16 B/lane streams).  PMC collection cannot run inside the timed bench, hence a recorded figure."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max), or None when unlimited / unknown: the
+    boxes this ran on expose 256 logical CPUs under a quota of 16."""
     try:
-        with open(path) as f:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(period)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pmc_recorded(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (fallback when rocprofv3 cannot run here)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
             d = json.load(f)
         k = d["kernels"][kernel + "_kernel"]
-        return float(k["hbm_bytes_per_launch"]), d.get("tag"), {x: k.get(x) for x in ("simd_cycles_per_valu_inst", "valu_insts_per_launch")}
-    except Exception:
-        return None, None, None
+        return float(k["hbm_bytes_per_launch"]), d.get("tag")
+    except Exception:  # noqa: BLE001
+        return None, None
 
 
-# ------------------------------------------------------------------------------------------------ CPU baseline
-class CpuRates:
-    """Rates of the CPU oracle (a port of src/finch.rs:48-97; the Rust reference cannot be built here) on this host's
-    cores, measured once on a bounded sample and applied to both workloads (1 000 and 10 000 genomes)."""
-
-    def __init__(self, args, hashes, lens, min_ani, gpu_pairs):
-        from concurrent.futures import ThreadPoolExecutor
-
-        import oracle
-
-        # threads: every logical CPU -- or, under a cgroup CPU quota, four per granted CPU: on the GPU boxes (256 logical
-        # CPUs, 16 granted) the port runs 20 % FASTER with 64 threads than with 256, and the strongest CPU figure is the fair one
-        quota = self.cpu_quota()
-        ncpu = os.cpu_count() or 1
-        self.cores = cores = args.cpu_threads or (max(1, min(ncpu, int(4 * quota))) if quota else ncpu)
-        n = hashes.shape[0]
-        self.sample = sample = min(max(args.cpu_sample_genomes, cores), n)
-        genomes = [oracle.synth_genome(args.seed, g // args.members, g % args.members, args.length, args.sub_rate)
-                   for g in range(sample)]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:  # finch sketches files in parallel (rayon); ctypes drops the GIL
-            sk = list(ex.map(lambda b: oracle.sketch_bytes(b, args.kmer, args.sketch_size, 0), genomes))
-        self.t_sketch_sample = time.perf_counter() - t0
-        for i in range(sample):
-            assert np.array_equal(sk[i], hashes[i, : lens[i]]), "GPU sketch differs from the CPU oracle"
-        # pair loop: the whole matrix up to --cpu-pair-sample genomes, else its leading square block
-        self.m = m = min(n, args.cpu_pair_sample)
-        self.p_sample = m * (m - 1) // 2
-        t0 = time.perf_counter()
-        serial = oracle.distances_from_sketches(hashes[:m], lens[:m], min_ani, args.kmer, threads=1)  # src/finch.rs:75-76 is serial
-        self.t_pairs_serial = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        par = oracle.distances_from_sketches(hashes[:m], lens[:m], min_ani, args.kmer, threads=cores)
-        self.t_pairs_par = time.perf_counter() - t0
-        assert serial.tobytes() == par.tobytes()
-        self.serial_pairs = serial
-        self.check_pairs(gpu_pairs)
-        # ANI leg: sketch the sample and time a sample of candidate pairs
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            ask = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b), genomes))
-        self.t_ani_sketch_sample = time.perf_counter() - t0
-        cand = [(int(p["i"]), int(p["j"])) for p in serial if p["i"] < sample and p["j"] < sample][:64]
-        t0 = time.perf_counter()
-        for a, b in cand:
-            oracle.ani_pair(ask[a], ask[b], args.min_aligned_fraction / 100.0)
-        self.n_ani_timed = len(cand)
-        self.t_ani_pair = (time.perf_counter() - t0) / max(len(cand), 1)
-
-    def check_pairs(self, gpu_pairs):
-        """Parity on the sampled block: every precluster pair, integers and f32 bits."""
-        sub = gpu_pairs[(gpu_pairs["i"] < self.m) & (gpu_pairs["j"] < self.m)]
-        assert sub.tobytes() == self.serial_pairs.tobytes(), "GPU precluster pairs differ from the CPU oracle"
-
-    @staticmethod
-    def cpu_quota():
-        """CPUs' worth of time the container may use per period (cgroup v2 cpu.max), or None when unlimited / unknown: the
-        boxes this ran on expose 256 logical CPUs under a quota of 16 -- the timed legs of the CPU baseline (and the gzip
-        ingest) are bound by it, the per-pair ANI term is divided by the THREAD count, which flatters the CPU."""
-        try:
-            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            return None if q == "max" else float(q) / float(period)
-        except Exception:  # noqa: BLE001
-            return None
-
-    def baseline(self, n: int, n_pairs_total: int, n_cand_total: int):
-        cores = self.cores
-        scale = n / self.sample
-        pscale = n_pairs_total / max(self.p_sample, 1)
-        t_fixed = (self.t_sketch_sample + self.t_ani_sketch_sample) * scale + self.t_ani_pair * n_cand_total / cores
-        t_b1 = t_fixed + self.t_pairs_serial * pscale
-        t_b2 = t_fixed + self.t_pairs_par * pscale
-        return {
-            "value": n_pairs_total / t_b2, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle (C port of finch path, -O3, {cores} threads): MinHash-sketched {self.sample} of {n} genomes in "
-                       f"{self.t_sketch_sample:.2f}s and ANI-sketched them in {self.t_ani_sketch_sample:.2f}s (scaled x{scale:.1f}); "
-                       f"{self.p_sample}-pair loop of {self.m} genomes (scaled x{pscale:.1f} to {n_pairs_total} pairs) serial "
-                       f"{self.t_pairs_serial:.2f}s / parallel {self.t_pairs_par:.2f}s; "
-                       f"{self.n_ani_timed} ANI pairs at {self.t_ani_pair * 1e3:.2f} ms each x {n_cand_total} candidates / {cores} cores; "
-                       f"value = B2 (all stages parallel)"),
-            "host_cgroup_cpu_quota": self.cpu_quota(),   # CPUs' worth of time the container gets (None = unlimited)
-            "b1_faithful_serial_pair_loop_value": n_pairs_total / t_b1,
-            "pair_stage_only_pairs_per_s": {"serial": self.p_sample / self.t_pairs_serial, "parallel": self.p_sample / self.t_pairs_par},
-        }
-
-
-# ------------------------------------------------------------------------------------------------ extra legs (N = 1)
-def north_star_10k(args, ctx, rates, min_ani, ani_thr, min_af):
-    """BASELINE north_star: >= 10x the CPU baseline's genome-pairs/s on 10 000 x 5 Mb at 95 % ANI on ONE MI355X.
-    Same generator, same step; 50 GB of bases resident in HBM."""
-    from galah_amd import distributed as gd
-    n_species, members = 1000, args.members
-    n = n_species * members
-    n_pairs = n * (n - 1) // 2
-    job = gd.DereplicationJob(ctx, 0, 1, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size, min_ani=min_ani,
-                              ani_threshold=ani_thr, min_af=min_af, lazy_ani=True)
-    job.load_synthetic(args.seed, members, args.length, args.sub_rate)
-    job.step()  # warm-up
+# ------------------------------------------------------------------------------------------------ one workload on one rank
+def timed_steps(job, steps, warmup, ctx, barrier=lambda: None):
+    """warmup untimed steps, then `steps` timed ones bracketed by barrier + synchronize; per-kernel HIP-event times."""
+    for _ in range(warmup):
+        job.step()
     job.reset_stage_timers()
     ctx.profile(True)
     ctx.profile_reset()
+    barrier()
     ctx.synchronize()
-    steps = 3
     t0 = time.perf_counter()
+    result = None
     for _ in range(steps):
-        res = job.step()
+        result = job.step()
     ctx.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
-    stats = ctx.kernel_stats()
-    out = {"workload": f"{n} synthetic genomes x {args.length} bp on 1 GPU ({n * args.length / 1e9:.0f} GB of bases in HBM)",
-           "genomes": n, "pairs": n_pairs, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-           "value": n_pairs * steps / elapsed, "unit": "genome-pairs/s",
-           "stage_ms_per_step": job.stage_ms(),
-           "kernel_avg_ms": {k: v[1] / v[0] for k, v in stats.items() if v[0]},
-           "result": {"precluster_pairs": int(res["n_pairs"]), "clusters": int(res["n_clusters"]),
-                      "ani_pairs_asked": res.get("ani_pairs_asked")}}
-    sk = out["kernel_avg_ms"].get("sketch_kmers")
-    if sk:
-        out["sketch_kmers_GBps"] = job.local_bases / (sk * 1e-3) / 1e9
-        out["sketch_kmers_frac_of_hbm_peak"] = out["sketch_kmers_GBps"] / HBM_PEAK_GBS
-    if rates is not None:
-        rates.check_pairs(res["pairs"])   # the leading block of the 10k run is the same genomes: same pairs, bit for bit
-        cb = rates.baseline(n, n_pairs, int(res["n_pairs"]))
-        out["cpu_baseline"] = cb
-        out["speedup_vs_cpu_b2"] = out["value"] / cb["value"]
-        out["target_10x_met"] = bool(out["value"] >= 10.0 * cb["value"])
-    del job
+    return elapsed, result, ctx.kernel_stats()
+
+
+def kernel_table(stats, job, sketch_size):
+    """avg launch time of every kernel; achieved algorithmic GB/s against the HBM peak where SURVEY 8(d) defines the bytes
+    (1 B per base for the passes over the bases; 2 s 8 B per genome pair for the pair stage, no reuse credited), and for
+    the dense pair kernel also against the LDS roof SURVEY 8(d) names (the sketch matrix is cache resident: the tiles are
+    served from LDS)."""
+    pairs = max(job.last_pairs_compared, 1)
+    alg = {"sketch_kmers": float(job.local_bases), "ani_seeds": float(job.local_bases),
+           "pair_intersect_tile": 16.0 * sketch_size * pairs, "pair_join": 16.0 * sketch_size * pairs}
+    kern = {}
+    for k, (launches, total_ms) in stats.items():
+        if not launches:
+            continue
+        avg = total_ms / launches
+        e = {"launches": launches, "avg_ms": avg}
+        if k in alg:
+            e["algorithmic_bytes_per_launch"] = alg[k]
+            e["achieved_GBps"] = alg[k] / (avg * 1e-3) / 1e9
+            e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBS
+        if k in ("pair_intersect_tile", "pair_join"):
+            e["pairs_per_s"] = pairs / (avg * 1e-3)
+        if k == "pair_intersect_tile":
+            e["frac_of_lds_roof"] = e["pairs_per_s"] / (LDS_ROOF_PAIRS_PER_S * 1000.0 / sketch_size)
+        kern[k] = e
+    return kern, alg
+
+
+def roofline_of(kern, alg, ctx):
+    dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
+    issue_roof = None
+    if dom == "sketch_kmers":
+        # the kernel's own roof, MEASURED in this run: the filter form of MurmurHash3_x64_128 (the 47 instructions of
+        # murmur21_asm.h that cannot be tabulated) issued for as many wave-positions as one launch hashes, on all
+        # SIMDs, nothing else in the loop (ghip_selftest_hash_floor)
+        floor_ms = ctx.hash_floor_ms(int(alg[dom]) // 64)
+        issue_roof = {"what": "MurmurHash3 filter instructions alone for the launch's wave-positions, measured in this run",
+                      "floor_ms_per_launch": floor_ms, "frac": floor_ms / kern[dom]["avg_ms"]}
+    traffic, tag = pmc_recorded("sketch_kmers21" if dom == "sketch_kmers" else dom)
+    return {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kern[dom]["frac_of_hbm_peak"], "traffic": None,
+            "traffic_unit": "bytes/launch; null until pmc_live has measured it in this run",
+            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"], "issue_roof": issue_roof,
+            "recorded_traffic": {"bytes_per_launch": traffic, "profile": tag} if traffic is not None else None,
+            "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is two thirds of its VALU "
+                     "instructions per base (DESIGN.md); the HBM fraction is reported because the tier asks for it -- the bases are "
+                     "resident as 2-bit codes + validity bits, so the kernel reads 0.375 B per algorithmic byte.  The pair kernel "
+                     "(pair_intersect_tile, or pair_join from 1200 genomes) is the HBM-roofline kernel of the path: see 'kernels' for "
+                     "its achieved GB/s (algorithmic 2*s*8 B per pair; above the HBM peak because tiles are reused from LDS / the join "
+                     "never touches non-sharing pairs) and, for the dense form, its fraction of the LDS roof")}
+
+
+def run_workload(args, ctx, n_species, members, length, steps, warmup, sketch_size=None, order=None, keep=False):
+    """One single-GPU workload: load synthetic genomes, warm up, time `steps` steps.  Returns (summary, job, last result)."""
+    from galah_amd import distributed as gd
+    s = sketch_size or args.sketch_size
+    n = n_species * members
+    job = gd.DereplicationJob(ctx, 0, 1, n_genomes=n, kmer=args.kmer, sketch_size=s, min_ani=parse_percentage(args.precluster_ani),
+                              ani_threshold=np.float32(parse_percentage(args.ani) * np.float32(100.0)),
+                              min_af=float(parse_percentage(args.min_aligned_fraction)), lazy_ani=True)
+    job.load_synthetic(args.seed, members, length, args.sub_rate)
+    if order is not None:
+        job.set_order(order)
+    elapsed, result, stats = timed_steps(job, steps, warmup, ctx)
+    kern, alg = kernel_table(stats, job, s)
+    n_pairs = n * (n - 1) // 2
+    out = {"workload": f"{n} synthetic genomes x {length} bp ({n_species} species x {members} members, ~95% ANI) on 1 GPU, "
+                       f"{job.local_bases * 3 / 8 / 1e9:.1f} GB resident (2-bit codes + validity bits)",
+           "genomes": n, "pairs": n_pairs, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "value": n_pairs * steps / elapsed, "unit": "genome-pairs/s", "genomes_per_s": n * steps / elapsed,
+           "stage_ms_per_step": job.stage_ms(), "kernels": kern, "roofline": roofline_of(kern, alg, ctx),
+           "result": {"precluster_pairs": int(result["n_pairs"]), "clusters": int(result["n_clusters"]),
+                      "ani_pairs_asked": result.get("ani_pairs_asked")}}
+    if not keep:
+        job = None
+    return out, job, result
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+class CpuWhole:
+    """The CPU oracle (a C port of src/finch.rs:48-97 + the build-defined ANI; the Rust reference cannot be built here) run on
+    the WHOLE configs[1] workload -- every genome sketched, every pair compared, every candidate pair's ANI -- on this
+    host's cores, unscaled, next to full-size parity asserts of the GPU results."""
+
+    def __init__(self, args, ctx, job, result):
+        from concurrent.futures import ThreadPoolExecutor
+
+        import oracle
+        self.quota = cpu_quota()
+        ncpu = os.cpu_count() or 1
+        # threads: every logical CPU -- or, under a cgroup CPU quota, four per granted CPU: on the GPU boxes (256 logical
+        # CPUs, 16 granted) the port runs 20 % FASTER with 64 threads than with 256, and the strongest CPU figure is the fair one
+        self.threads = threads = args.cpu_threads or (max(1, min(ncpu, int(4 * self.quota))) if self.quota else ncpu)
+        self.cores = int(round(self.quota)) if self.quota else ncpu
+        n = job.n
+        self.n = n
+        min_ani = job.min_ani
+        hashes, lens = job.sketches_to_host()
+        genomes = [job.genomes.to_host(i) for i in range(n)]   # the device generator = oracle.synth_genome (checked on a sample below)
+        for i in (0, n // 2, n - 1):
+            assert np.array_equal(genomes[i], oracle.synth_genome(args.seed, i // args.members, i % args.members, args.length, args.sub_rate)), "device generator differs from the oracle's"
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:  # finch sketches files in parallel (rayon); ctypes drops the GIL
+            sk = list(ex.map(lambda b: oracle.sketch_bytes(b, args.kmer, args.sketch_size, 0), genomes))
+        self.t_sketch = time.perf_counter() - t0
+        for i in range(n):
+            assert lens[i] == len(sk[i]) and np.array_equal(sk[i], hashes[i, : lens[i]]), f"GPU sketch {i} differs from the CPU oracle"
+        t0 = time.perf_counter()
+        serial = oracle.distances_from_sketches(hashes, lens, min_ani, args.kmer, threads=1)  # src/finch.rs:75-76 is serial
+        self.t_pairs_serial = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        par = oracle.distances_from_sketches(hashes, lens, min_ani, args.kmer, threads=threads)
+        self.t_pairs_par = time.perf_counter() - t0
+        assert serial.tobytes() == par.tobytes()
+        assert result["pairs"].tobytes() == serial.tobytes(), "GPU precluster pairs differ from the CPU oracle"
+        self.serial_pairs = serial
+        self.n_pairs = n * (n - 1) // 2
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            ask = list(ex.map(lambda b: oracle.AniSketch.from_bytes(b), genomes))
+        self.t_ani_sketch = time.perf_counter() - t0
+        del genomes
+        cand = [(int(p["i"]), int(p["j"])) for p in serial]
+        min_af = float(parse_percentage(args.min_aligned_fraction))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            cpu_ani = list(ex.map(lambda ab: oracle.ani_pair(ask[ab[0]], ask[ab[1]], min_af)[0], cand))
+        self.t_ani_pairs = time.perf_counter() - t0
+        self.n_cand = len(cand)
+        # every candidate pair's ANI on the GPU equals the oracle's, bit for bit
+        sk2, idx = ctx.sketch_and_index(job.genomes, args.kmer, args.sketch_size, 0)
+        gpu_ani = ctx.ani_pairs(idx, np.array(cand, dtype=np.uint32).reshape(-1, 2), min_af)
+        sk2.free(); idx.free()
+        assert [float(v) for v in gpu_ani] == [float(np.float32(v)) for v in cpu_ani], "GPU ANI differs from the CPU oracle"
+        look = dict(zip(cand, cpu_ani))
+        t0 = time.perf_counter()
+        oc = oracle.cluster(n, oracle.Cache.from_pairs(serial), float(job.ani_threshold), lambda a, b: look[(min(a, b), max(a, b))])
+        self.t_cluster = time.perf_counter() - t0
+        assert oc == result["clusters"], "GPU clusters differ from the CPU oracle's"
+
+    def check_leading_block(self, pairs):
+        """The leading block of a larger run of the same generator is the same genomes: same pairs, bit for bit."""
+        sub = pairs[(pairs["i"] < self.n) & (pairs["j"] < self.n)]
+        assert sub.tobytes() == self.serial_pairs.tobytes(), "GPU precluster pairs differ from the CPU oracle"
+
+    def whole(self):
+        t_b2 = self.t_sketch + self.t_ani_sketch + self.t_pairs_par + self.t_ani_pairs + self.t_cluster
+        t_b1 = t_b2 - self.t_pairs_par + self.t_pairs_serial
+        return {"value": self.n_pairs / t_b2, "unit": "genome-pairs/s", "cores": self.cores, "threads": self.threads, "kind": "port",
+                "sample": (f"the WHOLE workload, unscaled: oracle (C port of the finch path + the build-defined ANI, -O3) on {self.threads} threads "
+                           f"under a cgroup quota of {self.quota} CPUs: MinHash-sketched {self.n} genomes in {self.t_sketch:.2f}s, ANI-sketched them "
+                           f"in {self.t_ani_sketch:.2f}s, {self.n_pairs}-pair loop serial {self.t_pairs_serial:.2f}s / parallel {self.t_pairs_par:.2f}s, "
+                           f"{self.n_cand} ANI pairs in {self.t_ani_pairs:.2f}s, greedy clustering {self.t_cluster:.2f}s; value = B2 (all stages parallel)"),
+                "seconds": t_b2, "host_cgroup_cpu_quota": self.quota,
+                "b1_faithful_serial_pair_loop_value": self.n_pairs / t_b1,
+                "pair_stage_only_pairs_per_s": {"serial": self.n_pairs / self.t_pairs_serial, "parallel": self.n_pairs / self.t_pairs_par},
+                "parity_checked": f"all {self.n} sketches, all {self.n_pairs} pair results, all {self.n_cand} ANI values and the clusters equal the GPU's, bit for bit"}
+
+    def scaled(self, n, n_pairs, n_cand):
+        """The same measured stage times scaled to a larger run of the same generator (a bounded sample of that workload)."""
+        g, p, c = n / self.n, n_pairs / self.n_pairs, n_cand / max(self.n_cand, 1)
+        t_b2 = (self.t_sketch + self.t_ani_sketch) * g + self.t_pairs_par * p + self.t_ani_pairs * c + self.t_cluster * g
+        t_b1 = t_b2 - self.t_pairs_par * p + self.t_pairs_serial * p
+        return {"value": n_pairs / t_b2, "unit": "genome-pairs/s", "cores": self.cores, "threads": self.threads, "kind": "port",
+                "sample": (f"bounded sample = the whole configs[1] workload ({self.n} of the {n} genomes, {self.n_pairs} pairs, {self.n_cand} ANI pairs; "
+                           f"{self.t_sketch + self.t_ani_sketch + self.t_pairs_par + self.t_ani_pairs:.1f}s of CPU work on {self.threads} threads under a quota of "
+                           f"{self.quota} CPUs), its stage times scaled to this workload: sketching x{g:.0f}, pair loop x{p:.1f}, ANI pairs x{c:.1f}"),
+                "seconds_projected": t_b2, "host_cgroup_cpu_quota": self.quota, "b1_faithful_serial_pair_loop_value": n_pairs / t_b1}
+
+
+# ------------------------------------------------------------------------------------------------ extra legs (N = 1)
+def configs4_leg(args, ctx):
+    """BASELINE configs[4]: 50 000 genomes with CheckM2-style qualities, genomes ordered by Parks2020_reduced
+    (src/cluster_argument_parsing.rs:1078-1092), 90 % precluster / 95 % ANI two-stage -- 250 Gbases, 94 GB resident."""
+    import galah_amd
+    n = args.big_species * args.members
+    rng = np.random.default_rng(args.seed)
+    completeness = rng.uniform(70, 100, n).astype(np.float32) / np.float32(100)
+    contamination = rng.uniform(0, 5, n).astype(np.float32) / np.float32(100)
+    order = galah_amd.quality_order_parks2020_reduced(completeness, contamination, rng.integers(1, 400, n), rng.integers(0, 20000, n))
+    out, _job, result = run_workload(args, ctx, args.big_species, args.members, args.length, steps=3, warmup=1, order=order)
+    out["workload"] += "; synthetic CheckM2 qualities (completeness U(70,100), contamination U(0,5)), genomes clustered in Parks2020_reduced order = BASELINE configs[4]"
+    # clusters hold positions in quality order: a representative is the best genome of its cluster unless a member found a
+    # later representative closer (src/clusterer.rs:410-441 assigns a member to its HIGHEST-ANI representative)
+    out["result"]["clusters_led_by_their_best_genome"] = float(np.mean([c[0] == min(c) for c in result["clusters"]]))
     return out
 
 
@@ -233,22 +322,81 @@ def _fasta_bytes(seq: np.ndarray, name: str) -> bytes:
     return f">{name} synthetic\n".encode() + body
 
 
+def _scratch_dir(need_bytes):
+    import tempfile
+    base = next((d for d in ("/dev/shm", "/tmp") if os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes), None)
+    return (tempfile.mkdtemp(prefix="ghip_files_", dir=base), base) if base else (None, None)
+
+
+def configs3_leg(args, ctx):
+    """BASELINE configs[3]: 100 000 short contigs (2-20 kb log-uniform, 10 000 families x 10 at ~95 % identity), each a FASTA
+    file, FILES IN -> CLUSTERS OUT with small sketches (s' = 256; build-defined: finch itself refuses contigs,
+    src/finch.rs:26-33) and the per-genome seed density (a contig this short is seeded with every 15-mer)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import galah_amd
+    n, members = args.contigs, 10
+    fam = n // members
+    rng = np.random.default_rng(args.seed)
+    lens = np.exp(rng.uniform(np.log(2000), np.log(20000), fam)).astype(np.int64)
+    d, base = _scratch_dir(int(lens.sum()) * members * 1.3 + (1 << 28))
+    if d is None:
+        return {"skipped": "no scratch directory with room for the contig files"}
+    try:
+        t0 = time.perf_counter()
+        anc = rng.integers(0, 4, int(lens.sum()), dtype=np.uint8)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        paths = [os.path.join(d, f"c{i:06d}.fna") for i in range(n)]
+
+        def write_family(f):
+            a = anc[off[f]:off[f + 1]]
+            r = np.random.default_rng(args.seed * 1000003 + f).integers(0, 256, (members, len(a)), dtype=np.uint8)
+            m = (a[None, :] + np.where(r < 6, 1 + r % 3, 0).astype(np.uint8)) & 3   # ~2.3 % substitutions per copy
+            for k in range(members):
+                with open(paths[f * members + k], "wb") as fh:
+                    fh.write(b">contig%d\n" % (f * members + k) + acgt[m[k]].tobytes() + b"\n")
+
+        with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(write_family, range(fam)))
+        t_write = time.perf_counter() - t0
+        threads = min(64, os.cpu_count() or 1)
+
+        def run():
+            pre = galah_amd.FinchPreclusterer(float(parse_percentage(args.precluster_ani)), 256, args.kmer, ctx=ctx, io_threads=threads)
+            cl = galah_amd.HipAniClusterer(float(parse_percentage(args.ani)) * 100.0, float(parse_percentage(args.min_aligned_fraction)),
+                                           small_genomes=True, ctx=ctx, io_threads=threads)
+            t0 = time.perf_counter()
+            clusters = galah_amd.cluster(paths, pre, cl)
+            return time.perf_counter() - t0, clusters, len(pre.last_pairs), getattr(cl, "last_pairs_asked", None)
+
+        t_first, c0, n_pre, asked = run()
+        t_warm, c1, _, _ = run()
+        assert c0 == c1
+        sizes = np.bincount([len(c) for c in c0])
+        return {"workload": f"{n} contig FASTA files of 2-20 kb ({fam} families x {members}, ~95 % identity, {int(lens.sum()) * members / 1e9:.2f} Gbases) in {base}"
+                            f" -> clusters; sketches s'=256 k={args.kmer}, precluster {args.precluster_ani}%, ANI {args.ani}% = BASELINE configs[3]",
+                "contigs": n, "pairs": n * (n - 1) // 2, "files_written_s": t_write, "first_call_s": t_first, "warm_s": t_warm,
+                "pairs_per_s_end_to_end": n * (n - 1) // 2 / t_warm, "contigs_per_s_end_to_end": n / t_warm,
+                "precluster_pairs": n_pre, "ani_pairs_asked": asked, "clusters": len(c0),
+                "clusters_of_10": int(sizes[10]) if len(sizes) > 10 else 0}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def wall_clock(args, ctx):
     """BASELINE metric 2 (`galah cluster`: src/cluster_argument_parsing.rs:545-716 is files in -> clusters out): the
-    headline's 1 000 genomes written as 80-column FASTA (plain and gzip level 1), then
+    configs[1] genomes (1 000 x 5 Mb) written as 80-column FASTA (plain and gzip level 1), then
     galah_amd.cluster(paths, FinchPreclusterer, HipAniClusterer) timed first-call and warm."""
-    import tempfile
     import zlib
     from concurrent.futures import ThreadPoolExecutor
 
     import galah_amd
 
     n = 100 * args.members
-    need = n * (args.length + args.length // 80 + 64) * 1.4
-    base = next((d for d in ("/dev/shm", "/tmp") if os.path.isdir(d) and shutil.disk_usage(d).free > need), None)
-    if base is None:
-        return {"skipped": "no scratch directory with %.1f GB free" % (need / 1e9)}
-    d = tempfile.mkdtemp(prefix="ghip_files_", dir=base)
+    d, base = _scratch_dir(n * (args.length + args.length // 80 + 64) * 1.4)
+    if d is None:
+        return {"skipped": "no scratch directory with room for the genome files"}
     try:
         g = ctx.genomes_synthetic(args.seed, 100, args.members, args.length, args.sub_rate)
         t0 = time.perf_counter()
@@ -265,8 +413,7 @@ def wall_clock(args, ctx):
                 f.write(co.compress(data) + co.flush())
             return p
 
-        threads = min(64, os.cpu_count() or 1)   # what the ingest may use: plain files take 12 of them, gzip all (inflate-bound;
-        # 128 threads were no faster than 64 on the bench box: 0.67 s against 0.50 s)
+        threads = min(64, os.cpu_count() or 1)   # what the ingest may use: plain files take ~1.25 x the CPU quota of them, gzip 1.5 x
         with ThreadPoolExecutor(threads) as ex:
             paths = list(ex.map(write, range(n)))
         del seqs
@@ -306,14 +453,14 @@ def wall_clock(args, ctx):
         del src, dst
         out.update({"plain_first_call_s": t_first, "plain_s": t_warm, "gz_s": t_gz, "clusters": len(c0),
                     "ingest_only_s": t_ingest, "ingest_GBps": out["plain_bytes"] / t_ingest / 1e9,
-                    # the ingest ships 2-bit codes (a quarter of the bases' bytes; GHIP_INGEST=ascii ships them whole):
-                    # the floor of what actually crosses PCIe, and -- for reference -- of the file bytes
-                    "pcie_form": "2-bit codes + runs of the other bytes, expanded on the device (GHIP_INGEST=ascii: one byte per base)",
+                    # the ingest ships 2-bit codes, which ARE the resident form (GHIP_INGEST=ascii ships one byte per base and
+                    # packs on the device): the floor of what actually crosses PCIe, and -- for reference -- of the file bytes
+                    "pcie_form": "2-bit codes copied straight into place + the runs of the other bytes (GHIP_INGEST=ascii: one byte per base, packed on the device)",
                     "h2d_pinned_GBps": h2d, "pcie_bytes_shipped": n * args.length // 4,
                     "pcie_floor_s": (n * args.length / 4) / (h2d * 1e9),
                     "pcie_floor_if_ascii_s": out["plain_bytes"] / (h2d * 1e9),
                     "plain_s_minus_pcie_floor_ms": (t_warm - (n * args.length / 4) / (h2d * 1e9)) * 1e3,
-                    "host_cgroup_cpu_quota": CpuRates.cpu_quota(),   # what bounds the ingest now: read + parse + pack ~1 CPU-second per 5 GB
+                    "host_cgroup_cpu_quota": cpu_quota(),   # what bounds the ingest now: read + parse + pack ~1 CPU-second per 5 GB
                     "after_ingest_s": t_warm - t_ingest,
                     "pairs_per_s_end_to_end": n * (n - 1) // 2 / t_warm,
                     "genomes_per_s_end_to_end": n / t_warm})
@@ -323,10 +470,12 @@ def wall_clock(args, ctx):
 
 
 def skani_probe(ctx):
-    """if a `skani` binary is on PATH, compare the build-defined ANI with it on the fixture genomes."""
-    exe = shutil.which("skani")
-    if not exe:
-        return "absent -- ANI parity unpinned (no skani binary on this box; the estimator is build-defined, DESIGN.md section 5)"
+    """if a `skani` binary is available (GHIP_SKANI_BIN, else PATH), compare the build-defined ANI with it on
+    the fixture genomes: the one external anchor the ANI stage can have."""
+    exe = os.environ.get("GHIP_SKANI_BIN") or shutil.which("skani")
+    if not exe or not os.path.exists(exe):
+        return ("absent -- ANI parity unpinned (no skani binary on this box: GHIP_SKANI_BIN unset, none on PATH; the estimator is "
+                "build-defined and frozen by tests/golden/ani_golden.json, DESIGN.md section 5)")
     try:
         import gzip
         import tempfile
@@ -344,7 +493,7 @@ def skani_probe(ctx):
             plain.append(p)
         cl = galah_amd.HipAniClusterer(95.0, 0.15, ctx=ctx, io_threads=4)
         cl.prepare(plain)
-        worst, n_cmp, disagree = 0.0, 0, 0
+        worst, n_cmp, disagree, rows_out = 0.0, 0, 0, []
         for a in range(len(plain)):
             for b in range(a + 1, len(plain)):
                 r = subprocess.run([exe, "dist", "--min-af", "15", "-q", plain[a], "-r", plain[b]], capture_output=True, text=True, timeout=120)
@@ -354,18 +503,21 @@ def skani_probe(ctx):
                 if theirs > 0 and ours > 0:
                     worst = max(worst, abs(theirs - ours))
                     n_cmp += 1
+                    rows_out.append([names[a], names[b], theirs, ours])
                 disagree += int((theirs >= 95.0) != (ours >= 95.0))
         shutil.rmtree(d, ignore_errors=True)
-        return {"binary": exe, "pairs_both_reported": n_cmp, "max_abs_delta_ani_points": worst, "threshold_95_disagreements": disagree}
+        return {"binary": exe, "pairs_both_reported": n_cmp, "max_abs_delta_ani_points": worst, "threshold_95_disagreements": disagree,
+                "within_1e-4_fraction": bool(worst <= 0.01), "pairs": rows_out}
     except Exception as e:  # a probe must never fail the bench
         return f"present at {exe} but the probe failed: {e!r}"
 
 
-def pmc_live(dom_kernel: str):
-    """HBM bytes per launch of the dominant kernel MEASURED by this run: two short child runs of this script under
-    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate passes, kernel-trace only, as the guide's HBM
-    section prescribes), FETCH doubled for the 16 B/lane streaming kernels (gfx950 correction).  None if rocprofv3 is
-    not usable here."""
+def pmc_live():
+    """HBM bytes and VALU instructions of the headline's kernels MEASURED by this run: three short child runs of this
+    script's headline workload under `rocprofv3 --pmc <counter> --kernel-trace` (separate passes, kernel-trace only, as the
+    guide's HBM section prescribes), FETCH doubled for the 16 B/lane streaming kernels (gfx950 correction).  Figures are
+    PER STEP of the child (a step's sketch pass over 10 000 x 5 Mb is two dispatches -- one AQL dispatch holds < 2^21
+    workgroups -- and its ANI stage four launches; pair_join = all join_* kernels).  None if rocprofv3 is not usable here."""
     import csv
     import glob
     import re
@@ -373,50 +525,43 @@ def pmc_live(dom_kernel: str):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
-    label = {"sketch_kmers": "sketch_kmers21_kernel", "pair_intersect_tile": "pair_probe_tile_kernel"}.get(dom_kernel, dom_kernel + "_kernel")
-    wide = dom_kernel in ("sketch_kmers", "ani_seeds")
-    out = {}
+    groups = {"sketch_kmers": ("sketch_kmers21_kernel", True), "pair_join": (r"join_\w+_kernel", False), "sketch_select": ("sketch_select_kernel", False),
+              "ani_pairs": ("ani_pairs_kernel", False), "ani_bin": ("ani_bin_kernel", False), "pair_intersect_tile": ("pair_probe_tile_kernel", False)}   # label regex, FETCH x2?
+    out = {g: {} for g in groups}
     d = tempfile.mkdtemp(prefix="ghip_pmc_", dir="/tmp")
+    child_steps = 3   # 1 warm-up + 2 timed
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     try:
         env = dict(os.environ, TMPDIR="/tmp")
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, c), "-o", c, "--",
-                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU GRBM_GUI_ACTIVE"):
+            tag = c.split()[0]
+            cmd = [exe, "--pmc"] + c.split() + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, tag), "-o", tag, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 return {"error": f"rocprofv3 --pmc {c} exited {r.returncode}: {r.stderr[-300:]}"}
-            tot, n = 0.0, 0
-            for f in glob.glob(os.path.join(d, c, "**", "*counter_collection.csv"), recursive=True):
+            acc = {}
+            for f in glob.glob(os.path.join(d, tag, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if re.search(label, row["Kernel_Name"]) and row["Counter_Name"] == c:
-                        tot += float(row["Counter_Value"])
-                        n += 1
-            if n == 0:
-                return {"error": f"no {label} rows in the {c} pass"}
-            out[c + "_KB_per_launch"] = tot / n
-            out["launches_" + c] = n
-        f_b, w_b = out["FETCH_SIZE_KB_per_launch"] * 1024, out["WRITE_SIZE_KB_per_launch"] * 1024
-        out["fetch_x2"] = wide
-        out["hbm_bytes_per_launch"] = (2 * f_b if wide else f_b) + w_b
-        # third pass: how many VALU instructions the kernel issues (it is instruction-issue bound: DESIGN.md section 4)
-        try:
-            cmd = [exe, "--pmc", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, "SQ"),
-                   "-o", "SQ", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-            acc = {"SQ_INSTS_VALU": [0.0, 0], "GRBM_GUI_ACTIVE": [0.0, 0]}
-            for f in glob.glob(os.path.join(d, "SQ", "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if re.search(label, row["Kernel_Name"]) and row["Counter_Name"] in acc:
-                        acc[row["Counter_Name"]][0] += float(row["Counter_Value"])
-                        acc[row["Counter_Name"]][1] += 1
-            if r.returncode == 0 and acc["SQ_INSTS_VALU"][1]:
-                valu = acc["SQ_INSTS_VALU"][0] / acc["SQ_INSTS_VALU"][1]
-                out["valu_insts_per_launch"] = valu
-                if acc["GRBM_GUI_ACTIVE"][1]:   # summed over the 8 XCDs; 1024 SIMDs
-                    out["simd_cycles_per_valu_inst"] = 1024.0 * (acc["GRBM_GUI_ACTIVE"][0] / acc["GRBM_GUI_ACTIVE"][1]) / 8.0 / valu
-        except Exception:  # noqa: BLE001
-            pass
-        return out
+                    for g, (label, _x2) in groups.items():
+                        if re.search(label, row["Kernel_Name"]):
+                            a = acc.setdefault((g, row["Counter_Name"]), [0.0, 0])
+                            a[0] += float(row["Counter_Value"])
+                            a[1] += 1
+            for (g, cname), (tot, cnt) in acc.items():
+                out[g][cname + "_per_step"] = tot / child_steps
+                out[g]["dispatches_per_step"] = cnt / child_steps
+        for g, (_label, x2) in groups.items():
+            e = out[g]
+            if "FETCH_SIZE_per_step" in e and "WRITE_SIZE_per_step" in e:   # counters are in KB
+                f_b, w_b = e["FETCH_SIZE_per_step"] * 1024, e["WRITE_SIZE_per_step"] * 1024
+                e["fetch_x2"] = x2
+                e["hbm_read_bytes_per_step"] = 2 * f_b if x2 else f_b
+                e["hbm_write_bytes_per_step"] = w_b
+                e["hbm_bytes_per_step"] = e["hbm_read_bytes_per_step"] + w_b
+            if e.get("SQ_INSTS_VALU_per_step") and e.get("GRBM_GUI_ACTIVE_per_step"):   # GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+                e["simd_cycles_per_valu_inst"] = 1024.0 * e["GRBM_GUI_ACTIVE_per_step"] / 8.0 / e["SQ_INSTS_VALU_per_step"]
+        out["unit"] = "per step of the headline workload (child runs of 3 steps each)"
+        return {g: e for g, e in out.items() if e}
     except Exception as e:  # noqa: BLE001 -- a counter pass must never cost the headline
         return {"error": repr(e)}
     finally:
@@ -428,9 +573,6 @@ def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
-
-
-import contextlib
 
 
 @contextlib.contextmanager
@@ -455,6 +597,96 @@ def self_launch(n: int) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.call(cmd, env=env)
+
+
+def main_single(args, ctx, json_fd):
+    """N = 1: the north-star configuration as the headline, every other BASELINE configuration beside it."""
+    import gc
+    n_species = args.species or GENOMES_1GPU // args.members
+    n = n_species * args.members
+    # Host runtime hygiene, not part of the path: torch alone leaves ~170 000 long-lived objects, and a full (gen-2)
+    # cycle collection over them costs 20-35 ms -- triggered every few steps at 10 000 genomes, where a step builds
+    # thousands of small cluster lists.  Park everything that exists now in the permanent generation.
+    gc.collect()
+    gc.freeze()
+    head, job, result = run_workload(args, ctx, n_species, args.members, args.length, args.steps, args.warmup, keep=True)
+    is_north_star = (n, args.length, args.sketch_size) == (10000, 5_000_000, 1000)
+    out = {
+        "metric": "genome-pairs/sec (MinHash+ANI)", "value": head["value"], "unit": "genome-pairs/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{n} synthetic genomes x {args.length} bp ({n_species} species x {args.members} members, ~95% ANI) on 1 MI355X, "
+                               f"finch precluster s={args.sketch_size} k={args.kmer} at {args.precluster_ani}% + ANI at {args.ani}%, greedy clustering"
+                               + (" = the configuration BASELINE north_star quotes the metric on (configs[2]'s size on one GPU)" if is_north_star else ""),
+                   "genomes": n, "genomes_per_gpu": n, "genome_length": args.length, "pairs": head["pairs"],
+                   "resident_GB": job.local_bases * 3 / 8 / 1e9, "parallelism": "single", "transport": "self"},
+        "genomes_per_s": head["genomes_per_s"], "roofline": head["roofline"], "kernels": head["kernels"],
+        "stage_ms_per_step": head["stage_ms_per_step"], "result": head["result"],
+    }
+    head_pairs, n_cand = result["pairs"], int(result["n_pairs"])
+    job = result = None
+    if not args.no_extras or not args.no_cpu_baseline:
+        gc.unfreeze()
+        gc.collect()
+    legs = []
+    whole = None
+    if not args.no_cpu_baseline or not args.no_extras:
+        def configs1():
+            nonlocal whole
+            c1, j1, r1 = run_workload(args, ctx, 100, args.members, args.length, steps=25, warmup=2, keep=True)
+            c1["workload"] += " = BASELINE configs[1]"
+            if not args.no_cpu_baseline:
+                whole = CpuWhole(args, ctx, j1, r1)
+                c1["cpu_baseline"] = whole.whole()
+                c1["speedup_vs_cpu_b2"] = c1["value"] / c1["cpu_baseline"]["value"]
+                if is_north_star:
+                    whole.check_leading_block(head_pairs)
+                out["cpu_baseline"] = whole.scaled(n, head["pairs"], n_cand)
+                out["speedup_vs_cpu_b2"] = out["value"] / out["cpu_baseline"]["value"]
+                out["target_10x_met"] = bool(out["value"] >= 10.0 * out["cpu_baseline"]["value"])   # north_star: >= 10x the CPU baseline
+            return c1
+        legs.append(("configs1_1k", configs1))
+    if not args.no_extras:
+        legs += [("configs4_50k_quality_order", lambda: configs4_leg(args, ctx)), ("configs3_contigs", lambda: configs3_leg(args, ctx)),
+                 ("wall_clock", lambda: wall_clock(args, ctx)), ("skani", lambda: skani_probe(ctx))]
+
+        def live():
+            t = pmc_live()
+            if isinstance(t, dict) and "error" not in t:
+                dom = out["roofline"]["kernel"]
+                per_step = {g: out["kernels"][g]["launches"] / args.steps for g in out["kernels"]}   # launches (profile brackets) of a step
+                if t.get(dom, {}).get("hbm_bytes_per_step") is not None:   # measured in this run
+                    rf = out["roofline"]
+                    rf["traffic"] = t[dom]["hbm_bytes_per_step"] / per_step[dom]
+                    rf["traffic_unit"] = ("bytes/launch, measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "(separate passes, kernel-trace only; FETCH x2 for 16 B/lane streams on gfx950)")
+                    if dom == "sketch_kmers":
+                        # what the fused pass must move: the resident bases (3 bits each) in, the ANI seeds (8 B each) out
+                        seeds_out = 8.0 * rf["algorithmic_bytes_per_launch"] / 125.0
+                        rf["bytes_the_pass_must_move"] = rf["algorithmic_bytes_per_launch"] * 3 / 8 + seeds_out
+                        rf["traffic_over_must_move"] = rf["traffic"] / rf["bytes_the_pass_must_move"]
+                if t.get(dom, {}).get("SQ_INSTS_VALU_per_step"):
+                    v = t[dom]["SQ_INSTS_VALU_per_step"] / per_step[dom]
+                    out["roofline"]["valu"] = {"valu_insts_per_launch": v, "valu_insts_per_base": v * 64 / out["roofline"]["algorithmic_bytes_per_launch"],
+                                               "simd_cycles_per_valu_inst": t[dom].get("simd_cycles_per_valu_inst"),
+                                               "source": "measured by this run (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE)"}
+                for g in out["kernels"]:
+                    if g != dom and t.get(g, {}).get("hbm_bytes_per_step") is not None:
+                        out["kernels"][g]["pmc_hbm_bytes_per_launch"] = t[g]["hbm_bytes_per_step"] / per_step[g]
+            return t if t is not None else "rocprofv3 not on PATH: roofline.traffic stays null (roofline.recorded_traffic has the committed figure)"
+        legs.append(("pmc_live", live))
+    for name, fn in legs:
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except AssertionError:
+            raise   # a parity failure is a failure of the bench
+        except Exception as e:  # an extra leg (e.g. no room for 94 GB) must not cost the headline
+            out[name] = {"error": repr(e)}
+        if isinstance(out[name], dict):
+            out[name]["leg_seconds"] = time.perf_counter() - t0
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def main():
@@ -484,12 +716,14 @@ def main():
     backend = os.environ.get("GHIP_BENCH_BACKEND", "rccl")
     device = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        with stdout_to_stderr():   # gloo announces its connections ("[Gloo] Rank 0 is connected to ...") on STDOUT
-            dist.init_process_group("gloo")
-            dist.barrier()
     ctx = galah_amd.Context(device)
+    if world == 1:
+        return main_single(args, ctx, json_fd)
+
+    import torch.distributed as dist
+    with stdout_to_stderr():   # gloo announces its connections ("[Gloo] Rank 0 is connected to ...") on STDOUT
+        dist.init_process_group("gloo")
+        dist.barrier()
 
     # ---- workload shape
     if args.total_genomes is not None:
@@ -497,10 +731,10 @@ def main():
         assert n % args.members == 0, "--total-genomes must be a multiple of --members"
         scaling = "strong"
     elif args.strong:
-        n = (args.species or 100) * args.members
+        n = (args.species or 1000) * args.members
         scaling = "strong"
     else:
-        per_gpu = args.species * args.members if args.species else (GENOMES_PER_GPU_1 if world == 1 else GENOMES_PER_GPU_N)
+        per_gpu = args.species * args.members if args.species else GENOMES_PER_GPU_N
         n = per_gpu * world
         scaling = "weak"
     n_species = n // args.members
@@ -517,153 +751,53 @@ def main():
     job.load_synthetic(args.seed, args.members, args.length, args.sub_rate)  # untimed: inputs resident in HBM
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         job.step()
-    # Host runtime hygiene, not part of the path: torch alone leaves ~170 000 long-lived objects, and a full (gen-2)
-    # cycle collection over them costs 20-35 ms -- triggered every few steps at 10 000 genomes, where a step builds
-    # thousands of small cluster lists.  Park everything that exists now in the permanent generation.
-    import gc
     gc.collect()
     gc.freeze()
-    job.reset_stage_timers()
-    ctx.profile(True)
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    result = None
-    for _ in range(args.steps):
-        result = job.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.profile(False)
+    elapsed, result, stats = timed_steps(job, args.steps, 0, ctx, barrier)
     stage_ms = job.stage_ms()
-    per_rank = None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        per_rank = [None] * world   # per-rank stage times and kernel averages (outside the timed region)
-        dist.all_gather_object(per_rank, {"rank": rank, "device": device, "genomes": job.count, "stage_ms": stage_ms,
-                                          "kernel_avg_ms": {k: v[1] / v[0] for k, v in ctx.kernel_stats().items() if v[0]}})
-    stats = ctx.kernel_stats()
-
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    per_rank = [None] * world   # per-rank stage times and kernel averages (outside the timed region)
+    dist.all_gather_object(per_rank, {"rank": rank, "device": device, "genomes": job.count, "stage_ms": stage_ms,
+                                      "kernel_avg_ms": {k: v[1] / v[0] for k, v in stats.items() if v[0]}})
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_pairs_total * args.steps / elapsed
-        # ---- roofline of the dominant kernel (by total HIP-event time on the launch stream)
-        alg = {  # ALGORITHMIC bytes per launch on THIS rank (DESIGN.md "Kernels")
-            "sketch_kmers": float(job.local_bases),                              # 1 B per input base
-            "pair_intersect_tile": 16.0 * args.sketch_size * job.last_pairs_compared,  # 2*s*8 B per pair
-            # the inverted-index form covers the pairs of the gathered matrix that fall to this rank
-            "pair_join": 16.0 * args.sketch_size * max(job.last_pairs_compared, 1),
-            "ani_seeds": float(job.local_bases),
-        }
-        kern = {}
-        for k, (launches, total_ms) in stats.items():
-            if launches:
-                avg = total_ms / launches
-                e = {"launches": launches, "avg_ms": avg}
-                if k in alg:
-                    e["achieved_GBps"] = alg[k] / (avg * 1e-3) / 1e9
-                    e["frac_of_hbm_peak"] = e["achieved_GBps"] / HBM_PEAK_GBS
-                if world == 1:  # HBM bytes per launch of every kernel from the committed PMC passes (same workload)
-                    t, _tag, _v = pmc_traffic("pair_probe_tile" if k == "pair_intersect_tile" else k)
-                    if t is not None:
-                        e["pmc_hbm_bytes_per_launch"] = t
-                kern[k] = e
-        dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
-        traffic, traffic_tag, valu = pmc_traffic(dom) if world == 1 else (None, None, None)
-        issue_roof = None
-        if dom == "sketch_kmers":
-            # the kernel's own roof, MEASURED in this run: the filter form of MurmurHash3_x64_128 (the 47 instructions of
-            # murmur21_asm.h that cannot be tabulated) issued for as many wave-positions as one launch hashes, on all
-            # SIMDs, nothing else in the loop (ghip_selftest_hash_floor)
-            floor_ms = ctx.hash_floor_ms(int(alg[dom]) // 64)
-            issue_roof = {"what": "MurmurHash3 filter instructions alone for the launch's wave-positions, measured in this run",
-                          "floor_ms_per_launch": floor_ms, "frac": floor_ms / kern[dom]["avg_ms"]}
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
-                    "traffic_unit": ("bytes/launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/%s_pmc_traffic.json)" % traffic_tag
-                                     if traffic is not None else "PMC passes are collected for the 1-GPU run only"),
-                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
-                    "valu": valu,  # SQ_INSTS_VALU per launch and SIMD-cycles per VALU instruction, same PMC file
-                    "issue_roof": issue_roof,
-                    "note": ("sketch_kmers is integer-VALU bound: MurmurHash3_x64_128 of every 21-mer is about half of its "
-                             "VALU instructions per base (DESIGN.md); the HBM fraction is reported because the tier "
-                             "asks for it.  The pair kernel (pair_intersect_tile, or pair_join from 1200 genomes) is "
-                             "the HBM-roofline kernel of the path: see 'kernels' for its achieved GB/s (algorithmic "
-                             "2*s*8 B per pair; above the HBM peak because tiles are reused from LDS / the join never "
-                             "touches non-sharing pairs)")}
+        kern, alg = kernel_table(stats, job, args.sketch_size)
         gather_bytes = n * (args.sketch_size * 8 + 4)
         out = {
-            "metric": "genome-pairs/sec (MinHash+ANI)", "value": value, "unit": "genome-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64",
-            "data": "synthetic",
+            "metric": "genome-pairs/sec (MinHash+ANI)", "value": n_pairs_total * args.steps / elapsed, "unit": "genome-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{n} synthetic genomes x {args.length} bp ({n_species} species x {args.members} "
                                    f"members, ~95% ANI), finch precluster s={args.sketch_size} k={args.kmer} at "
                                    f"{args.precluster_ani}% + ANI at {args.ani}%, greedy clustering"
-                                   + (" = BASELINE configs[1]" if (n, world) == (1000, 1) else "")
                                    + (" = BASELINE configs[2]" if (n, world) == (10000, 8) else ""),
                        "genomes": n, "genomes_per_gpu": n // world, "genome_length": args.length, "pairs": n_pairs_total,
                        "parallelism": (f"genomes sharded x{world}: sketch + ANI where a genome lives, sketch matrix "
                                        f"all-gathered ({gather_bytes / 1e6:.1f} MB), pair stage on the gathered matrix "
-                                       f"dealt over the ranks, candidate lists and ANI values all-gathered") if world > 1 else "single",
+                                       f"dealt over the ranks, candidate lists and ANI values all-gathered"),
                        "transport": transport},
             "genomes_per_s": n * args.steps / elapsed,
-            "roofline": roofline,
-            "kernels": kern,
-            "stage_ms_per_step": stage_ms,
+            "roofline": roofline_of(kern, alg, ctx), "kernels": kern, "stage_ms_per_step": stage_ms,
             "result": {"precluster_pairs": int(result["n_pairs"]), "clusters": int(result["n_clusters"]),
-                       # one rank asks the clusterer's ANI lazily (only pairs that touch a representative, as the reference does)
                        "ani_pairs_asked": result.get("ani_pairs_asked")},
+            "allgather_sketches": {"bytes": gather_bytes, "ms": stage_ms.get("allgather_sketches"),
+                                   "GBps": gather_bytes / max(stage_ms.get("allgather_sketches", 0.0) * 1e-3, 1e-9) / 1e9},
+            "per_rank": per_rank,
         }
-        if world > 1:
-            out["allgather_sketches"] = {"bytes": gather_bytes, "ms": stage_ms.get("allgather_sketches"),
-                                         "GBps": gather_bytes / max(stage_ms.get("allgather_sketches", 0.0) * 1e-3, 1e-9) / 1e9}
-            out["per_rank"] = per_rank
-        rates = None
-        if not args.no_cpu_baseline and world == 1:
-            hashes, lens = job.sketches_to_host()
-            rates = CpuRates(args, hashes, lens, min_ani, result["pairs"])
-            out["cpu_baseline"] = rates.baseline(n, n_pairs_total, len(result["pairs"]))
-        if world == 1 and not args.no_extras:
-            del job, result
-            gc.unfreeze()
-            gc.collect()
-            def live_traffic():
-                t = pmc_live(dom)
-                if t and "hbm_bytes_per_launch" in t:   # measured in this run: replaces the recorded figure
-                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_unit"] = ("bytes/launch, measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                       "(separate passes, kernel-trace only; FETCH x2 for 16 B/lane streams on gfx950)")
-                if t and "valu_insts_per_launch" in t:  # likewise the VALU instruction count
-                    out["roofline"]["valu"] = {"valu_insts_per_launch": t["valu_insts_per_launch"],
-                                               "simd_cycles_per_valu_inst": t.get("simd_cycles_per_valu_inst"),
-                                               "source": "measured by this run (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE)"}
-                return t if t is not None else "rocprofv3 not on PATH: roofline.traffic is the recorded figure"
-
-            for name, fn in (("north_star_10k", lambda: north_star_10k(args, ctx, rates, min_ani, ani_thr, min_af)),
-                             ("wall_clock", lambda: wall_clock(args, ctx)), ("skani", lambda: skani_probe(ctx)),
-                             ("pmc_live", live_traffic)):
-                try:
-                    out[name] = fn()
-                except AssertionError:
-                    raise   # a parity failure is a failure of the bench
-                except Exception as e:  # an extra leg (e.g. no room for 50 GB) must not cost the headline
-                    out[name] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     job = None
-    if world > 1:
-        dist.barrier()
-        comm.close()          # ncclCommDestroy on every rank, while the runtime is still up
-        dist.destroy_process_group()
+    dist.barrier()
+    comm.close()          # ncclCommDestroy on every rank, while the runtime is still up
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -294,6 +294,17 @@ class DereplicationJob:
         self._steps = 0
         self._full = None
         self.last_pairs_compared = 0
+        self.rank_of = None
+
+    def set_order(self, order):
+        """Genome order of the clustering stage (one rank): order[x] = the genome that comes x-th -- galah sorts its input by
+        quality before clustering (src/cluster_argument_parsing.rs:863-1157), so the best genome of a cluster becomes its
+        representative.  Sketches, pairs and ANI are computed where the genomes lie; the pair list is re-indexed and re-sorted
+        before the greedy clusterer, whose clusters then hold positions in `order`."""
+        order = np.asarray(order, dtype=np.int64)
+        assert self.world == 1 and sorted(order.tolist()) == list(range(self.n))
+        self.rank_of = np.empty(self.n, dtype=np.uint32)
+        self.rank_of[order] = np.arange(self.n, dtype=np.uint32)
 
     def load_synthetic(self, seed: int, members: int, length: int, sub_rate: float):
         self.genomes = self.ctx.genomes_synthetic_range(seed, members, self.first, self.count, length, sub_rate)
@@ -325,6 +336,12 @@ class DereplicationJob:
         self.last_pairs_compared = self.ctx.last_pairs_compared
         t2 = time.perf_counter()
         pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
+        if self.rank_of is not None and len(pairs):   # the clusterer sees the genomes in quality order
+            a, b = self.rank_of[pairs["i"]], self.rank_of[pairs["j"]]
+            pairs = pairs.copy()
+            pairs["i"], pairs["j"] = np.minimum(a, b), np.maximum(a, b)
+            perm = np.lexsort((pairs["j"], pairs["i"]))
+            pairs, pi = pairs[perm], pi[perm]   # pi keeps the positions in the ANI index
         t_ani = [0.0]
 
         def ani_of(edges):

@@ -353,8 +353,7 @@ def test_bench_line_contract():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    small = ["--species", "6", "--members", "4", "--length", "300000", "--steps", "2", "--warmup", "1", "--no-extras",
-             "--cpu-sample-genomes", "4", "--cpu-pair-sample", "24"]
+    small = ["--species", "6", "--members", "4", "--length", "300000", "--steps", "2", "--warmup", "1", "--no-extras"]
     for extra, env in (([], {}), (["--gpus", "2"], {"GHIP_BENCH_BACKEND": "gloo"})):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small + extra, capture_output=True, text=True,
                            timeout=900, env=dict(os.environ, **env))
@@ -373,10 +372,11 @@ def test_bench_line_contract():
             assert k in rf, k
         assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
         if not extra:
-            cb = d["cpu_baseline"]
-            for k in ("value", "unit", "cores", "kind", "sample"):
-                assert k in cb, k
-            assert cb["kind"] in ("port", "reference") and cb["value"] > 0
+            for cb in (d["cpu_baseline"], d["configs1_1k"]["cpu_baseline"]):   # the headline's bounded sample = the whole configs[1]-shaped run
+                for k in ("value", "unit", "cores", "kind", "sample"):
+                    assert k in cb, k
+                assert cb["kind"] in ("port", "reference") and cb["value"] > 0
+            assert "parity_checked" in d["configs1_1k"]["cpu_baseline"] and "frac_of_lds_roof" in d["configs1_1k"]["kernels"]["pair_intersect_tile"]
         else:
             assert len(d["per_rank"]) == 2 and d["config"]["transport"] == "host-callback"
 
