@@ -61,6 +61,10 @@ SIGNATURES = {
     "ghip_sketches_copy_into": (_int, [_vp, _vp, _vp, _vp]),
     "ghip_sketches_save": (_int, [_vp, _vp, C.c_char_p]),
     "ghip_sketches_load": (_int, [_vp, C.c_char_p, _pp]),
+    "ghip_sketches_save_named": (_int, [_vp, _vp, _vp, _u64, C.c_char_p]),
+    "ghip_sketches_load_named": (_int, [_vp, C.c_char_p, _pp, _pp, C.POINTER(_sz), C.POINTER(_u64)]),
+    "ghip_sketches_concat": (_int, [_vp, _vp, _vp, _pp]),
+    "ghip_precluster_from": (_int, [_vp, _vp, _sz, _f32, _pp, C.POINTER(_sz)]),
     "ghip_sketches_count": (_sz, [_vp]),
     "ghip_sketches_size": (_u32, [_vp]),
     "ghip_sketches_kmer": (_u32, [_vp]),

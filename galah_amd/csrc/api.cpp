@@ -1021,43 +1021,120 @@ extern "C" int ghip_sketches_copy_into(ghip_ctx *ctx, const ghip_sketches *sk, v
     return GHIP_OK;
 }
 
-// On-disk sketch matrix (the reference has no finch counterpart -- skani's
-// --low-memory db dir, src/skani.rs:266-304, is the closest): "GHIPSK01", u32 k, u32 s, u64 n,
-// u32 len[n], u64 hashes[n][s], little-endian.
-extern "C" int ghip_sketches_save(ghip_ctx *ctx, const ghip_sketches *sk, const char *path) {
+// On-disk sketch matrix (the reference has no finch counterpart -- skani's --low-memory db dir,
+// src/skani.rs:266-304, and the sketched reference set of its --reference-genomes mode, src/skani.rs:502-565, are the
+// closest).  "GHIPSK02", little-endian:
+//   char[8] magic; u32 k; u32 s; u64 hash seed; u64 n; u64 names_bytes; u32 len[n]; u64 hashes[n][s];
+//   char names[names_bytes] (n NUL-terminated genome names, in row order); u64 FNV-1a-64 of every byte before it.
+// "GHIPSK01" (round 1-2: no seed, no names, no checksum) still loads.
+namespace {
+struct Fnv {
+    uint64_t h = 0xcbf29ce484222325ull;
+    void add(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; } }
+};
+bool put(FILE *f, Fnv &c, const void *p, size_t n) { c.add(p, n); return n == 0 || fwrite(p, 1, n, f) == n; }
+bool get(FILE *f, Fnv &c, void *p, size_t n) { if (n && fread(p, 1, n, f) != n) return false; c.add(p, n); return true; }
+}  // namespace
+
+extern "C" int ghip_sketches_save_named(ghip_ctx *ctx, const ghip_sketches *sk, const char *const *names, uint64_t seed, const char *path) {
     if (!ctx || !sk || !path) return GHIP_EINVAL;
     std::vector<uint64_t> h(sk->n * (size_t)sk->s);
     std::vector<uint32_t> l(sk->n);
     int rc = ghip_sketches_to_host(ctx, sk, h.data(), l.data());
     if (rc) return rc;
+    std::string blob;
+    for (size_t i = 0; i < sk->n; i++) { if (names && names[i]) blob += names[i]; blob.push_back('\0'); }
     FILE *f = fopen(path, "wb");
     if (!f) return ghip_set_error(ctx, GHIP_EIO, std::string("cannot write ") + path);
-    const uint64_t n = sk->n;
-    bool ok = fwrite("GHIPSK01", 1, 8, f) == 8 && fwrite(&sk->k, 4, 1, f) == 1 && fwrite(&sk->s, 4, 1, f) == 1 &&
-              fwrite(&n, 8, 1, f) == 1 && fwrite(l.data(), 4, l.size(), f) == l.size() &&
-              fwrite(h.data(), 8, h.size(), f) == h.size();
+    const uint64_t n = sk->n, nb = blob.size();
+    Fnv c;
+    bool ok = put(f, c, "GHIPSK02", 8) && put(f, c, &sk->k, 4) && put(f, c, &sk->s, 4) && put(f, c, &seed, 8) && put(f, c, &n, 8) &&
+              put(f, c, &nb, 8) && put(f, c, l.data(), 4 * l.size()) && put(f, c, h.data(), 8 * h.size()) && put(f, c, blob.data(), blob.size());
+    ok = ok && fwrite(&c.h, 8, 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
     return ok ? GHIP_OK : ghip_set_error(ctx, GHIP_EIO, std::string("short write to ") + path);
 }
 
-extern "C" int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches **out) {
+extern "C" int ghip_sketches_save(ghip_ctx *ctx, const ghip_sketches *sk, const char *path) {
+    return ghip_sketches_save_named(ctx, sk, nullptr, 0, path);
+}
+
+extern "C" int ghip_sketches_load_named(ghip_ctx *ctx, const char *path, ghip_sketches **out, char **out_names, size_t *out_names_bytes, uint64_t *out_seed) {
     if (!ctx || !path || !out) return GHIP_EINVAL;
+    if (out_names) *out_names = nullptr;
+    if (out_names_bytes) *out_names_bytes = 0;
+    if (out_seed) *out_seed = 0;
     FILE *f = fopen(path, "rb");
     if (!f) return ghip_set_error(ctx, GHIP_EIO, std::string("cannot read ") + path);
     char magic[8];
     uint32_t k = 0, s = 0;
-    uint64_t n = 0;
-    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GHIPSK01", 8) && fread(&k, 4, 1, f) == 1 &&
-              fread(&s, 4, 1, f) == 1 && fread(&n, 8, 1, f) == 1 && s >= 1 && s <= 4096 && n < (1ull << 32);
+    uint64_t n = 0, seed = 0, nb = 0;
+    Fnv c;
+    bool ok = get(f, c, magic, 8);
+    const bool v2 = ok && !memcmp(magic, "GHIPSK02", 8);
+    ok = ok && (v2 || !memcmp(magic, "GHIPSK01", 8)) && get(f, c, &k, 4) && get(f, c, &s, 4);
+    if (ok && v2) ok = get(f, c, &seed, 8);
+    ok = ok && get(f, c, &n, 8);
+    if (ok && v2) ok = get(f, c, &nb, 8);
+    ok = ok && s >= 1 && s <= GHIP_MAX_SKETCH_SIZE && n < (1ull << 32) && nb < (1ull << 40);
     std::vector<uint32_t> l;
     std::vector<uint64_t> h;
+    std::string blob;
     if (ok) {
-        l.resize(n); h.resize(n * (size_t)s);
-        ok = fread(l.data(), 4, l.size(), f) == l.size() && fread(h.data(), 8, h.size(), f) == h.size();
+        l.resize(n); h.resize(n * (size_t)s); blob.resize(nb);
+        ok = get(f, c, l.data(), 4 * l.size()) && get(f, c, h.data(), 8 * h.size()) && get(f, c, &blob[0], nb);
+    }
+    std::string why = "not a sketch matrix file: ";
+    if (ok && v2) {
+        uint64_t sum = 0;
+        ok = fread(&sum, 8, 1, f) == 1 && sum == c.h;
+        if (!ok) why = "sketch matrix file is damaged (checksum): ";
+        else if ((size_t)std::count(blob.begin(), blob.end(), '\0') != n) { ok = false; why = "sketch matrix file: name table does not match the row count: "; }
     }
     fclose(f);
-    if (!ok) return ghip_set_error(ctx, GHIP_EIO, std::string("not a sketch matrix file: ") + path);
-    return ghip_sketches_from_host(ctx, h.data(), l.data(), n, s, k, out);  // validates order and lengths
+    if (!ok) return ghip_set_error(ctx, GHIP_EIO, why + path);
+    const int rc = ghip_sketches_from_host(ctx, h.data(), l.data(), n, s, k, out);  // validates order and lengths
+    if (rc) return rc;
+    if (out_names) {
+        if (!v2) blob.assign(n, '\0');   // a GHIPSK01 file holds no names
+        char *p = (char *)malloc(std::max<size_t>(blob.size(), 1));
+        if (!p) { ghip_sketches_free(*out); *out = nullptr; return GHIP_ENOMEM; }
+        memcpy(p, blob.data(), blob.size());
+        *out_names = p;
+        if (out_names_bytes) *out_names_bytes = blob.size();
+    }
+    if (out_seed) *out_seed = seed;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches **out) {
+    return ghip_sketches_load_named(ctx, path, out, nullptr, nullptr, nullptr);
+}
+
+// rows of a followed by the rows of b (same k and s): the matrix of an incremental run = the saved one + the new genomes'
+extern "C" int ghip_sketches_concat(ghip_ctx *ctx, const ghip_sketches *a, const ghip_sketches *b, ghip_sketches **out) {
+    if (!ctx || !a || !b || !out) return GHIP_EINVAL;
+    if (a->s != b->s || a->k != b->k) return ghip_set_error(ctx, GHIP_EINVAL, "sketch matrices differ in sketch size or k-mer length");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ghip_sketches *sk = new ghip_sketches();
+    ctx->live_handles++;
+    sk->ctx = ctx; sk->n = a->n + b->n; sk->s = a->s; sk->k = a->k;
+    int rc = dmalloc(ctx, &sk->d_hashes, sk->n * (size_t)sk->s);
+    if (!rc) rc = dmalloc(ctx, &sk->d_lens, sk->n);
+    const ghip_sketches *parts[2] = {a, b};
+    size_t at = 0;
+    for (int x = 0; x < 2 && !rc; x++) {
+        const ghip_sketches *p = parts[x];
+        if (p->n && (hipMemcpyAsync(sk->d_hashes + at * sk->s, p->d_hashes, p->n * (size_t)sk->s * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                     hipMemcpyAsync(sk->d_lens + at, p->d_lens, p->n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
+            rc = ghip_set_error(ctx, GHIP_EHIP, "sketch concatenation failed");
+        at += p->n;
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "sketch concatenation failed");
+    if (rc) { free_sketches_locked(sk); return rc; }
+    *out = sk;
+    return GHIP_OK;
 }
 
 // finch::sketch_files replacement.  Exactness: a genome is accepted only when its candidate
@@ -1065,7 +1142,7 @@ extern "C" int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches
 static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s, uint64_t seed,
                                  const ghip_seed_args *seeds, ghip_sketches **out) {
     if (k < 1 || k > 32) return ghip_set_error(ctx, GHIP_EINVAL, "kmer_length must be in 1..=32");
-    if (s < 1 || s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "num_kmers must be in 1..=4096");
+    if (s < 1 || s > GHIP_MAX_SKETCH_SIZE) return ghip_set_error(ctx, GHIP_EINVAL, "num_kmers must be in 1..=65535");
     if (seed > 0xffffffffull) return ghip_set_error(ctx, GHIP_EINVAL, "hash_seed must fit 32 bits (murmurhash3 seed)");
     const size_t n = g->n;
     ghip_sketches *sk = new ghip_sketches();
@@ -1199,12 +1276,14 @@ static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
 
 // replicate_join: a multi-rank caller that prefers the whole list on every rank whenever the join form runs (its
 // cost, one pass over all N*s hashes, does not shard) to a share it then has to exchange.
+// row_lo > 0: the (new x all) rectangle of an incremental run -- only the pairs (i, j), i < j, with j >= row_lo.
 static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_ani, uint32_t rank, uint32_t world,
-                           bool replicate_join, ghip_pair **out_pairs, size_t *out_n, int *out_replicated) {
+                           bool replicate_join, size_t row_lo, ghip_pair **out_pairs, size_t *out_n, int *out_replicated) {
     ghip_sketches *sk = const_cast<ghip_sketches *>(sk_in);  // lazily caches the probe-form tables
     if (out_replicated) *out_replicated = 0;
     if (!ctx || !sk || !out_pairs || !out_n || world == 0 || rank >= world) return GHIP_EINVAL;
-    if (sk->s > 4096) return ghip_set_error(ctx, GHIP_EINVAL, "sketch size above 4096 is not supported");
+    if (sk->s > GHIP_MAX_SKETCH_SIZE) return ghip_set_error(ctx, GHIP_EINVAL, "sketch size above 65535 is not supported");
+    if (row_lo > sk->n || (row_lo && world > 1)) return ghip_set_error(ctx, GHIP_EINVAL, "row_lo must not exceed the sketch count (single rank only)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     *out_pairs = nullptr; *out_n = 0;
@@ -1225,9 +1304,13 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         const uint32_t max_total = 2 * s;
         std::vector<uint16_t> cmin(max_total + 2, 0xffff);
         for (uint32_t total = 0; total <= max_total; total++) {
-            uint32_t cmax = std::min(total, s);
-            for (uint32_t c = 0; c <= cmax; c++)
-                if (finch_ani(c, total, k) >= thr) { cmin[total] = (uint16_t)c; break; }
+            // finch_ani is non-decreasing in common for a fixed total: the smallest passing common by bisection (s = 10 000
+            // would cost 2e8 logarithms the linear way); total = 0 is the NaN corner (ANI 1.0 whatever common is)
+            const uint32_t cmax = std::min(total, s);
+            if (!(finch_ani(cmax, total, k) >= thr)) continue;   // nothing passes: 0xffff
+            uint32_t lo = 0, hi = cmax;                            // invariant: hi passes
+            while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (finch_ani(mid, total, k) >= thr) hi = mid; else lo = mid + 1; }
+            cmin[total] = (uint16_t)hi;
         }
         if (ctx->cmin.d_cmin) ghip_pool_free(ctx, ctx->cmin.d_cmin);
         ctx->cmin.valid = false;
@@ -1244,7 +1327,8 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     //   merge (pairs.hip)        dense, 64-way merge path; s > 1024, or a sketch holds 2^64-1 / a cuckoo insertion failed
     // GHIP_PAIR_KERNEL=join|probe|merge forces a form (join still declines what it cannot do).
     const char *force = getenv("GHIP_PAIR_KERNEL");
-    const bool want_join = force ? !strcmp(force, "join") : n >= GHIP_JOIN_MIN_N;
+    // (sketches too long for LDS tiles, s > 4096, go to the join whatever n is: the dense form left for them reads global memory)
+    const bool want_join = force ? !strcmp(force, "join") : (n >= GHIP_JOIN_MIN_N || s > 4096);
     bool use_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
     bool probe_checked = false;
 
@@ -1265,7 +1349,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         bool joined = false, late = false;
         if (want_join && !filter_share &&
             (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
-                                  replicate_join ? 0 : rank, replicate_join ? 1 : world,
+                                  replicate_join ? 0 : rank, replicate_join ? 1 : world, (uint32_t)row_lo,
                                   d_out, d_count, cap, &compared, &joined, &late))) return rc;
         if (joined && replicate_join) {  // every rank holds every pair; book an equal share of the comparisons
             compared = P / world + (rank < P % world ? 1 : 0);
@@ -1284,11 +1368,14 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if (joined) {
         } else if (use_probe) {
             ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, n, s, sk->probe_cb, sk->d_row_start,
-                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, d_out, d_count, cap);
+                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap);
             compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, drank, dworld);
+        } else if (s <= 4096) {
+            ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, &compared);
         } else {
-            ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, drank, dworld, d_out, d_count, cap, &compared);
+            ghip_launch_pairs_global(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, &compared);
         }
+        if (row_lo) compared = P - (uint64_t)row_lo * (row_lo - 1) / 2;   // the rectangle
         ctx->last_pairs = compared;
         unsigned long long cnt = 0;
         if ((rc = d2h(ctx, &cnt, d_count, 1))) return rc;
@@ -1329,7 +1416,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
 
 extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
                                      uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
-    return precluster_impl(ctx, sk, min_ani, rank, world, false, out_pairs, out_n, nullptr);
+    return precluster_impl(ctx, sk, min_ani, rank, world, false, 0, out_pairs, out_n, nullptr);
 }
 
 extern "C" int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,
@@ -1340,11 +1427,15 @@ extern "C" int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, flo
     // rank run the whole join and keep the whole list instead (no candidate exchange; DESIGN.md section 6 has both timings).
     const char *mode = getenv("GHIP_JOIN_RANKS");
     const bool replicate = world > 1 && mode && !strcmp(mode, "replicate");
-    return precluster_impl(ctx, sk, min_ani, rank, world, replicate, out_pairs, out_n, out_replicated);
+    return precluster_impl(ctx, sk, min_ani, rank, world, replicate, 0, out_pairs, out_n, out_replicated);
 }
 
 extern "C" int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, ghip_pair **out_pairs, size_t *out_n) {
-    return precluster_impl(ctx, sk, min_ani, 0, 1, false, out_pairs, out_n, nullptr);
+    return precluster_impl(ctx, sk, min_ani, 0, 1, false, 0, out_pairs, out_n, nullptr);
+}
+
+extern "C" int ghip_precluster_from(ghip_ctx *ctx, const ghip_sketches *sk, size_t row_lo, float min_ani, ghip_pair **out_pairs, size_t *out_n) {
+    return precluster_impl(ctx, sk, min_ani, 0, 1, false, row_lo, out_pairs, out_n, nullptr);
 }
 
 // ------------------------------------------------------------------------------------ ANI

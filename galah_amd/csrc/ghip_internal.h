@@ -230,15 +230,19 @@ void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, siz
 void ghip_pair_geometry(uint32_t s, uint32_t *s_pad, uint32_t *sp, uint32_t *pt);
 
 void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n,
-                       uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world,
+                       uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo,
                        ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
                        uint64_t *pairs_compared);
 
+void ghip_launch_pairs_global(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
+                              unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared);
+constexpr uint32_t GHIP_MAX_SKETCH_SIZE = 65535;   // common / total travel as u16 in the device filter table (the reference: no bound, src/finch.rs:55-61; its CLI hard-wires 1000)
 constexpr size_t GHIP_JOIN_MIN_N = 1200;  // the inverted-index form of the pair stage takes over from here (s = 1000: a tie with the
                                           // dense probe kernel at 1 000 genomes, 0.93 vs 1.40 ms at 1 500)
 uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin);
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                     unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline);
 
 size_t ghip_probe_table_slots(uint32_t s);
@@ -248,7 +252,7 @@ uint64_t ghip_probe_work_rows(size_t n, int num_cus, uint32_t *cb_out, std::vect
 uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t cb, const std::vector<uint64_t> &row_start, uint32_t rank, uint32_t world);
 void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
                              size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
-                             const uint16_t *d_cmin, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                             const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                              unsigned long long *d_count, uint64_t cap);
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, const uint32_t *d_seed_thr, uint32_t chunk,

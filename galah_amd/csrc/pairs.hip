@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t upper_bound_lds(const uint64_t *X, uint32_t 
 __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
     const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, uint32_t n, uint32_t s,
     uint32_t s_pad, uint32_t sp /* LDS elements per sketch */, uint32_t pt /* tile edge */,
-    uint32_t nt /* tiles per dim */, uint64_t n_tilepairs, uint32_t rank, uint32_t world,
+    uint32_t nt /* tiles per dim */, uint64_t n_tilepairs, uint32_t rank, uint32_t world, uint32_t row_lo,
     const uint16_t *__restrict__ cmin, ghip_pair *__restrict__ out,
     unsigned long long *__restrict__ out_count, uint64_t cap, int dbg_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
         while (ti + 1 < nt && row_off(ti + 1) <= t) ti++;
     }
     const uint32_t tj = ti + (uint32_t)(t - ((uint64_t)ti * nt - (uint64_t)ti * (ti - 1) / 2));
+    if ((uint64_t)(tj + 1) * pt <= row_lo) continue;   // incremental run: both tiles hold old genomes only
 
     // ---- stage 2*pt sketches into LDS (coalesced 8-B loads; pad rows with 2^64-1) ----
     for (uint32_t q = 0; q < 2 * pt; q++) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
                 else              { icnt = upper_bound_lds(A[c], na[c], maxb); jcnt = nb[c]; }
             }
             const uint32_t total = icnt + jcnt - cm;
-            if (lane == 0 && cm >= (uint32_t)cmin[total]) {
+            if (lane == 0 && cm >= (uint32_t)cmin[total] && gj[c] >= row_lo) {   // (row_lo: the rectangle of an incremental run)
                 unsigned long long idx = atomicAdd(out_count, 1ull);
                 if (idx < cap) {
                     ghip_pair r;
@@ -172,6 +173,65 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_intersect_tile_kernel(
         }
     }
     }  // grid-stride loop
+}
+
+
+// Sketches too long for two LDS tiles (s > 4096; the reference puts no bound on num_kmers, src/finch.rs:55-61): one
+// wavefront per pair straight from the packed matrix in global memory.  common = #{a in A : a in B} by binary search (a
+// lane takes every 64th element of A), the ranks by the closed form of the reference's merge loop.  Slow (~na log nb
+// dependent loads per pair) and rare: the inverted-index form takes such inputs first and only hands over what it declines.
+__device__ __forceinline__ uint32_t upper_bound_global(const uint64_t *__restrict__ row, uint32_t len, uint64_t x) {
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (row[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void pair_intersect_global_kernel(
+    const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, uint32_t n, uint32_t s, uint64_t n_pairs,
+    uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin, ghip_pair *__restrict__ out,
+    unsigned long long *__restrict__ out_count, uint64_t cap) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);; w += (uint64_t)gridDim.x * 4) {
+        const uint64_t p = w * world + rank;
+        if (p >= n_pairs) return;
+        // p -> (i, j), i < j, rows of the strict upper triangle: row i holds n - 1 - i pairs
+        uint32_t gi;
+        {
+            const double b = 2.0 * n - 1.0;
+            double r = (b - sqrt(b * b - 8.0 * (double)p)) * 0.5;
+            gi = (uint32_t)r;
+            if (gi >= n - 1) gi = n - 2;
+            auto row_off = [&](uint64_t x) { return x * (n - 1) - x * (x - 1) / 2; };
+            while (gi > 0 && row_off(gi) > p) gi--;
+            while (gi + 2 < n && row_off(gi + 1) <= p) gi++;
+        }
+        const uint32_t gj = gi + 1 + (uint32_t)(p - ((uint64_t)gi * (n - 1) - (uint64_t)gi * (gi - 1) / 2));
+        if (gj < row_lo) continue;
+        const uint32_t na = lens[gi], nb = lens[gj];
+        const uint64_t *A = hashes + (uint64_t)gi * s, *B = hashes + (uint64_t)gj * s;
+        uint32_t cm = 0;
+        for (uint32_t e = lane; e < na; e += 64) {
+            const uint64_t a = A[e];
+            const uint32_t ub = upper_bound_global(B, nb, a);
+            cm += (ub > 0 && B[ub - 1] == a) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cm += __shfl_xor(cm, off, 64);
+        uint32_t icnt = 0, jcnt = 0;
+        if (na > 0 && nb > 0) {
+            const uint64_t maxa = A[na - 1], maxb = B[nb - 1];
+            if (maxa <= maxb) { icnt = na; jcnt = upper_bound_global(B, nb, maxa); }
+            else              { icnt = upper_bound_global(A, na, maxb); jcnt = nb; }
+        }
+        const uint32_t total = icnt + jcnt - cm;
+        if (lane == 0 && cm >= (uint32_t)cmin[total]) {
+            unsigned long long idx = atomicAdd(out_count, 1ull);
+            if (idx < cap) {
+                ghip_pair r;
+                r.i = gi; r.j = gj; r.common = cm; r.total = total; r.ani = 0.0f;
+                out[idx] = r;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -187,7 +247,7 @@ void ghip_pair_geometry(uint32_t s, uint32_t *s_pad, uint32_t *sp, uint32_t *pt)
 }
 
 void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n,
-                       uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world,
+                       uint32_t s, const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo,
                        ghip_pair *d_out, unsigned long long *d_count, uint64_t cap,
                        uint64_t *pairs_compared) {
     uint32_t s_pad, sp, pt;
@@ -227,6 +287,20 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
     const unsigned grid = (unsigned)std::min<uint64_t>(my_tiles, 1u << 21);  // x 1024 threads < 2^32 work-items
     hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3(grid), dim3(PAIR_THREADS), lds_bytes,
                        ctx->stream, d_hashes, d_lens, (uint32_t)n, s, s_pad, sp, pt, nt, n_tilepairs, rank,
-                       world, d_cmin, d_out, d_count, cap, getenv("GHIP_PAIR_DEBUG") ? atoi(getenv("GHIP_PAIR_DEBUG")) : 0);
+                       world, row_lo, d_cmin, d_out, d_count, cap, getenv("GHIP_PAIR_DEBUG") ? atoi(getenv("GHIP_PAIR_DEBUG")) : 0);
+    ghip_prof_end(ctx);
+}
+
+// s > 4096: the global-memory form (pair_intersect_global_kernel); *pairs_compared = the pairs of this rank's share
+void ghip_launch_pairs_global(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
+                              unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared) {
+    const uint64_t P = (uint64_t)n * (n - 1) / 2;
+    const uint64_t mine = P > rank ? (P - rank + world - 1) / world : 0;
+    if (pairs_compared) *pairs_compared = mine;
+    if (mine == 0) return;
+    ghip_prof_begin(ctx, "pair_intersect_tile");
+    hipLaunchKernelGGL(pair_intersect_global_kernel, dim3((unsigned)std::min<uint64_t>((mine + 3) / 4, GHIP_MAX_GRID)), dim3(256), 0, ctx->stream,
+                       d_hashes, d_lens, (uint32_t)n, s, P, rank, world, row_lo, d_cmin, d_out, d_count, cap);
     ghip_prof_end(ctx);
 }

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
                                                                     const uint32_t *__restrict__ start2,
                                                                     uint32_t *__restrict__ rec_count, const uint32_t *__restrict__ rec_start,
                                                                     uint64_t *__restrict__ rec, uint32_t *__restrict__ flags,
-                                                                    unsigned long long *__restrict__ rec_total, uint32_t rank, uint32_t world) {
+                                                                    unsigned long long *__restrict__ rec_total, uint32_t rank, uint32_t world, uint32_t row_lo) {
     __shared__ uint64_t lk[J_WAVES][J_ELEM_CAP];
     __shared__ uint32_t lv[J_WAVES][J_ELEM_CAP];
     __shared__ uint32_t lcnt[J_WAVES];
@@ -339,6 +339,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
             if (gb == ga) continue;  // a sketch row is distinct; guards caller-supplied matrices
             found_all++;
             if (world > 1 && (ga + gb) % world != rank) continue;
+            if (max(ga, gb) < row_lo) continue;   // incremental run: a pair of two old genomes is not asked for
             if (EMIT) rec[out0 + atomicAdd(&lcnt[wave], 1u)] = ((uint64_t)min(ga, gb) << 32) | max(ga, gb);
             else found++;
         }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
 __global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *__restrict__ rec, const uint32_t *__restrict__ start2,
                                                                 const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
                                                                 uint32_t s, const uint16_t *__restrict__ cmin, uint32_t cmin_floor,
-                                                                uint32_t rank, uint32_t world, ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count,
+                                                                uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count,
                                                                 uint64_t cap, uint32_t *__restrict__ flags) {
     __shared__ unsigned long long tk[J_WAVES][J_TAB];
     __shared__ uint32_t tc[J_WAVES][J_TAB];
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *
         // Multi-GPU: every rank runs the whole (cheap) join, so all ranks take the same accept/decline decisions, and
         // reports the pairs with (i + j) mod world == rank.
         if (world > 1 && (gi + gj) % world != rank) continue;
+        if (gj < row_lo) continue;
         const uint32_t na = lens[gi], nb = lens[gj];  // both > 0: they share a hash
         const uint64_t *ra = hashes + (uint64_t)gi * s, *rb = hashes + (uint64_t)gj * s;
         const uint64_t maxa = ra[na - 1], maxb = rb[nb - 1];
@@ -489,7 +491,7 @@ uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin) {
 
 // *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                     unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline) {
     *used = false;
     if (late_decline) *late_decline = false;
@@ -521,7 +523,7 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
     if (!d_rcount || !d_rstart) { ghip_prof_end(ctx); return GHIP_EHIP; }
     hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total, rank, world);
+                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total, rank, world, row_lo);
     if ((rc = scan_counters(ctx, own.p, d_rcount, enb, d_rstart, nullptr))) { ghip_prof_end(ctx); return rc; }
     uint32_t flags[2];
     unsigned long long totals[2] = {0, 0};   // records of all ranks (what every rank decides on), records of this rank
@@ -536,7 +538,7 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) { ghip_prof_end(ctx); return GHIP_EHIP; }
     hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total, rank, world);
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total, rank, world, row_lo);
     // 3. records -> 65536 pair buckets -> common per pair -> candidates
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
@@ -544,7 +546,7 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr);
     if (rc) { ghip_prof_end(ctx); return rc; }
     hipLaunchKernelGGL(join_reduce_kernel, dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, d_pstart, d_hashes, d_lens, s,
-                       d_cmin, cmin_floor, rank, world, d_out, d_count, cap, d_flags);
+                       d_cmin, cmin_floor, rank, world, row_lo, d_out, d_count, cap, d_flags);
     ghip_prof_end(ctx);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

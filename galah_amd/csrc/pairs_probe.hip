@@ -81,7 +81,7 @@ template <int NT>
 __global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
     const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint64_t *__restrict__ tables,
     uint32_t n, uint32_t s, uint32_t buckets, uint32_t cb, const uint64_t *__restrict__ row_start, uint32_t nta,
-    uint64_t n_work, uint32_t rank, uint32_t world, const uint16_t *__restrict__ cmin,
+    uint64_t n_work, uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin,
     ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *sets = reinterpret_cast<uint4 *>(smem_raw);                                  // [TA][buckets]
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
         }
         const uint32_t ti = lo;
         const uint32_t j0 = ti * PROBE_TA + (uint32_t)(w - row_start[ti]) * cb;
+        if ((uint64_t)j0 + cb <= row_lo) continue;   // the (new x all) rectangle of an incremental run: every B-sketch of this item is an old genome
         __syncthreads();  // previous work item's LDS image is no longer read
         // ---- stage the 8 cuckoo sets (linear 16-byte copies), rank samples and lengths ----
         for (uint32_t q = 0; q < PROBE_TA; q++) {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
 
         for (uint32_t jj = wave; jj < cb; jj += PROBE_WAVES) {
             const uint32_t gj = j0 + jj;
-            if (gj >= n || gj <= ti * PROBE_TA) continue;  // no A of this tile has a smaller index
+            if (gj >= n || gj <= ti * PROBE_TA || gj < row_lo) continue;  // no A of this tile has a smaller index / an old genome
             const uint32_t nb = lens[gj];
             const uint64_t *brow = hashes + (uint64_t)gj * s;
             uint64_t b[NT];
@@ -232,7 +233,7 @@ uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t PROBE_CB, const std::vector
 
 void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
                              size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
-                             const uint16_t *d_cmin, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                             const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                              unsigned long long *d_count, uint64_t cap) {
     const uint64_t mine = n_work > rank ? (n_work - rank + world - 1) / world : 0;
     if (mine == 0) return;
@@ -244,9 +245,9 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     ghip_prof_begin(ctx, "pair_intersect_tile");
     if (s <= 256)
         hipLaunchKernelGGL(pair_probe_tile_kernel<4>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
-                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, d_cmin, d_out, d_count, cap);
+                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
     else
         hipLaunchKernelGGL(pair_probe_tile_kernel<16>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
-                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, d_cmin, d_out, d_count, cap);
+                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
     ghip_prof_end(ctx);
 }

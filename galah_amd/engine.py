@@ -96,8 +96,14 @@ class Sketches(_Handle):
     def device_lens(self) -> int:
         return int(_lib.lib().ghip_sketches_device_lens(self._h) or 0)
 
-    def save(self, path: str):
-        check(_lib.lib().ghip_sketches_save(self.ctx._h, self._h, path.encode()), self.ctx._h)
+    def save(self, path: str, names: Optional[Sequence[str]] = None, seed: int = 0):
+        """Persist the matrix ("GHIPSK02": k, s, hash seed, row lengths, hashes, genome names, checksum)."""
+        if names is None:
+            check(_lib.lib().ghip_sketches_save(self.ctx._h, self._h, path.encode()), self.ctx._h)
+            return
+        assert len(names) == len(self), "one name per sketch row"
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        check(_lib.lib().ghip_sketches_save_named(self.ctx._h, self._h, arr, seed, path.encode()), self.ctx._h)
 
     def to_host(self) -> Tuple[np.ndarray, np.ndarray]:
         n, s = len(self), self.size
@@ -230,6 +236,29 @@ class Context:
         h = C.c_void_p()
         check(_lib.lib().ghip_sketches_load(self._h, path.encode(), C.byref(h)), self._h)
         return Sketches(self, h)
+
+    def sketches_load_named(self, path: str) -> Tuple[Sketches, List[str], int]:
+        """-> (matrix, genome names in row order, hash seed) of a persisted matrix; a damaged file raises."""
+        h, names, nb, seed = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_uint64(0)
+        check(_lib.lib().ghip_sketches_load_named(self._h, path.encode(), C.byref(h), C.byref(names), C.byref(nb), C.byref(seed)), self._h)
+        try:
+            blob = C.string_at(names, nb.value) if names.value else b""
+        finally:
+            _lib.lib().ghip_free(names)
+        sk = Sketches(self, h)
+        parts = blob.split(b"\0")[: len(sk)]
+        return sk, [p.decode() for p in parts], int(seed.value)
+
+    def sketches_concat(self, a: Sketches, b: Sketches) -> Sketches:
+        h = C.c_void_p()
+        check(_lib.lib().ghip_sketches_concat(self._h, a._h, b._h, C.byref(h)), self._h)
+        return Sketches(self, h)
+
+    def precluster_from(self, sk: Sketches, row_lo: int, min_ani: float) -> np.ndarray:
+        """The (new x all) rectangle of an incremental run: pairs (i, j), i < j, with j >= row_lo (ghip_precluster_from)."""
+        p, n = C.c_void_p(), C.c_size_t(0)
+        check(_lib.lib().ghip_precluster_from(self._h, sk._h, row_lo, np.float32(min_ani), C.byref(p), C.byref(n)), self._h)
+        return self._take_pairs(p, n)
 
     def sketches_wrap_device(self, d_hashes: int, d_lens: int, n: int, s: int, k: int = 21) -> Sketches:
         h = C.c_void_p()

@@ -36,6 +36,59 @@ class FinchPreclusterer:
         return distances(genome_fasta_paths, self.min_ani, self.num_kmers, self.kmer_length,
                          ctx=self._context(), io_threads=self.io_threads, _keep=self)
 
+    # ---- persisted sketch matrix (no counterpart in the reference's finch back-end -- skani's sketched
+    # reference set, src/skani.rs:502-565, and docs/preludes/cluster_prelude.md:13-15 are the workflow it serves)
+    def distances_and_save(self, genome_fasta_paths: Sequence[str], matrix_path: str) -> SortedPairGenomeDistanceCache:
+        """distances(), and the sketch matrix with the genome names persisted for later incremental runs."""
+        if self.low_memory:
+            raise RuntimeError("Low-memory clustering currently only supported with skani preclusterer")
+        ctx = self._context()
+        try:
+            sk = ctx.sketch_files(list(genome_fasta_paths), self.kmer_length, self.num_kmers, 0, self.io_threads)
+        except Exception as e:  # finch.rs:72
+            raise RuntimeError(f"Failed to sketch genomes with finch: {e}") from e
+        sk.save(matrix_path, list(genome_fasta_paths), 0)
+        pairs = ctx.precluster(sk, np.float32(self.min_ani))
+        sk.free()
+        self.last_pairs = pairs
+        cache = SortedPairGenomeDistanceCache.from_pairs(pairs)
+        cache._pairs = pairs
+        return cache
+
+    def distances_incremental(self, matrix_path: str, new_genome_fasta_paths: Sequence[str], saved_pairs: Optional[np.ndarray] = None,
+                              save_to: Optional[str] = None):
+        """Incremental dereplication: the genome list is [the saved matrix's genomes ..., the new files ...]; only the NEW files
+        are read and sketched, and the pair stage runs on the (new x all) rectangle.  Returns (genome names, cache): with
+        `saved_pairs` (the earlier run's edge list, last_pairs) the cache is the one distances() over all the files would
+        produce; without, it holds the pairs that touch a new genome.  save_to: persist the grown matrix."""
+        if self.low_memory:
+            raise RuntimeError("Low-memory clustering currently only supported with skani preclusterer")
+        ctx = self._context()
+        saved, names, seed = ctx.sketches_load_named(matrix_path)
+        if (saved.kmer, saved.size, seed) != (self.kmer_length, self.num_kmers, 0):
+            raise RuntimeError(f"sketch matrix {matrix_path} was made with k={saved.kmer} s={saved.size} seed={seed}, "
+                               f"not k={self.kmer_length} s={self.num_kmers} seed=0")
+        try:
+            fresh = ctx.sketch_files(list(new_genome_fasta_paths), self.kmer_length, self.num_kmers, 0, self.io_threads)
+        except Exception as e:  # finch.rs:72
+            raise RuntimeError(f"Failed to sketch genomes with finch: {e}") from e
+        n_old = len(saved)
+        both = ctx.sketches_concat(saved, fresh)
+        saved.free(); fresh.free()
+        all_names = names + list(new_genome_fasta_paths)
+        if save_to is not None:
+            both.save(save_to, all_names, 0)
+        pairs = ctx.precluster_from(both, n_old, np.float32(self.min_ani))
+        both.free()
+        if saved_pairs is not None and len(saved_pairs):
+            assert int(saved_pairs["j"].max()) < n_old, "saved_pairs refer to genomes beyond the saved matrix"
+            pairs = np.concatenate([np.ascontiguousarray(saved_pairs, dtype=pairs.dtype), pairs])
+            pairs = pairs[np.lexsort((pairs["j"], pairs["i"]))]
+        self.last_pairs = pairs
+        cache = SortedPairGenomeDistanceCache.from_pairs(pairs)
+        cache._pairs = pairs
+        return all_names, cache
+
     def distances_contigs(self, _genome_fasta_paths, _contig_names) -> SortedPairGenomeDistanceCache:
         return SortedPairGenomeDistanceCache()  # finch.rs:26-33
 

@@ -111,7 +111,8 @@ void ghip_genomes_free(ghip_genomes *g);
 /* ---------------------------------------------------------------- MinHash sketching
  * Replaces finch::sketch_files (src/finch.rs:55-69): the s smallest distinct
  * murmurhash3_x64_128(canonical k-mer ASCII, seed).0, ascending; fewer than s allowed
- * (no_strict).  Layout: u64 hashes[n][s] row-major, rows padded with UINT64_MAX; u32 len[n]. */
+ * (no_strict).  Layout: u64 hashes[n][s] row-major, rows padded with UINT64_MAX; u32 len[n].
+ * k in 1..=32, s in 1..=65535 (the reference puts no bound on num_kmers, src/finch.rs:55-61; its CLI hard-wires 1000). */
 int ghip_sketch_genomes(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, uint32_t s,
                         uint64_t seed, ghip_sketches **out);
 int ghip_sketch_files(ghip_ctx *ctx, const char *const *paths, size_t n, uint32_t k, uint32_t s,
@@ -124,9 +125,18 @@ int ghip_sketches_wrap_device(ghip_ctx *ctx, void *d_hashes, void *d_lens, size_
 int ghip_sketches_to_host(ghip_ctx *ctx, const ghip_sketches *sk, uint64_t *hashes, uint32_t *lens);
 /* Device-to-device copy into caller-owned HBM (e.g. this rank's slice of an all-gather buffer). */
 int ghip_sketches_copy_into(ghip_ctx *ctx, const ghip_sketches *sk, void *d_hashes_dst, void *d_lens_dst);
-/* Persisted sketch matrix (incremental dereplication without re-sketching). */
+/* Persisted sketch matrix: incremental dereplication without re-sketching (the reference's closest relatives are
+ * skani's db directories, src/skani.rs:266-304 and :502-565, and the workflow of docs/preludes/cluster_prelude.md:13-15).
+ * File "GHIPSK02": k, s, hash seed, n, row lengths, hashes, genome NAMES (names[i] nullable = empty), FNV-1a checksum; a
+ * damaged file is refused with GHIP_EIO.  *out_names (nullable; free with ghip_free) = n NUL-terminated names back to
+ * back.  An incremental run = load, sketch the new files, ghip_sketches_concat, ghip_precluster_from(row_lo = saved n):
+ * the pairs that touch a new genome; with the saved run's own pairs that is the cache a full run would produce. */
 int ghip_sketches_save(ghip_ctx *ctx, const ghip_sketches *sk, const char *path);
+int ghip_sketches_save_named(ghip_ctx *ctx, const ghip_sketches *sk, const char *const *names, uint64_t seed, const char *path);
 int ghip_sketches_load(ghip_ctx *ctx, const char *path, ghip_sketches **out);
+int ghip_sketches_load_named(ghip_ctx *ctx, const char *path, ghip_sketches **out, char **out_names, size_t *out_names_bytes,
+                             uint64_t *out_seed);
+int ghip_sketches_concat(ghip_ctx *ctx, const ghip_sketches *a, const ghip_sketches *b, ghip_sketches **out);
 size_t ghip_sketches_count(const ghip_sketches *sk);
 uint32_t ghip_sketches_size(const ghip_sketches *sk);     /* s */
 uint32_t ghip_sketches_kmer(const ghip_sketches *sk);     /* k */
@@ -140,6 +150,10 @@ void ghip_sketches_free(ghip_sketches *sk);
  * The caller frees *out_pairs with ghip_free(). */
 int ghip_precluster(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani_fraction,
                     ghip_pair **out_pairs, size_t *out_n);
+/* The (new x all) rectangle of an incremental run: only the pairs (i, j), i < j, with j >= row_lo -- rows [0, row_lo) are the
+ * genomes of a saved matrix whose mutual pairs the caller already holds.  row_lo = 0 is ghip_precluster. */
+int ghip_precluster_from(ghip_ctx *ctx, const ghip_sketches *sk, size_t row_lo, float min_ani_fraction,
+                         ghip_pair **out_pairs, size_t *out_n);
 /* Multi-GPU share of the pair work: the dense forms deal the upper-triangle tiles block-cyclically (tile t -> rank
  * t % world); the inverted-index form (N >= 1200) keeps the pairs with (i + j) % world == rank -- its element stage runs
  * on every rank, its records are only materialised for the rank's own pairs.  Either way the shares of all ranks

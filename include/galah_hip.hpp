@@ -135,6 +135,74 @@ inline SortedPairGenomeDistanceCache distances(HipContext &hip, const std::vecto
     ghip_free(pairs);
     return cache;
 }
+// Incremental dereplication on a persisted sketch matrix (include/galah_hip.h "Persisted sketch matrix"; no counterpart
+// in the reference's finch back-end -- docs/preludes/cluster_prelude.md:13-15 is the workflow it serves).
+//   save: distances() whose sketch matrix and genome names are also written to `matrix_path`
+//   incremental: genome list = [the saved genomes ..., the new files ...]; only the NEW files are read and sketched, the
+//   pair stage runs on the (new x all) rectangle; with `saved_edges` (the earlier run's edge list) `edges` / the cache
+//   are what distances() over all the files would produce.  `names` receives the genome list.
+inline SortedPairGenomeDistanceCache distances_and_save(HipContext &hip, const std::vector<std::string> &genome_fasta_paths, float min_ani,
+                                                        size_t num_kmers, uint8_t kmer_length, const std::string &matrix_path, int threads = 1,
+                                                        std::vector<ghip_pair> *edges = nullptr) {
+    auto paths = detail::c_paths(genome_fasta_paths);
+    ghip_sketches *sk = nullptr;
+    if (ghip_sketch_files(hip.get(), paths.data(), paths.size(), kmer_length, (uint32_t)num_kmers, 0, threads, &sk) != GHIP_OK)
+        throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error());
+    ghip_pair *pairs = nullptr;
+    size_t n = 0;
+    int rc = ghip_sketches_save_named(hip.get(), sk, paths.data(), 0, matrix_path.c_str());
+    if (rc == GHIP_OK) rc = ghip_precluster(hip.get(), sk, min_ani, &pairs, &n);
+    ghip_sketches_free(sk);
+    if (rc != GHIP_OK) throw std::runtime_error("Failed to compare / save finch sketches: " + hip.last_error());
+    SortedPairGenomeDistanceCache cache;
+    for (size_t x = 0; x < n; x++) cache.insert({pairs[x].i, pairs[x].j}, pairs[x].ani);
+    if (edges) edges->assign(pairs, pairs + n);
+    ghip_free(pairs);
+    return cache;
+}
+
+inline SortedPairGenomeDistanceCache distances_incremental(HipContext &hip, const std::string &matrix_path,
+                                                           const std::vector<std::string> &new_genome_fasta_paths, float min_ani,
+                                                           size_t num_kmers, uint8_t kmer_length, const std::vector<ghip_pair> *saved_edges,
+                                                           std::vector<std::string> *names, int threads = 1,
+                                                           std::vector<ghip_pair> *edges = nullptr) {
+    ghip_sketches *saved = nullptr, *fresh = nullptr, *both = nullptr;
+    char *blob = nullptr;
+    size_t blob_bytes = 0;
+    uint64_t seed = 0;
+    if (ghip_sketches_load_named(hip.get(), matrix_path.c_str(), &saved, &blob, &blob_bytes, &seed) != GHIP_OK)
+        throw std::runtime_error("Failed to load the sketch matrix: " + hip.last_error());
+    const size_t n_old = ghip_sketches_count(saved);
+    std::vector<std::string> all;
+    for (size_t at = 0, g = 0; g < n_old && at < blob_bytes; g++) { all.emplace_back(blob + at); at += all.back().size() + 1; }
+    ghip_free(blob);
+    if (ghip_sketches_kmer(saved) != kmer_length || ghip_sketches_size(saved) != num_kmers || seed != 0) {
+        ghip_sketches_free(saved);
+        throw std::runtime_error("sketch matrix " + matrix_path + " was made with other sketch parameters");
+    }
+    auto paths = detail::c_paths(new_genome_fasta_paths);
+    int rc = ghip_sketch_files(hip.get(), paths.data(), paths.size(), kmer_length, (uint32_t)num_kmers, 0, threads, &fresh);
+    if (rc != GHIP_OK) { ghip_sketches_free(saved); throw std::runtime_error("Failed to sketch genomes with finch: " + hip.last_error()); }
+    rc = ghip_sketches_concat(hip.get(), saved, fresh, &both);
+    ghip_sketches_free(saved);
+    ghip_sketches_free(fresh);
+    ghip_pair *pairs = nullptr;
+    size_t n = 0;
+    if (rc == GHIP_OK) rc = ghip_precluster_from(hip.get(), both, n_old, min_ani, &pairs, &n);
+    ghip_sketches_free(both);
+    if (rc != GHIP_OK) throw std::runtime_error("Failed to compare finch sketches: " + hip.last_error());
+    std::vector<ghip_pair> merged;
+    if (saved_edges) merged = *saved_edges;
+    merged.insert(merged.end(), pairs, pairs + n);
+    ghip_free(pairs);
+    std::sort(merged.begin(), merged.end(), [](const ghip_pair &a, const ghip_pair &b) { return a.i != b.i ? a.i < b.i : a.j < b.j; });
+    SortedPairGenomeDistanceCache cache;
+    for (const ghip_pair &p : merged) cache.insert({p.i, p.j}, p.ani);
+    all.insert(all.end(), new_genome_fasta_paths.begin(), new_genome_fasta_paths.end());
+    if (names) *names = all;
+    if (edges) *edges = merged;
+    return cache;
+}
 }  // namespace finch
 
 class FinchPreclusterer : public PreclusterDistanceFinder {  // src/finch.rs:4-46

@@ -37,6 +37,26 @@ int main(int argc, char **argv) {
     auto fa = [&](const char *name) { return d + name + ".fna.gz"; };
     auto hip = std::make_shared<galah::HipContext>(0);
 
+    {   // a persisted sketch matrix + new files = the cache of a full run, only the new files sketched
+        const std::vector<std::string> old = {fa("abisko_S1X13"), fa("abisko_S2D19"), fa("set1_1mbp")}, fresh = {fa("abisko_S3X12"), fa("set1_500kb")};
+        std::vector<std::string> all = old;
+        all.insert(all.end(), fresh.begin(), fresh.end());
+        std::vector<ghip_pair> full_edges, old_edges, inc_edges;
+        std::vector<std::string> names;
+        const char *tmp = std::getenv("TMPDIR");
+        const std::string path = std::string(tmp ? tmp : "/tmp") + "/ghip_host_mirror_matrix.ghipsk";
+        auto full = galah::finch::distances(*hip, all, 0.9f, 1000, 21, 4, &full_edges);
+        galah::finch::distances_and_save(*hip, old, 0.9f, 1000, 21, path, 4, &old_edges);
+        auto inc = galah::finch::distances_incremental(*hip, path, fresh, 0.9f, 1000, 21, &old_edges, &names, 4, &inc_edges);
+        CHECK(names == all);
+        CHECK(inc_edges.size() == full_edges.size() && full_edges.size() >= 4);
+        bool same = inc_edges.size() == full_edges.size();
+        for (size_t x = 0; same && x < full_edges.size(); x++) same = std::memcmp(&inc_edges[x], &full_edges[x], sizeof(ghip_pair)) == 0;
+        CHECK(same);
+        CHECK(inc == full);
+        std::remove(path.c_str());
+    }
+
     {   // src/finch.rs:111-119 test_finch_hello_world
         galah::SortedPairGenomeDistanceCache expected;
         expected.insert({0, 1}, 0.9808188f);

@@ -302,21 +302,97 @@ def test_ingest_yields_reference_genome_stats(ctx):
         ctx.genomes_from_host([b"ACGT" * 10]).stats(0)   # only file-backed genomes carry statistics
 
 
-def test_sketch_matrix_save_load_round_trip(ctx, tmp_path):
-    rng = np.random.default_rng(12)
-    hashes, lens = random_sketches(rng, 23, 200, shared_groups=3, min_len=1)
-    sk = ctx.sketches_from_host(hashes, lens, 21)
-    path = str(tmp_path / "sketches.ghipsk")
-    sk.save(path)
-    sk2 = ctx.sketches_load(path)
-    h2, l2 = sk2.to_host()
-    h1, l1 = sk.to_host()
-    assert np.array_equal(h1, h2) and np.array_equal(l1, l2) and sk2.kmer == 21 and sk2.size == 200
-    assert ctx.precluster(sk2, np.float32(0.5)).tobytes() == ctx.precluster(sk, np.float32(0.5)).tobytes()
-    with open(path, "r+b") as f:
-        f.write(b"XXXX")
-    with pytest.raises(galah_amd.GalahHipError):
-        ctx.sketches_load(path)
+FIXTURE_GENOMES = ["set1_1mbp", "set1_500kb", "set2_1mbp", "set2_half", "abisko_S1X13", "abisko_S2D19", "abisko_S3X12", "abisko_S2D13",
+                   "antonio_MAG52", "antonio_MAG189", "clash_500kb", "abisko_S2D10", "abisko_S1D21", "abisko_S2M16"]
+
+
+def test_sketch_matrix_save_load_against_the_oracle(ctx, tmp_path):
+    """A persisted matrix ("GHIPSK02": names, seed, checksum) loads to the same rows and names, and the pair stage on the
+    LOADED matrix gives what the oracle computes from the files; a damaged file and a foreign file are refused; a
+    round-1/2 "GHIPSK01" file (no names) still loads."""
+    import struct
+    paths = [fasta(n) for n in FIXTURE_GENOMES]
+    sk = ctx.sketch_files(paths, 21, 1000, 0, 4)
+    p = str(tmp_path / "matrix.ghipsk")
+    sk.save(p, paths, 0)
+    back, names, seed = ctx.sketches_load_named(p)
+    assert names == paths and seed == 0 and (back.kmer, back.size, len(back)) == (21, 1000, len(paths))
+    h0, l0 = sk.to_host()
+    h1, l1 = back.to_host()
+    assert np.array_equal(h0, h1) and np.array_equal(l0, l1)
+    want = oracle.distances(paths, np.float32(0.9))
+    assert ctx.precluster(back, np.float32(0.9)).tobytes() == want.tobytes() and len(want) >= 20
+    back.free()
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    bad = str(tmp_path / "damaged.ghipsk")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(galah_amd.GalahHipError, match="damaged"):
+        ctx.sketches_load(bad)
+    open(bad, "wb").write(b">not a matrix\nACGT\n")
+    with pytest.raises(galah_amd.GalahHipError, match="not a sketch matrix"):
+        ctx.sketches_load(bad)
+    old = str(tmp_path / "v1.ghipsk")
+    with open(old, "wb") as f:   # the round-1/2 format: magic, k, s, n, lens, hashes
+        f.write(b"GHIPSK01" + struct.pack("<IIQ", 21, 1000, len(paths)) + l0.astype("<u4").tobytes() + h0.astype("<u8").tobytes())
+    v1, v1_names, _ = ctx.sketches_load_named(old)
+    assert v1_names == [""] * len(paths) and np.array_equal(v1.to_host()[0], h0)
+    v1.free(); sk.free()
+
+
+@pytest.mark.parametrize("form", [None, "merge", "join"])
+def test_incremental_dereplication_on_a_saved_matrix(ctx, tmp_path, monkeypatch, form):
+    """docs/preludes/cluster_prelude.md:13-15's workflow without re-sketching: a first run over 8 of the reference's fixture
+    genomes persists its sketch matrix; a second run names the matrix and 6 NEW files, reads and sketches only those, runs
+    the pair stage on the (new x all) rectangle and -- given the first run's pairs -- returns the cache a full run over all
+    14 files produces, checked against oracle.distances; in every form of the pair stage."""
+    if form:
+        monkeypatch.setenv("GHIP_PAIR_KERNEL", form)
+    paths = [fasta(n) for n in FIXTURE_GENOMES]
+    old, new = paths[:8], paths[8:]
+    full = oracle.distances(paths, np.float32(0.9))
+    pre = galah_amd.FinchPreclusterer(0.9, 1000, 21, ctx=ctx, io_threads=4)
+    m1, m2 = str(tmp_path / "first.ghipsk"), str(tmp_path / "grown.ghipsk")
+    first = pre.distances_and_save(old, m1)
+    first_pairs = pre.last_pairs
+    assert first_pairs.tobytes() == oracle.distances(old, np.float32(0.9)).tobytes() and len(first.items()) == len(first_pairs)
+    names, cache = pre.distances_incremental(m1, new, saved_pairs=first_pairs, save_to=m2)
+    assert names == paths and pre.last_pairs.tobytes() == full.tobytes()
+    assert repr(cache) == repr(galah_amd.SortedPairGenomeDistanceCache.from_pairs(full))
+    assert ctx.last_pairs_compared == 14 * 13 // 2 - 8 * 7 // 2   # the rectangle only
+    _, only_new = pre.distances_incremental(m1, new)                # without the first run's pairs: those touching a new genome
+    assert pre.last_pairs.tobytes() == full[full["j"] >= 8].tobytes()
+    # the grown matrix serves the next run: nothing new to sketch, an empty rectangle
+    names3, cache3 = pre.distances_incremental(m2, [], saved_pairs=full)
+    assert names3 == paths and pre.last_pairs.tobytes() == full.tobytes()
+    # a matrix made with other parameters is refused, not silently mixed
+    with pytest.raises(RuntimeError, match="was made with"):
+        galah_amd.FinchPreclusterer(0.9, 500, 21, ctx=ctx).distances_incremental(m1, new)
+
+
+def test_sketch_sizes_beyond_the_lds_tiles(ctx, monkeypatch):
+    """num_kmers has no bound in the reference (src/finch.rs:55-61): s = 10 000 -- candidate lists sorted in global memory,
+    the pair stage through the inverted index, and through the global-memory dense kernel where the join declines
+    (threshold 0, an empty sketch) or is switched off -- sketches and pair lists against the oracle."""
+    s = 10_000
+    seqs = [oracle.synth_genome(3, i // 3, i % 3, 400_000 + 1000 * i, 0.01) for i in range(6)] + [np.frombuffer(b"ACGTACGTAC", dtype=np.uint8)]
+    g = ctx.genomes_from_host(seqs)
+    sk = ctx.sketch_genomes(g, 21, s, 0)
+    hashes, lens = sk.to_host()
+    for i, q in enumerate(seqs):
+        o = oracle.sketch_bytes(q, 21, s, 0)
+        assert lens[i] == len(o) and np.array_equal(hashes[i, : lens[i]], o), i
+    assert lens[0] == s and lens[6] == 0
+    for thr, form in ((0.9, None), (0.0, None), (0.9, "merge"), (0.95, "merge")):
+        if form:
+            monkeypatch.setenv("GHIP_PAIR_KERNEL", form)
+        got = ctx.precluster(sk, np.float32(thr))
+        assert got.tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(thr)).tobytes(), (thr, form)
+        monkeypatch.delenv("GHIP_PAIR_KERNEL", raising=False)
+    assert len(ctx.precluster(sk, np.float32(0.9))) >= 6   # the members of a species pair up (and the empty sketch with everything: NaN quirk)
+    with pytest.raises(galah_amd.GalahHipError, match="65535"):
+        ctx.sketch_genomes(g, 21, 70_000, 0)
+    sk.free(); g.free()
 
 
 def test_fused_sketch_and_index_equals_separate_passes(ctx):
