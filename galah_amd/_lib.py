@@ -98,6 +98,7 @@ SIGNATURES = {
     "ghip_comm_allgather_host": (_int, [_vp, _vp, _sz, _vp]),
     "ghip_shard_range": (None, [_sz, _u32, _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "ghip_allgather_sketches": (_int, [_vp, _vp, _sz, _pp]),
+    "ghip_precluster_comm": (_int, [_vp, _vp, _f32, _pp, C.POINTER(_sz), C.POINTER(C.c_int)]),
     "ghip_allgather_pairs": (_int, [_vp, _vp, _sz, _pp, C.POINTER(_sz)]),
     "ghip_exchange_ani_index": (_int, [_vp, _vp, _sz, _vp, _sz, _pp, _vp]),
     "ghip_distances_and_ani_ranks": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _f32, _u32, _u32, _u32, _f32, _pp, _pp,

@@ -1276,9 +1276,73 @@ static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
 
 // replicate_join: a multi-rank caller that prefers the whole list on every rank whenever the join form runs (its
 // cost, one pass over all N*s hashes, does not shard) to a share it then has to exchange.
+// cmin[total] = smallest common whose reference ANI clears the threshold (src/finch.rs:91:
+// `distance >= min_ani as f64`).  The device filter only has to be a superset; the exact
+// test is repeated on the host for every emitted pair.  Cached in the context per (min_ani, s, k); ctx->mu held.
+int ghip_pair_filter_prepare(ghip_ctx *ctx, uint32_t s, uint32_t k, float min_ani) {
+    const double thr = (double)min_ani;
+    uint32_t ani_bits;
+    memcpy(&ani_bits, &min_ani, 4);
+    if (ctx->cmin.valid && ctx->cmin.ani_bits == ani_bits && ctx->cmin.s == s && ctx->cmin.k == k) return GHIP_OK;
+    const uint32_t max_total = 2 * s;
+    std::vector<uint16_t> cmin(max_total + 2, 0xffff);
+    for (uint32_t total = 0; total <= max_total; total++) {
+        // finch_ani is non-decreasing in common for a fixed total: the smallest passing common by bisection (s = 10 000
+        // would cost 2e8 logarithms the linear way); total = 0 is the NaN corner (ANI 1.0 whatever common is)
+        const uint32_t cmax = std::min(total, s);
+        if (!(finch_ani(cmax, total, k) >= thr)) continue;   // nothing passes: 0xffff
+        uint32_t lo = 0, hi = cmax;                            // invariant: hi passes
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (finch_ani(mid, total, k) >= thr) hi = mid; else lo = mid + 1; }
+        cmin[total] = (uint16_t)hi;
+    }
+    if (ctx->cmin.d_cmin) ghip_pool_free(ctx, ctx->cmin.d_cmin);
+    ctx->cmin.valid = false;
+    int rc;
+    if ((rc = dmalloc(ctx, &ctx->cmin.d_cmin, cmin.size()))) return rc;
+    if ((rc = h2d(ctx, ctx->cmin.d_cmin, cmin.data(), cmin.size()))) return rc;
+    ctx->cmin.ani_bits = ani_bits; ctx->cmin.s = s; ctx->cmin.k = k; ctx->cmin.valid = true;
+    ctx->cmin.floor = ghip_cmin_floor(cmin);
+    return GHIP_OK;
+}
+
+// The host end of the pair stage: exact reference arithmetic (f64 ANI, threshold, `as f32`) on every candidate the device
+// filter let through, then (i, j) order.  filter_share: keep only the pairs with (i + j) mod world == rank.
+// (serial on purpose: one f64 log per emitted pair is 1 ms per 45 000 pairs, and spawning threads on the 256-core
+// host cost more than that -- measured 4.7 -> 6.6 ms for the stage at 10 000 genomes)
+int ghip_pairs_finalize(ghip_ctx *ctx, std::vector<ghip_pair> &host, uint32_t k, float min_ani, size_t n, bool filter_share,
+                        uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
+    const double thr = (double)min_ani;
+    size_t m = 0;
+    for (size_t i = 0; i < host.size(); i++) {
+        if (filter_share && (host[i].i + host[i].j) % world != rank) continue;
+        const double ani = finch_ani(host[i].common, host[i].total, k);
+        if (ani >= thr) { host[i].ani = (float)ani; host[m++] = host[i]; }
+    }
+    host.resize(m);
+    // (i, j) order: counting sort by i straight into the result (O(m + n)), then the few entries of each i by j --
+    // a comparison sort of the whole list costs 0.24 ms at 4 500 hits and 3.8 ms at 45 000
+    ghip_pair *res = (ghip_pair *)malloc(std::max<size_t>(m, 1) * sizeof(ghip_pair));
+    if (!res) return ghip_set_error(ctx, GHIP_ENOMEM, "out of host memory");
+    {
+        std::vector<size_t> at(n + 1, 0);
+        for (size_t x = 0; x < m; x++) at[host[x].i + 1]++;
+        for (size_t g = 0; g < n; g++) at[g + 1] += at[g];
+        std::vector<size_t> fill(at.begin(), at.end() - 1);
+        for (size_t x = 0; x < m; x++) res[fill[host[x].i]++] = host[x];
+        for (size_t g = 0; g < n; g++)
+            if (at[g + 1] - at[g] > 1)
+                std::sort(res + at[g], res + at[g + 1], [](const ghip_pair &a, const ghip_pair &b) { return a.j < b.j; });
+    }
+    *out_pairs = res; *out_n = m;
+    return GHIP_OK;
+}
+
 // row_lo > 0: the (new x all) rectangle of an incremental run -- only the pairs (i, j), i < j, with j >= row_lo.
+// dense_share: no join; a dense pass over EVERY pair, of which the (i + j) mod world == rank share is returned (what a
+// rank of the hash-sharded join owes when its own second stage had to give up).
 static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_ani, uint32_t rank, uint32_t world,
-                           bool replicate_join, size_t row_lo, ghip_pair **out_pairs, size_t *out_n, int *out_replicated) {
+                           bool replicate_join, size_t row_lo, ghip_pair **out_pairs, size_t *out_n, int *out_replicated,
+                           bool dense_share = false) {
     ghip_sketches *sk = const_cast<ghip_sketches *>(sk_in);  // lazily caches the probe-form tables
     if (out_replicated) *out_replicated = 0;
     if (!ctx || !sk || !out_pairs || !out_n || world == 0 || rank >= world) return GHIP_EINVAL;
@@ -1292,33 +1356,9 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     ctx->last_pairs = 0;
     if (n < 2) return GHIP_OK;
 
-    // cmin[total] = smallest common whose reference ANI clears the threshold (src/finch.rs:91:
-    // `distance >= min_ani as f64`).  The device filter only has to be a superset; the exact
-    // test is repeated on the host for every emitted pair.
-    const double thr = (double)min_ani;
-    uint32_t ani_bits;
-    memcpy(&ani_bits, &min_ani, 4);
     DeviceFree tmp(ctx);
-    int rc = GHIP_OK;
-    if (!(ctx->cmin.valid && ctx->cmin.ani_bits == ani_bits && ctx->cmin.s == s && ctx->cmin.k == k)) {
-        const uint32_t max_total = 2 * s;
-        std::vector<uint16_t> cmin(max_total + 2, 0xffff);
-        for (uint32_t total = 0; total <= max_total; total++) {
-            // finch_ani is non-decreasing in common for a fixed total: the smallest passing common by bisection (s = 10 000
-            // would cost 2e8 logarithms the linear way); total = 0 is the NaN corner (ANI 1.0 whatever common is)
-            const uint32_t cmax = std::min(total, s);
-            if (!(finch_ani(cmax, total, k) >= thr)) continue;   // nothing passes: 0xffff
-            uint32_t lo = 0, hi = cmax;                            // invariant: hi passes
-            while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (finch_ani(mid, total, k) >= thr) hi = mid; else lo = mid + 1; }
-            cmin[total] = (uint16_t)hi;
-        }
-        if (ctx->cmin.d_cmin) ghip_pool_free(ctx, ctx->cmin.d_cmin);
-        ctx->cmin.valid = false;
-        if ((rc = dmalloc(ctx, &ctx->cmin.d_cmin, cmin.size()))) return rc;
-        if ((rc = h2d(ctx, ctx->cmin.d_cmin, cmin.data(), cmin.size()))) return rc;
-        ctx->cmin.ani_bits = ani_bits; ctx->cmin.s = s; ctx->cmin.k = k; ctx->cmin.valid = true;
-        ctx->cmin.floor = ghip_cmin_floor(cmin);
-    }
+    int rc = ghip_pair_filter_prepare(ctx, s, k, min_ani);
+    if (rc) return rc;
     uint16_t *d_cmin = ctx->cmin.d_cmin;
 
     // Three forms of the pair stage, identical results (tests/test_gpu_parity.py runs all three against the oracle):
@@ -1328,7 +1368,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     // GHIP_PAIR_KERNEL=join|probe|merge forces a form (join still declines what it cannot do).
     const char *force = getenv("GHIP_PAIR_KERNEL");
     // (sketches too long for LDS tiles, s > 4096, go to the join whatever n is: the dense form left for them reads global memory)
-    const bool want_join = force ? !strcmp(force, "join") : (n >= GHIP_JOIN_MIN_N || s > 4096);
+    const bool want_join = !dense_share && (force ? !strcmp(force, "join") : (n >= GHIP_JOIN_MIN_N || s > 4096));
     bool use_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
     bool probe_checked = false;
 
@@ -1338,7 +1378,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     if ((rc = dmalloc(ctx, &d_count, 1))) return rc;
     tmp.add(d_count);
     std::vector<ghip_pair> host;
-    bool filter_share = false;  // dense pass over ALL pairs, this rank's (i + j) mod world share picked on the host
+    bool filter_share = dense_share;  // dense pass over ALL pairs, this rank's (i + j) mod world share picked on the host
     bool listed = false;  // an attempt whose candidate list held every hit
     for (int attempt = 0; attempt < 4 && !listed; attempt++) {
         ghip_pair *d_out = nullptr;
@@ -1386,32 +1426,11 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         listed = true;
     }
     if (!listed) return ghip_set_error(ctx, GHIP_EHIP, "precluster candidate list overflowed on every attempt");
-    // exact reference arithmetic on the host: f64 ANI, threshold, `as f32`
-    // (serial on purpose: one f64 log per emitted pair is 1 ms per 45 000 pairs, and spawning threads on the 256-core
-    // host cost more than that -- measured 4.7 -> 6.6 ms for the stage at 10 000 genomes)
-    size_t m = 0;
-    for (size_t i = 0; i < host.size(); i++) {
-        if (filter_share && (host[i].i + host[i].j) % world != rank) continue;
-        const double ani = finch_ani(host[i].common, host[i].total, k);
-        if (ani >= thr) { host[i].ani = (float)ani; host[m++] = host[i]; }
-    }
-    host.resize(m);
-    // (i, j) order: counting sort by i straight into the result (O(m + n)), then the few entries of each i by j --
-    // a comparison sort of the whole list costs 0.24 ms at 4 500 hits and 3.8 ms at 45 000
-    ghip_pair *res = (ghip_pair *)malloc(std::max<size_t>(m, 1) * sizeof(ghip_pair));
-    if (!res) return ghip_set_error(ctx, GHIP_ENOMEM, "out of host memory");
-    {
-        std::vector<size_t> at(n + 1, 0);
-        for (size_t x = 0; x < m; x++) at[host[x].i + 1]++;
-        for (size_t g = 0; g < n; g++) at[g + 1] += at[g];
-        std::vector<size_t> fill(at.begin(), at.end() - 1);
-        for (size_t x = 0; x < m; x++) res[fill[host[x].i]++] = host[x];
-        for (size_t g = 0; g < n; g++)
-            if (at[g + 1] - at[g] > 1)
-                std::sort(res + at[g], res + at[g + 1], [](const ghip_pair &a, const ghip_pair &b) { return a.j < b.j; });
-    }
-    *out_pairs = res; *out_n = m;
-    return GHIP_OK;
+    return ghip_pairs_finalize(ctx, host, k, min_ani, n, filter_share, rank, world, out_pairs, out_n);
+}
+
+int ghip_precluster_dense_share(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
+    return precluster_impl(ctx, sk, min_ani, rank, world, false, 0, out_pairs, out_n, nullptr, true);
 }
 
 extern "C" int ghip_precluster_shard(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank,

@@ -7,6 +7,7 @@
 // Result semantics follow the reference with --threads 1: preclusters in disjoint-set order
 // (first element ascending) stable-sorted by size descending; within a precluster clusters in
 // representative order; representative first, members ascending.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,9 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
                         uint64_t *out_requested) {
     if (!out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
     if (n_pairs && !pairs) return GHIP_EINVAL;
+    const bool dbg = getenv("GHIP_CLUSTER_DEBUG") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[cluster] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; } };
     if (out_requested) *out_requested = 0;
     // an ANI source is only needed when there is an edge to ask about: unrelated genomes (no precluster pair) are
     // singleton clusters whatever the clusterer (clusterer.rs:182-259 never calls calculate_ani then)
@@ -50,6 +54,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
     for (size_t e = 0; e < n_pairs; e++)
         if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return GHIP_EINVAL;
 
+    lap("validate");
     // ---- partition_sketches (clusterer.rs:452-487): single linkage over cache keys ----
     Dsu dsu(n);
     for (size_t e = 0; e < n_pairs; e++) dsu.join(pairs[e].i, pairs[e].j);
@@ -81,6 +86,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return set_size[a] > set_size[b]; });
 
+    lap("partition");
     // adjacency in CSR form over local indices (== transform_ids, cache.rs:47-58)
     std::vector<uint64_t> adj_start(n + 1, 0);
     for (size_t e = 0; e < n_pairs; e++) { adj_start[pairs[e].i + 1]++; adj_start[pairs[e].j + 1]++; }
@@ -93,6 +99,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
             adj[fill[pairs[e].j]++] = {local[pairs[e].i], (uint32_t)e};
         }
     }
+    lap("adjacency");
     // a duplicate key would be a BTreeMap overwrite; the GPU stage never emits one
     // clusterer ANI per edge: state 0 = not computed, 1 = None, 2 = Some(value)
     std::vector<uint8_t> ani_state(n_pairs, 0);
@@ -185,17 +192,33 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
         }
     };
 
-    std::vector<uint32_t> out_m;
-    std::vector<uint64_t> out_o{0};
-    out_m.reserve(n);
+    lap("ani states / lazy rounds");
+    // The preclusters are independent (clusterer.rs:88 walks them with par_iter): ranges of `order` go to worker threads,
+    // each writing its preclusters' members straight to their final place in out_m (a precluster's clusters occupy the
+    // slots after those of the preclusters before it in `order`) and its cluster end offsets to a list of its own; the
+    // lists are concatenated in order afterwards.  A callback back-end (ani_cb) stays on the calling thread: the host's
+    // calculate_ani need not be re-entrant from threads it did not make.
+    std::vector<uint32_t> out_m(n);
+    std::vector<uint64_t> pre_base(nsets + 1, 0);   // first output slot of the oi-th precluster in `order`
+    for (size_t oi = 0; oi < nsets; oi++) pre_base[oi + 1] = pre_base[oi] + set_size[order[oi]];
     std::vector<uint32_t> assign(n, 0);      // genome -> representative genome
     struct Cand { uint32_t nbr_local; uint32_t edge; float pre; };
-    std::vector<Cand> cand;
+    std::atomic<int> failure{GHIP_OK};
 
-    for (size_t oi = 0; oi < nsets; oi++) {
+    auto run_range = [&](size_t o_lo, size_t o_hi, std::vector<uint64_t> &ends) {
+    std::vector<Cand> cand;
+    std::vector<uint32_t> rep_pos, cnt;
+    std::vector<uint64_t> cstart, fill;
+    for (size_t oi = o_lo; oi < o_hi && failure.load(std::memory_order_relaxed) == GHIP_OK; oi++) {
         const uint32_t s = order[oi];
         const uint32_t *orig = members.data() + set_start[s];
         const uint32_t m = set_size[s];
+        if (m == 1) {   // a genome with no precluster pair: its own cluster (most of a diverse collection)
+            is_rep[orig[0]] = 1; assign[orig[0]] = orig[0];
+            out_m[pre_base[oi]] = orig[0];
+            ends.push_back(pre_base[oi] + 1);
+            continue;
+        }
         // ---- find_precluster_cluster_representatives (clusterer.rs:182-259) ----
         for (uint32_t li = 0; li < m; li++) {
             const uint32_t gi = orig[li];
@@ -205,10 +228,11 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
                 if (lj < li && is_rep[orig[lj]]) cand.push_back({lj, adj[a].edge, pairs[adj[a].edge].ani});
             }
             // ascending by precluster ANI (clusterer.rs:200; sort_unstable -> ties by index here)
-            std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) {
-                if (x.pre != y.pre) return x.pre < y.pre;
-                return x.nbr_local < y.nbr_local;
-            });
+            if (cand.size() > 1)
+                std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) {
+                    if (x.pre != y.pre) return x.pre < y.pre;
+                    return x.nbr_local < y.nbr_local;
+                });
             bool rep = true;
             for (const Cand &c : cand) {
                 edge_ani(c.edge, orig[c.nbr_local], gi);
@@ -218,7 +242,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
                 }
             }
             is_rep[gi] = rep ? 1 : 0;
-            if (aborted) return GHIP_ECALLBACK;
+            if (aborted) { failure = GHIP_ECALLBACK; return; }
         }
         // ---- find_precluster_cluster_memberships (clusterer.rs:350-449) ----
         for (uint32_t li = 0; li < m; li++) {
@@ -237,28 +261,55 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
                 // so among equal ANIs the lowest-index representative is kept.
                 if (!have || v > best || (v == best && lj < best_local)) { have = true; best = v; best_local = lj; }
             }
-            if (aborted) return GHIP_ECALLBACK;
-            if (!have) return GHIP_EINVAL;  // reference: best_rep.unwrap() panics (clusterer.rs:444)
+            if (aborted) { failure = GHIP_ECALLBACK; return; }
+            if (!have) { failure = GHIP_EINVAL; return; }  // reference: best_rep.unwrap() panics (clusterer.rs:444)
             assign[gi] = orig[best_local];
         }
         // clusters of this precluster: representative first, then members ascending
-        const size_t base = out_m.size();
-        std::vector<uint32_t> rep_pos(m, UINT32_MAX), cnt;
+        const size_t base = pre_base[oi];
+        rep_pos.assign(m, UINT32_MAX);
         uint32_t nreps = 0;
         for (uint32_t li = 0; li < m; li++) if (is_rep[orig[li]]) { rep_pos[li] = nreps++; }
         cnt.assign(nreps, 0);
         for (uint32_t li = 0; li < m; li++) cnt[rep_pos[local[assign[orig[li]]]]]++;
-        std::vector<uint64_t> cstart(nreps + 1, 0);
+        cstart.assign(nreps + 1, 0);
         for (uint32_t r = 0; r < nreps; r++) cstart[r + 1] = cstart[r] + cnt[r];
-        out_m.resize(base + m);
-        std::vector<uint64_t> fill(cstart.begin(), cstart.end() - 1);
+        fill.assign(cstart.begin(), cstart.end() - 1);
         for (uint32_t li = 0; li < m; li++)  // representatives first
             if (is_rep[orig[li]]) out_m[base + fill[rep_pos[li]]++] = orig[li];
         for (uint32_t li = 0; li < m; li++)
             if (!is_rep[orig[li]]) out_m[base + fill[rep_pos[local[assign[orig[li]]]]]++] = orig[li];
-        for (uint32_t r = 0; r < nreps; r++) out_o.push_back(base + cstart[r + 1]);
+        for (uint32_t r = 0; r < nreps; r++) ends.push_back(base + cstart[r + 1]);
+    }
+    };
+    std::vector<uint64_t> out_o{0};
+    {
+        // threads only where they pay (spawning one costs ~30 us): ranges of >= 2 000 genomes, at most 8 workers
+        size_t workers = ani_cb ? 1 : std::min<size_t>({(size_t)8, n / 2000, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+        if (const char *e = getenv("GHIP_CLUSTER_THREADS")) workers = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));
+        workers = std::max<size_t>(1, std::min(workers, nsets));
+        std::vector<std::vector<uint64_t>> ends(workers);
+        if (workers == 1) run_range(0, nsets, ends[0]);
+        else {
+            // equal shares of the GENOMES (the big preclusters come first in `order`)
+            std::vector<size_t> cut(workers + 1, nsets);
+            cut[0] = 0;
+            for (size_t w = 1; w < workers; w++)
+                cut[w] = std::lower_bound(pre_base.begin(), pre_base.end(), (uint64_t)(n * w / workers)) - pre_base.begin();
+            for (size_t w = 1; w < workers; w++) cut[w] = std::min(std::max(cut[w], cut[w - 1]), nsets);
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < workers; w++) pool.emplace_back([&, w] { run_range(cut[w], cut[w + 1], ends[w]); });
+            run_range(cut[0], cut[1], ends[0]);
+            for (auto &t : pool) t.join();
+        }
+        if (failure.load() != GHIP_OK) return failure.load();
+        size_t total = 1;
+        for (auto &e : ends) total += e.size();
+        out_o.reserve(total);
+        for (auto &e : ends) out_o.insert(out_o.end(), e.begin(), e.end());
     }
 
+    lap("preclusters");
     uint32_t *om = (uint32_t *)malloc(std::max<size_t>(out_m.size(), 1) * sizeof(uint32_t));
     uint64_t *oo = (uint64_t *)malloc(out_o.size() * sizeof(uint64_t));
     if (!om || !oo) { free(om); free(oo); return GHIP_ENOMEM; }

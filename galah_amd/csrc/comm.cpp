@@ -89,6 +89,10 @@ struct ghip_comm {
     ghip_allgather_fn fn = nullptr;
     void *user = nullptr;
     std::string err;
+    // CALLBACK transport: pinned staging of device payloads, kept and grown on demand.  (Pageable staging made the runtime pin
+    // and unpin the vectors around every copy: the NEXT small device-to-host copy of the caller then stalled 12-24 ms.)
+    void *pin_send = nullptr, *pin_recv = nullptr;
+    size_t pin_send_bytes = 0, pin_recv_bytes = 0;
 };
 
 namespace {
@@ -151,11 +155,21 @@ int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t byte
         return GHIP_OK;
     }
     case T_CALLBACK: {
-        std::vector<uint8_t> hs(bytes), hr(bytes * c->world);
-        COMM_HIP(c, hipMemcpyAsync(hs.data(), d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        auto grow = [&](void *&p, size_t &have, size_t want) {
+            if (have >= want) return true;
+            if (p) hipHostFree(p);
+            p = nullptr; have = 0;
+            const size_t cap = std::max<size_t>(want + want / 4, 1u << 16);
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return false; }
+            have = cap;
+            return true;
+        };
+        if (!grow(c->pin_send, c->pin_send_bytes, bytes) || !grow(c->pin_recv, c->pin_recv_bytes, bytes * c->world))
+            return cerr_(c, GHIP_ENOMEM, "out of pinned host memory for the host-callback transport");
+        COMM_HIP(c, hipMemcpyAsync(c->pin_send, d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
         COMM_HIP(c, hipStreamSynchronize(ctx->stream));
-        if (c->fn(c->user, hs.data(), bytes, hr.data()) != 0) return cerr_(c, GHIP_ECALLBACK, "the host all-gather callback failed");
-        COMM_HIP(c, hipMemcpyAsync(d_recv, hr.data(), hr.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (c->fn(c->user, c->pin_send, bytes, c->pin_recv) != 0) return cerr_(c, GHIP_ECALLBACK, "the host all-gather callback failed");
+        COMM_HIP(c, hipMemcpyAsync(d_recv, c->pin_recv, bytes * c->world, hipMemcpyHostToDevice, ctx->stream));
         COMM_HIP(c, hipStreamSynchronize(ctx->stream));
         return GHIP_OK;
     }
@@ -293,6 +307,8 @@ extern "C" int ghip_comm_init_callback(ghip_ctx *ctx, uint32_t rank, uint32_t wo
 extern "C" void ghip_comm_destroy(ghip_comm *c) {
     if (!c) return;
     if (c->nccl) rccl().CommDestroy(c->nccl);
+    if (c->pin_send) hipHostFree(c->pin_send);
+    if (c->pin_recv) hipHostFree(c->pin_recv);
     if (c->group && --c->group->refs == 0) delete c->group;
     delete c;
 }
@@ -387,6 +403,111 @@ extern "C" int ghip_allgather_pairs(ghip_comm *c, const ghip_pair *local, size_t
     if (n) memcpy(res, a.data(), n * sizeof(ghip_pair));
     *out_all = res; *out_n = n;
     return GHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pair stage over the ranks
+// This rank's share of the precluster pair list of the gathered matrix `sk` (identical on every rank), sorted by (i, j);
+// the shares of all ranks partition the list.  From 1 200 genomes the inverted-index form runs HASH-SHARDED (pairs_join.hip:
+// ghip_pairs_join_partials / _finish): every rank partitions a 1/world share of the hashes, the per-pair partial counts
+// are exchanged (one small host all-gather of sizes and decline flags, one device all-gather of 16 bytes per sharing
+// pair and rank), every rank finishes the pairs with (i + j) % world == rank.  Where that form does not apply -- or
+// declines on any rank: all ranks learn it from the first collective and decide alike -- ghip_precluster_ranks delivers the
+// share (dense tiles, or the record-sharded join whose element stage is replicated; GHIP_JOIN_RANKS=records forces it).
+extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float min_ani, ghip_pair **out_pairs, size_t *out_n,
+                                    int *out_replicated) {
+    if (!c || !sk || !out_pairs || !out_n || !out_replicated) return GHIP_EINVAL;
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return GHIP_EINVAL;
+    *out_pairs = nullptr; *out_n = 0; *out_replicated = 0;
+    const size_t n = sk->n;
+    const uint32_t s = sk->s, world = c->world, rank = c->rank;
+    const char *force = getenv("GHIP_PAIR_KERNEL"), *mode = getenv("GHIP_JOIN_RANKS");
+    const bool want = world > 1 && !(mode && (!strcmp(mode, "replicate") || !strcmp(mode, "records"))) &&
+                      (force ? !strcmp(force, "join") : (n >= GHIP_JOIN_MIN_N || s > 4096)) && (uint64_t)n * s < (1ull << 32) && n >= 2;
+    if (!want) return ghip_precluster_ranks(ctx, sk, min_ani, rank, world, out_pairs, out_n, out_replicated);
+
+    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) { fprintf(stderr, "[precluster_comm rank %u] %s %.3f ms\n", rank, what, ms_since(t0)); t0 = std::chrono::steady_clock::now(); } };
+    // ---- stage 1: my share of the hashes -> partial common per sharing pair
+    void *d_ent = nullptr;
+    uint32_t n_ent = 0, status = 1, floor = 0;
+    unsigned long long rec_total = 0;
+    int rc = GHIP_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        COMM_HIP(c, hipSetDevice(ctx->device));
+        rc = ghip_pair_filter_prepare(ctx, s, sk->k, min_ani);
+        floor = ctx->cmin.floor;
+        // (min_ani <= 0: pairs without a common hash qualify -- the dense forms; the same verdict on every rank)
+        if (!rc && floor != 0 && floor != 0xffffu) rc = ghip_pairs_join_partials(ctx, sk->d_hashes, sk->d_lens, n, s, rank, world, &d_ent, &n_ent, &status, &rec_total);
+    }
+    struct Freer { ghip_ctx *ctx; void *&p; ~Freer() { if (p) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->stream); ghip_pool_free(ctx, p); } } } freer{ctx, d_ent};
+    lap("stage 1 (partials)");
+    // ---- exchange 1: who declined, how many records, how many entries (an error is a decline flag too: no rank waits alone)
+    uint64_t mine3[3] = {(uint64_t)(rc ? 3 : status), rec_total, n_ent};
+    std::vector<uint64_t> all3(3 * (size_t)world);
+    const int rc_x = allgather_host(c, mine3, sizeof(mine3), all3.data());
+    if (rc) return rc;
+    if (rc_x) return rc_x;
+    uint64_t any = 0, records = 0, m = 0;
+    for (uint32_t r = 0; r < world; r++) { any |= all3[3 * r]; records += all3[3 * r + 1]; m = std::max<uint64_t>(m, all3[3 * r + 2]); }
+    const uint64_t P = (uint64_t)n * (n - 1) / 2;
+    // a dense pass costs ~1 ns per pair, a record ~0.3 ns: beyond 4 records per pair the dense kernel is the better tool
+    if (any || records > 4 * P + (1u << 20) || records >= (1ull << 31) || m * world >= (1ull << 31))
+        return (any & 2) ? cerr_(c, GHIP_EHIP, "a peer rank failed in the pair stage") : ghip_precluster_ranks(ctx, sk, min_ani, rank, world, out_pairs, out_n, out_replicated);
+    lap("exchange 1");
+    // ---- exchange 2: the entries of every rank (blocks padded to the longest with key = 2^64 - 1)
+    const size_t block = std::max<uint64_t>(m, 1) * GHIP_JOIN_ENTRY_BYTES;
+    PoolBuf sb(ctx, block), rb(ctx, block * world);
+    if (!sb.p || !rb.p) return cerr_(c, GHIP_EHIP, "out of device memory for the partial-count exchange");
+    COMM_HIP(c, hipMemsetAsync(sb.p, 0xff, block, ctx->stream));
+    if (n_ent) COMM_HIP(c, hipMemcpyAsync(sb.p, d_ent, (size_t)n_ent * GHIP_JOIN_ENTRY_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = allgather_device(c, sb.p, rb.p, block))) return rc;
+    lap("exchange 2");
+    // ---- stage 2: the pairs I own
+    std::vector<ghip_pair> host;
+    bool ok = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        COMM_HIP(c, hipSetDevice(ctx->device));
+        const uint32_t n_all = (uint32_t)(std::max<uint64_t>(m, 1) * world);
+        const uint64_t cap = std::max<uint64_t>(1u << 16, n_all);   // at most one candidate per owned entry
+        unsigned long long *d_count = (unsigned long long *)ghip_pool_alloc(ctx, sizeof(unsigned long long));
+        ghip_pair *d_out = (ghip_pair *)ghip_pool_alloc(ctx, cap * sizeof(ghip_pair));
+        if (!d_count || !d_out) { ghip_pool_free(ctx, d_count); ghip_pool_free(ctx, d_out); return cerr_(c, GHIP_EHIP, "out of device memory for the candidate list"); }
+        unsigned long long cnt = 0;
+        hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream);
+        lap("stage 2 set-up");
+        if (e == hipSuccess) rc = ghip_pairs_join_finish(ctx, rb.p, n_all, n_all, sk->d_hashes, sk->d_lens, s, ctx->cmin.d_cmin, floor, rank, world, d_out, d_count, cap, &ok);
+        lap("stage 2 kernels");
+        if (e == hipSuccess && !rc && ok) {
+            e = hipMemcpyAsync(&cnt, d_count, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess && cnt > cap) ok = false;   // cannot happen (one candidate per owned pair at most): the dense share then
+            if (e == hipSuccess && ok) {
+                host.resize(cnt);
+                if (cnt) e = hipMemcpy(host.data(), d_out, cnt * sizeof(ghip_pair), hipMemcpyDeviceToHost);
+            }
+        }
+        hipStreamSynchronize(ctx->stream);
+        ghip_pool_free(ctx, d_count); ghip_pool_free(ctx, d_out);
+        lap("stage 2 copy-out");
+        if (e != hipSuccess) return cerr_(c, GHIP_EHIP, std::string("pair stage (sharded join): ") + hipGetErrorString(e));
+        if (rc) { if (c->group) c->group->fail(); return rc; }
+        if (ok) {   // pairs this rank answered for: (i + j) % world == rank
+            uint64_t cmp = 0;
+            for (uint64_t i = 0; i + 1 < n; i++) {
+                const uint64_t first = i + 1 + ((rank + 2 * (uint64_t)world - (2 * i + 1) % world) % world);
+                if (first < n) cmp += (n - 1 - first) / world + 1;
+            }
+            ctx->last_pairs = cmp;
+        }
+    }
+    lap(ok ? "stage 2 (finish)" : "stage 2 gave up: dense share");
+    // my tables overflowed (huge families): the other ranks deliver their shares, I owe exactly mine -- by a dense pass
+    if (!ok) return ghip_precluster_dense_share(ctx, sk, min_ani, rank, world, out_pairs, out_n);
+    return ghip_pairs_finalize(ctx, host, sk->k, min_ani, n, false, rank, world, out_pairs, out_n);
 }
 
 // ------------------------------------------------------------------------------------------------ ANI index slices
@@ -548,7 +669,7 @@ extern "C" int ghip_distances_and_ani_ranks(ghip_comm *c, const ghip_genomes *lo
     else if ((rc = ghip_allgather_sketches(c, sk_l, n_total, &sk))) { cleanup(); return rc; }
     lap(tm.allgather_sketches_ms);
     int replicated = 0;
-    rc = ghip_precluster_ranks(ctx, sk, min_ani, c->rank, c->world, &mine, &n_mine, &replicated);
+    rc = ghip_precluster_comm(c, sk, min_ani, &mine, &n_mine, &replicated);
     if (rc) { if (c->group) c->group->fail(); cleanup(); return rc; }
     tm.pairs_compared = ghip_last_pairs_compared(ctx);
     lap(tm.pairs_ms);

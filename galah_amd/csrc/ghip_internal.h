@@ -245,6 +245,19 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                     unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline);
 
+// hash-sharded multi-rank form of the join (pairs_join.hip; driven by comm.cpp)
+constexpr size_t GHIP_JOIN_ENTRY_BYTES = 16;   // {u64 pair key (i << 32 | j), u32 partial common, u32 pad}
+int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s, uint32_t hrank,
+                             uint32_t hworld, void **d_entries_out /* pool block, caller frees */, uint32_t *n_entries_out, uint32_t *status,
+                             unsigned long long *rec_total);
+int ghip_pairs_join_finish(ghip_ctx *ctx, const void *d_all, uint32_t n_all, uint32_t n_mine_bound, const uint64_t *d_hashes, const uint32_t *d_lens,
+                           uint32_t s, const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                           unsigned long long *d_count, uint64_t cap, bool *ok);
+// pieces of the pair stage shared with it (api.cpp; ctx->mu held by the caller of the first, not needed for the second)
+int ghip_pair_filter_prepare(ghip_ctx *ctx, uint32_t s, uint32_t k, float min_ani);
+int ghip_pairs_finalize(ghip_ctx *ctx, std::vector<ghip_pair> &host, uint32_t k, float min_ani, size_t n, bool filter_share,
+                        uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n);
+int ghip_precluster_dense_share(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n);
 size_t ghip_probe_table_slots(uint32_t s);
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                              uint64_t *d_tables, uint32_t *d_flags);

@@ -17,6 +17,7 @@
 // semantics its ANI with every other sketch is 1.0), a hash bucket or a record bucket beyond its LDS capacity
 // (large families: many genomes share each hash), more records than a dense pass would cost, N*s >= 2^32.
 #include <algorithm>
+#include <chrono>
 
 #include "ghip_internal.h"
 
@@ -37,15 +38,33 @@ struct ElemSrc {  // the packed sketch matrix as (hash, genome) elements; padded
     const uint32_t *lens;
     uint32_t s;
     uint32_t total;  // n * s < 2^32
+    uint32_t hrank, hworld;   // hash-sharded multi-rank form: only the hashes whose first-level digit d has d % hworld == hrank
     __device__ bool get(uint32_t t, uint64_t &key, uint32_t &val) const {
         if (t >= total) return false;
         const uint32_t g = t / s, r = t - g * s;
         if (r >= lens[g]) return false;
         key = hashes[t];
         val = g;
-        return true;
+        return hworld <= 1 || (mix(key) >> 12) % hworld == hrank;
     }
     __device__ static uint32_t mix(uint64_t key) { return (uint32_t)key & 0xfffffu; }  // 20 MurmurHash3 low bits: uniform
+};
+
+struct JoinEntry { uint64_t key; uint32_t count, pad; };   // partial common of one genome pair (hash-sharded form); 16 bytes
+static_assert(sizeof(JoinEntry) == GHIP_JOIN_ENTRY_BYTES, "entry size is part of the exchange layout");
+
+struct EntrySrc {  // the gathered partial counts of all ranks as weighted records; only the pairs this rank owns
+    const JoinEntry *e;
+    uint32_t total, rank, world;
+    __device__ bool get(uint32_t t, uint64_t &key, uint32_t &val) const {
+        if (t >= total) return false;
+        key = e[t].key;
+        val = e[t].count;
+        return key != ~0ull && ((uint32_t)(key >> 32) + (uint32_t)key) % world == rank;   // (padding entries hold 2^64 - 1)
+    }
+    __device__ static uint32_t mix(uint64_t key) {
+        return (((uint32_t)(key >> 32) * 0x9E3779B1u) ^ ((uint32_t)key * 0x85EBCA77u)) >> 12;  // 20 bits (as RecSrc)
+    }
 };
 
 struct RecSrc {  // genome-pair records (i << 32 | j), i < j
@@ -357,7 +376,14 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
 
 // ---- records of one bucket -> common per genome pair -> ranks, integer filter, candidate list --------------------
 // flags bit 1: more distinct genome pairs in a record bucket than the LDS table holds.
-__global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *__restrict__ rec, const uint32_t *__restrict__ start2,
+// WEIGHTED: record t counts weight[t] times (the gathered partial counts of the hash-sharded form).  PARTIAL != 0: no ranks,
+// no filter -- every (pair, count) of the table is this rank's partial common of that pair: PARTIAL = 1 counts the
+// bucket's pairs into ent_count[bucket], PARTIAL = 2 writes them at ent_start[bucket] (count -> scan -> emit, as for the
+// records: one returning atomic per entry on a shared counter cost 0.46 ms for 45 000 entries).
+template <bool WEIGHTED, int PARTIAL>
+__global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *__restrict__ rec, const uint32_t *__restrict__ weight,
+                                                                JoinEntry *__restrict__ entries, uint32_t *__restrict__ ent_count, const uint32_t *__restrict__ ent_start,
+                                                                const uint32_t *__restrict__ start2,
                                                                 const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
                                                                 uint32_t s, const uint16_t *__restrict__ cmin, uint32_t cmin_floor,
                                                                 uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count,
@@ -367,7 +393,7 @@ __global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t bucket = blockIdx.x * J_WAVES + wave;
     const uint32_t lo = start2[bucket], hi = start2[bucket + 1];
-    if (lo == hi) return;
+    if (lo == hi) { if (PARTIAL == 1 && lane == 0) ent_count[bucket] = 0; return; }
     for (uint32_t e = lane; e < J_TAB; e += 64) { tk[wave][e] = J_EMPTY; tc[wave][e] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -377,17 +403,33 @@ __global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *
         bool done = false;
         for (uint32_t it = 0; it < J_TAB && !done; it++) {
             const unsigned long long prev = atomicCAS(&tk[wave][slot], (unsigned long long)J_EMPTY, key);
-            if (prev == J_EMPTY || prev == key) { atomicAdd(&tc[wave][slot], 1u); done = true; }
+            if (prev == J_EMPTY || prev == key) { atomicAdd(&tc[wave][slot], WEIGHTED ? weight[t] : 1u); done = true; }
             else slot = (slot + 1) & (J_TAB - 1);
         }
         if (!done) atomicOr(flags, 2u);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (PARTIAL != 0) {
+        uint32_t run = 0;   // wave-uniform: entries of this bucket so far
+        const uint32_t out0 = PARTIAL == 2 ? ent_start[bucket] : 0u;
+        for (uint32_t e = lane; e < J_TAB; e += 64) {
+            const unsigned long long key = tk[wave][e];
+            const unsigned long long m = __ballot(key != J_EMPTY);
+            if (PARTIAL == 2 && key != J_EMPTY) {
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                entries[out0 + run + before] = JoinEntry{key, tc[wave][e], 0u};
+            }
+            run += (uint32_t)__popcll(m);
+        }
+        if (PARTIAL == 1 && lane == 0) ent_count[bucket] = run;
+        return;
+    }
     for (uint32_t e = lane; e < J_TAB; e += 64) {
         const unsigned long long key = tk[wave][e];
         const uint32_t common = tc[wave][e];
-        if (key == J_EMPTY || common < cmin_floor) continue;
+        if (key == J_EMPTY) continue;
+        if (common < cmin_floor) continue;
         const uint32_t gi = (uint32_t)(key >> 32), gj = (uint32_t)key;
         // Multi-GPU: every rank runs the whole (cheap) join, so all ranks take the same accept/decline decisions, and
         // reports the pairs with (i + j) mod world == rank.
@@ -443,6 +485,9 @@ template <typename Src>
 int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_t total_t, uint32_t n_valid_bound, uint32_t bits2,
               bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */) {
     const uint32_t nb = 256u << bits2;
+    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "    [partition] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
     uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256);   // hist1 | start1 | cursor1
     uint32_t *d_hist2 = jalloc<uint32_t>(ctx, owned, 2 * (size_t)nb);     // hist2 | cursor2
     uint32_t *d_start2 = jalloc<uint32_t>(ctx, owned, nb + 1);
@@ -450,6 +495,7 @@ int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_
     uint32_t *v1 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
     uint32_t *v2 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
     if (!d_hist1 || !d_hist2 || !d_start2 || !k1 || !k2 || (with_vals && (!v1 || !v2))) return GHIP_EHIP;
+    lap("alloc");
     uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_cursor2 = d_hist2 + nb;
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (256 + 257 + 256) * sizeof(uint32_t), ctx->stream));
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist2, 0, 2 * (size_t)nb * sizeof(uint32_t), ctx->stream));
@@ -461,12 +507,14 @@ int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_
     uint32_t hist1[256];
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(hist1, d_hist1, sizeof(hist1), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    lap("pass 1 + sync");
     const uint32_t big = *std::max_element(hist1, hist1 + 256);
     const unsigned tiles2 = (big + J_TILE - 1) / J_TILE;
     if (tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, d_start1, bits2, d_hist2);
     { const int src_ = scan_counters(ctx, owned, d_hist2, nb, d_start2, d_max); if (src_) return src_; }
     if (tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, d_start1, bits2,
                                    d_start2, d_cursor2, k2, v2);
+    lap("pass 2 launches");
     *keys_out = k2;
     if (vals_out) *vals_out = v2;
     *d_start2_out = d_start2;
@@ -515,7 +563,7 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     ghip_prof_begin(ctx, "pair_join");
     // 1. elements -> 65536 hash buckets
     uint64_t *ek = nullptr; uint32_t *ev = nullptr, *d_estart = nullptr;
-    ElemSrc es{d_hashes, d_lens, s, (uint32_t)(n * s)};
+    ElemSrc es{d_hashes, d_lens, s, (uint32_t)(n * s), 0u, 1u};
     const uint32_t ebits = bits2_for(n_elem, J_BITS2_MIN_ELEM), enb = 256u << ebits;
     int rc = partition(ctx, own.p, es, es.total, (uint32_t)n_elem, ebits, true, &ek, &ev, &d_estart, d_flags + 1);
     if (rc) { ghip_prof_end(ctx); return rc; }
@@ -545,7 +593,8 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     const uint32_t rbits = bits2_for(n_rec), rnb = 256u << rbits;  // ~350 records per sharing pair: few distinct pairs per bucket
     rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr);
     if (rc) { ghip_prof_end(ctx); return rc; }
-    hipLaunchKernelGGL(join_reduce_kernel, dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, d_pstart, d_hashes, d_lens, s,
+    hipLaunchKernelGGL((join_reduce_kernel<false, 0>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
+                       (JoinEntry *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s,
                        d_cmin, cmin_floor, rank, world, row_lo, d_out, d_count, cap, d_flags);
     ghip_prof_end(ctx);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -570,4 +619,124 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     }
     *used = true;
     return GHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hash-sharded form for several ranks (comm.cpp: precluster_join_sharded).  The one-rank join's element stage -- one pass
+// over all N*s hashes, three quarters of its time at 10 000 genomes -- does not shrink when the RECORDS are dealt over
+// the ranks; it does when the HASHES are: rank r partitions only the hashes whose first-level digit d has
+// d % world == r, finds the records of ALL genome pairs among them and reduces them to per-pair partial counts
+// (stage 1: ghip_pairs_join_partials).  The partial counts of all ranks are gathered (16 bytes per sharing pair and
+// rank: ~0.7 MB per rank at 10 000 genomes), and every rank sums those of the pairs it owns, (i + j) % world == rank,
+// through the same partition + LDS-table machinery with the counts as weights -- the sum IS common; ranks, integer
+// filter and candidate list as in the one-rank form (stage 2: ghip_pairs_join_finish).
+// *status bit 0: this rank declines (an element bucket beyond the LDS stage / a table overflow / more records than fit).
+
+int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s, uint32_t hrank,
+                             uint32_t hworld, void **d_entries_out, uint32_t *n_entries_out, uint32_t *status, unsigned long long *rec_total) {
+    *d_entries_out = nullptr; *n_entries_out = 0; *status = 1; *rec_total = 0;
+    if (n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
+    std::vector<uint32_t> lens(n);
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(lens.data(), d_lens, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t n_elem = 0;
+    for (uint32_t l : lens) { n_elem += l; if (l == 0) return GHIP_OK; }   // an empty sketch pairs with everything (NaN quirk): dense forms only
+    struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
+    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 8);  // [0] flags, [1] largest element bucket, [2..3] u64 records found, [4..5] records kept
+    if (!d_flags) return GHIP_EHIP;
+    unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_flags + 2);
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 8 * sizeof(uint32_t), ctx->stream));
+    ghip_prof_begin(ctx, "pair_join");
+    auto done = [&](int rc) { ghip_prof_end(ctx); return rc; };
+    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) { hipStreamSynchronize(ctx->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  [join_partials] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
+    uint64_t *ek = nullptr; uint32_t *ev = nullptr, *d_estart = nullptr;
+    ElemSrc es{d_hashes, d_lens, s, (uint32_t)(n * s), hrank, hworld};
+    const uint64_t mine_bound = n_elem;   // (an upper bound: the share is ~1/hworld of it, but a skewed input may put more here)
+    // (bucket count as in the one-rank form: a rank's hashes fill 1/hworld of the first-level digits, the buckets below
+    // each digit hold what they hold there)
+    const uint32_t ebits = bits2_for(n_elem, J_BITS2_MIN_ELEM), enb = 256u << ebits;
+    int rc = partition(ctx, own.p, es, es.total, (uint32_t)mine_bound, ebits, true, &ek, &ev, &d_estart, d_flags + 1);
+    if (rc) return done(rc);
+    lap("element partition");
+    uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
+    if (!d_rcount || !d_rstart) return done(GHIP_EHIP);
+    hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
+                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total, 0u, 1u, 0u);
+    if ((rc = scan_counters(ctx, own.p, d_rcount, enb, d_rstart, nullptr))) return done(rc);
+    uint32_t flags[2];
+    unsigned long long totals[2] = {0, 0};
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    lap("count records");
+    *rec_total = totals[0];
+    if ((flags[0] & 1u) || totals[0] >= (1ull << 31)) return done(GHIP_OK);   // declined (status bit 0 stays set)
+    const uint32_t n_rec = (uint32_t)totals[1];
+    uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
+    if (!d_rec) return done(GHIP_EHIP);
+    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total, 0u, 1u, 0u);
+    lap("emit records");
+    uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
+    RecSrc rs{d_rec, n_rec};
+    const uint32_t rbits = bits2_for(n_rec), rnb = 256u << rbits;
+    if ((rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr))) return done(rc);
+    // pairs per bucket -> their offsets -> the entries, compact and in bucket order (no atomics)
+    uint32_t *d_ecount = jalloc<uint32_t>(ctx, own.p, rnb), *d_estart2 = jalloc<uint32_t>(ctx, own.p, rnb + 1);
+    if (!d_ecount || !d_estart2) return done(GHIP_EHIP);
+    hipLaunchKernelGGL((join_reduce_kernel<false, 1>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
+                       (JoinEntry *)nullptr, d_ecount, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s, (const uint16_t *)nullptr, 0u, 0u, 1u, 0u,
+                       (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags);
+    if ((rc = scan_counters(ctx, own.p, d_ecount, rnb, d_estart2, nullptr))) return done(rc);
+    uint32_t f0 = 0, n_ent = 0;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&f0, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&n_ent, d_estart2 + rnb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    lap("count entries");
+    if (f0 & 2u) return done(GHIP_OK);   // a record table overflowed: declined
+    JoinEntry *d_ent = (JoinEntry *)ghip_pool_alloc(ctx, (size_t)std::max<uint32_t>(n_ent, 1) * sizeof(JoinEntry));
+    if (!d_ent) return done(GHIP_EHIP);
+    hipLaunchKernelGGL((join_reduce_kernel<false, 2>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
+                       d_ent, (uint32_t *)nullptr, d_estart2, d_pstart, d_hashes, d_lens, s, (const uint16_t *)nullptr, 0u, 0u, 1u, 0u,
+                       (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags);
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // (the scratch blocks go back to the pool on return)
+    lap("emit entries");
+    *d_entries_out = d_ent; *n_entries_out = n_ent; *status = 0;
+    return done(GHIP_OK);
+}
+
+// d_all: the entries of every rank, blocks padded with key = 2^64 - 1.  *ok = false: this rank's tables overflowed (huge
+// families); the caller owes its (i + j) % world share by a dense pass.
+int ghip_pairs_join_finish(ghip_ctx *ctx, const void *d_all, uint32_t n_all, uint32_t n_mine_bound, const uint64_t *d_hashes, const uint32_t *d_lens,
+                           uint32_t s, const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
+                           unsigned long long *d_count, uint64_t cap, bool *ok) {
+    *ok = false;
+    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  [join_finish] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
+    struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
+    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 2);
+    if (!d_flags) return GHIP_EHIP;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), ctx->stream));
+    ghip_prof_begin(ctx, "pair_join");
+    auto done = [&](int rc) { ghip_prof_end(ctx); return rc; };
+    uint64_t *rk = nullptr; uint32_t *rw = nullptr, *d_pstart = nullptr;
+    EntrySrc src{reinterpret_cast<const JoinEntry *>(d_all), n_all, rank, world};
+    const uint32_t bound = std::max<uint32_t>(std::min(n_all, n_mine_bound), 1u);
+    const uint32_t rbits = bits2_for((uint64_t)bound * 64), rnb = 256u << rbits;   // ~world entries per pair: tables of 256 pairs want few pairs per bucket
+    lap("set-up");
+    int rc = partition(ctx, own.p, src, n_all, bound, rbits, true, &rk, &rw, &d_pstart, nullptr);
+    if (rc) return done(rc);
+    lap("partition");
+    hipLaunchKernelGGL((join_reduce_kernel<true, 0>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, rw, (JoinEntry *)nullptr,
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s, d_cmin, cmin_floor, 0u, 1u, 0u, d_out, d_count, cap, d_flags);
+    uint32_t flags = 0;
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    lap("reduce + sync");
+    if (flags & 2u) { GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream)); return done(GHIP_OK); }
+    *ok = true;
+    return done(GHIP_OK);
 }

@@ -255,6 +255,13 @@ int ghip_comm_allgather_host(ghip_comm *comm, const void *send, size_t bytes_per
 void ghip_shard_range(size_t n_total, uint32_t rank, uint32_t world, size_t *first, size_t *count, size_t *block);
 /* local = the sketches of this rank's block -> the matrix of all n_total genomes on every rank (N*s*8 bytes, once) */
 int ghip_allgather_sketches(ghip_comm *comm, const ghip_sketches *local, size_t n_total, ghip_sketches **out_full);
+/* This rank's share of the precluster pairs of the gathered matrix (every rank passes the same matrix; collective): the
+ * multi-rank form of ghip_precluster.  From 1 200 genomes the inverted-index form runs hash-sharded -- every rank
+ * partitions 1/world of the hashes, the per-pair partial counts are exchanged (16 bytes per sharing pair and rank),
+ * every rank finishes the pairs with (i + j) % world == rank; otherwise, or when any rank declines, as
+ * ghip_precluster_ranks (GHIP_JOIN_RANKS=records forces that, =replicate the whole list on every rank). */
+int ghip_precluster_comm(ghip_comm *comm, const ghip_sketches *sk, float min_ani_fraction, ghip_pair **out_pairs, size_t *out_n,
+                         int *out_replicated);
 /* every rank's share of the candidate list (sorted by (i, j)) -> the whole list in (i, j) order on every rank */
 int ghip_allgather_pairs(ghip_comm *comm, const ghip_pair *local, size_t n_local, ghip_pair **out_all, size_t *out_n);
 /* The ANI index slices a rank needs but does not own (second genomes of pairs whose first genome it owns; `pairs` is

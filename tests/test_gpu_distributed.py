@@ -105,14 +105,16 @@ def test_lazy_ani_on_one_rank_equals_all_pairs(ctx, monkeypatch):
             assert asked < len(full["pairs"])       # family of 8: 7 edges to the representative, the other 21 never asked
 
 
-@pytest.mark.parametrize("mode", ["shard", "replicate"])
-def test_three_ranks_join_form_equals_single_rank(ctx, mode):
-    """N = 2100 short genomes on three ranks (ragged shards): the pair stage takes the join form -- sharded at record
-    emission by (i + j) mod world with the shares gathered and merged (default), or run whole on every rank
-    (GHIP_JOIN_RANKS=replicate).  Families straddle the shard boundaries, so ANI index slices are exchanged too."""
+@pytest.mark.parametrize("mode,world", [("shard", 3), ("records", 3), ("replicate", 3), ("shard", 8)])
+def test_ranks_join_form_equals_single_rank(ctx, mode, world):
+    """N = 2100 short genomes on three and on eight ranks (ragged shards): the pair stage takes the join form -- HASH-SHARDED
+    (default: every rank partitions 1/world of the hashes, the per-pair partial counts are exchanged, a rank finishes the
+    pairs with (i + j) mod world = rank), sharded at record emission with the element stage replicated
+    (GHIP_JOIN_RANKS=records), or run whole on every rank (=replicate).  Families straddle the shard boundaries, so ANI
+    index slices are exchanged too."""
     import oracle
     n, length = 2100, 30_000
-    got = _run(3, n=n, length=length, env={"GHIP_JOIN_RANKS": mode})
+    got = _run(world, n=n, length=length, env={"GHIP_JOIN_RANKS": mode})
     want, hashes, lens = _single(ctx, n, length)
     _same(got, want, hashes, lens)
     assert got["compared"] == n * (n - 1) // 2          # the ranks' shares partition the triangle
