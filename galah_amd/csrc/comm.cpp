@@ -361,7 +361,7 @@ extern "C" int ghip_allgather_sketches(ghip_comm *c, const ghip_sketches *local,
         COMM_HIP(c, hipMemsetAsync((char *)sendl.p + count * 4, 0, (block - count) * 4, ctx->stream));
     }
     int rc = count ? ghip_sketches_copy_into(ctx, local, sendh.p, sendl.p) : GHIP_OK;
-    if (rc) return rc;
+    if (rc) return cerr_(c, rc, std::string("sketch all-gather: ") + ghip_last_error(ctx));   // (tells the peers of a LOCAL group)
     if ((rc = allgather_device(c, sendh.p, recvh.p, block * (size_t)s * 8))) return rc;
     if ((rc = allgather_device(c, sendl.p, recvl.p, block * 4))) return rc;
     ghip_sketches *full = nullptr;
@@ -520,8 +520,13 @@ struct IndexField { const void *src; size_t esz; const std::vector<uint64_t> *st
 // A pair's ANI is computed on the rank that owns its FIRST genome; that rank needs the index slices of second genomes
 // it does not own.  `pairs` is the whole list (identical on every rank).  On return *out_index serves this rank's pairs:
 // the local index itself (*out_index == local, nothing was exchanged) or a combined index = local genomes followed by
-// every exchanged genome in ascending order; out_local_ids[g] maps global genome ids to positions in that index
-// (UINT32_MAX: not present on this rank).
+// the foreign genomes THIS rank's pairs reference, in ascending order; out_local_ids[g] maps global genome ids to
+// positions in that index (UINT32_MAX: not present on this rank).
+// Transport: every owner offers the slices of its genomes that ANY rank needs, packed back to back, in one all-gather
+// per array (the primitive the three transports share); a rank keeps only what its own pairs reference -- the combined
+// index does not grow with the world size.  (Traffic does: with input in arbitrary order nearly every clustered genome
+// is needed somewhere.  Send/receive of exactly the wanted slices is the next step where that matters; for input whose
+// families are contiguous -- sorted by taxonomy or by a previous clustering, as in the bench -- little or nothing moves.)
 extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local, size_t n_total, const ghip_pair *pairs,
                                        size_t n_pairs, ghip_ani_index **out_index, uint32_t *out_local_ids /* [n_total] */) {
     if (!c || !local || !out_index || !out_local_ids || (n_pairs && !pairs)) return GHIP_EINVAL;
@@ -532,11 +537,12 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     if (local->n != count) return cerr_(c, GHIP_EINVAL, "local ANI index does not match this rank's block");
     for (size_t g = 0; g < n_total; g++) out_local_ids[g] = UINT32_MAX;
     for (size_t g = 0; g < count; g++) out_local_ids[first + g] = (uint32_t)g;
-    // second genomes of pairs that span two ranks, ascending, the same list on every rank
+    // second genomes of pairs that span two ranks: `needed` (ascending, the same list on every rank) and, of those, the ones
+    // MY pairs reference
     std::vector<uint8_t> mark(n_total, 0);
     for (size_t x = 0; x < n_pairs; x++) {
         if (pairs[x].i >= n_total || pairs[x].j >= n_total) return cerr_(c, GHIP_EINVAL, "pair index out of range");
-        if (pairs[x].i / block != pairs[x].j / block) mark[pairs[x].j] = 1;
+        if (pairs[x].i / block != pairs[x].j / block) mark[pairs[x].j] |= (pairs[x].i / block == c->rank) ? 3 : 1;
     }
     std::vector<uint32_t> needed;
     for (size_t g = 0; g < n_total; g++) if (mark[g]) needed.push_back((uint32_t)g);
@@ -560,13 +566,18 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     if (n_recv != needed.size()) return cerr_(c, GHIP_EINVAL, "ranks disagree on the genomes to exchange");
     const uint64_t *rm = reinterpret_cast<const uint64_t *>(meta_all.data());
 
-    // combined metadata: local genomes, then the exchanged ones (owners ascending == genome ids ascending)
-    const size_t nc = count + n_recv;
+    // combined metadata: local genomes, then the foreign genomes my pairs reference (ascending)
+    std::vector<size_t> wanted;   // positions in `needed`
+    for (size_t x = 0; x < n_recv; x++) if ((mark[needed[x]] & 2) && out_local_ids[needed[x]] == UINT32_MAX) wanted.push_back(x);
+    const size_t nc = count + wanted.size();
     std::vector<uint64_t> glen(nc), cap(nc);
     std::vector<uint32_t> cnt(nc);
     for (size_t g = 0; g < count; g++) { glen[g] = local->glen[g]; cap[g] = local->seed_start[g + 1] - local->seed_start[g]; cnt[g] = local->seed_count[g]; }
-    for (size_t x = 0; x < n_recv; x++) { glen[count + x] = rm[3 * x]; cap[count + x] = rm[3 * x + 1]; cnt[count + x] = (uint32_t)rm[3 * x + 2]; }
-    for (size_t x = 0; x < n_recv; x++) if (out_local_ids[needed[x]] == UINT32_MAX) out_local_ids[needed[x]] = (uint32_t)(count + x);
+    for (size_t w = 0; w < wanted.size(); w++) {
+        const size_t x = wanted[w];
+        glen[count + w] = rm[3 * x]; cap[count + w] = rm[3 * x + 1]; cnt[count + w] = (uint32_t)rm[3 * x + 2];
+        out_local_ids[needed[x]] = (uint32_t)(count + w);
+    }
     std::vector<uint64_t> cseed(nc + 1, 0), cchunk(nc + 1, 0);
     for (size_t g = 0; g < nc; g++) {
         cseed[g + 1] = cseed[g] + cap[g];
@@ -576,6 +587,12 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     std::vector<uint64_t> lbin(count + 1), cbin(nc + 1);
     for (size_t g = 0; g <= count; g++) lbin[g] = g * bins;
     for (size_t g = 0; g <= nc; g++) cbin[g] = g * bins;
+    // per-genome slots of every exchanged genome in each array (from the gathered metadata): seeds, seeds, bins, chunks
+    auto slots_of = [&](int field, size_t x) -> uint64_t {
+        if (field <= 1) return rm[3 * x + 1];
+        if (field == 2) return bins;
+        return (rm[3 * x] + local->chunk - 1) / local->chunk;
+    };
 
     // the flat arrays of the index: element size, per-genome slot offsets (local layout, combined layout)
     struct Field { const void *src; size_t esz; const std::vector<uint64_t> *lstart; const std::vector<uint64_t> *cstart; void *dst; };
@@ -588,14 +605,19 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     COMM_HIP(c, hipSetDevice(ctx->device));
     std::vector<void *> owned;
     auto drop = [&]() { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->stream); for (void *p : owned) ghip_pool_free(ctx, p); };
-    for (Field &f : fields) {
+    // every early return below goes through fail(): the peers are told (LOCAL: the group's flag; the others learn it at
+    // their next collective) and the combined arrays go back to the pool
+    auto fail = [&](int code, const std::string &msg) { drop(); return cerr_(c, code, msg); };
+    for (int fi = 0; fi < 4; fi++) {
+        Field &f = fields[fi];
         PoolBuf dst(ctx, std::max<uint64_t>((*f.cstart)[nc], 1) * f.esz);
-        if (!dst.p) { drop(); return cerr_(c, GHIP_EHIP, "out of device memory for the combined ANI index"); }
+        if (!dst.p) return fail(GHIP_EHIP, "out of device memory for the combined ANI index");
         f.dst = dst.release();
         owned.push_back(f.dst);
         // local part: one copy
         const uint64_t lbytes = (*f.lstart)[count] * f.esz;
-        if (lbytes) COMM_HIP(c, hipMemcpyAsync(f.dst, f.src, lbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        hipError_t e = lbytes ? hipMemcpyAsync(f.dst, f.src, lbytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
+        if (e != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
         // what I send, packed back to back
         uint64_t mine = 0;
         for (uint32_t g : send) mine += ((*f.lstart)[g + 1] - (*f.lstart)[g]) * f.esz;
@@ -604,27 +626,44 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
         const uint64_t m = (*std::max_element(sizes.begin(), sizes.end()) + 15) / 16 * 16;
         if (m == 0) continue;
         PoolBuf sb(ctx, m), rb(ctx, m * c->world);
-        if (!sb.p || !rb.p) { drop(); return cerr_(c, GHIP_EHIP, "out of device memory for the ANI index exchange"); }
+        if (!sb.p || !rb.p) return fail(GHIP_EHIP, "out of device memory for the ANI index exchange");
         uint64_t at = 0;
         for (uint32_t g : send) {
             const uint64_t b = ((*f.lstart)[g + 1] - (*f.lstart)[g]) * f.esz;
-            if (b) COMM_HIP(c, hipMemcpyAsync((char *)sb.p + at, (const char *)f.src + (*f.lstart)[g] * f.esz, b, hipMemcpyDeviceToDevice, ctx->stream));
+            if (b && (e = hipMemcpyAsync((char *)sb.p + at, (const char *)f.src + (*f.lstart)[g] * f.esz, b, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess)
+                return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
             at += b;
         }
         if ((rc = allgather_device(c, sb.p, rb.p, m))) { drop(); return rc; }
-        // the ranks' packed runs, in rank order, are the exchanged genomes in ascending order
-        uint64_t dst_at = (*f.cstart)[count] * f.esz;
-        for (uint32_t r = 0; r < c->world; r++) {
-            if (sizes[r]) COMM_HIP(c, hipMemcpyAsync((char *)f.dst + dst_at, (const char *)rb.p + (size_t)r * m, sizes[r], hipMemcpyDeviceToDevice, ctx->stream));
-            dst_at += sizes[r];
+        // the ranks' packed runs, in rank order, are the exchanged genomes in ascending order: walk them, keep the wanted
+        // ones (consecutive wanted genomes of one owner move in one copy)
+        std::vector<uint64_t> run_at(c->world, 0);
+        size_t w = 0;
+        uint64_t pend_src = 0, pend_dst = 0, pend_bytes = 0;
+        auto flush = [&]() -> hipError_t {
+            hipError_t r = pend_bytes ? hipMemcpyAsync((char *)f.dst + pend_dst, (const char *)rb.p + pend_src, pend_bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
+            pend_bytes = 0;
+            return r;
+        };
+        for (size_t x = 0; x < n_recv; x++) {
+            const uint32_t owner = (uint32_t)(needed[x] / block);
+            const uint64_t b = slots_of(fi, x) * f.esz, src_at = (uint64_t)owner * m + run_at[owner];
+            run_at[owner] += b;
+            if (w < wanted.size() && wanted[w] == x) {
+                const uint64_t dst_at = (*f.cstart)[count + w] * f.esz;
+                if (pend_bytes && pend_src + pend_bytes == src_at && pend_dst + pend_bytes == dst_at) pend_bytes += b;
+                else { if ((e = flush()) != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e)); pend_src = src_at; pend_dst = dst_at; pend_bytes = b; }
+                w++;
+            }
         }
-        if (dst_at != (*f.cstart)[nc] * f.esz) { drop(); return cerr_(c, GHIP_EINVAL, "ANI index exchange: sizes do not add up"); }
-        COMM_HIP(c, hipStreamSynchronize(ctx->stream));   // sb/rb go back to the pool
+        if ((e = flush()) != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
+        for (uint32_t r = 0; r < c->world; r++) if (run_at[r] != sizes[r]) return fail(GHIP_EINVAL, "ANI index exchange: sizes do not add up");
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));   // sb/rb go back to the pool
     }
     ghip_ani_index *idx = nullptr;
     rc = ghip_ani_index_wrap_device(ctx, nc, local->k, local->c, local->chunk, glen.data(), cap.data(), cnt.data(), fields[0].dst,
                                     fields[1].dst, fields[2].dst, fields[3].dst, &idx);
-    if (rc) { drop(); return rc; }
+    if (rc) { drop(); if (c->group) c->group->fail(); return rc; }
     idx->owned = true;   // the combined arrays belong to the handle
     *out_index = idx;
     return GHIP_OK;
@@ -695,7 +734,7 @@ extern "C" int ghip_distances_and_ani_ranks(ghip_comm *c, const ghip_genomes *lo
     }
     lap(tm.ani_pairs_ms);
     ani = (float *)malloc(std::max<size_t>(n_all, 1) * sizeof(float));
-    if (!ani) { cleanup(); ghip_free(all); return GHIP_ENOMEM; }
+    if (!ani) { cleanup(); ghip_free(all); return cerr_(c, GHIP_ENOMEM, "out of host memory for the ANI values"); }
     if (c->world == 1) { if (n_all) memcpy(ani, ani_mine.data(), n_all * sizeof(float)); }
     else {  // the ranks' runs are consecutive in rank order: a variable-length gather IS the whole array
         std::vector<uint8_t> got;

@@ -266,7 +266,8 @@ int ghip_precluster_comm(ghip_comm *comm, const ghip_sketches *sk, float min_ani
 int ghip_allgather_pairs(ghip_comm *comm, const ghip_pair *local, size_t n_local, ghip_pair **out_all, size_t *out_n);
 /* The ANI index slices a rank needs but does not own (second genomes of pairs whose first genome it owns; `pairs` is
  * the whole list).  *out_index = `local` itself when nothing had to move, else a new handle (free it) = local genomes
- * followed by the exchanged ones; out_local_ids[g] = position of global genome g in it, UINT32_MAX if absent. */
+ * followed by the foreign genomes THIS rank's pairs reference; out_local_ids[g] = position of global genome g in it,
+ * UINT32_MAX if absent.  (Owners offer what any rank needs in one all-gather per array; a rank keeps what it wants.) */
 int ghip_exchange_ani_index(ghip_comm *comm, const ghip_ani_index *local, size_t n_total, const ghip_pair *pairs,
                             size_t n_pairs, ghip_ani_index **out_index, uint32_t *out_local_ids /* [n_total] */);
 typedef struct {   /* wall milliseconds of one ghip_distances_and_ani_ranks call on this rank */
