@@ -9,9 +9,9 @@ ANI on the surviving pairs -> host greedy clustering at 95 %.  value = genome pa
 Workloads (BASELINE.json):
   --gpus 1            the configuration BASELINE's north_star quotes the metric on: 10 000 synthetic ~5 Mb genomes
                       (1 000 species x 10 members at ~95 % identity), s = 1000, on ONE MI355X (configs[2]'s size).
-  --gpus N (N > 1)    1 250 genomes per GPU, i.e. configs[2] -- 10 000 genomes -- on 8 GPUs (weak scaling: per-GPU
-                      sketch/ANI work is fixed, the all-vs-all pair count grows as N^2, so `value` grows faster than N;
-                      `genomes_per_s` is the linear figure).  --total-genomes T pins the total instead (strong scaling).
+  --gpus N (N > 1)    the SAME 10 000 genomes sharded over the N GPUs (strong scaling: the values at N = 1, 2, 4, 8 are
+                      one workload's, directly comparable; N = 8 is BASELINE configs[2]).  --species S gives every GPU
+                      S species instead (weak scaling: the all-vs-all pair count then grows as N^2).
 Genomes are sketched where they live, the sketch matrix is all-gathered over RCCL, the pair stage runs on the
 gathered matrix, ANI runs where a pair's first genome lives.
 
@@ -49,7 +49,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 LDS_ROOF_PAIRS_PER_S = 9.4e9  # ~150 TB/s aggregate LDS bandwidth / 16 000 algorithmic bytes per pair (s = 1000)
 GENOMES_1GPU = 10_000        # north_star: 10k x 5 Mb on one MI355X
-GENOMES_PER_GPU_N = 1250     # configs[2] = 10 000 genomes on 8 GPUs
 
 
 def parse():
@@ -57,8 +56,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--species", type=int, default=None, help="species per GPU (default 1 000 at --gpus 1, 125 per GPU above)")
-    ap.add_argument("--total-genomes", type=int, default=None, help="total genomes sharded over the ranks (strong scaling)")
+    ap.add_argument("--species", type=int, default=None, help="species per GPU (weak scaling); default: 1 000 species in total, whatever --gpus is")
+    ap.add_argument("--total-genomes", type=int, default=None, help="total genomes sharded over the ranks (strong scaling; default 10 000)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --species is the total, sharded over the ranks")
     ap.add_argument("--members", type=int, default=10)
     ap.add_argument("--length", type=int, default=5_000_000)
@@ -614,7 +613,8 @@ def main_single(args, ctx, json_fd):
     out = {
         "metric": "genome-pairs/sec (MinHash+ANI)", "value": head["value"], "unit": "genome-pairs/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        # strong: --gpus N shards this same workload (the default); weak with --species (a per-GPU size)
+        "higher_is_better": True, "scaling": "weak" if args.species else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{n} synthetic genomes x {args.length} bp ({n_species} species x {args.members} members, ~95% ANI) on 1 MI355X, "
                                f"finch precluster s={args.sketch_size} k={args.kmer} at {args.precluster_ani}% + ANI at {args.ani}%, greedy clustering"
                                + (" = the configuration BASELINE north_star quotes the metric on (configs[2]'s size on one GPU)" if is_north_star else ""),
@@ -733,10 +733,12 @@ def main():
     elif args.strong:
         n = (args.species or 1000) * args.members
         scaling = "strong"
-    else:
-        per_gpu = args.species * args.members if args.species else GENOMES_PER_GPU_N
-        n = per_gpu * world
+    elif args.species:
+        n = args.species * args.members * world
         scaling = "weak"
+    else:
+        n = GENOMES_1GPU // args.members * args.members   # the north-star workload, sharded: strong scaling
+        scaling = "strong"
     n_species = n // args.members
     n_pairs_total = n * (n - 1) // 2
     min_ani = parse_percentage(args.precluster_ani)           # fraction (finch.rs:5-6)

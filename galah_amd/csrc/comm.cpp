@@ -507,6 +507,7 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
     lap(ok ? "stage 2 (finish)" : "stage 2 gave up: dense share");
     // my tables overflowed (huge families): the other ranks deliver their shares, I owe exactly mine -- by a dense pass
     if (!ok) return ghip_precluster_dense_share(ctx, sk, min_ani, rank, world, out_pairs, out_n);
+    std::lock_guard<std::mutex> lk(ctx->mu);   // (the recheck's table of f64 results lives in the context)
     return ghip_pairs_finalize(ctx, host, sk->k, min_ani, n, false, rank, world, out_pairs, out_n);
 }
 

@@ -77,6 +77,8 @@ struct ghip_ctx {
     std::mutex pool_mu;  // the pool itself: taken inside ghip_pool_alloc/free, so that the file ingest can allocate while
                          // another call holds `mu` for the length of its kernels (lock order: mu, then pool_mu)
     ghip_cmin_cache cmin;
+    std::vector<double> ani_memo;   // finch_ani(common, total) of the pair stage's host recheck, [total][common] for (k, s) below; NaN = not yet (under mu)
+    uint32_t ani_memo_k = 0, ani_memo_s = 0;
     uint64_t *d_kmer_luts = nullptr;  // MurmurHash3 first-stage tables of sketch_kmers21 (12 KiB, built once; pool-owned)
     // ingest staging (ghip_genomes_from_files): pinned double buffers of the worker threads and two copy streams, kept
     // for the life of the context (hipHostMalloc costs ~0.16 ms/MB, hipStreamCreate ~3 ms)

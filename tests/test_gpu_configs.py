@@ -365,7 +365,7 @@ def test_bench_line_contract():
                   "vs_baseline", "dtype", "data", "config", "roofline"):
             assert k in d, k
         assert d["metric"].startswith("genome-pairs/sec") and d["unit"] == "genome-pairs/s" and d["higher_is_better"] is True
-        assert d["n_gpus"] == (2 if extra else 1) and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+        assert d["n_gpus"] == (2 if extra else 1) and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"   # (--species: per-GPU work fixed)
         assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
         rf = d["roofline"]
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
