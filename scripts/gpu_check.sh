@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -4
-timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('value %.3e  ms/step %.2f' % (d['value'], d['ms_per_step']))
