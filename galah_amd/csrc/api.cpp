@@ -575,8 +575,18 @@ static int genomes_from_files_two_phase(ghip_ctx *ctx, const char *const *paths,
 // it straight to its final place in HBM while the other threads are still parsing -- parsing (~12 GB/s per
 // thread on clean lines) and PCIe (~55 GB/s) overlap instead of adding up.  Gaps between capacity and actual length stay 'N'
 // (the buffer is 'N'-filled).
+static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads, const uint64_t *known_caps,
+                                   ghip_genomes **out);
+
 extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads,
                                        ghip_genomes **out) {
+    return genomes_from_files_impl(ctx, paths, n, io_threads, nullptr, out);
+}
+
+// known_caps (nullable): the capacity hints of the files, already looked up by the caller (one stat per file is 0.1-0.2 s
+// for 100 000 contig files: not twice)
+static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads, const uint64_t *known_caps,
+                                   ghip_genomes **out) {
     if (!ctx || !out || (n && !paths)) return GHIP_EINVAL;
     if (getenv("GHIP_INGEST") && !strcmp(getenv("GHIP_INGEST"), "two-phase"))
         return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);
@@ -585,8 +595,8 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<uint64_t> cap(n);
     uint64_t max_cap = 0;
-    // (five system calls per file: 5 ms per 1 000 files on one thread)
-    parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b, size_t e) {
+    if (known_caps) std::copy(known_caps, known_caps + n, cap.begin());
+    else parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) cap[i] = ghip_stream_capacity_hint(paths[i]);
     });
     for (size_t i = 0; i < n; i++) max_cap = std::max(max_cap, cap[i]);
@@ -682,7 +692,11 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
         for (int x = 0; x < ctx->n_copy_streams; x++) use_pinned = use_pinned && ctx->copy_stream[x];
         // (the packed form stages a quarter of the bytes: streams of up to four times the size go through the slots)
         const bool packed_wanted = use_pinned && !(ing && !strcmp(ing, "ascii"));
-        const size_t slot_bytes = std::min<size_t>(((size_t)max_cap + 64 + 4095) / 4096 * 4096, packed_wanted ? 4 * GHIP_PINNED_SLOT_MAX : GHIP_PINNED_SLOT_MAX);
+        // (a slot holds the largest file -- or, where the files are small, a group of them: 4 Mbases, see `units` below)
+        uint64_t sum_cap = 0;
+        for (size_t i = 0; i < n; i++) sum_cap += cap[i] + 2 * GHIP_TAIL_PAD;
+        const size_t slot_want = std::max<size_t>((size_t)max_cap + 64, packed_wanted ? (size_t)std::min<uint64_t>(4u << 20, sum_cap) : 0);
+        const size_t slot_bytes = std::min<size_t>((slot_want + 4095) / 4096 * 4096, packed_wanted ? 4 * GHIP_PINNED_SLOT_MAX : GHIP_PINNED_SLOT_MAX);
         // Packed form (the default; GHIP_INGEST=ascii turns it off): the stream crosses PCIe as 2-bit codes plus the runs
         // of its other bytes -- a quarter of the bytes, and PCIe is what bounds files -> clusters (5 GB: 88 ms).  The
         // codes ARE the resident form: they are copied straight to their place; the run table goes to a small device
@@ -754,17 +768,34 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
             { std::lock_guard<std::mutex> l(smu); sl->state = state; sl->seq = ++slot_seq; }
             scv.notify_one();
         };
+        // work units: a file, or a run of consecutive SMALL files shipped as one group (packed form only)
+        std::vector<std::pair<size_t, size_t>> units;
+        {
+            constexpr uint64_t SMALL_FILE = 256u << 10, GROUP_BASES = 4u << 20;
+            constexpr size_t GROUP_FILES = 512;
+            const bool grouping = packed_mode && n_slots && !getenv("GHIP_INGEST_NO_GROUPS");
+            for (size_t i = 0; i < n;) {
+                size_t j = i + 1;
+                if (grouping && cap[i] <= SMALL_FILE) {
+                    uint64_t bases = next_genome_offset(0, cap[i]);
+                    while (j < n && j - i < GROUP_FILES && cap[j] <= SMALL_FILE && bases + next_genome_offset(0, cap[j]) <= std::min<uint64_t>(GROUP_BASES, slot_bytes)) {
+                        bases += next_genome_offset(0, cap[j]);
+                        j++;
+                    }
+                }
+                units.push_back({i, j});
+                i = j;
+            }
+        }
         auto worker = [&](int me) {
             if (hipSetDevice(ctx->device) != hipSuccess) { fail(GHIP_EHIP, "hipSetDevice failed in an ingest thread"); return; }
             hipStream_t cs = ctx->copy_stream[me % ctx->n_copy_streams];
             std::vector<uint8_t> &raw = ctx->io.raw[me];
             std::vector<uint8_t> heap_buf;
-            for (;;) {
-                if (status.load() != GHIP_OK || over.load()) break;
-                const size_t i = next.fetch_add(1);
-                if (i >= n) break;
+            // one file: parse, ship, build its validity bits.  Returns true when the worker must stop.
+            auto ingest_one = [&](const size_t i) -> bool {
                 const auto t0 = std::chrono::steady_clock::now();
-                if (!ghip_slurp(paths[i], raw)) { fail(GHIP_EIO, std::string("Failed to open fasta file ") + paths[i]); break; }
+                if (!ghip_slurp(paths[i], raw)) { fail(GHIP_EIO, std::string("Failed to open fasta file ") + paths[i]); return true; }
                 const auto t1 = std::chrono::steady_clock::now();
                 size_t len = 0;
                 std::string e;
@@ -785,8 +816,8 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                     bool fit = false;
                     // (the run table is bounded by the slot's device staging area: a stream with more runs "does not fit")
                     const size_t table_at = (((size_t)cap[i] + 3) / 4 + 15) / 16 * 16;
-                    r = ghip_parse_fasta_packed(raw.data(), raw.size(), paths[i], slot->p, std::min(slot->bytes, table_at + slot->dbytes), (size_t)cap[i],
-                                                &len, g->stats[i], e, &used, &runs_off, &n_runs, &fit);
+                    r = ghip_parse_fasta_packed(raw.data(), raw.size(), paths[i], slot->p, std::min(slot->bytes, table_at + slot->dbytes) - 8, (size_t)cap[i],
+                                                &len, g->stats[i], e, &used, &runs_off, &n_runs, &fit);   // (- 8: the one-entry genome table goes behind the runs)
                     t2 = std::chrono::steady_clock::now();
                     if (r != GHIP_OK) { fail(r, e); stop = true; done = true; }
                     else if (fit) {
@@ -795,9 +826,12 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                         if (len) {
                             // the codes to their place (whole 16-byte groups: the slot is zero-padded, the genome's room is longer)
                             ce = hipMemcpyAsync(reinterpret_cast<uint8_t *>(g->d_packed) + g->starts[i] / 4, slot->p, ((len + 3) / 4 + 15) / 16 * 16, hipMemcpyHostToDevice, cs);
-                            if (ce == hipSuccess && n_runs) ce = hipMemcpyAsync(slot->d, slot->p + runs_off, (size_t)12 * n_runs, hipMemcpyHostToDevice, cs);
+                            uint32_t gtab[2] = {0u, (uint32_t)len};   // (len < 2^32: the packed parser refuses longer streams)
+                            memcpy(slot->p + runs_off + (size_t)12 * n_runs, gtab, 8);
+                            if (ce == hipSuccess) ce = hipMemcpyAsync(slot->d, slot->p + runs_off, (size_t)12 * n_runs + 8, hipMemcpyHostToDevice, cs);
                             if (ce == hipSuccess) {
-                                ghip_launch_valid_from_runs(cs, reinterpret_cast<const uint32_t *>(slot->d), n_runs, g->d_valid + g->starts[i] / 32, len);
+                                ghip_launch_valid_from_runs(cs, reinterpret_cast<const uint32_t *>(slot->d) + 3 * (size_t)n_runs, 1, len,
+                                                            reinterpret_cast<const uint32_t *>(slot->d), n_runs, g->d_valid + g->starts[i] / 32, true);
                                 ce = hipGetLastError();   // (per thread: the two launches just made)
                                 if (ce == hipSuccess) ce = hipEventRecord(slot->ev, cs);
                                 inflight = true;
@@ -853,8 +887,78 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
                 t_read += std::chrono::duration<double>(t1 - t0).count();
                 t_parse += std::chrono::duration<double>(t2 - t1b).count();
                 if (slot) give_slot(slot, inflight ? 2 : 0);
-                if (stop) break;
+                if (stop) return true;
                 t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() + std::chrono::duration<double>(t1b - t1).count();
+                return false;
+            };
+            // a GROUP of small files (consecutive in the list, hence in the device layout): every member parsed and packed
+            // into ONE slot image laid out exactly like the group's region of the device arrays, shipped with one copy, its
+            // members' validity bits built by one pair of launches -- a file of a few kilobases otherwise costs the copy
+            // streams five operations of its own (100 000 contigs: 1.1 s of a 1.8 s run).  A member that does not fit the
+            // packed form (too many runs, outgrown hint) sends the whole group through the one-file path.
+            auto ingest_group = [&](const size_t first, const size_t last) -> bool {
+                const uint64_t base = g->starts[first], end = next_genome_offset(g->starts[last - 1], cap[last - 1]);
+                const size_t codes_bytes = (size_t)((end - base) / 4), m = last - first;
+                ghip_ctx::pinned_slot *slot = take_slot();
+                uint32_t *gtab = reinterpret_cast<uint32_t *>(slot->p + codes_bytes), *runs = gtab + 2 * m;
+                const size_t run_cap = std::min((slot->bytes - codes_bytes) / 4, slot->dbytes / 4) > 2 * m ? (std::min((slot->bytes - codes_bytes) / 4, slot->dbytes / 4) - 2 * m) / 3 : 0;
+                std::vector<uint8_t> &scratch = ctx->io.ascii[me];
+                size_t n_runs_all = 0;
+                uint64_t max_len = 0;
+                bool ok = true, stop = false;
+                for (size_t i = first; i < last && ok; i++) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (!ghip_slurp(paths[i], raw)) { fail(GHIP_EIO, std::string("Failed to open fasta file ") + paths[i]); stop = true; break; }
+                    const auto t1 = std::chrono::steady_clock::now();
+                    const size_t need = (((size_t)cap[i] + 3) / 4 + 15) / 16 * 16 + 12 * 1024 + 64;   // codes + room for 1 024 runs
+                    if (scratch.size() < need) scratch.resize(need);
+                    size_t len = 0, used = 0, runs_off = 0;
+                    uint32_t n_runs = 0;
+                    bool fit = false;
+                    std::string e;
+                    const int r = ghip_parse_fasta_packed(raw.data(), raw.size(), paths[i], scratch.data(), need, (size_t)cap[i], &len, g->stats[i], e, &used, &runs_off, &n_runs, &fit);
+                    const auto t2 = std::chrono::steady_clock::now();
+                    t_read += std::chrono::duration<double>(t1 - t0).count();
+                    t_parse += std::chrono::duration<double>(t2 - t1).count();
+                    if (r != GHIP_OK) { fail(r, e); stop = true; break; }
+                    if (!fit || n_runs_all + n_runs > run_cap) { ok = false; break; }
+                    g->lens[i] = len;
+                    max_len = std::max<uint64_t>(max_len, len);
+                    memcpy(slot->p + (size_t)((g->starts[i] - base) / 4), scratch.data(), ((len + 3) / 4 + 15) / 16 * 16);
+                    gtab[2 * (i - first)] = (uint32_t)((g->starts[i] - base) / 32);
+                    gtab[2 * (i - first) + 1] = (uint32_t)len;
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(scratch.data() + runs_off);
+                    for (uint32_t x = 0; x < n_runs; x++) {
+                        runs[3 * (n_runs_all + x)] = src[3 * x]; runs[3 * (n_runs_all + x) + 1] = src[3 * x + 1]; runs[3 * (n_runs_all + x) + 2] = (uint32_t)(i - first);
+                    }
+                    n_runs_all += n_runs;
+                }
+                if (stop || !ok) {
+                    give_slot(slot, 0);
+                    if (stop) return true;
+                    for (size_t i = first; i < last; i++) if (ingest_one(i)) return true;   // the careful way, file by file
+                    return false;
+                }
+                const auto t3 = std::chrono::steady_clock::now();
+                hipError_t ce = hipMemcpyAsync(reinterpret_cast<uint8_t *>(g->d_packed) + base / 4, slot->p, codes_bytes, hipMemcpyHostToDevice, cs);
+                if (ce == hipSuccess) ce = hipMemcpyAsync(slot->d, gtab, (2 * m + 3 * n_runs_all) * sizeof(uint32_t), hipMemcpyHostToDevice, cs);
+                if (ce == hipSuccess) {
+                    ghip_launch_valid_from_runs(cs, reinterpret_cast<const uint32_t *>(slot->d), (uint32_t)m, max_len,
+                                                reinterpret_cast<const uint32_t *>(slot->d) + 2 * m, (uint32_t)n_runs_all, g->d_valid + base / 32, false);
+                    ce = hipGetLastError();
+                    if (ce == hipSuccess) ce = hipEventRecord(slot->ev, cs);
+                }
+                give_slot(slot, ce == hipSuccess ? 2 : 0);
+                t_alloc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t3).count();
+                if (ce != hipSuccess) { fail(GHIP_EHIP, "ingest copy failed"); return true; }
+                return false;
+            };
+            for (;;) {
+                if (status.load() != GHIP_OK || over.load()) break;
+                const size_t u = next.fetch_add(1);
+                if (u >= units.size()) break;
+                const size_t first = units[u].first, last = units[u].second;
+                if (last - first > 1 ? ingest_group(first, last) : ingest_one(first)) break;
             }
         };
         ctx->io.run(threads, worker);
@@ -1690,9 +1794,9 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
     // run (sketch + seed pass, ~2.2 ms per GB), the ingest threads already fill batch b + 1 over PCIe (~19 ms per GB):
     // inputs above 1 GiB go in 4 pieces (at least 512 MiB each; every piece costs ~2 ms of set-up, synchronisations and
     // concatenation, so 8 pieces gave back what they hid), ingested by a producer thread one piece ahead.
-    std::vector<uint64_t> caps(n);
+    std::vector<uint64_t> caps(n), hints(n);
     parallel_ranges(n, 64, (size_t)std::min(std::max(1, io_threads), 8), [&](size_t b0, size_t e0) {
-        for (size_t i = b0; i < e0; i++) caps[i] = ghip_stream_capacity_hint(paths[i]) + GHIP_TAIL_PAD + GHIP_BASE_ALIGN;   // base positions
+        for (size_t i = b0; i < e0; i++) { hints[i] = ghip_stream_capacity_hint(paths[i]); caps[i] = hints[i] + GHIP_TAIL_PAD + GHIP_BASE_ALIGN; }   // base positions
     });
     uint64_t total_bytes = 0;
     for (uint64_t c : caps) total_bytes += c;
@@ -1728,7 +1832,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
     bool abort_producer = false;
     auto ingest = [&](size_t b) {
         ghip_genomes *g = nullptr;
-        const int rc = ghip_genomes_from_files(ctx, paths + ranges[b].first, ranges[b].second - ranges[b].first, io_threads, &g);
+        const int rc = genomes_from_files_impl(ctx, paths + ranges[b].first, ranges[b].second - ranges[b].first, io_threads, hints.data() + ranges[b].first, &g);
         std::lock_guard<std::mutex> l(qmu);
         ready[b] = Ingested{g, rc};
         produced = b + 1;

@@ -209,7 +209,8 @@ struct ghip_seed_args {  // fused seeding: where sketch_kmers<K, true> puts the 
 // resident base format <-> stream bytes, and the validity bits of a genome that arrived as 2-bit codes + runs (sketch.hip)
 void ghip_launch_pack_bases(hipStream_t stream, const uint8_t *d_src, uint64_t n, uint64_t gbase_plus_pos0, uint32_t *d_packed, uint32_t *d_valid);
 void ghip_launch_unpack_bases(hipStream_t stream, const uint32_t *d_packed, const uint32_t *d_valid, uint64_t gbase, uint8_t *d_out, uint64_t len);
-void ghip_launch_valid_from_runs(hipStream_t stream, const uint32_t *d_runs, uint32_t n_runs, uint32_t *d_valid_genome, uint64_t len);
+void ghip_launch_valid_from_runs(hipStream_t stream, const uint32_t *d_gtab /* [2 * n_members]: bitmap word offset, length */, uint32_t n_members,
+                                 uint64_t max_len, const uint32_t *d_runs /* [3 * n_runs] */, uint32_t n_runs, uint32_t *d_valid_group, bool single);
 // packs stream[0, len) into dst: ceil(len / 4) bytes rounded up to 16, then the run table (3 x u32 each) -- false if
 // dst_bytes is too small or len >= 2^32.  *used = bytes written, *runs_off = offset of the table, *n_runs its entries
 bool ghip_pack_stream(const uint8_t *stream, size_t len, uint8_t *dst, size_t dst_bytes, size_t *used, size_t *runs_off, uint32_t *n_runs);

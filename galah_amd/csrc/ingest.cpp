@@ -5,6 +5,7 @@
 // Sequence::normalize(iupac=false).  One stream per file: every record's normalised bytes
 // followed by a single 'N' so that no k-mer spans two records.
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <zlib.h>
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
@@ -408,6 +409,15 @@ bool ghip_slurp(const char *path, std::vector<uint8_t> &buf) { return slurp(path
 // is replaced by one 'N', so a plain file's stream is no longer than the file; for a single-member gzip the
 // trailer holds the uncompressed size (mod 2^32).  0 = unknown (unreadable; the parse reports the error).
 uint64_t ghip_stream_capacity_hint(const char *path) {
+    {   // a name that does not end in ".gz": the file size bounds the stream -- one system call instead of five.  (A gzip
+        // file without the extension then outgrows its hint; the ingest notices and takes the two-phase form.)
+        const size_t l = strlen(path);
+        if (!(l > 3 && !strcmp(path + l - 3, ".gz"))) {
+            struct stat st;
+            if (stat(path, &st) != 0) return 0;
+            return (uint64_t)st.st_size + 1;
+        }
+    }
     FILE *f = fopen(path, "rb");
     if (!f) return 0;
     unsigned char magic[2] = {0, 0};

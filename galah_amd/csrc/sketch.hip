@@ -585,22 +585,27 @@ __global__ __launch_bounds__(256) void unpack_bases_kernel(const uint32_t *__res
     out[t] = make_uint4(a[0], a[1], a[2], a[3]);
 }
 
-// validity bitmap of a genome that arrived as 2-bit codes + runs (the packed ingest): bits [0, len) set, the rest of its
-// words clear (the allocation is zero-filled), then the runs cleared.
-__global__ __launch_bounds__(256) void valid_fill_kernel(uint32_t *__restrict__ vw /* the genome's first bitmap word */, uint64_t len) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (32 * t >= len) return;
-    const uint64_t left = len - 32 * t;
-    vw[t] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+// Validity bitmaps of a GROUP of genomes that arrived as 2-bit codes + runs (the packed ingest ships many small files in
+// one copy): gtab[2 m] = first bitmap word of member m relative to vw (the group's first bitmap word), gtab[2 m + 1] = its
+// length in bases.  Bits [0, len) of every member are set, the rest of its words stay clear (the allocation is
+// zero-filled), then the runs -- (start, length, member) triples, start relative to the member -- are cleared.
+__global__ __launch_bounds__(256) void valid_fill_group_kernel(const uint32_t *__restrict__ gtab, uint32_t *__restrict__ vw) {
+    const uint32_t off = gtab[2 * blockIdx.y], len = gtab[2 * blockIdx.y + 1];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; 32ull * t < len; t += gridDim.x * blockDim.x) {
+        const uint32_t left = len - 32 * t;
+        vw[off + t] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+    }
 }
-__global__ __launch_bounds__(64) void valid_clear_runs_kernel(const uint32_t *__restrict__ runs /* start, len, byte */, uint32_t *__restrict__ vw) {
-    const uint32_t start = runs[3 * blockIdx.x], n = runs[3 * blockIdx.x + 1];
-    // word-wise: the first and last word of the run by atomicAnd (a neighbouring run may share them), the words between by stores
+__global__ __launch_bounds__(64) void valid_clear_runs_group_kernel(const uint32_t *__restrict__ runs /* start, len, member */, const uint32_t *__restrict__ gtab,
+                                                                    uint32_t *__restrict__ vw, int single) {
+    const uint32_t start = runs[3 * blockIdx.x], n = runs[3 * blockIdx.x + 1], member = single ? 0u : runs[3 * blockIdx.x + 2];
+    uint32_t *mine = vw + gtab[2 * member];
+    // word-wise: a neighbouring run may share a word, hence atomicAnd
     const uint32_t w0 = start >> 5, w1 = (start + n - 1) >> 5;
     for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 64) {
         const uint32_t lo = w == w0 ? (start & 31u) : 0u, hi = w == w1 ? ((start + n - 1) & 31u) : 31u;
         const uint32_t m = (hi == 31u ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-        atomicAnd(&vw[w], ~m);
+        atomicAnd(&mine[w], ~m);
     }
 }
 
@@ -668,14 +673,16 @@ void ghip_launch_unpack_bases(hipStream_t stream, const uint32_t *d_packed, cons
                        reinterpret_cast<uint4 *>(d_out), len);
 }
 
-// The packed ingest: the 2-bit codes are copied straight to their place; this builds the genome's validity bits from the
-// run table that travelled with them (both kernels on `stream`, after the copy that brought `d_runs`; the bitmap
-// allocation is zero-filled, so the words past the genome's length stay clear).
-void ghip_launch_valid_from_runs(hipStream_t stream, const uint32_t *d_runs, uint32_t n_runs, uint32_t *d_valid_genome, uint64_t len) {
-    if (len == 0) return;
-    const uint64_t words = (len + 31) / 32;
-    hipLaunchKernelGGL(valid_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_valid_genome, len);
-    if (n_runs) hipLaunchKernelGGL(valid_clear_runs_kernel, dim3(n_runs), dim3(64), 0, stream, d_runs, d_valid_genome);
+// The packed ingest: the 2-bit codes are copied straight to their place; this builds the validity bits of the group's
+// members from the tables that travelled with them: gtab (2 u32 per member) and the runs (3 u32 each).
+// Both kernels on `stream`, after the copy that brought the tables.  single: one member whose runs carry the byte value in
+// their third field (the one-file parser's table), not a member index.
+void ghip_launch_valid_from_runs(hipStream_t stream, const uint32_t *d_gtab, uint32_t n_members, uint64_t max_len, const uint32_t *d_runs,
+                                 uint32_t n_runs, uint32_t *d_valid_group, bool single) {
+    if (n_members == 0 || max_len == 0) return;
+    const uint64_t words = (max_len + 31) / 32;
+    hipLaunchKernelGGL(valid_fill_group_kernel, dim3((unsigned)std::min<uint64_t>((words + 255) / 256, 4096), n_members), dim3(256), 0, stream, d_gtab, d_valid_group);
+    if (n_runs) hipLaunchKernelGGL(valid_clear_runs_group_kernel, dim3(n_runs), dim3(64), 0, stream, d_runs, d_gtab, d_valid_group, single ? 1 : 0);
 }
 
 // timing experiment only (scripts/sketch_variants.sh): unused dynamic LDS caps the workgroups per CU
