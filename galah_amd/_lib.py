@@ -106,6 +106,7 @@ SIGNATURES = {
     "ghip_cluster_files_multi": (_int, [_pp, _u32, C.POINTER(C.c_char_p), _sz, _u32, _u32, _f32, _f32, _f32, _u32, _int, _pp, _pp,
                                         C.POINTER(_sz)]),
     "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
+    "ghip_cluster_index": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _f32, _f32, _pp, _pp, C.POINTER(_sz), _vp]),
     "ghip_cluster_lazy": (_int, [_sz, _vp, _sz, _f32, ANI_BATCH_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz), C.POINTER(_u64)]),
     "ghip_free": (None, [_vp]),
 }

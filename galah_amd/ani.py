@@ -85,6 +85,12 @@ class HipAniClusterer:
         assert self._index is not None, "call prepare() first"
         return self._context().ani_pairs(self._index, pairs, float(self.min_aligned_threshold))
 
+    def cluster_on_index(self, n_genomes: int, pairs: np.ndarray, threshold) -> tuple:
+        """clusterer::cluster over the prepared index, whole in native code (ghip_cluster_index) -> (clusters, pairs asked)."""
+        assert self._index is not None, "call prepare() first"
+        clusters, st = self._context().cluster_index(self._index, n_genomes, pairs, threshold, float(self.min_aligned_threshold))
+        return clusters, st["asked"]
+
     # ---- the trait method
     def calculate_ani(self, fasta1: str, fasta2: str) -> Optional[np.float32]:
         # The reference calls this from rayon workers (clusterer.rs:267-270,283-293,375-399).  One lock for the whole

@@ -120,9 +120,12 @@ def _cluster(genomes, preclusterer, clusterer, cluster_contigs, contig_names, re
         if not clusterer.prepared_for(genomes):
             clusterer.prepare(list(genomes))
         # the ANI of a precluster pair is only ever needed when it touches a representative (clusterer.rs:194-204,
-        # 377-405): asked lazily, one batch per round of the greedy clusterer (ghip_cluster_lazy)
-        idx = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
-        clusters, asked = cluster_pairs_lazy(n, pairs, threshold, lambda edges: clusterer.calculate_ani_indices(idx[edges]))
+        # 377-405): asked lazily, one batch per round of the greedy clusterer
+        if hasattr(clusterer, "cluster_on_index"):   # the HIP clusterer: the rounds stay in native code (ghip_cluster_index)
+            clusters, asked = clusterer.cluster_on_index(n, pairs, threshold)
+        else:
+            idx = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
+            clusters, asked = cluster_pairs_lazy(n, pairs, threshold, lambda edges: clusterer.calculate_ani_indices(idx[edges]))
         clusterer.last_pairs_asked = asked
         return clusters
     return cluster_pairs(n, pairs, threshold, None, False,

@@ -253,7 +253,7 @@ __device__ __forceinline__ unsigned long long collect_aligned(const uint32_t *vo
 // (ghip_ani_density): it is evaluated at the sparser one, the denser genome's seeds are filtered by their selection hash
 // and its per-chunk totals recounted.  `sel` (nullable) = the indices of the pairs this launch handles.
 template <uint32_t ANI_PAIR_WAVES, bool GENERAL>
-__global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
+__global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6))) void ani_pairs_kernel(
     const uint32_t *__restrict__ pairs, uint32_t n_pairs, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ seed_code,
     const uint32_t *__restrict__ seed_loc, const uint64_t *__restrict__ seed_start,
     const uint32_t *__restrict__ bin_start, const uint32_t *__restrict__ chunk_total,
@@ -334,31 +334,60 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) void ani_pairs_kernel(
         if (tmax > 41000) rbins = tmax > 1312000 ? 1u : tmax > 656000 ? 2u : tmax > 328000 ? 4u : tmax > 164000 ? 8u : (tmax > 82000 ? 16u : 32u);
         else if (ro_cap > 1024) rbins = tmax <= 3000 ? 1024u : (tmax <= 12000 ? 256u : 64u);
     }
-    // the bounds of the next round are fetched while this round is joined
-    uint32_t n_rs = rb[min(wave * rbins + lane, BIN_COUNT)], n_qlo = qb[wave * rbins], n_qhi = qb[wave * rbins + rbins], n_rhi = rb[wave * rbins + rbins];
-    PH(0);   // prologue
-    for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += ANI_PAIR_WAVES * rbins) {
-        const uint32_t rs = n_rs, q_lo = n_qlo, q_hi = n_qhi, r_hi = n_rhi;
-        const uint32_t r_lo = __shfl(rs, 0, 64);
-        if (b0 + ANI_PAIR_WAVES * rbins < BIN_COUNT) {
-            const uint32_t f = b0 + ANI_PAIR_WAVES * rbins;
-            n_rs = rb[min(f + lane, BIN_COUNT)]; n_qlo = qb[f]; n_qhi = qb[f + rbins]; n_rhi = rb[f + rbins];
+    // Software pipeline over the rounds of a wave: the BOUNDS of round t + 2 and the SEEDS of round t + 1 (three per lane and
+    // array, held in registers) are fetched while round t is joined out of LDS -- a round's ~8 dependent global-memory
+    // round trips (bounds, then the runs) overlap the previous round's join instead of preceding its own.
+    struct Bounds { uint32_t rs, q_lo, q_hi, r_hi; };
+    constexpr uint32_t STAGE_REGS = ANI_STAGE / 64;
+    const uint32_t stride = ANI_PAIR_WAVES * rbins;
+    auto load_bounds = [&](uint32_t b) {
+        Bounds o{0, 0, 0, 0};
+        if (b < BIN_COUNT) { o.rs = rb[min(b + lane, BIN_COUNT)]; o.q_lo = qb[b]; o.q_hi = qb[b + rbins]; o.r_hi = rb[b + rbins]; }
+        return o;
+    };
+    // a round is joined out of the stage when both runs are non-empty and fit it (else: skipped, or the global-memory walk)
+    auto is_staged = [&](const Bounds &o) {
+        const uint32_t r_lo = __shfl(o.rs, 0, 64);
+        return o.q_lo != o.q_hi && r_lo != o.r_hi && o.q_hi - o.q_lo <= ANI_STAGE && o.r_hi - r_lo <= ANI_STAGE;
+    };
+    uint32_t pc1[STAGE_REGS], ph1[STAGE_REGS], pc2[STAGE_REGS], ph2[STAGE_REGS];
+    auto fetch_runs = [&](const Bounds &o) {
+        const uint32_t r_lo = __shfl(o.rs, 0, 64), nqs = o.q_hi - o.q_lo, nrs = o.r_hi - r_lo;
+#pragma unroll
+        for (uint32_t u = 0; u < STAGE_REGS; u++) {
+            const uint32_t k = lane + 64 * u;
+            pc1[u] = 0; ph1[u] = 0; pc2[u] = 0; ph2[u] = 0;
+            if (k < nqs) { pc1[u] = qc[o.q_lo + k]; ph1[u] = ql[o.q_lo + k]; }
+            if (k < nrs) { pc2[u] = rc[r_lo + k]; ph2[u] = rl[r_lo + k]; }
         }
-        if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
-        const bool staged = (q_hi - q_lo <= ANI_STAGE) && (r_hi - r_lo <= ANI_STAGE);
+    };
+    Bounds cur = load_bounds(wave * rbins), nxt = load_bounds(wave * rbins + stride);
+    if (is_staged(cur)) fetch_runs(cur);
+    PH(0);   // prologue
+    for (uint32_t b0 = wave * rbins; b0 < BIN_COUNT; b0 += stride) {
+        const Bounds c = cur;
+        const uint32_t rs = c.rs, q_lo = c.q_lo, q_hi = c.q_hi, r_hi = c.r_hi;
+        const uint32_t r_lo = __shfl(rs, 0, 64);
+        const bool staged = is_staged(c);
+        cur = nxt;
+        nxt = load_bounds(b0 + 2 * stride);
         PH(1);   // bounds
         if (staged) {
-            {   // both runs in one loop: the four loads of an iteration are in flight together
+            {
                 const uint32_t nqs = q_hi - q_lo, nrs = r_hi - r_lo;
-                for (uint32_t k = lane; k < max(nqs, nrs); k += 64) {
-                    uint32_t c1 = 0, c2 = 0, h1 = 0, h2 = 0;
-                    if (k < nqs) { c1 = qc[q_lo + k]; h1 = ql[q_lo + k]; }
-                    if (k < nrs) { c2 = rc[r_lo + k]; h2 = rl[r_lo + k]; }
+#pragma unroll
+                for (uint32_t u = 0; u < STAGE_REGS; u++) {
+                    const uint32_t k = lane + 64 * u;
+                    uint32_t c2 = pc2[u];
                     if constexpr (GENERAL) { if (filt_r && k < nrs && !at_pair_density(c2)) c2 = 0xffffffffu; }   // never a code: matches nothing
-                    if (k < nqs) { sq[k] = c1; lq[k] = h1; }
-                    if (k < nrs) { sr[k] = c2; lr[k] = h2; }
+                    if (k < nqs) { sq[k] = pc1[u]; lq[k] = ph1[u]; }
+                    if (k < nrs) { sr[k] = c2; lr[k] = ph2[u]; }
                 }
             }
+        }
+        if (is_staged(cur)) fetch_runs(cur);   // the next round's runs: in flight during this round's join
+        if (q_lo == q_hi || r_lo == r_hi) continue;  // wave-uniform: one genome has no seed in these bins
+        if (staged) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             PH(2);   // staging
@@ -607,14 +636,15 @@ int ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32
     uint32_t fast_chunks = 1;
     bool small_fast = false, small_gen = false;   // some genome small enough for the wide rounds (their offset table costs LDS)
     size_t n_gen = 0;
+    const bool force_general = getenv("GHIP_ANI_FORCE_GENERAL") != nullptr;   // measurement aid: every pair through the general form
     for (size_t p = 0; p < n_pairs; p++) {
         const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1], nch = nch_of(q) + nch_of(r);
-        n_gen += (idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) ? 1 : 0;
+        n_gen += (force_general || idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) ? 1 : 0;
     }
     for (size_t p = 0; p < n_pairs; p++) {
         const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1], nch = nch_of(q) + nch_of(r);
         const bool small = idx->seed_count[q] <= 12000 || idx->seed_count[r] <= 12000;
-        if (idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) { sel_gen.push_back((uint32_t)p); small_gen |= small; }
+        if (force_general || idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) { sel_gen.push_back((uint32_t)p); small_gen |= small; }
         else { if (n_gen) sel_fast.push_back((uint32_t)p); fast_chunks = std::max(fast_chunks, nch); small_fast |= small; }
     }
     const size_t n_fast = n_pairs - n_gen;

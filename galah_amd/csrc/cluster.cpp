@@ -335,3 +335,93 @@ extern "C" int ghip_cluster_lazy(size_t n, const ghip_pair *pairs, size_t n_pair
     return cluster_impl(n, pairs, n_pairs, nullptr, 0, ani_threshold, nullptr, batch_cb, user, out_members, out_offsets, out_n_clusters,
                         out_pairs_requested);
 }
+
+// ---- clusterer::cluster with the device ANI index as the ClusterDistanceFinder, whole in native code ----
+// (src/clusterer.rs:56-152 with SkaniClusterer, src/skani.rs:718-788): the lazy rounds of ghip_cluster_lazy answered by
+// ghip_ani_pairs without a trip through the host language per round.  `order` (nullable) is galah's quality order
+// (src/cluster_argument_parsing.rs:863-1157 sorts the genomes before anything else): order[x] = the genome that comes x-th.
+// The sketches, the pair list and the ANI index stay where the genomes lie; the pair list is renumbered to positions and
+// re-sorted (LSD radix over the bits two positions need), the ANI of an edge is asked for by its genomes.
+namespace {
+struct IndexAni {
+    ghip_ctx *ctx;
+    const ghip_ani_index *idx;
+    const ghip_pair *by_genome;        // the caller's pair list (genome indices)
+    const uint32_t *orig;              // sorted edge -> index into by_genome (null: identity)
+    float min_af;
+    std::vector<uint32_t> buf;
+    uint64_t rounds = 0, ns_ani = 0;
+    int rc = GHIP_OK;
+};
+int index_ani_batch(void *user, const uint32_t *edge, size_t n, float *out) {
+    IndexAni *s = static_cast<IndexAni *>(user);
+    const auto t0 = std::chrono::steady_clock::now();
+    s->buf.resize(2 * n);
+    for (size_t x = 0; x < n; x++) {
+        const ghip_pair &p = s->by_genome[s->orig ? s->orig[edge[x]] : edge[x]];
+        s->buf[2 * x] = p.i; s->buf[2 * x + 1] = p.j;
+    }
+    s->rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), n, s->min_af, out, nullptr);
+    s->rounds++;
+    s->ns_ani += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return s->rc == GHIP_OK ? 0 : 1;
+}
+}  // namespace
+
+extern "C" int ghip_cluster_index(ghip_ctx *ctx, const ghip_ani_index *idx, size_t n, const ghip_pair *pairs, size_t n_pairs,
+                                  const uint32_t *order, float ani_threshold, float min_aligned_fraction,
+                                  uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats) {
+    if (!ctx || !out_members || !out_offsets || !out_n_clusters || (n_pairs && (!pairs || !idx))) return GHIP_EINVAL;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (out_stats) memset(out_stats, 0, 4 * sizeof(uint64_t));
+    for (size_t e = 0; e < n_pairs; e++)
+        if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return ghip_set_error(ctx, GHIP_EINVAL, "pair list names a genome out of range");
+    std::vector<ghip_pair> sorted;
+    std::vector<uint32_t> orig;
+    if (order && n_pairs) {
+        std::vector<uint32_t> rank_of(n, UINT32_MAX);
+        for (size_t x = 0; x < n; x++) {
+            if (order[x] >= n || rank_of[order[x]] != UINT32_MAX) return ghip_set_error(ctx, GHIP_EINVAL, "order is not a permutation of the genomes");
+            rank_of[order[x]] = (uint32_t)x;
+        }
+        uint32_t bits = 1;
+        while (((uint64_t)1 << bits) < n) bits++;
+        std::vector<uint64_t> key(n_pairs), key2(n_pairs);
+        std::vector<uint32_t> ix(n_pairs), ix2(n_pairs);
+        for (size_t e = 0; e < n_pairs; e++) {
+            const uint32_t a = rank_of[pairs[e].i], b = rank_of[pairs[e].j];
+            key[e] = ((uint64_t)std::min(a, b) << bits) | std::max(a, b);
+            ix[e] = (uint32_t)e;
+        }
+        constexpr uint32_t DIGIT = 11;
+        std::vector<uint32_t> hist((size_t)1 << DIGIT);
+        for (uint32_t sh = 0; sh < 2 * bits; sh += DIGIT) {
+            std::fill(hist.begin(), hist.end(), 0u);
+            for (size_t e = 0; e < n_pairs; e++) hist[(key[e] >> sh) & ((1u << DIGIT) - 1)]++;
+            uint32_t run = 0;
+            for (uint32_t &h : hist) { const uint32_t c = h; h = run; run += c; }
+            for (size_t e = 0; e < n_pairs; e++) {
+                const uint32_t p = hist[(key[e] >> sh) & ((1u << DIGIT) - 1)]++;
+                key2[p] = key[e]; ix2[p] = ix[e];
+            }
+            key.swap(key2); ix.swap(ix2);
+        }
+        sorted.resize(n_pairs);
+        for (size_t e = 0; e < n_pairs; e++) {
+            sorted[e] = pairs[ix[e]];   // common / total / ani are symmetric in the pair
+            sorted[e].i = (uint32_t)(key[e] >> bits);
+            sorted[e].j = (uint32_t)(key[e] & (((uint64_t)1 << bits) - 1));
+        }
+        orig.swap(ix);
+    }
+    IndexAni st{ctx, idx, pairs, orig.empty() ? nullptr : orig.data(), min_aligned_fraction};
+    uint64_t asked = 0;
+    const int rc = cluster_impl(n, sorted.empty() ? pairs : sorted.data(), n_pairs, nullptr, 0, ani_threshold, nullptr,
+                                n_pairs ? index_ani_batch : nullptr, &st, out_members, out_offsets, out_n_clusters, &asked);
+    if (out_stats) {
+        out_stats[0] = asked; out_stats[1] = st.rounds; out_stats[2] = st.ns_ani;
+        out_stats[3] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (rc == GHIP_ECALLBACK && st.rc != GHIP_OK) return st.rc;   // the ANI launch failed: its own code and message
+    return rc;
+}

@@ -294,7 +294,7 @@ class DereplicationJob:
         self._steps = 0
         self._full = None
         self.last_pairs_compared = 0
-        self.rank_of = None
+        self.order = None
 
     def set_order(self, order):
         """Genome order of the clustering stage (one rank): order[x] = the genome that comes x-th -- galah sorts its input by
@@ -303,8 +303,7 @@ class DereplicationJob:
         before the greedy clusterer, whose clusters then hold positions in `order`."""
         order = np.asarray(order, dtype=np.int64)
         assert self.world == 1 and sorted(order.tolist()) == list(range(self.n))
-        self.rank_of = np.empty(self.n, dtype=np.uint32)
-        self.rank_of[order] = np.arange(self.n, dtype=np.uint32)
+        self.order = order.astype(np.uint32)
 
     def load_synthetic(self, seed: int, members: int, length: int, sub_rate: float):
         self.genomes = self.ctx.genomes_synthetic_range(seed, members, self.first, self.count, length, sub_rate)
@@ -328,38 +327,24 @@ class DereplicationJob:
         return self._full.to_host()
 
     def _step_lazy(self) -> Dict:
-        from .engine import cluster_pairs_lazy
         t0 = time.perf_counter()
         sk, idx = self.ctx.sketch_and_index(self.genomes, self.kmer, self.s, 0, self.ani_k, self.ani_c, self.ani_chunk)
         t1 = time.perf_counter()
         pairs = self.ctx.precluster(sk, self.min_ani)
         self.last_pairs_compared = self.ctx.last_pairs_compared
         t2 = time.perf_counter()
-        pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 2), np.uint32)
-        if self.rank_of is not None and len(pairs):   # the clusterer sees the genomes in quality order
-            a, b = self.rank_of[pairs["i"]], self.rank_of[pairs["j"]]
-            pairs = pairs.copy()
-            pairs["i"], pairs["j"] = np.minimum(a, b), np.maximum(a, b)
-            perm = np.lexsort((pairs["j"], pairs["i"]))
-            pairs, pi = pairs[perm], pi[perm]   # pi keeps the positions in the ANI index
-        t_ani = [0.0]
-
-        def ani_of(edges):
-            a0 = time.perf_counter()
-            out = self.ctx.ani_pairs(idx, pi[edges], self.min_af)
-            t_ani[0] += time.perf_counter() - a0
-            return out
-
-        clusters, asked = cluster_pairs_lazy(self.n, pairs, self.ani_threshold, ani_of)
+        # clusterer::cluster in native code (ghip_cluster_index): the lazy rounds are answered by the resident ANI index;
+        # with a quality order the clusterer sees the genomes in that order and the clusters hold positions in it
+        clusters, st = self.ctx.cluster_index(idx, self.n, pairs, self.ani_threshold, self.min_af, self.order)
         t3 = time.perf_counter()
         idx.free()
         self._full = sk
-        self.last_pairs_asked = asked
-        for k, v in (("sketch", t1 - t0), ("pairs", t2 - t1), ("ani_pairs", t_ani[0]), ("host_cluster", t3 - t2 - t_ani[0])):
+        self.last_pairs_asked = st["asked"]
+        for k, v in (("sketch", t1 - t0), ("pairs", t2 - t1), ("ani_pairs", st["ani_ms"] * 1e-3), ("host_cluster", t3 - t2 - st["ani_ms"] * 1e-3)):
             self._stage[k] = self._stage.get(k, 0.0) + v * 1e3
         self._steps += 1
         return {"n_pairs": len(pairs), "n_clusters": len(clusters), "clusters": clusters, "pairs": pairs, "pair_ani": None,
-                "ani_pairs_asked": asked}
+                "ani_pairs_asked": st["asked"], "lazy_rounds": st["rounds"]}
 
     def step(self) -> Dict:
         if self._full is not None:

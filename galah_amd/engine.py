@@ -345,6 +345,31 @@ class Context:
                                         af.ctypes.data if want_af else None), self._h)
         return (out, af) if want_af else out
 
+    def cluster_index(self, idx: AniIndex, n_genomes: int, pairs: np.ndarray, ani_threshold: float, min_af: float = 0.15,
+                      order: Optional[np.ndarray] = None) -> Tuple[List[List[int]], Dict[str, float]]:
+        """ghip_cluster_index: the greedy clusterer with the resident ANI index answering its lazy rounds, whole in native
+        code.  `order` (optional) = the quality order, order[x] = genome that comes x-th; clusters then hold positions x.
+        -> (clusters, {"asked", "rounds", "ani_ms", "total_ms"})."""
+        L = _lib.lib()
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+            assert order.shape == (n_genomes,)
+        members, offsets, nc = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        stats = np.zeros(4, dtype=np.uint64)
+        check(L.ghip_cluster_index(self._h, idx._h if idx is not None else None, n_genomes, pairs.ctypes.data, pairs.shape[0],
+                                   order.ctypes.data if order is not None else None, np.float32(ani_threshold), np.float32(min_af),
+                                   C.byref(members), C.byref(offsets), C.byref(nc), stats.ctypes.data), self._h)
+        try:
+            off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), shape=(nc.value + 1,)).copy()
+            mem = np.ctypeslib.as_array(C.cast(members, C.POINTER(C.c_uint32)), shape=(max(int(off[-1]), 1),)).copy()
+        finally:
+            L.ghip_free(members)
+            L.ghip_free(offsets)
+        mem_l, off_l = mem.tolist(), off.tolist()
+        return ([mem_l[off_l[c]:off_l[c + 1]] for c in range(nc.value)],
+                {"asked": int(stats[0]), "rounds": int(stats[1]), "ani_ms": float(stats[2]) * 1e-6, "total_ms": float(stats[3]) * 1e-6})
+
     def ani_pairs_detail(self, idx: AniIndex, pairs: np.ndarray) -> np.ndarray:
         """u64[n][6] = M, T of the lower-median chunk, aligned chunks, aligned bases of q, of r, c_pair (ghip_ani_pairs_detail)."""
         pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)

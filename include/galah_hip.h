@@ -319,6 +319,18 @@ int ghip_cluster_lazy(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, 
                       ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members, uint64_t **out_offsets,
                       size_t *out_n_clusters, uint64_t *out_pairs_requested);
 
+/* clusterer::cluster with the resident ANI index as the ClusterDistanceFinder (src/clusterer.rs:56-152 driven by
+ * SkaniClusterer::calculate_ani, src/skani.rs:718-788), whole in native code: ghip_cluster_lazy's rounds answered by
+ * ghip_ani_pairs(idx, ..., min_aligned_fraction) -- no host-language callback per round.  `pairs` = the precluster pairs of
+ * the index's genomes (ghip_precluster's list).  `order` (nullable) = galah's quality order (the reference sorts its genomes
+ * before clustering, src/cluster_argument_parsing.rs:863-1157): order[x] = the genome that comes x-th; the clusters then hold
+ * POSITIONS x (the genome is order[x]), representative first, exactly what the reference returns for the sorted list; with
+ * order == NULL positions are genome indices.  out_stats (nullable, u64[4]) = pairs asked, rounds, nanoseconds spent in
+ * ghip_ani_pairs, nanoseconds in total.  Same clusters as ghip_cluster given the ANI of every pair. */
+int ghip_cluster_index(ghip_ctx *ctx, const ghip_ani_index *idx, size_t n_genomes, const ghip_pair *pairs, size_t n_pairs,
+                       const uint32_t *order, float ani_threshold, float min_aligned_fraction,
+                       uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats);
+
 void ghip_free(void *p);
 
 #ifdef __cplusplus

@@ -792,3 +792,43 @@ def test_randomised_differential_runs():
                          ("fuzz_ingest.py", ["25", "2"])):   # random FASTA files through every ingest form
         r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_cluster_on_the_resident_index_native_rounds(ctx):
+    """ghip_cluster_index (clusterer::cluster with the device index as ClusterDistanceFinder, src/clusterer.rs:56-152 +
+    src/skani.rs:718-788, whole in native code) against the lazy clusterer driven from the host language and against the
+    oracle's clusterer fed every pair's ANI -- in genome order and in a quality order (positions of the order)."""
+    n_species, members = 40, 6
+    n = n_species * members
+    g = ctx.genomes_synthetic(11, n_species, members, 200_000, 0.0253)
+    sk, idx = ctx.sketch_and_index(g, 21, 1000, 0)
+    pairs = ctx.precluster(sk, np.float32(0.9))
+    assert len(pairs) >= n_species * members * (members - 1) // 2 * 0.9
+    pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32)
+    thr = np.float32(95.0)   # ~95 % ANI between members: some join their species' representative, some found a new one
+    every = ctx.ani_pairs(idx, pi, 0.15)
+    assert 0.1 < float(np.mean(every >= thr)) < 0.9
+
+    got, st = ctx.cluster_index(idx, n, pairs, thr, 0.15)
+    want, asked = galah_amd.cluster_pairs_lazy(n, pairs, thr, lambda e: ctx.ani_pairs(idx, pi[e], 0.15))
+    assert got == want and st["asked"] == asked and 1 <= st["rounds"] <= members + 1
+    look = {(int(a), int(b)): float(v) for (a, b), v in zip(pi, every)}
+    assert got == oracle.cluster(n, oracle.Cache.from_pairs(pairs), float(thr), lambda a, b: look[(min(a, b), max(a, b))])
+
+    order = np.random.default_rng(5).permutation(n).astype(np.uint32)
+    got_o, st_o = ctx.cluster_index(idx, n, pairs, thr, 0.15, order)
+    rank_of = np.empty(n, np.uint32)
+    rank_of[order] = np.arange(n, dtype=np.uint32)
+    re = pairs.copy()
+    a, b = rank_of[pairs["i"]], rank_of[pairs["j"]]
+    re["i"], re["j"] = np.minimum(a, b), np.maximum(a, b)
+    perm = np.lexsort((re["j"], re["i"]))
+    re, every_o = re[perm], every[perm]
+    look_o = {(int(p["i"]), int(p["j"])): float(v) for p, v in zip(re, every_o)}
+    assert got_o == oracle.cluster(n, oracle.Cache.from_pairs(re), float(thr), lambda a, b: look_o[(min(a, b), max(a, b))])
+    assert sorted(x for c in got_o for x in c) == list(range(n))
+    # no pairs: every genome its own cluster, no index needed
+    assert ctx.cluster_index(None, 3, np.zeros(0, dtype=galah_amd.PAIR_DTYPE), thr)[0] == [[0], [1], [2]]
+    with pytest.raises(galah_amd.GalahHipError):
+        ctx.cluster_index(idx, n, pairs, thr, 0.15, np.zeros(n, np.uint32))   # not a permutation
