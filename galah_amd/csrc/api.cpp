@@ -1046,7 +1046,7 @@ extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t
 static void free_sketches_locked(ghip_sketches *sk) {  // ctx->mu held
     ghip_ctx *ctx = sk->ctx;
     if (sk->owned) { ghip_pool_free(ctx, sk->d_hashes); ghip_pool_free(ctx, sk->d_lens); }
-    ghip_pool_free(ctx, sk->d_tables); ghip_pool_free(ctx, sk->d_row_start);
+    ghip_pool_free(ctx, sk->d_tables); ghip_pool_free(ctx, sk->d_tags); ghip_pool_free(ctx, sk->d_row_start);
     ctx->live_handles--;
     delete sk;
 }
@@ -1366,10 +1366,11 @@ static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
     int rc;
     uint32_t *d_flags = nullptr;
     if ((rc = dmalloc(ctx, &sk->d_tables, sk->n * slots))) return rc;
+    if ((rc = dmalloc(ctx, &sk->d_tags, sk->n * slots))) return rc;
     if ((rc = dmalloc(ctx, &d_flags, 1))) return rc;
     DeviceFree tmp(ctx); tmp.add(d_flags);
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
-    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, d_flags);
+    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, sk->d_tags, d_flags);
     sk->n_work = ghip_probe_work_rows(sk->n, ctx->num_cus, &sk->probe_cb, sk->row_start);
     if ((rc = dmalloc(ctx, &sk->d_row_start, sk->row_start.size()))) return rc;
     if ((rc = h2d(ctx, sk->d_row_start, sk->row_start.data(), sk->row_start.size()))) return rc;
@@ -1525,7 +1526,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         }
         if (joined) {
         } else if (use_probe) {
-            ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, n, s, sk->probe_cb, sk->d_row_start,
+            ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, sk->d_tags, n, s, sk->probe_cb, sk->d_row_start,
                                     (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap);
             compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, drank, dworld);
         } else if (s <= 4096) {

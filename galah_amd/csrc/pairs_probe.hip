@@ -5,16 +5,21 @@
 // for the intersection itself.  Every sketch is turned once into a cuckoo set (2 hash positions x
 // 2-slot 16-byte buckets, 2*next_pow2(s) slots, load <= 0.5) by pair_table_build.  Then
 //
-//   pair_intersect_tile (probe form): one workgroup = 8 A-sketches as cuckoo sets in LDS
-//   (8 x 16 KiB) x 64 B-sketches.  One sketch pair per wavefront: the wave holds its B-sketch
-//   in registers (lane l owns elements l, l+64, ...; coalesced 8-byte loads of the packed matrix
-//   row) and probes the A-set with exactly two ds_read_b128 per element -- no sorted merge, no
-//   data-dependent loop.  A B-sketch is loaded once per 8 pairs and an A-set once per 64.
+//   pair_intersect_tile (probe form): one workgroup = 8 A-sketches as cuckoo sets in LDS x 64 B-sketches.  One
+//   sketch pair per wavefront: the wave holds its B-sketch in registers (lane l owns elements l, l+64, ...; coalesced
+//   8-byte loads of the packed matrix row) and probes the A-set -- no sorted merge, no data-dependent loop.  A B-sketch
+//   is loaded once per 8 pairs and an A-set once per 64.
 //       common = #hits;  m = min(max A, max B)
 //       max A <= max B :  i = |A|, j = #{b <= max A}          (counted while probing)
 //       max A >  max B :  j = |B|, i = #{a <= max B}          (64 LDS samples + one 16-element
 //                                                              row segment of the sorted matrix)
-//   ~240 VALU instructions per pair instead of ~1150 for the 64-way merge path; LDS-bound.
+//   The kernel is bound by LDS reads at random addresses (bank conflicts), so the sets in LDS hold 31-bit TAGS of
+//   the hashes (bits no bucket index uses) instead of the hashes: a probe is two ds_read_b64 (16 bytes) where the full
+//   keys took two ds_read_b128 (32 bytes), the tag and the two bucket addresses of a B element are computed once per B row
+//   and reused for its 8 A-sets, and a set is 8 KiB, so two workgroups share a CU.  A tag can match where the key does
+//   not (never the reverse): the tag pass counts common' >= common, total' <= total, and since cmin[] is non-decreasing
+//   its list is a SUPERSET of the exact one; pair_verify then recounts every listed pair against the full 64-bit
+//   cuckoo set in global memory (a few thousand pairs out of N^2/2), so what leaves the stage is exact.
 //
 // Integer work only; a pair is emitted iff common >= cmin[total] (host table from the f64
 // formula) and the host recomputes the exact f32.  Exactness guards: a sketch that holds the
@@ -32,6 +37,11 @@ constexpr uint64_t EMPTY = ~0ull;
 
 __device__ __forceinline__ uint32_t bucket1(uint64_t x, uint32_t mask) { return (uint32_t)x & mask; }
 __device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask) { return (uint32_t)(x >> 20) & mask; }
+// 31 bits of the hash that neither bucket index can use (bits 10..19 and 30..50; s <= 1024: at most 10-bit indices) under a
+// presence bit: an empty slot's tag (0) matches nothing
+__device__ __forceinline__ uint32_t tag_of(uint64_t x) {
+    return 0x80000000u | (((uint32_t)(x >> 30) & 0x1fffffu) << 10) | (((uint32_t)x >> 10) & 0x3ffu);
+}
 
 // ---------------------------------------------------------------------------------------------
 // pair_table_build: one 256-thread block per sketch, cuckoo insertion with 64-bit LDS atomics.
@@ -40,7 +50,7 @@ __device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask) { return 
 __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *__restrict__ hashes,
                                                                const uint32_t *__restrict__ lens, uint32_t s,
                                                                uint32_t buckets, uint64_t *__restrict__ tables,
-                                                               uint32_t *__restrict__ flags) {
+                                                               uint32_t *__restrict__ tags, uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *tab = reinterpret_cast<unsigned long long *>(smem_raw);
     const uint32_t g = blockIdx.x;
@@ -71,20 +81,21 @@ __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *_
     }
     __syncthreads();
     uint64_t *dst = tables + (uint64_t)g * slots;
-    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) dst[i] = tab[i];
+    uint32_t *tdst = tags + (uint64_t)g * slots;
+    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) { dst[i] = tab[i]; tdst[i] = tab[i] == EMPTY ? 0u : tag_of(tab[i]); }
 }
 
 // ---------------------------------------------------------------------------------------------
 // probe kernel; NT = 64-element register slices of a B-sketch (s <= 64*NT)
 // ---------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
-    const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint64_t *__restrict__ tables,
+__global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void pair_probe_tile_kernel(
+    const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint32_t *__restrict__ tags,
     uint32_t n, uint32_t s, uint32_t buckets, uint32_t cb, const uint64_t *__restrict__ row_start, uint32_t nta,
     uint64_t n_work, uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin,
     ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4 *sets = reinterpret_cast<uint4 *>(smem_raw);                                  // [TA][buckets]
+    uint2 *sets = reinterpret_cast<uint2 *>(smem_raw);                                  // [TA][buckets]: the two tags of a bucket
     uint64_t *samp = reinterpret_cast<uint64_t *>(sets + (size_t)PROBE_TA * buckets);   // [TA][64]
     uint64_t *a_max = samp + PROBE_TA * 64;                                             // [TA]
     uint32_t *a_len = reinterpret_cast<uint32_t *>(a_max + PROBE_TA);                   // [TA]
@@ -104,12 +115,13 @@ __global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
         const uint32_t j0 = ti * PROBE_TA + (uint32_t)(w - row_start[ti]) * cb;
         if ((uint64_t)j0 + cb <= row_lo) continue;   // the (new x all) rectangle of an incremental run: every B-sketch of this item is an old genome
         __syncthreads();  // previous work item's LDS image is no longer read
-        // ---- stage the 8 cuckoo sets (linear 16-byte copies), rank samples and lengths ----
+        // ---- stage the 8 tag sets (linear 16-byte copies), rank samples and lengths ----
         for (uint32_t q = 0; q < PROBE_TA; q++) {
             const uint32_t g = ti * PROBE_TA + q;
-            const uint4 *src = reinterpret_cast<const uint4 *>(tables + (uint64_t)g * 2 * buckets);
-            for (uint32_t e = threadIdx.x; e < buckets; e += PROBE_THREADS)
-                sets[(size_t)q * buckets + e] = (g < n) ? src[e] : make_uint4(~0u, ~0u, ~0u, ~0u);
+            const uint4 *src = reinterpret_cast<const uint4 *>(tags + (uint64_t)g * 2 * buckets);
+            uint4 *dst = reinterpret_cast<uint4 *>(sets + (size_t)q * buckets);
+            for (uint32_t e = threadIdx.x; e < buckets / 2; e += PROBE_THREADS)
+                dst[e] = (g < n) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
         }
         if (threadIdx.x < PROBE_TA * 64) {
             const uint32_t q = threadIdx.x >> 6, l = threadIdx.x & 63u;
@@ -121,37 +133,49 @@ __global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
         }
         __syncthreads();
 
+        uint64_t amax[PROBE_TA];   // wave-uniform: scalar registers
+#pragma unroll
+        for (uint32_t q = 0; q < PROBE_TA; q++) {
+            const uint64_t v = a_max[q];
+            amax[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        }
         for (uint32_t jj = wave; jj < cb; jj += PROBE_WAVES) {
             const uint32_t gj = j0 + jj;
             if (gj >= n || gj <= ti * PROBE_TA || gj < row_lo) continue;  // no A of this tile has a smaller index / an old genome
             const uint32_t nb = lens[gj];
             const uint64_t *brow = hashes + (uint64_t)gj * s;
-            uint64_t b[NT];
-            uint32_t vmask = 0;  // bit t: element lane + 64 t exists
+            // per element of the B row, once for all 8 A-sets: its tag (1: no element -- matches no slot, an empty one
+            // included), the byte offsets of its two buckets inside a set, and its contribution to #{b <= max A} of every
+            // A of the tile; the hash itself is not kept (registers: the probe loop below wants its reads in flight)
+            uint32_t tg[NT], op[NT];   // op: offset of bucket 1 | offset of bucket 2 << 16 (a set is at most 8 KiB)
+            uint32_t le[PROBE_TA];
+#pragma unroll
+            for (uint32_t q = 0; q < PROBE_TA; q++) le[q] = 0;
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 const uint32_t e = lane + 64u * t;
-                b[t] = (e < s) ? brow[e] : EMPTY;
-                vmask |= (e < nb ? 1u : 0u) << t;
+                const uint64_t x = (e < nb) ? brow[e] : EMPTY;            // (EMPTY is > every max A: never counted)
+                tg[t] = (e < nb) ? tag_of(x) : 1u;
+                op[t] = (bucket1(x, mask) * 8u) | ((bucket2(x, mask) * 8u) << 16);
+#pragma unroll
+                for (uint32_t q = 0; q < PROBE_TA; q++) le[q] += (x <= amax[q]) ? 0x10000u : 0u;
             }
             const uint64_t maxb = nb ? brow[nb - 1] : 0ull;
-            for (uint32_t q = 0; q < PROBE_TA; q++) {
+#pragma unroll
+            for (uint32_t q = 0; q < PROBE_TA; q++) {   // unrolled: a set's base is an immediate offset of the LDS reads
                 const uint32_t gi = ti * PROBE_TA + q;
                 if (gi >= gj) break;
                 const uint32_t na = a_len[q];
-                const uint64_t maxa = a_max[q];
-                const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(sets + (size_t)q * buckets);
-                uint32_t packed = 0;  // low 16 bits: hits, high 16 bits: #{b <= max A}
+                const uint64_t maxa = amax[q];
+                const unsigned char *set = reinterpret_cast<const unsigned char *>(sets + (size_t)q * buckets);
+                uint32_t packed = le[q];  // low 16 bits: hits, high 16 bits: #{b <= max A}
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const uint64_t x = b[t];
-                    const ulonglong2 v1 = set[bucket1(x, mask)];  // both buckets are always read: no
-                    const ulonglong2 v2 = set[bucket2(x, mask)];  // data-dependent branch in the probe
-                    const uint32_t hit = (uint32_t)(v1.x == x) | (uint32_t)(v1.y == x) | (uint32_t)(v2.x == x) | (uint32_t)(v2.y == x);
-                    const uint32_t ok = (vmask >> t) & 1u;
-                    packed += (hit & ok) + (((uint32_t)(x <= maxa) & ok) << 16);
-                    // at most 8 bucket reads (32 VGPRs) in flight: 1024-thread blocks cap a lane at 128 VGPRs
-                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    const uint2 v1 = *reinterpret_cast<const uint2 *>(set + (op[t] & 0xffffu));  // both buckets are always read: no
+                    const uint2 v2 = *reinterpret_cast<const uint2 *>(set + (op[t] >> 16));      // data-dependent branch in the probe
+                    const uint32_t x = tg[t];
+                    packed += (uint32_t)(v1.x == x) | (uint32_t)(v1.y == x) | (uint32_t)(v2.x == x) | (uint32_t)(v2.y == x);
+                    if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 16 bucket reads (32 VGPRs) in flight
                 }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) packed += __shfl_xor(packed, off, 64);
@@ -168,17 +192,53 @@ __global__ __launch_bounds__(PROBE_THREADS) void pair_probe_tile_kernel(
                         icnt = 16 * full + (uint32_t)__popcll(__ballot(in));
                     }
                 }
-                const uint32_t total = icnt + jcnt - common;
+                // (tag hits can exceed the exact count: keep the index inside cmin[0 .. 2 s + 1])
+                const uint32_t total = min(icnt + jcnt - min(common, icnt + jcnt), 2u * s + 1u);
                 if (lane == 0 && common >= (uint32_t)cmin[total]) {
                     unsigned long long idx = atomicAdd(out_count, 1ull);
                     if (idx < cap) {
                         ghip_pair r;
                         r.i = gi; r.j = gj; r.common = common; r.total = total; r.ani = 0.0f;
-                        out[idx] = r;
+                        out[idx] = r;   // provisional: pair_verify_kernel recounts it against the full keys
                     }
                 }
             }
         }
+    }
+}
+
+// Exact (common, total) of every listed pair: one wavefront per pair probes the A-sketch's full 64-bit cuckoo set in global
+// memory (L2) with the B row -- the arithmetic of raw_distance (src/finch.rs:74-96 via finch::distance), nothing approximate
+// left.  The host's f64 recheck (ghip_pairs_finalize) then drops what only the tags let through.
+__global__ __launch_bounds__(256) void pair_verify_kernel(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
+                                                          const uint64_t *__restrict__ tables, uint32_t s, uint32_t buckets,
+                                                          ghip_pair *__restrict__ out, const unsigned long long *__restrict__ out_count,
+                                                          uint64_t cap) {
+    const uint64_t listed = min((uint64_t)*out_count, cap);
+    const uint32_t lane = threadIdx.x & 63u, mask = buckets - 1;
+    for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < listed; c += (uint64_t)gridDim.x * 4) {
+        const uint32_t gi = out[c].i, gj = out[c].j;
+        const uint32_t na = lens[gi], nb = lens[gj];
+        const uint64_t *arow = hashes + (uint64_t)gi * s, *brow = hashes + (uint64_t)gj * s;
+        const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(tables + (uint64_t)gi * 2 * buckets);
+        const uint64_t maxa = na ? arow[na - 1] : 0ull, maxb = nb ? brow[nb - 1] : 0ull;
+        uint32_t common = 0, b_le = 0, a_le = 0;
+        for (uint32_t e = lane; e < nb; e += 64) {
+            const uint64_t x = brow[e];
+            const ulonglong2 v1 = set[bucket1(x, mask)], v2 = set[bucket2(x, mask)];
+            common += (v1.x == x || v1.y == x || v2.x == x || v2.y == x) ? 1u : 0u;
+            b_le += x <= maxa ? 1u : 0u;
+        }
+        for (uint32_t e = lane; e < na; e += 64) a_le += arow[e] <= maxb ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            common += __shfl_xor(common, off, 64); b_le += __shfl_xor(b_le, off, 64); a_le += __shfl_xor(a_le, off, 64);
+        }
+        uint32_t icnt = 0, jcnt = 0;
+        if (na > 0 && nb > 0) {
+            if (maxa <= maxb) { icnt = na; jcnt = b_le; } else { jcnt = nb; icnt = a_le; }
+        }
+        if (lane == 0) { out[c].common = common; out[c].total = icnt + jcnt - common; }
     }
 }
 
@@ -191,12 +251,12 @@ size_t ghip_probe_table_slots(uint32_t s) {
 }
 
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                             uint64_t *d_tables, uint32_t *d_flags) {
+                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags) {
     if (n == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
     ghip_prof_begin(ctx, "pair_table_build");
     hipLaunchKernelGGL(pair_table_build_kernel, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
-                       ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_flags);
+                       ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_tags, d_flags);
     ghip_prof_end(ctx);
 }
 
@@ -232,22 +292,24 @@ uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t PROBE_CB, const std::vector
 }
 
 void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
-                             size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
+                             const uint32_t *d_tags, size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                              unsigned long long *d_count, uint64_t cap) {
     const uint64_t mine = n_work > rank ? (n_work - rank + world - 1) / world : 0;
     if (mine == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
-    const size_t lds = (size_t)PROBE_TA * buckets * 16 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;
+    const size_t lds = (size_t)PROBE_TA * buckets * 8 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<16>), 160 * 1024);
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<4>), 160 * 1024);
     const unsigned grid = (unsigned)std::min<uint64_t>(mine, GHIP_MAX_GRID);
     ghip_prof_begin(ctx, "pair_intersect_tile");
     if (s <= 256)
         hipLaunchKernelGGL(pair_probe_tile_kernel<4>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
-                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
+                           d_tags, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
     else
         hipLaunchKernelGGL(pair_probe_tile_kernel<16>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
-                           d_tables, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
+                           d_tags, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
+    // the listed pairs again, against the full keys (part of the same profiled stage: the list is a few thousand pairs)
+    hipLaunchKernelGGL(pair_verify_kernel, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_out, d_count, cap);
     ghip_prof_end(ctx);
 }
