@@ -18,8 +18,9 @@
 //   keys took two ds_read_b128 (32 bytes), the tag and the two bucket addresses of a B element are computed once per B row
 //   and reused for its 8 A-sets, and a set is 8 KiB, so two workgroups share a CU.  A tag can match where the key does
 //   not (never the reverse): the tag pass counts common' >= common, total' <= total, and since cmin[] is non-decreasing
-//   its list is a SUPERSET of the exact one; pair_verify then recounts every listed pair against the full 64-bit
-//   cuckoo set in global memory (a few thousand pairs out of N^2/2), so what leaves the stage is exact.
+//   its list is a SUPERSET of the exact one; pair_verify then recounts every listed pair against the full 64-bit cuckoo
+//   set in global memory (a few thousand pairs out of N^2/2), so what leaves the stage is exact.  (Recounting inside the
+//   probe kernel, by the wave that found the pair, cost the probe loop its registers: 0.41 -> 0.59 ms.)
 //
 // Integer work only; a pair is emitted iff common >= cmin[total] (host table from the f64
 // formula) and the host recomputes the exact f32.  Exactness guards: a sketch that holds the
@@ -85,6 +86,42 @@ __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *_
     for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) { dst[i] = tab[i]; tdst[i] = tab[i] == EMPTY ? 0u : tag_of(tab[i]); }
 }
 
+// Exact (common, total) of one pair, by the calling wavefront: the B row probes the A-sketch's full 64-bit cuckoo set in
+// global memory (L2) -- the arithmetic of raw_distance (src/finch.rs:74-96 via finch::distance), nothing approximate left.
+__device__ __forceinline__ uint2 exact_pair(const uint64_t *__restrict__ arow, uint32_t na, const uint64_t *__restrict__ brow,
+                                                      uint32_t nb, const uint64_t *__restrict__ table, uint32_t mask, uint32_t lane) {
+    const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(table);
+    const uint64_t maxa = na ? arow[na - 1] : 0ull, maxb = nb ? brow[nb - 1] : 0ull;
+    uint32_t common = 0, b_le = 0, a_le = 0;
+    // eight elements per lane and step: their loads, then their sixteen bucket reads, are independent (a step is three
+    // memory round trips, not twenty-four)
+    for (uint32_t e0 = lane; e0 < nb; e0 += 512) {
+        uint64_t x[8];
+        ulonglong2 v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = e0 + 64u * u < nb ? brow[e0 + 64u * u] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { v1[u] = set[bucket1(x[u], mask)]; v2[u] = set[bucket2(x[u], mask)]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool have = e0 + 64u * u < nb;
+            common += (have && (v1[u].x == x[u] || v1[u].y == x[u] || v2[u].x == x[u] || v2[u].y == x[u])) ? 1u : 0u;
+            b_le += (have && x[u] <= maxa) ? 1u : 0u;
+        }
+    }
+    if (maxa > maxb)   // (wave-uniform) the other rank is only needed then
+        for (uint32_t e = lane; e < na; e += 64) a_le += arow[e] <= maxb ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        common += __shfl_xor(common, off, 64); b_le += __shfl_xor(b_le, off, 64); a_le += __shfl_xor(a_le, off, 64);
+    }
+    uint32_t icnt = 0, jcnt = 0;
+    if (na > 0 && nb > 0) {
+        if (maxa <= maxb) { icnt = na; jcnt = b_le; } else { jcnt = nb; icnt = a_le; }
+    }
+    return make_uint2(common, icnt + jcnt - common);
+}
+
 // ---------------------------------------------------------------------------------------------
 // probe kernel; NT = 64-element register slices of a B-sketch (s <= 64*NT)
 // ---------------------------------------------------------------------------------------------
@@ -95,8 +132,9 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
     uint64_t n_work, uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin,
     ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint2 *sets = reinterpret_cast<uint2 *>(smem_raw);                                  // [TA][buckets]: the two tags of a bucket
-    uint64_t *samp = reinterpret_cast<uint64_t *>(sets + (size_t)PROBE_TA * buckets);   // [TA][64]
+    // [TA] tag sets at a compile-time stride (the largest set of this NT), the two tags of a bucket side by side
+    constexpr uint32_t SET_BYTES = (NT > 4 ? 1024u : 256u) * 8u;
+    uint64_t *samp = reinterpret_cast<uint64_t *>(smem_raw + PROBE_TA * SET_BYTES);     // [TA][64]
     uint64_t *a_max = samp + PROBE_TA * 64;                                             // [TA]
     uint32_t *a_len = reinterpret_cast<uint32_t *>(a_max + PROBE_TA);                   // [TA]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -119,7 +157,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
         for (uint32_t q = 0; q < PROBE_TA; q++) {
             const uint32_t g = ti * PROBE_TA + q;
             const uint4 *src = reinterpret_cast<const uint4 *>(tags + (uint64_t)g * 2 * buckets);
-            uint4 *dst = reinterpret_cast<uint4 *>(sets + (size_t)q * buckets);
+            uint4 *dst = reinterpret_cast<uint4 *>(smem_raw + q * SET_BYTES);
             for (uint32_t e = threadIdx.x; e < buckets / 2; e += PROBE_THREADS)
                 dst[e] = (g < n) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
         }
@@ -147,7 +185,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
             // per element of the B row, once for all 8 A-sets: its tag (1: no element -- matches no slot, an empty one
             // included), the byte offsets of its two buckets inside a set, and its contribution to #{b <= max A} of every
             // A of the tile; the hash itself is not kept (registers: the probe loop below wants its reads in flight)
-            uint32_t tg[NT], op[NT];   // op: offset of bucket 1 | offset of bucket 2 << 16 (a set is at most 8 KiB)
+            uint32_t tg[NT], o1[NT], o2[NT];
             uint32_t le[PROBE_TA];
 #pragma unroll
             for (uint32_t q = 0; q < PROBE_TA; q++) le[q] = 0;
@@ -156,26 +194,39 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
                 const uint32_t e = lane + 64u * t;
                 const uint64_t x = (e < nb) ? brow[e] : EMPTY;            // (EMPTY is > every max A: never counted)
                 tg[t] = (e < nb) ? tag_of(x) : 1u;
-                op[t] = (bucket1(x, mask) * 8u) | ((bucket2(x, mask) * 8u) << 16);
+                o1[t] = bucket1(x, mask) * 8u;
+                o2[t] = bucket2(x, mask) * 8u;
 #pragma unroll
                 for (uint32_t q = 0; q < PROBE_TA; q++) le[q] += (x <= amax[q]) ? 0x10000u : 0u;
             }
             const uint64_t maxb = nb ? brow[nb - 1] : 0ull;
 #pragma unroll
-            for (uint32_t q = 0; q < PROBE_TA; q++) {   // unrolled: a set's base is an immediate offset of the LDS reads
+            for (uint32_t q = 0; q < PROBE_TA; q++) {   // unrolled: a set's base (q * SET_BYTES) is the immediate offset of its LDS reads
                 const uint32_t gi = ti * PROBE_TA + q;
                 if (gi >= gj) break;
                 const uint32_t na = a_len[q];
                 const uint64_t maxa = amax[q];
-                const unsigned char *set = reinterpret_cast<const unsigned char *>(sets + (size_t)q * buckets);
+                const unsigned char *set = smem_raw + q * SET_BYTES;
                 uint32_t packed = le[q];  // low 16 bits: hits, high 16 bits: #{b <= max A}
+                // four elements at a time: their eight bucket reads are issued back to back (16 VGPRs in flight), then
+                // compared -- the scheduler is fenced between the two halves, or it serialises read -> wait -> compare
+                // per element and the wave idles on LDS latency (both buckets are always read: no data-dependent branch)
+                constexpr int GROUP = 4;
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const uint2 v1 = *reinterpret_cast<const uint2 *>(set + (op[t] & 0xffffu));  // both buckets are always read: no
-                    const uint2 v2 = *reinterpret_cast<const uint2 *>(set + (op[t] >> 16));      // data-dependent branch in the probe
-                    const uint32_t x = tg[t];
-                    packed += (uint32_t)(v1.x == x) | (uint32_t)(v1.y == x) | (uint32_t)(v2.x == x) | (uint32_t)(v2.y == x);
-                    if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 16 bucket reads (32 VGPRs) in flight
+                for (int t0 = 0; t0 < NT; t0 += GROUP) {
+                    uint2 v1[GROUP], v2[GROUP];
+#pragma unroll
+                    for (int u = 0; u < GROUP; u++) {
+                        v1[u] = *reinterpret_cast<const uint2 *>(set + o1[t0 + u]);
+                        v2[u] = *reinterpret_cast<const uint2 *>(set + o2[t0 + u]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < GROUP; u++) {
+                        const uint32_t x = tg[t0 + u];
+                        packed += (uint32_t)(v1[u].x == x) | (uint32_t)(v1[u].y == x) | (uint32_t)(v2[u].x == x) | (uint32_t)(v2[u].y == x);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) packed += __shfl_xor(packed, off, 64);
@@ -207,38 +258,19 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
-// Exact (common, total) of every listed pair: one wavefront per pair probes the A-sketch's full 64-bit cuckoo set in global
-// memory (L2) with the B row -- the arithmetic of raw_distance (src/finch.rs:74-96 via finch::distance), nothing approximate
-// left.  The host's f64 recheck (ghip_pairs_finalize) then drops what only the tags let through.
+// Exact (common, total) of every listed pair, one wavefront per pair (exact_pair).  The host's f64 recheck
+// (ghip_pairs_finalize) then drops what only the tags let through.
 __global__ __launch_bounds__(256) void pair_verify_kernel(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
                                                           const uint64_t *__restrict__ tables, uint32_t s, uint32_t buckets,
                                                           ghip_pair *__restrict__ out, const unsigned long long *__restrict__ out_count,
                                                           uint64_t cap) {
     const uint64_t listed = min((uint64_t)*out_count, cap);
-    const uint32_t lane = threadIdx.x & 63u, mask = buckets - 1;
+    const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < listed; c += (uint64_t)gridDim.x * 4) {
         const uint32_t gi = out[c].i, gj = out[c].j;
-        const uint32_t na = lens[gi], nb = lens[gj];
-        const uint64_t *arow = hashes + (uint64_t)gi * s, *brow = hashes + (uint64_t)gj * s;
-        const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(tables + (uint64_t)gi * 2 * buckets);
-        const uint64_t maxa = na ? arow[na - 1] : 0ull, maxb = nb ? brow[nb - 1] : 0ull;
-        uint32_t common = 0, b_le = 0, a_le = 0;
-        for (uint32_t e = lane; e < nb; e += 64) {
-            const uint64_t x = brow[e];
-            const ulonglong2 v1 = set[bucket1(x, mask)], v2 = set[bucket2(x, mask)];
-            common += (v1.x == x || v1.y == x || v2.x == x || v2.y == x) ? 1u : 0u;
-            b_le += x <= maxa ? 1u : 0u;
-        }
-        for (uint32_t e = lane; e < na; e += 64) a_le += arow[e] <= maxb ? 1u : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            common += __shfl_xor(common, off, 64); b_le += __shfl_xor(b_le, off, 64); a_le += __shfl_xor(a_le, off, 64);
-        }
-        uint32_t icnt = 0, jcnt = 0;
-        if (na > 0 && nb > 0) {
-            if (maxa <= maxb) { icnt = na; jcnt = b_le; } else { jcnt = nb; icnt = a_le; }
-        }
-        if (lane == 0) { out[c].common = common; out[c].total = icnt + jcnt - common; }
+        const uint2 ex = exact_pair(hashes + (uint64_t)gi * s, lens[gi], hashes + (uint64_t)gj * s, lens[gj],
+                                    tables + (uint64_t)gi * 2 * buckets, buckets - 1, lane);
+        if (lane == 0) { out[c].common = ex.x; out[c].total = ex.y; }
     }
 }
 
@@ -298,7 +330,7 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     const uint64_t mine = n_work > rank ? (n_work - rank + world - 1) / world : 0;
     if (mine == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
-    const size_t lds = (size_t)PROBE_TA * buckets * 8 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;
+    const size_t lds = (size_t)PROBE_TA * (s <= 256 ? 256 : 1024) * 8 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;   // (pair_probe_tile_kernel: SET_BYTES)
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<16>), 160 * 1024);
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<4>), 160 * 1024);
     const unsigned grid = (unsigned)std::min<uint64_t>(mine, GHIP_MAX_GRID);
