@@ -210,6 +210,22 @@ __device__ __forceinline__ void cast_vote(uint32_t *votes, uint32_t c, uint32_t 
     atomicAdd(&votes[c * ANI_VOTE_WORDS + (single ? (band >> 1) : 8u)], single ? 1u << (16u * (band & 1u)) : 1u);
 }
 
+// The vote of an r seed is settled as its anchors arrive, by the lanes that find them: `old` = the seed's band mask before
+// this anchor (the value the atomicOr returned, which orders the anchors of a seed).  First anchor: a vote for its band.
+// An anchor in a DIFFERENT band while the mask held exactly one: that vote moves to the chunk's repeat counter.  Anything
+// later changes nothing.  (u16 halves of a word: -1 on a half is +0xffff0000 / +0xffffffff on the word, which leaves the
+// other half alone once the matching +1 has landed -- and word arithmetic mod 2^32 commutes, so the order the two
+// atomics of different lanes land in does not matter.)  Same final counters as one cast_vote per seed on its full mask.
+__device__ __forceinline__ void settle_r_vote(uint32_t *votes, uint32_t c, uint32_t old, uint32_t band) {
+    if (old == 0) {
+        atomicAdd(&votes[c * ANI_VOTE_WORDS + (band >> 1)], 1u << (16u * (band & 1u)));
+    } else if ((old & (old - 1)) == 0 && old != (1u << band)) {
+        const uint32_t b1 = (uint32_t)__builtin_ctz(old);
+        atomicAdd(&votes[c * ANI_VOTE_WORDS + (b1 >> 1)], 0u - (1u << (16u * (b1 & 1u))));
+        atomicAdd(&votes[c * ANI_VOTE_WORDS + 8u], 1u);
+    }
+}
+
 // Appends (M_c << 32 | T_c) of every aligned chunk (M_c*10000 >= 510*T_c) to `list` and returns this
 // thread's share of the aligned bases.  M_c = votes of the bands holding >= ANI_MIN_COLINEAR seeds, plus the repeat seeds
 // of a chunk that has such a band, capped at T_c.
@@ -393,8 +409,8 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
             PH(2);   // staging
             // Flattened join: q seeds are dealt to the lanes one each (not one BIN per lane, whose cost is the
             // largest bin of the wave squared); a seed's bin, hence its short r range, follows from its code.
-            // Every anchor sets its band in the q seed's mask (a register) and in the r seed's mask (LDS); the
-            // votes of the r seeds are cast in a second balanced pass.
+            // Every anchor sets its band in the q seed's mask (a register) and in the r seed's mask (LDS); the q seed votes
+            // once its bin is compared, the r seed's vote is settled by the lanes that find its anchors (settle_r_vote).
             const uint32_t nq = q_hi - q_lo, nr = r_hi - r_lo;
             if (lane < rbins) ro[lane] = (uint16_t)(rs - r_lo);   // r range of bin b0 + x = [ro[x], ro[x + 1])
             for (uint32_t u = 64 + lane; u < rbins; u += 64) ro[u] = (uint16_t)(rb[b0 + u] - r_lo);
@@ -427,15 +443,15 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
                     while (mm) {
                         const uint32_t j = j0 + (uint32_t)__builtin_ctz(mm);
                         mm &= mm - 1;
-                        const uint32_t band = anchor_band(qloc, qpos, lr[j], chunk);
+                        const uint32_t rloc = lr[j], band = anchor_band(qloc, qpos, rloc, chunk), sh = 16u * (j & 1u);
                         qmask |= 1u << band;
-                        atomicOr(&rm[j >> 1], (1u << band) << (16u * (j & 1u)));
+                        settle_r_vote(vr, rloc >> 16, (atomicOr(&rm[j >> 1], (1u << band) << sh) >> sh) & 0xffffu, band);
                     }
                     for (uint32_t j = j0 + 8; j < jz; j++)
                         if (sr[j] == c) {
-                            const uint32_t band = anchor_band(qloc, qpos, lr[j], chunk);
+                            const uint32_t rloc = lr[j], band = anchor_band(qloc, qpos, rloc, chunk), sh = 16u * (j & 1u);
                             qmask |= 1u << band;
-                            atomicOr(&rm[j >> 1], (1u << band) << (16u * (j & 1u)));
+                            settle_r_vote(vr, rloc >> 16, (atomicOr(&rm[j >> 1], (1u << band) << sh) >> sh) & 0xffffu, band);
                         }
                     cast_vote(vq, qloc >> 16, qmask);
                 }
@@ -443,16 +459,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             PH(4);   // join
-#ifndef GHIP_DBG_ANI_NORVOTES   // timing experiment only: wrong results
-            for (uint32_t w = lane; w < (nr + 1) / 2; w += 64) {
-                const uint32_t m2 = rm[w];
-                if (m2) {
-                    rm[w] = 0;
-                    if (m2 & 0xffffu) cast_vote(vr, lr[2 * w] >> 16, m2 & 0xffffu);
-                    if (m2 >> 16) cast_vote(vr, lr[2 * w + 1] >> 16, m2 >> 16);
-                }
-            }
-#endif
+            for (uint32_t w = lane; w < (nr + 1) / 2; w += 64) rm[w] = 0;   // the r votes were settled as the anchors arrived
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the stage is rewritten in the next round
             PH(5);   // r votes
