@@ -1312,7 +1312,7 @@ static int sketch_genomes_locked(ghip_ctx *ctx, const ghip_genomes *g, uint32_t 
         // (no synchronisation here: the three host vectors stay as they are until the one after the kernels)
         ghip_launch_sketch_kmers(ctx, g->d_packed, g->d_valid, g->d_starts, g->d_lens, d_slot_genome, d_thr, d_cstart, d_cap,
                                  d_work, n_work, k, (uint32_t)seed, d_cand, d_count, first ? seeds : nullptr);
-        ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, s, sk->d_hashes,
+        ghip_launch_sketch_select(ctx, d_slot_genome, ns, d_cand, d_count, d_cstart, d_cap, *std::max_element(slot_cap.begin(), slot_cap.end()), s, sk->d_hashes,
                                   sk->d_lens, d_status);
         std::vector<uint32_t> status(ns), count(ns);
         if ((rc = d2h_nosync(ctx, status.data(), d_status, ns))) break;

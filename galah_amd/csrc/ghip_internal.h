@@ -229,7 +229,7 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint32_t *d_packed, const uin
                               uint32_t *d_cand_count, const ghip_seed_args *seeds /* nullable */);
 void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, size_t n_slots,
                                uint64_t *d_cand, const uint32_t *d_cand_count,
-                               const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap,
+                               const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap, uint32_t max_cap,
                                uint32_t s, uint64_t *d_hashes, uint32_t *d_lens, uint32_t *d_status);
 void ghip_pair_geometry(uint32_t s, uint32_t *s_pad, uint32_t *sp, uint32_t *pt);
 

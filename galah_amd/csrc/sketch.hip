@@ -415,13 +415,22 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel_rt(
 // sketch_select: one 1024-thread block per pending genome.
 // status bits: 1 = candidate list overflowed (count > cap), 2 = fewer than s distinct hashes.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t SELECT_THREADS = 1024;
-constexpr uint32_t SELECT_LDS_ELEMS = 8192;  // 64 KiB
+constexpr uint32_t SELECT_THREADS = 256;     // small blocks: eight per CU overlap one another's loads and barriers (1 024-thread blocks: two)
+constexpr uint32_t SELECT_LDS_ELEMS = 8192;  // 64 KiB at most; a launch asks for what its longest list needs
 
+// Thread t of a step exchanges elements lo = 2t - (t & (stride - 1)) and lo + stride: for stride <= 64 the 64 threads of a
+// wavefront stay inside ITS 128 consecutive elements, so consecutive steps of small strides only need the wave's own
+// writes to be visible -- a wavefront fence, not a block barrier.  Of the 66 steps of a 2 048-element sort 14 need the block
+// (a stride above 64, or the step after one): the kernel was barrier-bound (16 SIMD-cycles per VALU instruction).
+// LOCAL = the buffer is LDS (the global-memory path of very long candidate lists keeps the block barrier everywhere).
+template <bool LOCAL>
 __device__ __forceinline__ void bitonic_sort(uint64_t *buf, uint32_t m /* pow2 */) {
+    uint32_t prev = ~0u;   // the fill before the sort was block-wide
     for (uint32_t size = 2; size <= m; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (!LOCAL || stride > 64 || prev > 64) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+            prev = stride;
             for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
                 uint32_t lo = 2 * t - (t & (stride - 1));
                 uint32_t hi = lo + stride;
@@ -437,9 +446,9 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *buf, uint32_t m /* pow2 *
 __global__ __launch_bounds__(SELECT_THREADS) void sketch_select_kernel(
     const uint32_t *__restrict__ slot_genome, uint64_t *__restrict__ cand,
     const uint32_t *__restrict__ cand_count, const uint64_t *__restrict__ slot_cand_start,
-    const uint32_t *__restrict__ slot_cand_cap, uint32_t s, uint64_t *__restrict__ hashes,
+    const uint32_t *__restrict__ slot_cand_cap, uint32_t s, uint32_t lds_elems, uint64_t *__restrict__ hashes,
     uint32_t *__restrict__ out_lens, uint32_t *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // lds_elems x 8 bytes
     uint64_t *lds = reinterpret_cast<uint64_t *>(smem_raw);
     __shared__ uint32_t wave_tot[SELECT_THREADS / 64];
 
@@ -456,14 +465,14 @@ __global__ __launch_bounds__(SELECT_THREADS) void sketch_select_kernel(
     while (m < count) m <<= 1;
     if (m < 2) m = 2;
     uint64_t *buf;
-    if (m <= SELECT_LDS_ELEMS) {
+    if (m <= lds_elems) {
         buf = lds;
         for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) buf[i] = (i < count) ? gbuf[i] : ~0ull;
     } else {
         buf = gbuf;  // cap is a power of two >= m on this path
         for (uint32_t i = count + threadIdx.x; i < m; i += blockDim.x) buf[i] = ~0ull;
     }
-    bitonic_sort(buf, m);
+    if (m <= lds_elems) bitonic_sort<true>(buf, m); else bitonic_sort<false>(buf, m);
 
     // distinct rank of every element; first s distinct go to the output row
     const uint32_t per = (m + blockDim.x - 1) / blockDim.x;
@@ -735,12 +744,16 @@ void ghip_launch_sketch_kmers(ghip_ctx *ctx, const uint32_t *d_packed, const uin
 
 void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, size_t n_slots,
                                uint64_t *d_cand, const uint32_t *d_cand_count,
-                               const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap,
+                               const uint64_t *d_slot_cand_start, const uint32_t *d_slot_cand_cap, uint32_t max_cap,
                                uint32_t s, uint64_t *d_hashes, uint32_t *d_lens, uint32_t *d_status) {
     if (n_slots == 0) return;
+    // the LDS a block asks for follows the launch's longest candidate list (caps are powers of two): 32 KiB at the
+    // default s = 1000, so that five blocks share a CU; lists beyond 8 192 entries are sorted in global memory
+    uint32_t lds_elems = 2;
+    while (lds_elems < max_cap && lds_elems < SELECT_LDS_ELEMS) lds_elems <<= 1;
     ghip_prof_begin(ctx, "sketch_select");
     hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)n_slots), dim3(SELECT_THREADS),
-                       SELECT_LDS_ELEMS * sizeof(uint64_t), ctx->stream, d_slot_genome, d_cand, d_cand_count,
-                       d_slot_cand_start, d_slot_cand_cap, s, d_hashes, d_lens, d_status);
+                       lds_elems * sizeof(uint64_t), ctx->stream, d_slot_genome, d_cand, d_cand_count,
+                       d_slot_cand_start, d_slot_cand_cap, s, lds_elems, d_hashes, d_lens, d_status);
     ghip_prof_end(ctx);
 }
