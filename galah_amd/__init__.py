@@ -12,10 +12,10 @@ from .cache import SortedPairGenomeDistanceCache
 from .engine import Context, cluster_pairs, cluster_pairs_lazy, device_count, fasta_stream
 from .finch import FinchPreclusterer, distances
 from .ani import HipAniClusterer
-from .clusterer import cluster
+from .clusterer import GalahClusterer, cluster
 from .quality import parks2020_reduced_score, quality_order_parks2020_reduced
 from ._lib import GalahHipError, PAIR_DTYPE
 
 __all__ = ["SortedPairGenomeDistanceCache", "Context", "cluster_pairs", "cluster_pairs_lazy", "device_count", "fasta_stream", "FinchPreclusterer",
-           "distances", "HipAniClusterer", "cluster", "GalahHipError", "PAIR_DTYPE", "parks2020_reduced_score",
+           "distances", "HipAniClusterer", "cluster", "GalahClusterer", "GalahHipError", "PAIR_DTYPE", "parks2020_reduced_score",
            "quality_order_parks2020_reduced"]

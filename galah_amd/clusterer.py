@@ -130,3 +130,22 @@ def _cluster(genomes, preclusterer, clusterer, cluster_contigs, contig_names, re
         return clusters
     return cluster_pairs(n, pairs, threshold, None, False,
                          ani_callback=lambda a, b: clusterer.calculate_ani(genomes[a], genomes[b]))
+
+
+class GalahClusterer:
+    """The library entry CoverM and `galah process` use (src/cluster_argument_parsing.rs:108-115, 1514-1530): a carrier of
+    the genome list and the two back-ends whose cluster() is clusterer::cluster -- Vec<Vec<usize>>, element 0 of every inner
+    list the representative (src/cluster_argument_parsing.rs:730)."""
+
+    def __init__(self, genome_fasta_paths: Sequence[str], preclusterer, clusterer, cluster_contigs: bool = False,
+                 contig_names: Optional[Sequence[str]] = None, reference_genomes: Optional[Sequence[str]] = None):
+        self.genome_fasta_paths = list(genome_fasta_paths)
+        self.preclusterer = preclusterer
+        self.clusterer = clusterer
+        self.cluster_contigs = cluster_contigs
+        self.contig_names = contig_names
+        self.reference_genomes = list(reference_genomes) if reference_genomes is not None else None
+
+    def cluster(self) -> List[List[int]]:
+        return cluster(self.genome_fasta_paths, self.preclusterer, self.clusterer, self.cluster_contigs, self.contig_names,
+                       self.reference_genomes)

@@ -448,6 +448,22 @@ inline std::vector<std::vector<size_t>> cluster(const std::vector<std::string> &
     return out;
 }
 
+// GalahClusterer (src/cluster_argument_parsing.rs:108-115, 1514-1530): the library entry CoverM and `galah process` use
+// (src/process.rs:128-145) -- the genome list and the two back-ends; cluster() is clusterer::cluster, element 0 of every
+// inner vector the representative (src/cluster_argument_parsing.rs:730).
+struct GalahClusterer {
+    std::vector<std::string> genome_fasta_paths;
+    PreclusterDistanceFinder *preclusterer = nullptr;
+    ClusterDistanceFinder *clusterer = nullptr;
+    bool cluster_contigs = false;
+    const std::vector<std::string> *contig_names = nullptr;       // Option<Vec<&str>>
+    const std::vector<std::string> *reference_genomes = nullptr;  // Option<Vec<String>>
+    std::vector<std::vector<size_t>> cluster() const {
+        if (!preclusterer || !clusterer) throw std::invalid_argument("GalahClusterer needs a preclusterer and a clusterer");
+        return galah::cluster(genome_fasta_paths, *preclusterer, *clusterer, cluster_contigs, contig_names, reference_genomes);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // The same `cluster` on SEVERAL GPUs driven by this one process (galah's CLI is a single process): one context and one
 // thread per device, genomes in contiguous blocks, sketch matrix all-gathered by peer copies over xGMI, pair work dealt

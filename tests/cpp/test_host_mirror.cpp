@@ -93,6 +93,10 @@ int main(int argc, char **argv) {
         CHECK((sorted(galah::cluster(abisko, pre, cl)) == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(galah::last_ani_pairs_requested() == 3);
         unsetenv("GHIP_LAZY_FLUSH_BELOW");
+        // the library entry (GalahClusterer, src/cluster_argument_parsing.rs:108-115,1514-1530): same call, same clusters
+        galah::GalahClusterer gc;
+        gc.genome_fasta_paths = abisko; gc.preclusterer = &pre; gc.clusterer = &cl;
+        CHECK((sorted(gc.cluster()) == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
     }
     {   // src/clusterer.rs:661-690: at 99 -> [[0,1,3],[2]]
         galah::FinchPreclusterer pre(hip, 0.9f, 1000, 21);

@@ -93,6 +93,31 @@ def test_cluster_mirror_refuses_like_reference():
         galah_amd.cluster(["a"], pre, cl, cluster_contigs=True, contig_names=["c"])  # clusterer.rs:38-41
     with pytest.raises(AssertionError):
         galah_amd.HipAniClusterer(0.95).initialise()        # skani.rs:696-698 (threshold is percent)
+    # GalahClusterer (src/cluster_argument_parsing.rs:108-115, 1514-1530) is the same call behind a struct
+    gc = galah_amd.GalahClusterer(["a"], pre, cl, cluster_contigs=True, contig_names=["c"])
+    assert (gc.genome_fasta_paths, gc.reference_genomes) == (["a"], None)
+    with pytest.raises(RuntimeError, match="finch does not support contig comparisons"):
+        gc.cluster()
+
+
+def test_galah_clusterer_is_cluster_behind_a_struct():
+    """GalahClusterer.cluster() == clusterer::cluster on its fields; with back-ends of one name the precluster ANI is reused
+    (src/clusterer.rs:32-36), so no GPU is needed: a stub preclusterer hands over a cache."""
+    class Pre:
+        def method_name(self): return "stub"
+        def distances(self, genomes):
+            c = galah_amd.SortedPairGenomeDistanceCache()
+            c.insert((0, 1), np.float32(0.99)); c.insert((2, 3), np.float32(0.5)); c.insert((1, 4), np.float32(0.97))
+            return c
+    class Cl:
+        def initialise(self): pass
+        def method_name(self): return "stub"
+        def get_ani_threshold(self): return np.float32(0.95)
+    g = ["a", "b", "c", "d", "e"]
+    want = galah_amd.cluster(g, Pre(), Cl())
+    assert galah_amd.GalahClusterer(g, Pre(), Cl()).cluster() == want
+    # 4 only hits 1, which is not a representative: 4 founds its own cluster (src/clusterer.rs:194-204)
+    assert sorted(map(sorted, want)) == [[0, 1], [2], [3], [4]] and all(c[0] == min(c) for c in want)
 
 
 def test_host_fasta_parser_matches_the_oracle(tmp_path):
