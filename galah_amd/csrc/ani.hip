@@ -539,13 +539,13 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
             step_sync(kk);
             const uint32_t half = kk >> 1;
             for (uint32_t t = threadIdx.x; t < P / 2; t += blockDim.x) {
-                const uint32_t i = kk * (t / half) + (t % half);
+                const uint32_t i = 2 * t - (t & (half - 1));   // = kk * (t / half) + t % half, half a power of two (no division)
                 exchange(i, i ^ (kk - 1));
             }
             for (uint32_t j = half >> 1; j > 0; j >>= 1) {
                 step_sync(2 * j);
                 for (uint32_t t = threadIdx.x; t < P / 2; t += blockDim.x) {
-                    const uint32_t i = 2 * j * (t / j) + (t % j);
+                    const uint32_t i = 2 * t - (t & (j - 1));   // = 2 j * (t / j) + t % j, j a power of two
                     exchange(i, i + j);
                 }
             }

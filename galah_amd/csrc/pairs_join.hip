@@ -291,19 +291,21 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
                                                                     const uint32_t *__restrict__ start2,
                                                                     uint32_t *__restrict__ rec_count, const uint32_t *__restrict__ rec_start,
                                                                     uint64_t *__restrict__ rec, uint32_t *__restrict__ flags,
-                                                                    unsigned long long *__restrict__ rec_total, uint32_t rank, uint32_t world, uint32_t row_lo) {
-    __shared__ uint64_t lk[J_WAVES][J_ELEM_CAP];
-    __shared__ uint32_t lv[J_WAVES][J_ELEM_CAP];
+                                                                    uint32_t *__restrict__ all_count, uint32_t rank, uint32_t world, uint32_t row_lo,
+                                                                    uint32_t elem_cap) {
+    // elem_cap elements per wave: keys, then genome ids (dynamic LDS: a launch sized for the buckets it expects keeps eight
+    // blocks on a CU; with room for J_ELEM_CAP elements per wave three fit, and the sort is bound by its steps' latency)
+    extern __shared__ __attribute__((aligned(16))) unsigned char jraw[];
     __shared__ uint32_t lcnt[J_WAVES];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t bucket = blockIdx.x * J_WAVES + wave;
     const uint32_t lo = start2[bucket], cnt = start2[bucket + 1] - lo;
-    if (cnt > J_ELEM_CAP) {
-        if (lane == 0) { atomicOr(flags, 1u); if (!EMIT) rec_count[bucket] = 0; }
+    if (cnt > elem_cap) {
+        if (lane == 0) { atomicOr(flags, 1u); if (!EMIT) { rec_count[bucket] = 0; all_count[bucket] = 0; } }
         return;
     }
-    uint64_t *k = lk[wave];
-    uint32_t *v = lv[wave];
+    uint64_t *k = reinterpret_cast<uint64_t *>(jraw) + (size_t)wave * elem_cap;
+    uint32_t *v = reinterpret_cast<uint32_t *>(jraw + (size_t)J_WAVES * elem_cap * sizeof(uint64_t)) + (size_t)wave * elem_cap;
     for (uint32_t e = lane; e < cnt; e += 64) { k[e] = keys[lo + e]; v[e] = vals[lo + e]; }
     if (lane == 0) lcnt[wave] = 0;
     if (!EMIT && cnt > 1) {
@@ -326,14 +328,14 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
             __builtin_amdgcn_wave_barrier();
             const uint32_t half = kk >> 1;
             for (uint32_t t = lane; t < P / 2; t += 64) {
-                const uint32_t i = kk * (t / half) + (t % half);
+                const uint32_t i = 2 * t - (t & (half - 1));   // = kk * (t / half) + t % half, half a power of two (no division)
                 exchange(i, i ^ (kk - 1));
             }
             for (uint32_t j = half >> 1; j > 0; j >>= 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t t = lane; t < P / 2; t += 64) {
-                    const uint32_t i = 2 * j * (t / j) + (t % j);
+                    const uint32_t i = 2 * t - (t & (j - 1));   // = 2 j * (t / j) + t % j, j a power of two
                     exchange(i, i + j);
                 }
             }
@@ -366,11 +368,9 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
     if (!EMIT) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { found += __shfl_xor(found, off, 64); found_all += __shfl_xor(found_all, off, 64); }
-        if (lane == 0) {
-            rec_count[bucket] = found;
-            if (found_all) atomicAdd(rec_total, (unsigned long long)found_all);  // 64-bit: the 32-bit offsets may wrap
-            if (found) atomicAdd(rec_total + 1, (unsigned long long)found);
-        }
+        // (the totals are summed from these two arrays by join_totals_kernel: one atomic pair per wave on the same two
+        // addresses serialised 131 072 L2 atomics and WAS the kernel's duration, 1.6 ms at 10 000 genomes)
+        if (lane == 0) { rec_count[bucket] = found; all_count[bucket] = found_all; }
     }
 }
 
@@ -537,6 +537,56 @@ uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin) {
     return f;
 }
 
+// totals[0] = records of all ranks, totals[1] = records this rank keeps: 64-bit sums of the per-bucket counts (the 32-bit
+// offsets of the scan may wrap; the caller declines then)
+__global__ __launch_bounds__(1024) void join_totals_kernel(const uint32_t *__restrict__ all_count, const uint32_t *__restrict__ rec_count,
+                                                           uint32_t nb, unsigned long long *__restrict__ totals) {
+    __shared__ unsigned long long part[2][16];
+    unsigned long long a = 0, b = 0;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) { a += all_count[i]; b += rec_count[i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if ((threadIdx.x & 63u) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; w++) t += part[threadIdx.x][w];
+        totals[threadIdx.x] = t;
+    }
+}
+
+// The counting pass of the element stage (sort every bucket, count its records), optimistically with LDS for J_ELEM_SMALL
+// elements per wave -- eight blocks per CU instead of three; a bucket beyond that raises flag bit 0 and the pass is repeated
+// once with room for J_ELEM_CAP (the limit of the join form: beyond it the caller declines, as before).  *cap_used = the
+// capacity the emitting pass has to be launched with.  flags / totals = what the host needs next (read back here).
+constexpr uint32_t J_ELEM_SMALL = 384;
+static size_t elem_pairs_lds(uint32_t cap) { return (size_t)J_WAVES * cap * (sizeof(uint64_t) + sizeof(uint32_t)); }
+static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t enb, uint64_t *ek, uint32_t *ev, const uint32_t *d_estart,
+                            uint32_t *d_rcount, uint32_t *d_rstart, uint32_t *d_flags, unsigned long long *d_total, uint32_t rank,
+                            uint32_t world, uint32_t row_lo, uint32_t flags[2], unsigned long long totals[2], uint32_t *cap_used) {
+    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_kernel<false>), elem_pairs_lds(J_ELEM_CAP));
+    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_kernel<true>), elem_pairs_lds(J_ELEM_CAP));
+    uint32_t *d_all = jalloc<uint32_t>(ctx, owned, enb);
+    if (!d_all) return GHIP_EHIP;
+    for (uint32_t cap : {J_ELEM_SMALL, J_ELEM_CAP}) {
+        *cap_used = cap;
+        hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), elem_pairs_lds(cap), ctx->stream, ek, ev,
+                           d_estart, d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_all, rank, world, row_lo, cap);
+        hipLaunchKernelGGL(join_totals_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_all, d_rcount, enb, d_total);
+        int rc = scan_counters(ctx, owned, d_rcount, enb, d_rstart, nullptr);
+        if (rc) return rc;
+        totals[0] = totals[1] = 0;
+        GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GHIP_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!(flags[0] & 1u) || cap == J_ELEM_CAP) break;
+        // a bucket did not fit the small stage (flags[1] = the largest one): once more, with the full stage
+        if (flags[1] > J_ELEM_CAP) break;   // no stage holds it: the caller declines
+        GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
+    }
+    return GHIP_OK;
+}
+
 // *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
@@ -570,14 +620,9 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     // 2. records per bucket, their offsets, their number
     uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
     if (!d_rcount || !d_rstart) { ghip_prof_end(ctx); return GHIP_EHIP; }
-    hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total, rank, world, row_lo);
-    if ((rc = scan_counters(ctx, own.p, d_rcount, enb, d_rstart, nullptr))) { ghip_prof_end(ctx); return rc; }
-    uint32_t flags[2];
+    uint32_t flags[2], ecap = 0;
     unsigned long long totals[2] = {0, 0};   // records of all ranks (what every rank decides on), records of this rank
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, rank, world, row_lo, flags, totals, &ecap))) { ghip_prof_end(ctx); return rc; }
     const unsigned long long total_rec = totals[0];
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     // a dense pass costs ~1 ns per pair, a record ~0.3 ns: beyond 4 records per pair the dense kernel is the better tool
@@ -585,8 +630,8 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     const uint32_t n_rec = (uint32_t)totals[1];
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) { ghip_prof_end(ctx); return GHIP_EHIP; }
-    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total, rank, world, row_lo);
+    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), elem_pairs_lds(ecap), ctx->stream, ek, ev, d_estart,
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, (uint32_t *)nullptr, rank, world, row_lo, ecap);
     // 3. records -> 65536 pair buckets -> common per pair -> candidates
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
@@ -662,22 +707,17 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     lap("element partition");
     uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
     if (!d_rcount || !d_rstart) return done(GHIP_EHIP);
-    hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_total, 0u, 1u, 0u);
-    if ((rc = scan_counters(ctx, own.p, d_rcount, enb, d_rstart, nullptr))) return done(rc);
-    uint32_t flags[2];
+    uint32_t flags[2], ecap = 0;
     unsigned long long totals[2] = {0, 0};
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, 0u, 1u, 0u, flags, totals, &ecap))) return done(rc);
     lap("count records");
     *rec_total = totals[0];
     if ((flags[0] & 1u) || totals[0] >= (1ull << 31)) return done(GHIP_OK);   // declined (status bit 0 stays set)
     const uint32_t n_rec = (uint32_t)totals[1];
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) return done(GHIP_EHIP);
-    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, ek, ev, d_estart,
-                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, d_total, 0u, 1u, 0u);
+    hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), elem_pairs_lds(ecap), ctx->stream, ek, ev, d_estart,
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, (uint32_t *)nullptr, 0u, 1u, 0u, ecap);
     lap("emit records");
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
