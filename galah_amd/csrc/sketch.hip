@@ -417,6 +417,7 @@ __global__ __launch_bounds__(GHIP_SKETCH_THREADS) void sketch_kmers_kernel_rt(
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t SELECT_THREADS = 256;     // small blocks: eight per CU overlap one another's loads and barriers (1 024-thread blocks: two)
 constexpr uint32_t SELECT_LDS_ELEMS = 8192;  // 64 KiB at most; a launch asks for what its longest list needs
+constexpr uint32_t SELECT_BUCKETS = 2048, SELECT_PER_THREAD = 16, SELECT_BUCKET_MAX = 12;   // counting-sort form of the selection
 
 // Thread t of a step exchanges elements lo = 2t - (t & (stride - 1)) and lo + stride: for stride <= 64 the 64 threads of a
 // wavefront stay inside ITS 128 consecutive elements, so consecutive steps of small strides only need the wave's own
@@ -451,6 +452,8 @@ __global__ __launch_bounds__(SELECT_THREADS) void sketch_select_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // lds_elems x 8 bytes
     uint64_t *lds = reinterpret_cast<uint64_t *>(smem_raw);
     __shared__ uint32_t wave_tot[SELECT_THREADS / 64];
+    __shared__ uint64_t wave_max[SELECT_THREADS / 64];
+    __shared__ uint32_t worst;   // largest bucket of the counting sort if above SELECT_BUCKET_MAX, else 0
 
     const uint32_t slot = blockIdx.x;
     const uint32_t g = slot_genome[slot];
@@ -465,14 +468,82 @@ __global__ __launch_bounds__(SELECT_THREADS) void sketch_select_kernel(
     while (m < count) m <<= 1;
     if (m < 2) m = 2;
     uint64_t *buf;
-    if (m <= lds_elems) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (m <= lds_elems && count <= SELECT_PER_THREAD * SELECT_THREADS) {
+        // The candidates are hashes below a threshold, i.e. spread evenly over [0, max]: a counting sort on their top 11
+        // bits puts every one within a few places of its final position in ONE pass (histogram by LDS atomic, scan,
+        // scatter), and the handful that share a bucket are ordered by insertion -- about a fifth of the LDS traffic of
+        // the 66-step bitonic network, which remains for inputs that are not spread (a bucket of more than
+        // SELECT_BUCKET_MAX: highly repetitive sequence) and for lists beyond the LDS.
+        buf = lds;
+        uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + (size_t)lds_elems * sizeof(uint64_t));   // [SELECT_BUCKETS]
+        uint64_t v[SELECT_PER_THREAD];
+        uint32_t rk[SELECT_PER_THREAD];
+        uint64_t vmax = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < SELECT_PER_THREAD; u++) {
+            const uint32_t i = threadIdx.x + u * SELECT_THREADS;
+            v[u] = i < count ? gbuf[i] : 0ull;
+            vmax = v[u] > vmax ? v[u] : vmax;
+        }
+        for (uint32_t b = threadIdx.x; b < SELECT_BUCKETS; b += SELECT_THREADS) hist[b] = 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint64_t o = __shfl_xor(vmax, off, 64); vmax = o > vmax ? o : vmax; }
+        if (lane == 0) wave_max[wave] = vmax;
+        if (threadIdx.x == 0) worst = 0;
+        __syncthreads();
+        for (uint32_t w = 0; w < SELECT_THREADS / 64; w++) vmax = wave_max[w] > vmax ? wave_max[w] : vmax;
+        const uint32_t top = vmax ? 64u - (uint32_t)__builtin_clzll(vmax) : 1u, sh = top > 11u ? top - 11u : 0u;   // (vmax >> sh) < 2048
+#pragma unroll
+        for (uint32_t u = 0; u < SELECT_PER_THREAD; u++)
+            if (threadIdx.x + u * SELECT_THREADS < count) rk[u] = atomicAdd(&hist[(uint32_t)(v[u] >> sh)], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 2 048 counters: eight per thread, then the block's 256 partial sums
+            constexpr uint32_t PER = SELECT_BUCKETS / SELECT_THREADS;
+            uint32_t c[PER], sum = 0, big = 0;
+#pragma unroll
+            for (uint32_t x = 0; x < PER; x++) { c[x] = hist[threadIdx.x * PER + x]; sum += c[x]; big = c[x] > big ? c[x] : big; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
+            if (lane == 63) wave_tot[wave] = incl;
+            if (big > SELECT_BUCKET_MAX) atomicMax(&worst, big);
+            __syncthreads();
+            uint32_t base = incl - sum;
+            for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+#pragma unroll
+            for (uint32_t x = 0; x < PER; x++) { hist[threadIdx.x * PER + x] = base; base += c[x]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < SELECT_PER_THREAD; u++)
+            if (threadIdx.x + u * SELECT_THREADS < count) buf[hist[(uint32_t)(v[u] >> sh)] + rk[u]] = v[u];
+        __syncthreads();
+        if (worst == 0) {
+            // order inside the buckets: bucket b holds buf[hist[b] .. hist[b + 1]) (the last one up to count)
+            for (uint32_t b = threadIdx.x; b < SELECT_BUCKETS; b += SELECT_THREADS) {
+                const uint32_t lo = hist[b], hi = b + 1 < SELECT_BUCKETS ? hist[b + 1] : count;
+                for (uint32_t i = lo + 1; i < hi; i++) {
+                    const uint64_t x = buf[i];
+                    uint32_t j = i;
+                    while (j > lo && buf[j - 1] > x) { buf[j] = buf[j - 1]; j--; }
+                    buf[j] = x;
+                }
+            }
+            __syncthreads();
+        } else {   // (block-uniform) not spread: the general network over the same LDS image
+            for (uint32_t i = count + threadIdx.x; i < m; i += blockDim.x) buf[i] = ~0ull;
+            bitonic_sort<true>(buf, m);
+        }
+    } else if (m <= lds_elems) {
         buf = lds;
         for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) buf[i] = (i < count) ? gbuf[i] : ~0ull;
+        bitonic_sort<true>(buf, m);
     } else {
         buf = gbuf;  // cap is a power of two >= m on this path
         for (uint32_t i = count + threadIdx.x; i < m; i += blockDim.x) buf[i] = ~0ull;
+        bitonic_sort<false>(buf, m);
     }
-    if (m <= lds_elems) bitonic_sort<true>(buf, m); else bitonic_sort<false>(buf, m);
 
     // distinct rank of every element; first s distinct go to the output row
     const uint32_t per = (m + blockDim.x - 1) / blockDim.x;
@@ -481,7 +552,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void sketch_select_kernel(
     for (uint32_t i = i0; i < i0 + per && i < count; i++) local += (i == 0 || buf[i] != buf[i - 1]) ? 1u : 0u;
     // block exclusive scan of `local`
     uint32_t incl = local;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __syncthreads();   // (wave_tot is reused)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         uint32_t v = __shfl_up(incl, off, 64);
@@ -751,9 +822,11 @@ void ghip_launch_sketch_select(ghip_ctx *ctx, const uint32_t *d_slot_genome, siz
     // default s = 1000, so that five blocks share a CU; lists beyond 8 192 entries are sorted in global memory
     uint32_t lds_elems = 2;
     while (lds_elems < max_cap && lds_elems < SELECT_LDS_ELEMS) lds_elems <<= 1;
+    const size_t select_lds = lds_elems * sizeof(uint64_t) + SELECT_BUCKETS * sizeof(uint32_t);
+    if (select_lds > 48 * 1024) ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(sketch_select_kernel), select_lds);
     ghip_prof_begin(ctx, "sketch_select");
     hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)n_slots), dim3(SELECT_THREADS),
-                       lds_elems * sizeof(uint64_t), ctx->stream, d_slot_genome, d_cand, d_cand_count,
+                       select_lds, ctx->stream, d_slot_genome, d_cand, d_cand_count,
                        d_slot_cand_start, d_slot_cand_cap, s, lds_elems, d_hashes, d_lens, d_status);
     ghip_prof_end(ctx);
 }
