@@ -89,7 +89,7 @@ class HipAniClusterer:
         """clusterer::cluster over the prepared index, whole in native code (ghip_cluster_index) -> (clusters, pairs asked)."""
         assert self._index is not None, "call prepare() first"
         clusters, st = self._context().cluster_index(self._index, n_genomes, pairs, threshold, float(self.min_aligned_threshold))
-        return clusters, st["asked"]
+        return clusters.tolist(), st["asked"]   # (clusterer::cluster's Vec<Vec<usize>>: plain lists for the caller)
 
     # ---- the trait method
     def calculate_ani(self, fasta1: str, fasta2: str) -> Optional[np.float32]:

@@ -41,7 +41,7 @@ struct Dsu {
 static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const float *pair_ani,
                         int skip_clusterer, float ani_threshold, ghip_ani_callback ani_cb, ghip_ani_batch_callback batch_cb,
                         void *user, uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters,
-                        uint64_t *out_requested) {
+                        uint64_t *out_requested, ghip_ctx *pool_ctx = nullptr) {
     if (!out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
     if (n_pairs && !pairs) return GHIP_EINVAL;
     const bool dbg = getenv("GHIP_CLUSTER_DEBUG") != nullptr;
@@ -297,10 +297,17 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
             for (size_t w = 1; w < workers; w++)
                 cut[w] = std::lower_bound(pre_base.begin(), pre_base.end(), (uint64_t)(n * w / workers)) - pre_base.begin();
             for (size_t w = 1; w < workers; w++) cut[w] = std::min(std::max(cut[w], cut[w - 1]), nsets);
-            std::vector<std::thread> pool;
-            for (size_t w = 1; w < workers; w++) pool.emplace_back([&, w] { run_range(cut[w], cut[w + 1], ends[w]); });
-            run_range(cut[0], cut[1], ends[0]);
-            for (auto &t : pool) t.join();
+            // the context's persistent I/O workers when the caller has a context and no ingest holds them (a wake-up is ~10 us,
+            // a fresh thread ~30 us to spawn and as much to join); fresh threads otherwise
+            if (pool_ctx && pool_ctx->ingest_mu.try_lock()) {
+                pool_ctx->io.run((int)workers, [&](int w) { run_range(cut[w], cut[w + 1], ends[w]); });
+                pool_ctx->ingest_mu.unlock();
+            } else {
+                std::vector<std::thread> pool;
+                for (size_t w = 1; w < workers; w++) pool.emplace_back([&, w] { run_range(cut[w], cut[w + 1], ends[w]); });
+                run_range(cut[0], cut[1], ends[0]);
+                for (auto &t : pool) t.join();
+            }
         }
         if (failure.load() != GHIP_OK) return failure.load();
         size_t total = 1;
@@ -417,7 +424,7 @@ extern "C" int ghip_cluster_index(ghip_ctx *ctx, const ghip_ani_index *idx, size
     IndexAni st{ctx, idx, pairs, orig.empty() ? nullptr : orig.data(), min_aligned_fraction};
     uint64_t asked = 0;
     const int rc = cluster_impl(n, sorted.empty() ? pairs : sorted.data(), n_pairs, nullptr, 0, ani_threshold, nullptr,
-                                n_pairs ? index_ani_batch : nullptr, &st, out_members, out_offsets, out_n_clusters, &asked);
+                                n_pairs ? index_ani_batch : nullptr, &st, out_members, out_offsets, out_n_clusters, &asked, ctx);
     if (out_stats) {
         out_stats[0] = asked; out_stats[1] = st.rounds; out_stats[2] = st.ns_ani;
         out_stats[3] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
