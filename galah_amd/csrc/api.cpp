@@ -1491,6 +1491,14 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     bool use_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
     bool probe_checked = false;
 
+    const bool dbg_laps = getenv("GHIP_PRECLUSTER_DEBUG") != nullptr;   // host laps of the stage on stderr
+    auto lap_t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg_laps) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[precluster] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - lap_t0).count());
+        lap_t0 = t;
+    };
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     uint64_t cap = std::min<uint64_t>(P, std::max<uint64_t>(1u << 20, 64ull * n));
     unsigned long long *d_count = nullptr;
@@ -1537,15 +1545,20 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if (row_lo) compared = P - (uint64_t)row_lo * (row_lo - 1) / 2;   // the rectangle
         ctx->last_pairs = compared;
         unsigned long long cnt = 0;
+        lap("kernels issued");
         if ((rc = d2h(ctx, &cnt, d_count, 1))) return rc;
+        lap("count back (kernels done)");
         { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("pair_intersect_tile: ") + hipGetErrorString(e)); }
         if (cnt > cap) { cap = cnt; continue; }  // list overflowed: rerun with room for every hit
         host.resize(cnt);
         if ((rc = d2h(ctx, host.data(), d_out, cnt))) return rc;
+        lap("candidates back");
         listed = true;
     }
     if (!listed) return ghip_set_error(ctx, GHIP_EHIP, "precluster candidate list overflowed on every attempt");
-    return ghip_pairs_finalize(ctx, host, k, min_ani, n, filter_share, rank, world, out_pairs, out_n);
+    rc = ghip_pairs_finalize(ctx, host, k, min_ani, n, filter_share, rank, world, out_pairs, out_n);
+    lap("finalize (f64 recheck, (i, j) order)");
+    return rc;
 }
 
 int ghip_precluster_dense_share(ghip_ctx *ctx, const ghip_sketches *sk, float min_ani, uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n) {
