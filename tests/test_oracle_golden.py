@@ -71,7 +71,9 @@ CHECKM = {"abisko_S1D21": (95.21, 0.00), "abisko_S2M16": (95.92, 0.65)}
 
 def test_reference_cli_quality_order_and_skani_cluster():
     """tests/test_cmdline.rs:36-61 (Parks2020_reduced picks S2M.16 over S1D.21) and :304-352 (finch precluster +
-    skani clusterer put both in one cluster whose representative is S2M.16)."""
+    skani clusterer put both in one cluster whose representative is S2M.16).  test_github53 (:612-631) is the same pair as
+    gzip files with a CheckM2 report whose completeness / contamination for the two genomes are these very numbers
+    (tests/data/abisko4/abisko4_quality_report.tsv rows 8 and 17): the fixtures here ARE gzip files, so it is this test."""
     import galah_amd.quality as q
     names = ["abisko_S1D21", "abisko_S2M16"]          # order of the CLI's --genome-fasta-files
     st = [oracle.genome_stats(fasta(n)) for n in names]
