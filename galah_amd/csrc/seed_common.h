@@ -61,6 +61,7 @@ struct SeedLds {  // per-block LDS state; slot-major so that the 64 lanes of a w
     uint32_t raw[SEED_LANE_CAP][GHIP_SKETCH_THREADS];   // forward code as the pass holds it (see seed_canon)
     uint32_t ctot[SEED_LDS_CHUNKS];
     uint32_t seg_n[SEGMENTS], seg_base[SEGMENTS];
+    uint32_t seg_over[SEGMENTS], seg_cur[SEGMENTS];   // seeds beyond a lane's rows (dense genomes): their number, their cursor
 };
 
 // Per-thread view of one block's seeding state.  A lane owns 64 consecutive positions; WHICH of them hold a seed is a
@@ -108,7 +109,7 @@ __device__ __forceinline__ SeedBlock seed_block_begin(SeedLds &sl, const SeedOut
     sb.m16 = 0;
     sb.mask = 0;
     if (threadIdx.x < SEED_LDS_CHUNKS) sl.ctot[threadIdx.x] = 0;
-    if (threadIdx.x < SEGMENTS) sl.seg_n[threadIdx.x] = 0;
+    if (threadIdx.x < SEGMENTS) { sl.seg_n[threadIdx.x] = 0; sl.seg_over[threadIdx.x] = 0; sl.seg_cur[threadIdx.x] = 0; }
     __syncthreads();
     return sb;
 }
@@ -172,10 +173,33 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
             place_r[i] = (seg << 28) | (strand << 27) | atomicAdd(&sl.seg_n[seg], 1u);
         }
     }
+    // The seeds that found no row (a lane with more than SEED_LANE_CAP of them: rare at c = 125, the RULE for genomes seeded
+    // densely -- short contigs take every 15-mer, 64 per lane) are filed through the same segment runs, behind the rowed
+    // ones: counted here, written below with a cursor per segment, their code read back from the packed bases both times
+    // (two words and a funnel shift; the forward big-endian code is the little-endian field with its bases reversed, the
+    // reverse complement's is simply its complement).  Emitting them one by one with two global atomics each, as this
+    // did, made the 100 000-contig workload's pass 85x slower per base than a genome's.
+    const uint32_t kmask = so.k < 16 ? (1u << (2 * so.k)) - 1u : ~0u;
+    auto code_at = [&](uint32_t rel, uint32_t &canon, uint32_t &strand) {
+        const uint32_t w0 = block_packed[rel >> 4], w1 = block_packed[(rel >> 4) + 1];
+        const uint32_t le = __builtin_amdgcn_alignbit(w1, w0, 2u * (rel & 15u)) & kmask;
+        uint32_t x = __brev(le);
+        x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+        const uint32_t f = x >> (32 - 2 * so.k), r = ~le & kmask;
+        canon = min(f, r);
+        strand = r < f ? 1u : 0u;
+    };
+    uint64_t over = sb.mask;   // the positions beyond the rowed ones
+    for (uint32_t i = 0; i < rowed; i++) over &= over - 1;
+    for (uint64_t m = over; m; m &= m - 1) {
+        uint32_t canon, strand;
+        code_at(rel0 + (uint32_t)__builtin_ctzll(m), canon, strand);
+        atomicAdd(&sl.seg_over[code_segment(canon)], 1u);
+    }
     __syncthreads();
     // one global atomic per segment and block reserves the block's run in the genome's segment
     if (threadIdx.x < SEGMENTS) {
-        const uint32_t c = sl.seg_n[threadIdx.x];
+        const uint32_t c = sl.seg_n[threadIdx.x] + sl.seg_over[threadIdx.x];
         sl.seg_base[threadIdx.x] = c ? atomicAdd(&so.seg_count[(uint64_t)sb.g * SEGMENTS + threadIdx.x], c) : 0u;
     }
     __syncthreads();
@@ -197,13 +221,19 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
             else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
         }
     }
-    for (uint32_t i = rowed; i < mine; i++) {   // the code again, from the bases
-        const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
-        mask &= mask - 1;
-        uint32_t f = 0, canon, strand;
-        for (uint32_t j = 0; j < so.k; j++) f = (f << 2) | ((block_packed[(rel + j) >> 4] >> (2u * ((rel + j) & 15u))) & 3u);
-        seed_canon<false>(f, so.k, canon, strand);
-        seed_emit_global(so, sb, canon, strand, rel);
+    for (uint64_t m = over; m; m &= m - 1) {   // the seeds without a row: behind the rowed ones of their segment
+        const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(m);
+        uint32_t canon, strand;
+        code_at(rel, canon, strand);
+        const uint32_t at = sb.rem_first + rel, chrel = seed_chunk_of(at, so.chunk_magic), seg = code_segment(canon);
+        const uint32_t idx = sl.seg_base[seg] + sl.seg_n[seg] + atomicAdd(&sl.seg_cur[seg], 1u);
+        if (idx < sb.scap) {
+            const uint64_t o = sb.sstart + (uint64_t)seg * sb.scap + idx;
+            so.seed_code[o] = canon;
+            so.seed_loc[o] = seed_loc(sb.ch_first + chrel, strand, at - chrel * so.chunk);
+        }
+        if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
+        else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
     }
     __syncthreads();
     if (threadIdx.x < SEED_LDS_CHUNKS && sl.ctot[threadIdx.x]) atomicAdd(&sb.ctot[sb.ch_first + threadIdx.x], sl.ctot[threadIdx.x]);
