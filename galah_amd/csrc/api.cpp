@@ -1505,6 +1505,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     if ((rc = dmalloc(ctx, &d_count, 1))) return rc;
     tmp.add(d_count);
     std::vector<ghip_pair> host;
+    std::vector<uint32_t> empties;   // empty sketches of a joined run: their pairs are added on the host
     bool filter_share = dense_share;  // dense pass over ALL pairs, this rank's (i + j) mod world share picked on the host
     bool listed = false;  // an attempt whose candidate list held every hit
     for (int attempt = 0; attempt < 4 && !listed; attempt++) {
@@ -1514,10 +1515,12 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         uint64_t compared = 0;
         bool joined = false, late = false;
+        empties.clear();
         if (want_join && !filter_share &&
             (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
                                   replicate_join ? 0 : rank, replicate_join ? 1 : world, (uint32_t)row_lo,
-                                  d_out, d_count, cap, &compared, &joined, &late))) return rc;
+                                  d_out, d_count, cap, &compared, &joined, &late, &empties))) return rc;
+        if (!joined) empties.clear();   // a dense form enumerates every pair itself
         if (joined && replicate_join) {  // every rank holds every pair; book an equal share of the comparisons
             compared = P / world + (rank < P % world ? 1 : 0);
             if (out_replicated) *out_replicated = 1;
@@ -1554,6 +1557,22 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if ((rc = d2h(ctx, host.data(), d_out, cnt))) return rc;
         lap("candidates back");
         listed = true;
+        // the pairs of the empty sketches, which share no hash with anybody and pair with everybody (ANI 1.0 by the
+        // reference's NaN arithmetic, common = total = 0): N - 1 each, in this rank's share of a sharded join
+        if (!empties.empty()) {
+            std::vector<uint8_t> is_empty(n, 0);
+            for (uint32_t e : empties) is_empty[e] = 1;
+            const uint32_t jrank = replicate_join ? 0 : rank, jworld = replicate_join ? 1 : world;
+            for (uint32_t e : empties)
+                for (size_t x = 0; x < n; x++) {
+                    if (x == e || (is_empty[x] && x < e)) continue;   // two empty sketches: once
+                    const uint32_t i = (uint32_t)std::min<size_t>(e, x), j = (uint32_t)std::max<size_t>(e, x);
+                    if (j < row_lo) continue;
+                    if (jworld > 1 && (i + j) % jworld != jrank) continue;
+                    ghip_pair r; r.i = i; r.j = j; r.common = 0; r.total = 0; r.ani = 0.0f;
+                    host.push_back(r);
+                }
+        }
     }
     if (!listed) return ghip_set_error(ctx, GHIP_EHIP, "precluster candidate list overflowed on every attempt");
     rc = ghip_pairs_finalize(ctx, host, k, min_ani, n, filter_share, rank, world, out_pairs, out_n);

@@ -619,7 +619,8 @@ static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t 
 // *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
-                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline) {
+                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline,
+                    std::vector<uint32_t> *empties) {
     *used = false;
     if (late_decline) *late_decline = false;
     if (cmin_floor == 0 || cmin_floor == 0xffffu || n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
@@ -631,8 +632,13 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     for (uint32_t l : lens) { n_elem += l; n_empty += (l == 0); }
     // An empty sketch ends the reference's merge loop at once: common = total = 0, Jaccard 0/0 = NaN, and Rust's
     // NaN-dropping f64::max/min turn that into ANI 1.0 -- it pairs with EVERY other sketch without sharing a hash.
-    // Only the dense forms enumerate those pairs.
-    if (n_empty >= 1) return GHIP_OK;
+    // The join cannot find those pairs; a caller that takes the list of empty sketches (`empties`) adds them itself
+    // (N - 1 pairs per empty sketch, no kernel needed), for any other caller the join declines and a dense form runs.
+    if (n_empty >= 1) {
+        if (!empties) return GHIP_OK;
+        for (size_t g = 0; g < n; g++) if (lens[g] == 0) empties->push_back((uint32_t)g);
+        if (n_elem == 0) { *used = true; if (pairs_compared) *pairs_compared = (uint64_t)n * (n - 1) / 2; return GHIP_OK; }   // nothing but empty sketches
+    }
     struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
     uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 6);  // [0] flags, [1] largest element bucket, [2..3] u64 records of all ranks, [4..5] of this rank
     if (!d_flags) return GHIP_EHIP;

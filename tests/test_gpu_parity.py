@@ -591,7 +591,7 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
                 parts.append(part)
             assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
     ctx.profile(False)
-    # two empty sketches: (empty, empty) has ANI 1.0 -- only the dense forms can report it
+    # two empty sketches: (empty, empty) has ANI 1.0 -- the join finds no such pair; the host adds the pairs of empty sketches
     M = np.uint64(0xFFFFFFFFFFFFFFFF)
     hashes = np.full((5, 8), M, dtype=np.uint64)
     lens = np.array([0, 0, 3, 8, 8], dtype=np.uint32)
@@ -605,6 +605,25 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
     sk = ctx.sketches_from_host(hashes1, lens1, 21)
     want = oracle.distances_from_sketches(hashes1, lens1, np.float32(0.5))
     assert ctx.precluster(sk, np.float32(0.5)).tobytes() == want.tobytes() and (want["total"] == 0).sum() == 4
+    # ... at any size and in every share: 3 empty sketches among 300, joined (no dense pass), whole and as 2 / 3 shares
+    rng = np.random.default_rng(77)
+    hashes, lens = random_sketches(rng, 300, 256, shared_groups=30, min_len=100)
+    for e in (0, 17, 299):
+        lens[e] = 0; hashes[e] = M
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9))
+    assert (want["total"] == 0).sum() == 3 * 299 - 3
+    ctx.profile(True); ctx.profile_reset()
+    assert ctx.precluster(sk, np.float32(0.9)).tobytes() == want.tobytes()
+    st = ctx.kernel_stats()
+    assert st["pair_join"][0] > 0 and st["pair_intersect_tile"][0] == 0
+    ctx.profile(False)
+    for world in (2, 3):
+        parts = [ctx.precluster(sk, np.float32(0.9), r, world) for r in range(world)]
+        assert all(all((p["i"] + p["j"]) % world == r) for r, p in enumerate(parts))
+        assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
+        parts = [ctx.precluster_ranks(sk, np.float32(0.9), r, world)[0] for r in range(world)]
+        assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
     # one big family (every genome shares most hashes with every other): records outnumber pairs -> declined
     rng = np.random.default_rng(5)
     hashes, lens = random_sketches(rng, 200, 1000, shared_groups=1)
