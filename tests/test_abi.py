@@ -294,3 +294,20 @@ def test_lazy_clusterer_none_answers_and_failures():
     with pytest.raises(ValueError, match="boom"):
         cluster_pairs_lazy(4, pairs, np.float32(95.0), lambda e: (_ for _ in ()).throw(ValueError("boom")))
     assert cluster_pairs_lazy(3, np.zeros(0, dtype=PAIR_DTYPE), np.float32(95.0), None) == ([[0], [1], [2]], 0)
+
+
+def test_cluster_list_behaves_like_the_list_of_lists():
+    """engine.ClusterList (what Context.cluster_index returns): the C ABI's members / offsets arrays read as
+    clusterer::cluster's Vec<Vec<usize>> without building the lists until somebody looks."""
+    from galah_amd.engine import ClusterList
+    mem = np.array([3, 1, 2, 0, 4, 9, 9], dtype=np.uint32)     # (two slack entries past the last offset)
+    off = np.array([0, 3, 4, 5], dtype=np.uint64)
+    c = ClusterList(mem, off)
+    want = [[3, 1, 2], [0], [4]]
+    assert len(c) == 3 and c[0] == [3, 1, 2] and c[-1] == [4] and c[1:] == [[0], [4]]
+    assert c == want and want == c and not (c != want) and c != [[3, 1, 2]]
+    assert list(c) == want and sorted(map(sorted, c)) == [[0], [1, 2, 3], [4]] and repr(c) == repr(want)
+    assert c == ClusterList(mem[:5].copy(), off.copy()) and c != ClusterList(mem, np.array([0, 2, 4, 5], dtype=np.uint64))
+    with pytest.raises(IndexError):
+        ClusterList(mem, off)[3]
+    assert len(ClusterList(np.zeros(1, np.uint32), np.zeros(1, np.uint64))) == 0
