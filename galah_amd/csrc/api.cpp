@@ -115,6 +115,7 @@ static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
     if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
     for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
+    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1609,8 +1610,20 @@ extern "C" int ghip_precluster_from(ghip_ctx *ctx, const ghip_sketches *sk, size
 }
 
 // ------------------------------------------------------------------------------------ ANI
+int ghip_index_wait(ghip_ctx *ctx, const ghip_ani_index *idx) {
+    if (!idx->bin_done) return GHIP_OK;
+    const hipError_t e = hipEventSynchronize(idx->bin_done);
+    hipEventDestroy(idx->bin_done);
+    idx->bin_done = nullptr;
+    for (void *p : idx->bin_scratch) ghip_pool_free(ctx, p);   // the unordered lists, the segment counts
+    idx->bin_scratch.clear();
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
+    return GHIP_OK;
+}
+
 static void free_index_arrays_locked(ghip_ani_index *idx) {
     ghip_ctx *ctx = idx->ctx;
+    (void)ghip_index_wait(ctx, idx);   // the side stream may still be writing them
     if (idx->owned) {
         ghip_pool_free(ctx, idx->d_seed_code); ghip_pool_free(ctx, idx->d_seed_loc);
         ghip_pool_free(ctx, idx->d_bin_start); ghip_pool_free(ctx, idx->d_chunk_total);
@@ -1738,17 +1751,38 @@ static int index_seed_standalone(ghip_ctx *ctx, const ghip_genomes *g, ghip_ani_
 }
 
 // reorder every genome's seed list by hash bin and record the bin offsets (the join index)
-static int index_finish(ghip_ctx *ctx, ghip_ani_index *idx) {
+static int index_finish(ghip_ctx *ctx, ghip_ani_index *idx, bool defer = false) {
     const size_t n = idx->n;
     int rc;
     uint32_t *d_code2 = nullptr, *d_pos = nullptr, *d_chunk2 = nullptr;
     if (!(rc = dmalloc(ctx, &idx->d_bin_start, n * (size_t)(GHIP_ANI_BIN_COUNT + 1))) &&
         !(rc = dmalloc(ctx, &d_code2, idx->seed_start[n])) && !(rc = dmalloc(ctx, &d_chunk2, idx->seed_start[n])) &&
         !(rc = dmalloc(ctx, &d_pos, idx->seed_start[n]))) {
+        hipEvent_t seeded = nullptr;
+        if (defer && !ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { ctx->side_stream = nullptr; defer = false; (void)hipGetLastError(); }
+        if (defer && (hipEventCreateWithFlags(&seeded, hipEventDisableTiming) != hipSuccess || hipEventRecord(seeded, ctx->stream) != hipSuccess ||
+                      hipStreamWaitEvent(ctx->side_stream, seeded, 0) != hipSuccess ||
+                      hipEventCreateWithFlags(&idx->bin_done, hipEventDisableTiming) != hipSuccess)) {
+            if (idx->bin_done) { hipEventDestroy(idx->bin_done); idx->bin_done = nullptr; }
+            defer = false; (void)hipGetLastError();
+        }
+        if (seeded) hipEventDestroy(seeded);   // (the wait it feeds is already enqueued)
+        // deferred: the binning goes to the side stream, behind the seeding kernels of the main one, and this call returns
+        // without waiting for it -- the main stream's next stage (the pair stage: sketches only) runs next to it
+        hipStream_t main_stream = ctx->stream;
+        if (defer) ctx->stream = ctx->side_stream;   // (ctx->mu held: the launcher and its profiling events follow ctx->stream)
         ghip_launch_ani_bin(ctx, n, idx->d_seed_code, idx->d_seed_loc, d_code2, d_chunk2, idx->d_seed_start,
                             idx->d_seg_count, idx->d_bin_start, d_pos);
+        ctx->stream = main_stream;
         std::swap(idx->d_seed_code, d_code2);
         std::swap(idx->d_seed_loc, d_chunk2);
+        if (defer) {
+            if (hipEventRecord(idx->bin_done, ctx->side_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
+            idx->bin_scratch = {d_code2, d_chunk2, d_pos, idx->d_seg_count};
+            idx->d_seg_count = nullptr;
+            if (rc) (void)ghip_index_wait(ctx, idx);
+            return rc;
+        }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
             rc = ghip_set_error(ctx, GHIP_EHIP, "ANI index kernels failed");
     }
@@ -1799,7 +1833,7 @@ extern "C" int ghip_sketch_and_index(ghip_ctx *ctx, const ghip_genomes *g, uint3
         rc = sketch_genomes_locked(ctx, g, k, s, seed, nullptr, &sk);
         if (!rc) rc = index_seed_standalone(ctx, g, idx, cap);
     }
-    if (!rc) rc = index_finish(ctx, idx);
+    if (!rc) rc = index_finish(ctx, idx, getenv("GHIP_NO_OVERLAP") == nullptr);   // the binning overlaps the caller's pair stage
     if (rc) { if (sk) free_sketches_locked(sk); free_index_locked(idx); return rc; }
     *out_sk = sk;
     *out_idx = idx;
@@ -1998,6 +2032,7 @@ static int ani_pairs_device(ghip_ctx *ctx, const ghip_ani_index *idx, const uint
     // (calculate_ani arrives from many rayon workers at once, src/clusterer.rs:267-296)
     std::lock_guard<std::mutex> lk(ctx->mu);
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    { const int rcw = ghip_index_wait(ctx, idx); if (rcw) return rcw; }
     DeviceFree tmp(ctx);
     uint32_t *d_pairs = nullptr;
     uint64_t *d_out = nullptr;
@@ -2072,6 +2107,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
 
 extern "C" int ghip_ani_index_layout(const ghip_ani_index *idx, ghip_ani_layout *out) {
     if (!idx || !out) return GHIP_EINVAL;
+    { std::lock_guard<std::mutex> lk(idx->ctx->mu); const int rcw = ghip_index_wait(idx->ctx, idx); if (rcw) return rcw; }   // the arrays it names must be final
     out->n = idx->n;
     out->n_seed_slots = idx->seed_start[idx->n];
     out->n_bin_slots = (uint64_t)idx->n * (GHIP_ANI_BIN_COUNT + 1);

@@ -536,6 +536,7 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     size_t first, count, block;
     ghip_shard_range(n_total, c->rank, c->world, &first, &count, &block);
     if (local->n != count) return cerr_(c, GHIP_EINVAL, "local ANI index does not match this rank's block");
+    { std::lock_guard<std::mutex> lk(ctx->mu); if (ghip_index_wait(ctx, local) != GHIP_OK) return cerr_(c, GHIP_EHIP, "ANI index kernels failed"); }
     for (size_t g = 0; g < n_total; g++) out_local_ids[g] = UINT32_MAX;
     for (size_t g = 0; g < count; g++) out_local_ids[first + g] = (uint32_t)g;
     // second genomes of pairs that span two ranks: `needed` (ascending, the same list on every rank) and, of those, the ones

@@ -60,6 +60,7 @@ struct ghip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // work that overlaps the main stream's next stage (the deferred ani_bin); made on first use
     std::string err;
     std::mutex err_mu;  // `err` alone: the file ingest runs on a producer thread next to the consumer's kernels, both may fail
     std::mutex mu;  // serialises API calls on this ctx (ghip_ani_pairs is called from rayon workers)
@@ -165,7 +166,13 @@ struct ghip_ani_index {
     std::vector<uint32_t> seed_count;
     uint32_t max_chunks = 0;
     bool owned = true;  // false: the four flat arrays are borrowed (ghip_ani_index_wrap_device)
+    // Deferred finish (ghip_sketch_and_index): ani_bin runs on the context's side stream, next to whatever the caller does
+    // next on the main stream (the pair stage reads only the sketch matrix); every use of the device arrays waits for it
+    // first (ghip_index_wait).  bin_done = the event behind ani_bin, bin_scratch = its inputs, freed once it is done.
+    mutable hipEvent_t bin_done = nullptr;
+    mutable std::vector<void *> bin_scratch;
 };
+int ghip_index_wait(ghip_ctx *ctx, const ghip_ani_index *idx);   // ctx->mu held; returns an error if the deferred kernel failed
 
 #define GHIP_ANI_BIN_BITS 14
 #define GHIP_ANI_BIN_COUNT (1u << GHIP_ANI_BIN_BITS)
