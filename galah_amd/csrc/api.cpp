@@ -1507,6 +1507,8 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     tmp.add(d_count);
     std::vector<ghip_pair> host;
     std::vector<uint32_t> empties;   // empty sketches of a joined run: their pairs are added on the host
+    uint8_t *d_big = nullptr;        // genomes of element buckets too large for the join (their mutual pairs: dense, below)
+    bool big_pending = false;
     bool filter_share = dense_share;  // dense pass over ALL pairs, this rank's (i + j) mod world share picked on the host
     bool listed = false;  // an attempt whose candidate list held every hit
     for (int attempt = 0; attempt < 4 && !listed; attempt++) {
@@ -1517,11 +1519,15 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         uint64_t compared = 0;
         bool joined = false, late = false;
         empties.clear();
-        if (want_join && !filter_share &&
-            (rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
-                                  replicate_join ? 0 : rank, replicate_join ? 1 : world, (uint32_t)row_lo,
-                                  d_out, d_count, cap, &compared, &joined, &late, &empties))) return rc;
-        if (!joined) empties.clear();   // a dense form enumerates every pair itself
+        bool has_big = false;
+        if (want_join && !filter_share) {
+            if (!d_big) { if ((rc = dmalloc(ctx, &d_big, n))) return rc; tmp.add(d_big); }
+            GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_big, 0, n, ctx->stream));
+            if ((rc = ghip_pairs_join(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, ctx->cmin.floor,
+                                      replicate_join ? 0 : rank, replicate_join ? 1 : world, (uint32_t)row_lo,
+                                      d_out, d_count, cap, &compared, &joined, &late, &empties, d_big, &has_big))) return rc;
+        }
+        if (!joined) { empties.clear(); has_big = false; }   // a dense form enumerates every pair itself
         if (joined && replicate_join) {  // every rank holds every pair; book an equal share of the comparisons
             compared = P / world + (rank < P % world ? 1 : 0);
             if (out_replicated) *out_replicated = 1;
@@ -1558,6 +1564,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if ((rc = d2h(ctx, host.data(), d_out, cnt))) return rc;
         lap("candidates back");
         listed = true;
+        big_pending = has_big;
         // the pairs of the empty sketches, which share no hash with anybody and pair with everybody (ANI 1.0 by the
         // reference's NaN arithmetic, common = total = 0): N - 1 each, in this rank's share of a sharded join
         if (!empties.empty()) {
@@ -1576,6 +1583,61 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         }
     }
     if (!listed) return ghip_set_error(ctx, GHIP_EHIP, "precluster candidate list overflowed on every attempt");
+    if (big_pending) {
+        // The join left out the pairs of two genomes that both sit in an element bucket too large for it (a hash shared by
+        // more than J_ELEM_CAP genomes: one very large family).  Those genomes' rows are gathered into a compact matrix, a
+        // dense form runs over it, and the pairs come back under their own indices: the family costs |G|^2 / 2 probes, the
+        // rest of the collection stays with the join (a dense pass over everything is 0.9 s at 50 000 genomes).
+        std::vector<uint8_t> big(n);
+        if ((rc = d2h(ctx, big.data(), d_big, n))) return rc;
+        std::vector<uint32_t> G;
+        for (size_t g = 0; g < n; g++) if (big[g]) G.push_back((uint32_t)g);
+        if (G.size() >= 2) {
+            ghip_sketches sub;
+            sub.ctx = ctx; sub.n = G.size(); sub.s = s; sub.k = k; sub.owned = false;
+            uint32_t *d_G = nullptr;
+            if ((rc = dmalloc(ctx, &d_G, G.size())) || (tmp.add(d_G), false) || (rc = h2d(ctx, d_G, G.data(), G.size())) ||
+                (rc = dmalloc(ctx, &sub.d_hashes, G.size() * (size_t)s)) || (tmp.add(sub.d_hashes), false) ||
+                (rc = dmalloc(ctx, &sub.d_lens, G.size())) || (tmp.add(sub.d_lens), false)) return rc;
+            ghip_launch_gather_rows(ctx, sk->d_hashes, sk->d_lens, d_G, G.size(), s, sub.d_hashes, sub.d_lens);
+            bool sub_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
+            if (sub_probe) {
+                if ((rc = prepare_probe(ctx, &sub))) return rc;
+                tmp.add(sub.d_tables); tmp.add(sub.d_tags); tmp.add(sub.d_row_start);
+                sub_probe = sub.probe_flags == 0;
+            }
+            const uint64_t Ps = (uint64_t)G.size() * (G.size() - 1) / 2;
+            uint64_t scap = std::min<uint64_t>(Ps, std::max<uint64_t>(1u << 20, 64ull * G.size()));
+            bool sub_listed = false;
+            for (int attempt = 0; attempt < 4 && !sub_listed; attempt++) {
+                ghip_pair *d_sub = nullptr;
+                if ((rc = dmalloc(ctx, &d_sub, scap))) return rc;
+                DeviceFree t3(ctx); t3.add(d_sub);
+                GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+                uint64_t unused = 0;
+                if (sub_probe)
+                    ghip_launch_pairs_probe(ctx, sub.d_hashes, sub.d_lens, sub.d_tables, sub.d_tags, sub.n, s, sub.probe_cb, sub.d_row_start,
+                                            (uint32_t)(sub.row_start.size() - 1), sub.n_work, d_cmin, 0, 1, 0, d_sub, d_count, scap);
+                else if (s <= 4096) ghip_launch_pairs(ctx, sub.d_hashes, sub.d_lens, sub.n, s, d_cmin, 0, 1, 0, d_sub, d_count, scap, &unused);
+                else ghip_launch_pairs_global(ctx, sub.d_hashes, sub.d_lens, sub.n, s, d_cmin, 0, 1, 0, d_sub, d_count, scap, &unused);
+                unsigned long long cnt = 0;
+                if ((rc = d2h(ctx, &cnt, d_count, 1))) return rc;
+                if (cnt > scap) { scap = cnt; continue; }
+                std::vector<ghip_pair> part(cnt);
+                if ((rc = d2h(ctx, part.data(), d_sub, cnt))) return rc;
+                const uint32_t jrank = replicate_join ? 0 : rank, jworld = replicate_join ? 1 : world;
+                for (ghip_pair &r : part) {
+                    r.i = G[r.i]; r.j = G[r.j];   // (G ascends: i < j stays)
+                    if (r.j < row_lo) continue;
+                    if (jworld > 1 && (r.i + r.j) % jworld != jrank) continue;
+                    host.push_back(r);
+                }
+                sub_listed = true;
+            }
+            if (!sub_listed) return ghip_set_error(ctx, GHIP_EHIP, "precluster candidate list overflowed on every attempt");
+            lap("dense pass over the genomes of oversized buckets");
+        }
+    }
     rc = ghip_pairs_finalize(ctx, host, k, min_ani, n, filter_share, rank, world, out_pairs, out_n);
     lap("finalize (f64 recheck, (i, j) order)");
     return rc;

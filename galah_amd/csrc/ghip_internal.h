@@ -255,7 +255,12 @@ uint32_t ghip_cmin_floor(const std::vector<uint16_t> &cmin);
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                     unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline,
-                    std::vector<uint32_t> *empties = nullptr /* out: the empty sketches, whose pairs the caller adds (null: decline on any) */);
+                    std::vector<uint32_t> *empties = nullptr /* out: the empty sketches, whose pairs the caller adds (null: decline on any) */,
+                    uint8_t *d_big = nullptr /* n zeroed bytes: genomes of element buckets too large for the join are marked, their mutual pairs left to
+                                                the caller's dense pass over the marked rows (null: such a bucket makes the join decline) */,
+                    bool *has_big = nullptr);
+void ghip_launch_gather_rows(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint32_t *d_idx, size_t m, uint32_t s,
+                             uint64_t *d_out, uint32_t *d_out_lens);
 
 // hash-sharded multi-rank form of the join (pairs_join.hip; driven by comm.cpp)
 constexpr size_t GHIP_JOIN_ENTRY_BYTES = 16;   // {u64 pair key (i << 32 | j), u32 partial common, u32 pad}

@@ -30,6 +30,9 @@ constexpr uint32_t J_BITS2_MIN_ELEM = 6;   // the element buckets may go down to
 constexpr uint32_t J_D2_MAX = 1u << J_BITS2_MAX;
 constexpr uint32_t J_ELEM_CAP = 1024;   // elements of one hash bucket staged per wave (expected N*s/65536)
 constexpr uint32_t J_TAB = 256;         // distinct genome pairs counted per record bucket
+constexpr uint32_t J_RUN_MAX = 256;     // a hash shared by more genomes than this is left to the caller's dense pass (`big`)
+constexpr uint32_t J_BIG_CAP = 8192;    // elements of a bucket too large for a wave's stage, sorted by a whole block instead
+constexpr uint32_t J_BIG_LIST = 65536;  // such buckets per launch
 constexpr uint32_t J_WAVES = J_THREADS / 64;
 constexpr uint64_t J_EMPTY = ~0ull;
 
@@ -286,13 +289,102 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter2_kernel(const uint64_t
 // elements of its run of equal hashes; the emitting pass (EMIT = true) reads the sorted bucket and writes those pairs
 // at rec_start[bucket].  (Comparing every element with every later one cost cnt^2 / 2 dependent LDS reads per bucket:
 // 0.85 + 0.56 ms of the 2.6 ms join at 8 000 genomes.)  flags bit 0: a bucket exceeds the LDS stage.
+// Does element a of the sorted stage k[0..cnt) belong to a run of more than J_RUN_MAX equal hashes?  Two reads screen
+// out everything shorter than half of that (a longer run reaches J_RUN_MAX / 2 places one way or the other from any of
+// its members); the exact length, by two binary searches, is only taken behind the screen.
+__device__ __forceinline__ bool join_in_long_run(const uint64_t *k, uint32_t cnt, uint32_t a, uint64_t ka) {
+    constexpr uint32_t H = J_RUN_MAX / 2;
+    const bool fwd = a + H < cnt && k[a + H] == ka, bwd = a >= H && k[a - H] == ka;
+    if (!fwd && !bwd) return false;
+    uint32_t lo = 0, hi = a;            // first index holding ka
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (k[mid] < ka) lo = mid + 1; else hi = mid; }
+    uint32_t lo2 = a + 1, hi2 = cnt;    // one past the last
+    while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (k[mid] <= ka) lo2 = mid + 1; else hi2 = mid; }
+    return lo2 - lo > J_RUN_MAX;
+}
+
+// The buckets no wave's stage holds (up to J_BIG_CAP elements: a hash shared by a thousand genomes, next to the bucket's
+// ordinary ones), one per BLOCK: the same sort, the same run scan, the same long-run rule as join_elem_pairs_kernel.
+template <bool EMIT>
+__global__ __launch_bounds__(J_THREADS) void join_elem_pairs_big_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                                        const uint32_t *__restrict__ start2, uint32_t *__restrict__ rec_count,
+                                                                        const uint32_t *__restrict__ rec_start, uint64_t *__restrict__ rec,
+                                                                        uint32_t *__restrict__ flags, uint32_t *__restrict__ all_count, uint32_t rank,
+                                                                        uint32_t world, uint32_t row_lo, uint8_t *__restrict__ big,
+                                                                        const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char jraw[];
+    uint64_t *k = reinterpret_cast<uint64_t *>(jraw);
+    uint32_t *v = reinterpret_cast<uint32_t *>(jraw + (size_t)J_BIG_CAP * sizeof(uint64_t));
+    __shared__ uint32_t n_found, n_all, n_marked;
+    const uint32_t listed = min(*big_n, J_BIG_LIST);
+    for (uint32_t bi = blockIdx.x; bi < listed; bi += gridDim.x) {
+        const uint32_t bucket = big_list[bi];
+        const uint32_t lo = start2[bucket], cnt = start2[bucket + 1] - lo;
+        __syncthreads();   // the previous bucket's stage is no longer read
+        for (uint32_t e = threadIdx.x; e < cnt; e += J_THREADS) { k[e] = keys[lo + e]; v[e] = vals[lo + e]; }
+        if (threadIdx.x == 0) { n_found = 0; n_all = 0; n_marked = 0; }
+        if (!EMIT) {
+            uint32_t P = 64;
+            while (P < cnt) P <<= 1;
+            auto exchange = [&](uint32_t i, uint32_t x) {
+                if (x >= cnt) return;
+                const uint64_t ka = k[i], kb = k[x];
+                if (ka > kb) { const uint32_t va = v[i], vb = v[x]; k[i] = kb; k[x] = ka; v[i] = vb; v[x] = va; }
+            };
+            for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+                __syncthreads();
+                const uint32_t half = kk >> 1;
+                for (uint32_t t = threadIdx.x; t < P / 2; t += J_THREADS) { const uint32_t i = 2 * t - (t & (half - 1)); exchange(i, i ^ (kk - 1)); }
+                for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+                    __syncthreads();
+                    for (uint32_t t = threadIdx.x; t < P / 2; t += J_THREADS) { const uint32_t i = 2 * t - (t & (j - 1)); exchange(i, i + j); }
+                }
+            }
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < cnt; e += J_THREADS) { keys[lo + e] = k[e]; vals[lo + e] = v[e]; }   // the emitting pass reads it sorted
+        }
+        __syncthreads();
+        const uint32_t out0 = EMIT ? rec_start[bucket] : 0u;
+        uint32_t found = 0, found_all = 0;
+        bool marked = false;
+        for (uint32_t a = threadIdx.x; a < cnt; a += J_THREADS) {
+            const uint64_t ka = k[a];
+            const uint32_t ga = v[a];
+            if (join_in_long_run(k, cnt, a, ka)) {
+                if (!EMIT) { big[ga] = 1; marked = true; }
+                continue;
+            }
+            for (uint32_t b = a + 1; b < cnt && k[b] == ka; b++) {
+                const uint32_t gb = v[b];
+                if (gb == ga) continue;
+                found_all++;
+                if (world > 1 && (ga + gb) % world != rank) continue;
+                if (max(ga, gb) < row_lo) continue;
+                if (EMIT) rec[out0 + atomicAdd(&n_found, 1u)] = ((uint64_t)min(ga, gb) << 32) | max(ga, gb);
+                else found++;
+            }
+        }
+        if (!EMIT) {
+            if (found) atomicAdd(&n_found, found);
+            if (found_all) atomicAdd(&n_all, found_all);
+            if (marked) atomicOr(&n_marked, 1u);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                rec_count[bucket] = n_found; all_count[bucket] = n_all;
+                if (n_marked) atomicOr(flags, 4u);
+            }
+        }
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                     const uint32_t *__restrict__ start2,
                                                                     uint32_t *__restrict__ rec_count, const uint32_t *__restrict__ rec_start,
                                                                     uint64_t *__restrict__ rec, uint32_t *__restrict__ flags,
                                                                     uint32_t *__restrict__ all_count, uint32_t rank, uint32_t world, uint32_t row_lo,
-                                                                    uint32_t elem_cap) {
+                                                                    uint32_t elem_cap, uint8_t *__restrict__ big, uint32_t *__restrict__ big_list,
+                                                                    uint32_t *__restrict__ big_n) {
     // elem_cap elements per wave: keys, then genome ids (dynamic LDS: a launch sized for the buckets it expects keeps eight
     // blocks on a CU; with room for J_ELEM_CAP elements per wave three fit, and the sort is bound by its steps' latency)
     extern __shared__ __attribute__((aligned(16))) unsigned char jraw[];
@@ -301,7 +393,15 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
     const uint32_t bucket = blockIdx.x * J_WAVES + wave;
     const uint32_t lo = start2[bucket], cnt = start2[bucket + 1] - lo;
     if (cnt > elem_cap) {
-        if (lane == 0) { atomicOr(flags, 1u); if (!EMIT) { rec_count[bucket] = 0; all_count[bucket] = 0; } }
+        // no stage of a wave holds the bucket.  With `big` (the last attempt of a caller that can finish the pairs of very
+        // large families densely) a bucket of up to J_BIG_CAP elements goes to join_elem_pairs_big_kernel, a block per
+        // bucket; anything else raises flags bit 0: the caller retries with a larger stage or declines.
+        if (big && cnt <= J_BIG_CAP) {
+            if (!EMIT && lane == 0) {
+                const uint32_t at = atomicAdd(big_n, 1u);
+                if (at < J_BIG_LIST) big_list[at] = bucket; else atomicOr(flags, 1u);
+            }
+        } else if (lane == 0) { atomicOr(flags, 1u); if (!EMIT) { rec_count[bucket] = 0; all_count[bucket] = 0; } }
         return;
     }
     uint64_t *k = reinterpret_cast<uint64_t *>(jraw) + (size_t)wave * elem_cap;
@@ -352,9 +452,14 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
     // ranks, so every rank decides alike.
     const uint32_t out0 = EMIT ? rec_start[bucket] : 0u;
     uint32_t found = 0, found_all = 0;
+    bool marked = false;
     for (uint32_t a = lane; a < cnt; a += 64) {
         const uint64_t ka = k[a];
         const uint32_t ga = v[a];
+        if (big && join_in_long_run(k, cnt, a, ka)) {   // a hash of a very large family: its genomes are marked, it emits nothing
+            if (!EMIT) { big[ga] = 1; marked = true; }
+            continue;
+        }
         for (uint32_t b = a + 1; b < cnt && k[b] == ka; b++) {
             const uint32_t gb = v[b];
             if (gb == ga) continue;  // a sketch row is distinct; guards caller-supplied matrices
@@ -371,6 +476,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
         // (the totals are summed from these two arrays by join_totals_kernel: one atomic pair per wave on the same two
         // addresses serialised 131 072 L2 atomics and WAS the kernel's duration, 1.6 ms at 10 000 genomes)
         if (lane == 0) { rec_count[bucket] = found; all_count[bucket] = found_all; }
+        if (__builtin_amdgcn_ballot_w64(marked) != 0 && lane == 0) atomicOr(flags, 4u);
     }
 }
 
@@ -387,7 +493,7 @@ __global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *
                                                                 const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
                                                                 uint32_t s, const uint16_t *__restrict__ cmin, uint32_t cmin_floor,
                                                                 uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count,
-                                                                uint64_t cap, uint32_t *__restrict__ flags) {
+                                                                uint64_t cap, uint32_t *__restrict__ flags, const uint8_t *__restrict__ big) {
     __shared__ unsigned long long tk[J_WAVES][J_TAB];
     __shared__ uint32_t tc[J_WAVES][J_TAB];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -446,6 +552,7 @@ __global__ __launch_bounds__(J_THREADS) void join_reduce_kernel(const uint64_t *
         // reports the pairs with (i + j) mod world == rank.
         if (take && world > 1 && (gi + gj) % world != rank) take = false;
         if (take && gj < row_lo) take = false;
+        if (take && big && big[gi] && big[gj]) take = false;   // two genomes of an oversized bucket: their count here is short; the dense pass has them
         uint32_t total = 0;
         if (take) {
             const uint32_t na = lens[gi], nb = lens[gj];  // both > 0: they share a hash
@@ -590,17 +697,40 @@ __global__ __launch_bounds__(1024) void join_totals_kernel(const uint32_t *__res
 // capacity the emitting pass has to be launched with.  flags / totals = what the host needs next (read back here).
 constexpr uint32_t J_ELEM_SMALL = 384;
 static size_t elem_pairs_lds(uint32_t cap) { return (size_t)J_WAVES * cap * (sizeof(uint64_t) + sizeof(uint32_t)); }
+constexpr size_t J_BIG_LDS = (size_t)J_BIG_CAP * (sizeof(uint64_t) + sizeof(uint32_t));
+struct JoinBig {   // a caller's means to finish the pairs of very large families densely (ghip_pairs_join's d_big)
+    uint8_t *d_big = nullptr;      // [n] marks
+    uint32_t *d_list = nullptr;    // buckets beyond a wave's stage, for join_elem_pairs_big_kernel
+    uint32_t *d_n = nullptr;
+    bool used = false;             // the counting pass that succeeded ran with the marks on: the emitting pass must too
+};
 static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t enb, uint64_t *ek, uint32_t *ev, const uint32_t *d_estart,
                             uint32_t *d_rcount, uint32_t *d_rstart, uint32_t *d_flags, unsigned long long *d_total, uint32_t rank,
-                            uint32_t world, uint32_t row_lo, uint32_t flags[2], unsigned long long totals[2], uint32_t *cap_used) {
+                            uint32_t world, uint32_t row_lo, uint32_t flags[2], unsigned long long totals[2], uint32_t *cap_used,
+                            JoinBig *jb = nullptr) {
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_kernel<false>), elem_pairs_lds(J_ELEM_CAP));
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_kernel<true>), elem_pairs_lds(J_ELEM_CAP));
     uint32_t *d_all = jalloc<uint32_t>(ctx, owned, enb);
     if (!d_all) return GHIP_EHIP;
+    if (jb && jb->d_big) {
+        jb->d_list = jalloc<uint32_t>(ctx, owned, J_BIG_LIST);
+        jb->d_n = jalloc<uint32_t>(ctx, owned, 1);
+        if (!jb->d_list || !jb->d_n) return GHIP_EHIP;
+        ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_big_kernel<false>), J_BIG_LDS);
+        ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_big_kernel<true>), J_BIG_LDS);
+    }
     for (uint32_t cap : {J_ELEM_SMALL, J_ELEM_CAP}) {
         *cap_used = cap;
+        // only the last attempt may hand buckets to the block kernel and long runs to the caller's dense pass
+        const bool with_big = jb && jb->d_big && cap == J_ELEM_CAP;
+        if (jb) jb->used = with_big;
+        if (with_big) GHIP_HIP_CHECK(ctx, hipMemsetAsync(jb->d_n, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL((join_elem_pairs_kernel<false>), dim3(enb / J_WAVES), dim3(J_THREADS), elem_pairs_lds(cap), ctx->stream, ek, ev,
-                           d_estart, d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_all, rank, world, row_lo, cap);
+                           d_estart, d_rcount, (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_all, rank, world, row_lo, cap,
+                           with_big ? jb->d_big : (uint8_t *)nullptr, with_big ? jb->d_list : (uint32_t *)nullptr, with_big ? jb->d_n : (uint32_t *)nullptr);
+        if (with_big)
+            hipLaunchKernelGGL((join_elem_pairs_big_kernel<false>), dim3(256), dim3(J_THREADS), J_BIG_LDS, ctx->stream, ek, ev, d_estart, d_rcount,
+                               (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_all, rank, world, row_lo, jb->d_big, jb->d_list, jb->d_n);
         hipLaunchKernelGGL(join_totals_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_all, d_rcount, enb, d_total);
         int rc = scan_counters(ctx, owned, d_rcount, enb, d_rstart, nullptr);
         if (rc) return rc;
@@ -610,18 +740,32 @@ static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t 
         GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!(flags[0] & 1u) || cap == J_ELEM_CAP) break;
         // a bucket did not fit the small stage (flags[1] = the largest one): once more, with the full stage
-        if (flags[1] > J_ELEM_CAP) break;   // no stage holds it: the caller declines
+        if (flags[1] > J_ELEM_CAP && !(jb && jb->d_big)) break;   // no stage holds it: the caller declines
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
     }
     return GHIP_OK;
+}
+
+// rows idx[0..m) of a packed sketch matrix -> a compact matrix of m rows (the dense pass over the genomes of oversized buckets)
+__global__ __launch_bounds__(256) void join_gather_rows_kernel(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
+                                                               const uint32_t *__restrict__ idx, uint32_t s, uint64_t *__restrict__ out,
+                                                               uint32_t *__restrict__ out_lens) {
+    const uint32_t g = idx[blockIdx.x];
+    for (uint32_t e = threadIdx.x; e < s; e += blockDim.x) out[(uint64_t)blockIdx.x * s + e] = hashes[(uint64_t)g * s + e];
+    if (threadIdx.x == 0) out_lens[blockIdx.x] = lens[g];
+}
+void ghip_launch_gather_rows(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint32_t *d_idx, size_t m, uint32_t s,
+                             uint64_t *d_out, uint32_t *d_out_lens) {
+    if (m) hipLaunchKernelGGL(join_gather_rows_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_idx, s, d_out, d_out_lens);
 }
 
 // *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
 int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
                     const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
                     unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline,
-                    std::vector<uint32_t> *empties) {
+                    std::vector<uint32_t> *empties, uint8_t *d_big, bool *has_big) {
     *used = false;
+    if (has_big) *has_big = false;
     if (late_decline) *late_decline = false;
     if (cmin_floor == 0 || cmin_floor == 0xffffu || n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
     std::vector<uint32_t> lens(n);
@@ -657,7 +801,11 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     if (!d_rcount || !d_rstart) { ghip_prof_end(ctx); return GHIP_EHIP; }
     uint32_t flags[2], ecap = 0;
     unsigned long long totals[2] = {0, 0};   // records of all ranks (what every rank decides on), records of this rank
-    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, rank, world, row_lo, flags, totals, &ecap))) { ghip_prof_end(ctx); return rc; }
+    JoinBig jb;
+    jb.d_big = d_big;
+    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, rank, world, row_lo, flags, totals, &ecap, &jb))) { ghip_prof_end(ctx); return rc; }
+    if (has_big) *has_big = jb.used && (flags[0] & 4u) != 0;
+    uint8_t *const big_used = jb.used ? d_big : nullptr;
     const unsigned long long total_rec = totals[0];
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     // a dense pass costs ~1 ns per pair, a record ~0.3 ns: beyond 4 records per pair the dense kernel is the better tool
@@ -666,7 +814,10 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) { ghip_prof_end(ctx); return GHIP_EHIP; }
     hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), elem_pairs_lds(ecap), ctx->stream, ek, ev, d_estart,
-                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, (uint32_t *)nullptr, rank, world, row_lo, ecap);
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, (uint32_t *)nullptr, rank, world, row_lo, ecap, big_used, jb.d_list, jb.d_n);
+    if (big_used)
+        hipLaunchKernelGGL((join_elem_pairs_big_kernel<true>), dim3(256), dim3(J_THREADS), J_BIG_LDS, ctx->stream, ek, ev, d_estart, (uint32_t *)nullptr,
+                           d_rstart, d_rec, d_flags, (uint32_t *)nullptr, rank, world, row_lo, big_used, jb.d_list, jb.d_n);
     // 3. records -> 65536 pair buckets -> common per pair -> candidates
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
@@ -675,7 +826,7 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     if (rc) { ghip_prof_end(ctx); return rc; }
     hipLaunchKernelGGL((join_reduce_kernel<false, 0>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
                        (JoinEntry *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s,
-                       d_cmin, cmin_floor, rank, world, row_lo, d_out, d_count, cap, d_flags);
+                       d_cmin, cmin_floor, rank, world, row_lo, d_out, d_count, cap, d_flags, big_used);
     ghip_prof_end(ctx);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -752,7 +903,7 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     uint64_t *d_rec = jalloc<uint64_t>(ctx, own.p, n_rec);
     if (!d_rec) return done(GHIP_EHIP);
     hipLaunchKernelGGL((join_elem_pairs_kernel<true>), dim3(enb / J_WAVES), dim3(J_THREADS), elem_pairs_lds(ecap), ctx->stream, ek, ev, d_estart,
-                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, (uint32_t *)nullptr, 0u, 1u, 0u, ecap);
+                       (uint32_t *)nullptr, d_rstart, d_rec, d_flags, (uint32_t *)nullptr, 0u, 1u, 0u, ecap, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     lap("emit records");
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
@@ -763,7 +914,7 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     if (!d_ecount || !d_estart2) return done(GHIP_EHIP);
     hipLaunchKernelGGL((join_reduce_kernel<false, 1>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
                        (JoinEntry *)nullptr, d_ecount, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s, (const uint16_t *)nullptr, 0u, 0u, 1u, 0u,
-                       (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags);
+                       (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags, (const uint8_t *)nullptr);
     if ((rc = scan_counters(ctx, own.p, d_ecount, rnb, d_estart2, nullptr))) return done(rc);
     uint32_t f0 = 0, n_ent = 0;
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&f0, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -775,7 +926,7 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     if (!d_ent) return done(GHIP_EHIP);
     hipLaunchKernelGGL((join_reduce_kernel<false, 2>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
                        d_ent, (uint32_t *)nullptr, d_estart2, d_pstart, d_hashes, d_lens, s, (const uint16_t *)nullptr, 0u, 0u, 1u, 0u,
-                       (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags);
+                       (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags, (const uint8_t *)nullptr);
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // (the scratch blocks go back to the pool on return)
     lap("emit entries");
     *d_entries_out = d_ent; *n_entries_out = n_ent; *status = 0;
@@ -806,7 +957,7 @@ int ghip_pairs_join_finish(ghip_ctx *ctx, const void *d_all, uint32_t n_all, uin
     if (rc) return done(rc);
     lap("partition");
     hipLaunchKernelGGL((join_reduce_kernel<true, 0>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, rw, (JoinEntry *)nullptr,
-                       (uint32_t *)nullptr, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s, d_cmin, cmin_floor, 0u, 1u, 0u, d_out, d_count, cap, d_flags);
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s, d_cmin, cmin_floor, 0u, 1u, 0u, d_out, d_count, cap, d_flags, (const uint8_t *)nullptr);
     uint32_t flags = 0;
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -631,6 +631,37 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
     assert ctx.precluster(sk, np.float32(0.9)).tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(0.9)).tobytes()
 
 
+def test_join_with_one_very_large_family_goes_hybrid(ctx):
+    """A hash shared by more genomes than an element bucket of the join holds (one family of 1 300 among 2 600 sketches):
+    the join marks the genomes of such buckets, keeps every pair with an unmarked member, and the pairs of two marked
+    genomes come from a dense pass over the marked rows -- same bytes as the oracle's pair loop, whole and in shares, with
+    both the join and a dense kernel on the clock."""
+    rng = np.random.default_rng(99)
+    n, s, fam = 2600, 64, 1300
+    hashes, lens = random_sketches(rng, n, s, shared_groups=130)
+    core = np.sort(rng.integers(0, 2**62, size=40, dtype=np.uint64))
+    for i in range(fam):
+        own = rng.integers(0, 2**63, size=s - len(core), dtype=np.uint64)
+        u = np.unique(np.concatenate([core, own]))[:s]
+        hashes[i] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        hashes[i, : len(u)] = u
+        lens[i] = len(u)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9))
+    assert len(want) >= fam * (fam - 1) // 2
+    ctx.profile(True); ctx.profile_reset()
+    got = ctx.precluster(sk, np.float32(0.9))
+    st = ctx.kernel_stats()
+    ctx.profile(False)
+    assert got.tobytes() == want.tobytes()
+    assert st["pair_join"][0] > 0 and st["pair_intersect_tile"][0] > 0     # the join AND the dense pass over the family
+    assert ctx.last_pairs_compared == n * (n - 1) // 2
+    for world in (2, 3):
+        parts = [ctx.precluster(sk, np.float32(0.9), r, world) for r in range(world)]
+        assert all(all((p["i"] + p["j"]) % world == r) for r, p in enumerate(parts))
+        assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
+
+
 def test_join_form_takes_over_at_scale_with_awkward_families(ctx):
     """N = 2500 (the automatic switch to the join form): identical genomes, subset sketches, short sketches,
     one family of 120 -- every pair result equal to the oracle's (parallel) pair loop."""
