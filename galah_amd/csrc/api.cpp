@@ -1428,6 +1428,22 @@ int ghip_pairs_finalize(ghip_ctx *ctx, std::vector<ghip_pair> &host, uint32_t k,
         ctx->ani_memo.assign((size_t)(2 * s_max + 1) * (s_max + 1), std::nan(""));
         ctx->ani_memo_k = k; ctx->ani_memo_s = s_max;
     }
+    if (host.size() >= 200000 && ctx && ctx->ingest_mu.try_lock()) {
+        // long lists (a large collection, a very large family): the f64 values on the context's workers, each over its own
+        // range and without the table (its slots are written on first use: not from several threads); -1.0f marks a pair
+        // that fails (an ANI is never negative)
+        const size_t total_n = host.size(), workers = std::min<size_t>(16, total_n / 50000), per = (total_n + workers - 1) / workers;
+        ctx->io.run((int)workers, [&](int w) {
+            for (size_t i = std::min(total_n, (size_t)w * per), e = std::min(total_n, ((size_t)w + 1) * per); i < e; i++) {
+                host[i].ani = -1.0f;
+                if (filter_share && (host[i].i + host[i].j) % world != rank) continue;
+                const double ani = finch_ani(host[i].common, host[i].total, k);
+                if (ani >= thr) host[i].ani = (float)ani;
+            }
+        });
+        ctx->ingest_mu.unlock();
+        for (size_t i = 0; i < total_n; i++) if (host[i].ani != -1.0f) host[m++] = host[i];
+    } else
     for (size_t i = 0; i < host.size(); i++) {
         if (filter_share && (host[i].i + host[i].j) % world != rank) continue;
         double ani;
@@ -1449,9 +1465,20 @@ int ghip_pairs_finalize(ghip_ctx *ctx, std::vector<ghip_pair> &host, uint32_t k,
         for (size_t g = 0; g < n; g++) at[g + 1] += at[g];
         std::vector<size_t> fill(at.begin(), at.end() - 1);
         for (size_t x = 0; x < m; x++) res[fill[host[x].i]++] = host[x];
-        for (size_t g = 0; g < n; g++)
-            if (at[g + 1] - at[g] > 1)
-                std::sort(res + at[g], res + at[g + 1], [](const ghip_pair &a, const ghip_pair &b) { return a.j < b.j; });
+        auto sort_rows = [&](size_t g0, size_t g1) {
+            for (size_t g = g0; g < g1; g++)
+                if (at[g + 1] - at[g] > 1)
+                    std::sort(res + at[g], res + at[g + 1], [](const ghip_pair &a, const ghip_pair &b) { return a.j < b.j; });
+        };
+        if (m >= 200000 && ctx && ctx->ingest_mu.try_lock()) {   // long lists: the rows on the context's workers, equal shares of the ENTRIES
+            const size_t workers = std::min<size_t>(16, m / 50000);
+            std::vector<size_t> cut(workers + 1, n);
+            cut[0] = 0;
+            for (size_t w = 1; w < workers; w++) cut[w] = std::lower_bound(at.begin(), at.end(), m * w / workers) - at.begin();
+            for (size_t w = 1; w <= workers; w++) cut[w] = std::min(std::max(cut[w], cut[w - 1]), n);
+            ctx->io.run((int)workers, [&](int w) { sort_rows(cut[w], cut[w + 1]); });
+            ctx->ingest_mu.unlock();
+        } else sort_rows(0, n);
     }
     *out_pairs = res; *out_n = m;
     return GHIP_OK;
