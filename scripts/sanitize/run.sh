@@ -18,9 +18,9 @@ for name, eol, w in (("t9_mixed.fna", "\n", 60), ("t10_crlf.fna", "\r\n", 71), (
             f.write(">r%d x" % i + eol + eol.join(r[j:j + w] for j in range(0, len(r), w)) + eol)
 PY
 printf ">a\nACGT\n" | gzip > t5.fna.gz; head -c 20 t5.fna.gz > t6_trunc.fna.gz; printf "\x1f\x8bgarbagegarbagegarbage" > t7_bad.fna.gz; : > t8_empty.fna
-g++ $FLAGS "$R/scripts/sanitize/ingest_main.cpp" "$R/galah_amd/csrc/ingest.cpp" -o ingest_t -lz -lpthread 2>/dev/null
+g++ $FLAGS "$R/scripts/sanitize/ingest_main.cpp" "$R/galah_amd/csrc/ingest.cpp" -o ingest_t -lz -lpthread -ldl 2>&1 | grep -E "error|undefined" || true
 ./ingest_t t*.fna t*.fna.gz "$R"/tests/golden/fasta/*.gz | tail -4
 printf '#include <cstdlib>\nextern "C" void ghip_free(void *p) { free(p); }\n' > stub.cpp
-g++ $FLAGS "$R/scripts/sanitize/cluster_main.cpp" stub.cpp "$R/galah_amd/csrc/cluster.cpp" -o cluster_t -lpthread 2>/dev/null
+g++ $FLAGS "$R/scripts/sanitize/cluster_main.cpp" stub.cpp "$R/galah_amd/csrc/cluster.cpp" -o cluster_t -lpthread 2>&1 | grep -E "error|undefined" || true
 ./cluster_t
 rm -rf "$T"
