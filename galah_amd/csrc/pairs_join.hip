@@ -12,10 +12,17 @@
 // j = #{b <= m} come from binary searches in the sorted rows, the integer filter common >= cmin[total] and the host's
 // exact f64 recheck are those of the dense path.  Work ~ N*s + #records instead of N^2*s.
 //
-// The join form declines (the caller then runs a dense kernel) when it would not pay or cannot be exact in its
-// fixed-size buffers: min_ani <= 0 (pairs without a common hash qualify), an empty sketch (by the reference's NaN
-// semantics its ANI with every other sketch is 1.0), a hash bucket or a record bucket beyond its LDS capacity
-// (large families: many genomes share each hash), more records than a dense pass would cost, N*s >= 2^32.
+// Two inputs that used to make the join decline are handled around it instead.  Empty sketches (by the reference's
+// NaN semantics their ANI with every other sketch is 1.0) take no part: the caller passes their indices (`empties`)
+// and lists their N - 1 pairs itself.  Large families (many genomes sharing each hash: a hash run beyond J_RUN_MAX
+// genomes, or a bucket beyond the LDS stage) go hybrid: a block per oversized bucket (join_elem_pairs_big_kernel)
+// marks the genomes of the long runs in `big`, the join drops the pairs whose two genomes are both marked, and the
+// caller counts exactly those pairs with a dense kernel over the marked rows (api.cpp, precluster_impl).
+//
+// The join form still declines (the caller then runs a dense kernel over everything) when it would not pay or cannot
+// be exact in its fixed-size buffers: min_ani <= 0 (pairs without a common hash qualify), a bucket beyond J_BIG_CAP
+// elements or more than J_BIG_LIST oversized buckets, a record table overflow, more records than a dense pass would cost,
+// N*s >= 2^32.
 #include <algorithm>
 #include <chrono>
 
