@@ -95,6 +95,7 @@ SIGNATURES = {
     "ghip_comm_transport": (C.c_char_p, [_vp]),
     "ghip_comm_last_error": (C.c_char_p, [_vp]),
     "ghip_comm_allgather_device": (_int, [_vp, _vp, _vp, _sz]),
+    "ghip_comm_exchange_device": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "ghip_comm_allgather_host": (_int, [_vp, _vp, _sz, _vp]),
     "ghip_shard_range": (None, [_sz, _u32, _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "ghip_allgather_sketches": (_int, [_vp, _vp, _sz, _pp]),

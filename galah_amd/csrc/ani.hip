@@ -609,6 +609,25 @@ void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const
 }
 
 namespace {
+// Index slices on the move (comm.cpp, ghip_exchange_ani_index): run x copies runs[3x + 2] 32-bit words from
+// src + runs[3x] to dst + runs[3x + 1].  One launch packs everything a rank sends out of one array of the index.
+__global__ void __launch_bounds__(256) copy_runs_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, const uint64_t *__restrict__ runs) {
+    const uint64_t *r = runs + 3 * (size_t)blockIdx.x;
+    const uint32_t *s = src + r[0];
+    uint32_t *d = dst + r[1];
+    const uint64_t n = r[2];
+    for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += 256ull * gridDim.y) d[i] = s[i];
+}
+}  // namespace
+
+void ghip_launch_copy_runs(hipStream_t stream, const uint32_t *d_src, uint32_t *d_dst, const uint64_t *d_runs, size_t n_runs) {
+    for (size_t off = 0; off < n_runs; off += 1u << 20) {
+        const size_t m = std::min<size_t>(n_runs - off, 1u << 20);
+        hipLaunchKernelGGL(copy_runs_kernel, dim3((unsigned)m, 8), dim3(256), 0, stream, d_src, d_dst, d_runs + 3 * off);
+    }
+}
+
+namespace {
 struct DeviceFree_ {   // pool blocks handed back at scope exit (the caller synchronises the stream before they are reused)
     ghip_ctx *ctx;
     std::vector<void *> ptrs;

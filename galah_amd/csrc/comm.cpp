@@ -1,8 +1,9 @@
 // Multi-GPU exchange behind the C ABI (include/galah_hip.h "multi-GPU"): the two real exchange steps of the path --
 // all-gather of the packed sketch matrix, gather of candidate lists / ANI index slices / ANI values -- over one of
-// three transports that share every line of the logic above the two primitives (all-gather of device bytes, all-gather
-// of host bytes):
-//   RCCL      one process per GPU: ncclAllGather over xGMI on the context's stream.  librccl is bound at run time
+// three transports that share every line of the logic above the three primitives (all-gather of device bytes,
+// all-gather of host bytes, all-to-all-v of device bytes):
+//   RCCL      one process per GPU: ncclAllGather (and grouped ncclSend / ncclRecv for the ANI index slices, which go
+//             only where they are wanted) over xGMI on the context's stream.  librccl is bound at run time
 //             (dlopen), so the library loads on hosts without it and shares the copy a host such as PyTorch mapped.
 //   LOCAL     one process, one context (and one thread) per GPU -- how a single-process host like galah's CLI drives
 //             8 devices: every rank pulls its peers' blocks with hipMemcpyPeerAsync (xGMI peer copies).
@@ -30,6 +31,10 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
@@ -46,9 +51,15 @@ Rccl &rccl() {
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
         x.AllGather = (decltype(x.AllGather))dlsym(x.handle, "ncclAllGather");
+        x.Send = (decltype(x.Send))dlsym(x.handle, "ncclSend");
+        x.Recv = (decltype(x.Recv))dlsym(x.handle, "ncclRecv");
+        x.GroupStart = (decltype(x.GroupStart))dlsym(x.handle, "ncclGroupStart");
+        x.GroupEnd = (decltype(x.GroupEnd))dlsym(x.handle, "ncclGroupEnd");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
-        if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.CommDestroy || !x.GetErrorString) x.err = "librccl lacks an expected symbol";
+        if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.Send || !x.Recv || !x.GroupStart || !x.GroupEnd || !x.CommDestroy ||
+            !x.GetErrorString)
+            x.err = "librccl lacks an expected symbol";
         return x;
     }();
     return r;
@@ -62,6 +73,7 @@ struct LocalGroup {
     uint32_t arrived = 0;
     uint64_t generation = 0;
     std::vector<const void *> slot;   // what each rank published for the collective in flight
+    std::vector<std::vector<uint64_t>> offer;   // exchange_device: each rank's send offsets (copies: they outlive a failing rank's frame)
     std::vector<int> device;
     std::atomic<int> refs{0};
     std::atomic<int> failed{0};       // a rank hit an error: every later barrier returns it instead of waiting for ever
@@ -177,6 +189,90 @@ int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t byte
     return GHIP_EINVAL;
 }
 
+int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv);
+
+// All-to-all-v of device bytes: my bytes [send_off[d], send_off[d + 1]) of d_send arrive at rank d's d_recv + its
+// recv_off[me]; recv_off[r + 1] - recv_off[r] is what I expect from rank r (both arrays hold world + 1 offsets, and the
+// two sides of every (sender, receiver) must agree on the size -- the callers derive both from data every rank holds).
+// Every rank calls it, also with nothing to send or receive.
+//   RCCL      one ncclSend and one ncclRecv per peer with bytes, in one group: a slice crosses exactly one xGMI link
+//   LOCAL     every rank pulls its parts out of the peers' send buffers (hipMemcpyPeerAsync)
+//   CALLBACK  the host all-gather is the only collective there is: whole send buffers are gathered, a rank keeps its parts
+int exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, void *d_recv, const uint64_t *recv_off) {
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return cerr_(c, GHIP_EINVAL, "this communicator has no device context");
+    const uint32_t me = c->rank, world = c->world;
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    auto sends = [&](uint32_t d) { return send_off[d + 1] - send_off[d]; };
+    auto recvs = [&](uint32_t r) { return recv_off[r + 1] - recv_off[r]; };
+    switch (c->transport) {
+    case T_SELF:
+        if (sends(0) != recvs(0)) return cerr_(c, GHIP_EINVAL, "exchange: send and receive sizes differ");
+        if (sends(0)) COMM_HIP(c, hipMemcpyAsync((char *)d_recv + recv_off[0], (const char *)d_send + send_off[0], sends(0), hipMemcpyDeviceToDevice, ctx->stream));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        return GHIP_OK;
+    case T_RCCL: {
+        ncclResult_t r = rccl().GroupStart();
+        for (uint32_t p = 0; p < world && r == ncclSuccess; p++) {
+            if (sends(p)) r = rccl().Send((const char *)d_send + send_off[p], sends(p), ncclUint8, (int)p, c->nccl, ctx->stream);
+            if (r == ncclSuccess && recvs(p)) r = rccl().Recv((char *)d_recv + recv_off[p], recvs(p), ncclUint8, (int)p, c->nccl, ctx->stream);
+        }
+        const ncclResult_t e = rccl().GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return cerr_(c, GHIP_EHIP, std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(r));
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        return GHIP_OK;
+    }
+    case T_LOCAL: {
+        LocalGroup *g = c->group;
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));   // my send buffer is written before anyone reads it
+        g->slot[me] = d_send;
+        g->offer[me].assign(send_off, send_off + world + 1);
+        if (!g->barrier()) return cerr_(c, GHIP_EHIP, "a peer rank failed");
+        bool mismatch = false;
+        hipError_t e = hipSuccess;
+        for (uint32_t r = 0; r < world && e == hipSuccess; r++) {
+            const std::vector<uint64_t> &o = g->offer[r];
+            const uint64_t b = o[me + 1] - o[me];
+            if (b != recvs(r)) { mismatch = true; continue; }
+            if (b) e = hipMemcpyPeerAsync((char *)d_recv + recv_off[r], ctx->device, (const char *)g->slot[r] + o[me], g->device[r], b, ctx->stream);
+        }
+        const hipError_t es = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = es;
+        const bool peers_ok = g->barrier();   // peers are done reading my buffer
+        if (e != hipSuccess) return cerr_(c, GHIP_EHIP, std::string("exchange (peer copy): ") + hipGetErrorString(e));
+        if (mismatch) return cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects");
+        if (!peers_ok) return cerr_(c, GHIP_EHIP, "a peer rank failed");
+        return GHIP_OK;
+    }
+    case T_CALLBACK: {
+        std::vector<uint64_t> all_off((size_t)(world + 1) * world);
+        int rc = allgather_host(c, send_off, (size_t)(world + 1) * sizeof(uint64_t), all_off.data());
+        if (rc) return rc;
+        uint64_t m = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            const uint64_t *o = &all_off[(size_t)r * (world + 1)];
+            m = std::max(m, o[world] - o[0]);
+            if (o[me + 1] - o[me] != recvs(r)) return cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects");
+        }
+        if (m == 0) return GHIP_OK;
+        m = (m + 15) / 16 * 16;
+        PoolBuf sb(ctx, m), rb(ctx, m * world);
+        if (!sb.p || !rb.p) return cerr_(c, GHIP_EHIP, "out of device memory for the exchange");
+        if (send_off[world] > send_off[0])
+            COMM_HIP(c, hipMemcpyAsync(sb.p, (const char *)d_send + send_off[0], send_off[world] - send_off[0], hipMemcpyDeviceToDevice, ctx->stream));
+        if ((rc = allgather_device(c, sb.p, rb.p, m))) return rc;
+        for (uint32_t r = 0; r < world; r++) {
+            const uint64_t *o = &all_off[(size_t)r * (world + 1)];
+            if (recvs(r)) COMM_HIP(c, hipMemcpyAsync((char *)d_recv + recv_off[r], (const char *)rb.p + (size_t)r * m + (o[me] - o[0]), recvs(r), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        return GHIP_OK;
+    }
+    }
+    return GHIP_EINVAL;
+}
+
 int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv) {
     if (bytes == 0) return GHIP_OK;
     switch (c->transport) {
@@ -274,6 +370,7 @@ extern "C" int ghip_comm_init_local(ghip_ctx *const *ctxs, uint32_t world, ghip_
     LocalGroup *g = new LocalGroup();
     g->world = world;
     g->slot.assign(world, nullptr);
+    g->offer.assign(world, std::vector<uint64_t>(world + 1, 0));
     g->device.resize(world);
     for (uint32_t r = 0; r < world; r++) g->device[r] = ctxs[r]->device;
     for (uint32_t r = 0; r < world; r++) {   // direct xGMI reads of the peers' HBM (best effort: staged copies work without it)
@@ -325,6 +422,13 @@ extern "C" const char *ghip_comm_last_error(const ghip_comm *c) { return c ? c->
 extern "C" int ghip_comm_allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank) {
     if (!c || (bytes_per_rank && (!d_send || !d_recv))) return GHIP_EINVAL;
     return allgather_device(c, d_send, d_recv, bytes_per_rank);
+}
+
+extern "C" int ghip_comm_exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, void *d_recv, const uint64_t *recv_off) {
+    if (!c || !send_off || !recv_off) return GHIP_EINVAL;
+    if ((send_off[c->world] > send_off[0] && !d_send) || (recv_off[c->world] > recv_off[0] && !d_recv)) return GHIP_EINVAL;
+    for (uint32_t r = 0; r < c->world; r++) if (send_off[r + 1] < send_off[r] || recv_off[r + 1] < recv_off[r]) return GHIP_EINVAL;
+    return exchange_device(c, d_send, send_off, d_recv, recv_off);
 }
 
 extern "C" int ghip_comm_allgather_host(ghip_comm *c, const void *send, size_t bytes_per_rank, void *recv) {
@@ -512,65 +616,66 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
 }
 
 // ------------------------------------------------------------------------------------------------ ANI index slices
-namespace {
-
-struct IndexField { const void *src; size_t esz; const std::vector<uint64_t> *start; uint64_t fixed; };  // per-genome slots: start[g+1]-start[g], or `fixed`
-
-}  // namespace
-
 // A pair's ANI is computed on the rank that owns its FIRST genome; that rank needs the index slices of second genomes
 // it does not own.  `pairs` is the whole list (identical on every rank).  On return *out_index serves this rank's pairs:
 // the local index itself (*out_index == local, nothing was exchanged) or a combined index = local genomes followed by
 // the foreign genomes THIS rank's pairs reference, in ascending order; out_local_ids[g] maps global genome ids to
 // positions in that index (UINT32_MAX: not present on this rank).
-// Transport: every owner offers the slices of its genomes that ANY rank needs, packed back to back, in one all-gather
-// per array (the primitive the three transports share); a rank keeps only what its own pairs reference -- the combined
-// index does not grow with the world size.  (Traffic does: with input in arbitrary order nearly every clustered genome
-// is needed somewhere.  Send/receive of exactly the wanted slices is the next step where that matters; for input whose
-// families are contiguous -- sorted by taxonomy or by a previous clustering, as in the bench -- little or nothing moves.)
+// Transport: every rank derives from `pairs` which genomes each rank wants of each owner.  An owner packs, per
+// destination, the slices that destination wants (one copy_runs launch per array of the index) and the all-to-all-v
+// above delivers them straight into the combined arrays -- a slice moves only to the ranks whose pairs reference it,
+// and neither the combined index nor the traffic into a rank grows with the world size.  (The host-callback transport
+// has no point-to-point primitive: there the packed buffers are all-gathered and a rank keeps its parts.)  Per-genome
+// metadata (length, seed capacity, seed count: 24 bytes) of every exchanged genome is all-gathered once on the host.
 extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local, size_t n_total, const ghip_pair *pairs,
                                        size_t n_pairs, ghip_ani_index **out_index, uint32_t *out_local_ids /* [n_total] */) {
     if (!c || !local || !out_index || !out_local_ids || (n_pairs && !pairs)) return GHIP_EINVAL;
     ghip_ctx *ctx = c->ctx;
     if (!ctx) return GHIP_EINVAL;
+    const uint32_t me = c->rank, world = c->world;
     size_t first, count, block;
-    ghip_shard_range(n_total, c->rank, c->world, &first, &count, &block);
+    ghip_shard_range(n_total, me, world, &first, &count, &block);
     if (local->n != count) return cerr_(c, GHIP_EINVAL, "local ANI index does not match this rank's block");
     { std::lock_guard<std::mutex> lk(ctx->mu); if (ghip_index_wait(ctx, local) != GHIP_OK) return cerr_(c, GHIP_EHIP, "ANI index kernels failed"); }
     for (size_t g = 0; g < n_total; g++) out_local_ids[g] = UINT32_MAX;
     for (size_t g = 0; g < count; g++) out_local_ids[first + g] = (uint32_t)g;
-    // second genomes of pairs that span two ranks: `needed` (ascending, the same list on every rank) and, of those, the ones
-    // MY pairs reference
-    std::vector<uint8_t> mark(n_total, 0);
+    // second genomes of pairs that span two ranks: wants[g] = the ranks (bit d of word d / 64) whose pairs reference g
+    const size_t W = (world + 63) / 64;
+    std::vector<uint64_t> wants(n_total * W, 0);
+    bool any = false;
     for (size_t x = 0; x < n_pairs; x++) {
         if (pairs[x].i >= n_total || pairs[x].j >= n_total) return cerr_(c, GHIP_EINVAL, "pair index out of range");
-        if (pairs[x].i / block != pairs[x].j / block) mark[pairs[x].j] |= (pairs[x].i / block == c->rank) ? 3 : 1;
+        const size_t d = pairs[x].i / block;
+        if (d != pairs[x].j / block) { wants[pairs[x].j * W + d / 64] |= 1ull << (d % 64); any = true; }
     }
-    std::vector<uint32_t> needed;
-    for (size_t g = 0; g < n_total; g++) if (mark[g]) needed.push_back((uint32_t)g);
-    if (needed.empty() || c->world == 1) { *out_index = const_cast<ghip_ani_index *>(local); return GHIP_OK; }
-
-    std::vector<uint32_t> send;   // local ids of my genomes that somebody needs
-    for (uint32_t g : needed) if (g >= first && g < first + count) send.push_back((uint32_t)(g - first));
-    // per-genome metadata of what I send: length, seed capacity, seed count
-    std::vector<uint64_t> meta(3 * send.size());
-    for (size_t x = 0; x < send.size(); x++) {
-        const uint32_t g = send[x];
-        meta[3 * x] = local->glen[g];
-        meta[3 * x + 1] = local->seed_start[g + 1] - local->seed_start[g];
-        meta[3 * x + 2] = local->seed_count[g];
+    if (!any || world == 1) { *out_index = const_cast<ghip_ani_index *>(local); return GHIP_OK; }
+    auto wanted_by = [&](size_t g, uint32_t d) { return (wants[g * W + d / 64] >> (d % 64)) & 1; };
+    std::vector<uint32_t> needed;   // exchanged genomes, ascending: the same list on every rank
+    for (size_t g = 0; g < n_total; g++) {
+        bool some = false;
+        for (size_t w = 0; w < W; w++) some |= wants[g * W + w] != 0;
+        if (some) needed.push_back((uint32_t)g);
     }
+    // per-genome metadata of my genomes among them: length, seed capacity, seed count
+    std::vector<uint64_t> meta;
+    for (uint32_t g : needed)
+        if (g >= first && g < first + count) {
+            const uint32_t l = (uint32_t)(g - first);
+            meta.push_back(local->glen[l]);
+            meta.push_back(local->seed_start[l + 1] - local->seed_start[l]);
+            meta.push_back(local->seed_count[l]);
+        }
     std::vector<uint8_t> meta_all;
     std::vector<uint64_t> meta_sizes;
     int rc = allgatherv_host(c, meta.data(), meta.size() * 8, meta_all, meta_sizes);
     if (rc) return rc;
     const size_t n_recv = meta_all.size() / 24;
     if (n_recv != needed.size()) return cerr_(c, GHIP_EINVAL, "ranks disagree on the genomes to exchange");
-    const uint64_t *rm = reinterpret_cast<const uint64_t *>(meta_all.data());
+    const uint64_t *rm = reinterpret_cast<const uint64_t *>(meta_all.data());   // rank order = ascending genome order
 
-    // combined metadata: local genomes, then the foreign genomes my pairs reference (ascending)
+    // combined metadata: local genomes, then the foreign genomes my pairs reference (ascending, so grouped by owner)
     std::vector<size_t> wanted;   // positions in `needed`
-    for (size_t x = 0; x < n_recv; x++) if ((mark[needed[x]] & 2) && out_local_ids[needed[x]] == UINT32_MAX) wanted.push_back(x);
+    for (size_t x = 0; x < n_recv; x++) if (wanted_by(needed[x], me)) wanted.push_back(x);
     const size_t nc = count + wanted.size();
     std::vector<uint64_t> glen(nc), cap(nc);
     std::vector<uint32_t> cnt(nc);
@@ -589,20 +694,14 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     std::vector<uint64_t> lbin(count + 1), cbin(nc + 1);
     for (size_t g = 0; g <= count; g++) lbin[g] = g * bins;
     for (size_t g = 0; g <= nc; g++) cbin[g] = g * bins;
-    // per-genome slots of every exchanged genome in each array (from the gathered metadata): seeds, seeds, bins, chunks
-    auto slots_of = [&](int field, size_t x) -> uint64_t {
-        if (field <= 1) return rm[3 * x + 1];
-        if (field == 2) return bins;
-        return (rm[3 * x] + local->chunk - 1) / local->chunk;
-    };
 
-    // the flat arrays of the index: element size, per-genome slot offsets (local layout, combined layout)
-    struct Field { const void *src; size_t esz; const std::vector<uint64_t> *lstart; const std::vector<uint64_t> *cstart; void *dst; };
+    // the flat arrays of the index (all of 32-bit words): per-genome slot offsets in the local and the combined layout
+    struct Field { const uint32_t *src; const std::vector<uint64_t> *lstart; const std::vector<uint64_t> *cstart; uint32_t *dst; };
     Field fields[4] = {
-        {local->d_seed_code, sizeof(uint32_t), &local->seed_start, &cseed, nullptr},
-        {local->d_seed_loc, sizeof(*local->d_seed_loc), &local->seed_start, &cseed, nullptr},
-        {local->d_bin_start, sizeof(uint32_t), &lbin, &cbin, nullptr},
-        {local->d_chunk_total, sizeof(uint32_t), &local->chunk_start, &cchunk, nullptr},
+        {local->d_seed_code, &local->seed_start, &cseed, nullptr},
+        {local->d_seed_loc, &local->seed_start, &cseed, nullptr},
+        {local->d_bin_start, &lbin, &cbin, nullptr},
+        {local->d_chunk_total, &local->chunk_start, &cchunk, nullptr},
     };
     COMM_HIP(c, hipSetDevice(ctx->device));
     std::vector<void *> owned;
@@ -610,57 +709,57 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     // every early return below goes through fail(): the peers are told (LOCAL: the group's flag; the others learn it at
     // their next collective) and the combined arrays go back to the pool
     auto fail = [&](int code, const std::string &msg) { drop(); return cerr_(c, code, msg); };
+    std::vector<uint64_t> runs, send_off(world + 1), recv_off(world + 1);
     for (int fi = 0; fi < 4; fi++) {
         Field &f = fields[fi];
-        PoolBuf dst(ctx, std::max<uint64_t>((*f.cstart)[nc], 1) * f.esz);
+        PoolBuf dst(ctx, std::max<uint64_t>((*f.cstart)[nc], 1) * 4);
         if (!dst.p) return fail(GHIP_EHIP, "out of device memory for the combined ANI index");
-        f.dst = dst.release();
+        f.dst = static_cast<uint32_t *>(dst.release());
         owned.push_back(f.dst);
         // local part: one copy
-        const uint64_t lbytes = (*f.lstart)[count] * f.esz;
+        const uint64_t lbytes = (*f.lstart)[count] * 4;
         hipError_t e = lbytes ? hipMemcpyAsync(f.dst, f.src, lbytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
         if (e != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
-        // what I send, packed back to back
-        uint64_t mine = 0;
-        for (uint32_t g : send) mine += ((*f.lstart)[g + 1] - (*f.lstart)[g]) * f.esz;
-        std::vector<uint64_t> sizes(c->world, 0);
-        if ((rc = allgather_host(c, &mine, 8, sizes.data()))) { drop(); return rc; }
-        const uint64_t m = (*std::max_element(sizes.begin(), sizes.end()) + 15) / 16 * 16;
-        if (m == 0) continue;
-        PoolBuf sb(ctx, m), rb(ctx, m * c->world);
-        if (!sb.p || !rb.p) return fail(GHIP_EHIP, "out of device memory for the ANI index exchange");
+        // what I send: per destination, the slices of my genomes it wants, packed back to back (consecutive genomes are
+        // one run: they are neighbours in the index arrays)
+        runs.clear();
         uint64_t at = 0;
-        for (uint32_t g : send) {
-            const uint64_t b = ((*f.lstart)[g + 1] - (*f.lstart)[g]) * f.esz;
-            if (b && (e = hipMemcpyAsync((char *)sb.p + at, (const char *)f.src + (*f.lstart)[g] * f.esz, b, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess)
-                return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
-            at += b;
-        }
-        if ((rc = allgather_device(c, sb.p, rb.p, m))) { drop(); return rc; }
-        // the ranks' packed runs, in rank order, are the exchanged genomes in ascending order: walk them, keep the wanted
-        // ones (consecutive wanted genomes of one owner move in one copy)
-        std::vector<uint64_t> run_at(c->world, 0);
-        size_t w = 0;
-        uint64_t pend_src = 0, pend_dst = 0, pend_bytes = 0;
-        auto flush = [&]() -> hipError_t {
-            hipError_t r = pend_bytes ? hipMemcpyAsync((char *)f.dst + pend_dst, (const char *)rb.p + pend_src, pend_bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
-            pend_bytes = 0;
-            return r;
-        };
-        for (size_t x = 0; x < n_recv; x++) {
-            const uint32_t owner = (uint32_t)(needed[x] / block);
-            const uint64_t b = slots_of(fi, x) * f.esz, src_at = (uint64_t)owner * m + run_at[owner];
-            run_at[owner] += b;
-            if (w < wanted.size() && wanted[w] == x) {
-                const uint64_t dst_at = (*f.cstart)[count + w] * f.esz;
-                if (pend_bytes && pend_src + pend_bytes == src_at && pend_dst + pend_bytes == dst_at) pend_bytes += b;
-                else { if ((e = flush()) != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e)); pend_src = src_at; pend_dst = dst_at; pend_bytes = b; }
-                w++;
+        for (uint32_t d = 0; d < world; d++) {
+            send_off[d] = at * 4;
+            if (d == me) continue;
+            uint64_t prev_end = ~0ull;
+            for (size_t l = 0; l < count; l++) {
+                if (!wanted_by(first + l, d)) continue;
+                const uint64_t a = (*f.lstart)[l], n = (*f.lstart)[l + 1] - a;
+                if (n == 0) continue;
+                if (a == prev_end) runs.back() += n;
+                else { runs.push_back(a); runs.push_back(at); runs.push_back(n); }
+                prev_end = a + n;
+                at += n;
             }
         }
-        if ((e = flush()) != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
-        for (uint32_t r = 0; r < c->world; r++) if (run_at[r] != sizes[r]) return fail(GHIP_EINVAL, "ANI index exchange: sizes do not add up");
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));   // sb/rb go back to the pool
+        send_off[world] = at * 4;
+        // what I receive: my wanted genomes, owner by owner, land behind the local part in the combined layout
+        {
+            size_t w = 0;
+            uint64_t got = 0;
+            for (uint32_t r = 0; r < world; r++) {
+                recv_off[r] = got * 4;
+                for (; w < wanted.size() && needed[wanted[w]] / block == r; w++) got += (*f.cstart)[count + w + 1] - (*f.cstart)[count + w];
+            }
+            recv_off[world] = got * 4;
+            if (w != wanted.size() || got != (*f.cstart)[nc] - (*f.cstart)[count]) return fail(GHIP_EINVAL, "ANI index exchange: sizes do not add up");
+        }
+        PoolBuf sb(ctx, std::max<uint64_t>(at, 1) * 4), dr(ctx, std::max<size_t>(runs.size(), 1) * sizeof(uint64_t));
+        if (!sb.p || !dr.p) return fail(GHIP_EHIP, "out of device memory for the ANI index exchange");
+        if (!runs.empty()) {
+            e = hipMemcpyAsync(dr.p, runs.data(), runs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (`runs` is pageable and reused by the next array)
+            if (e != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
+            ghip_launch_copy_runs(ctx->stream, f.src, static_cast<uint32_t *>(sb.p), static_cast<const uint64_t *>(dr.p), runs.size() / 3);
+        }
+        if ((rc = exchange_device(c, sb.p, send_off.data(), (char *)f.dst + (*f.cstart)[count] * 4, recv_off.data()))) { drop(); return rc; }
+        // (exchange_device returns with the stream idle: sb and dr go back to the pool)
     }
     ghip_ani_index *idx = nullptr;
     rc = ghip_ani_index_wrap_device(ctx, nc, local->k, local->c, local->chunk, glen.data(), cap.data(), cnt.data(), fields[0].dst,

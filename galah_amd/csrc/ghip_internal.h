@@ -289,6 +289,8 @@ void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, con
                            uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,
                            uint32_t *d_seg_count, uint32_t *d_chunk_total, const uint64_t *d_chunk_start,
                            const ghip_sketch_work *d_work, size_t n_work);
+void ghip_launch_copy_runs(hipStream_t stream, const uint32_t *d_src, uint32_t *d_dst, const uint64_t *d_runs /* [n][3]: source word, destination word, words */,
+                           size_t n_runs);
 void ghip_launch_ani_bin(ghip_ctx *ctx, size_t n, const uint32_t *in_code, const uint32_t *in_loc, uint32_t *out_code,
                          uint32_t *out_loc, const uint64_t *d_seed_start, const uint32_t *d_seg_count,
                          uint32_t *d_bin_start, uint32_t *d_pos_tmp);

@@ -156,6 +156,14 @@ class Comm:
     def allgather_device(self, d_send: int, d_recv: int, nbytes: int):
         self._check(_lib.lib().ghip_comm_allgather_device(self._h, C.c_void_p(d_send), C.c_void_p(d_recv), nbytes))
 
+    def exchange_device(self, d_send: int, send_off, d_recv: int, recv_off):
+        """All-to-all-v of device bytes (ghip_comm_exchange_device): byte offsets, world + 1 each."""
+        so = np.ascontiguousarray(send_off, dtype=np.uint64)
+        ro = np.ascontiguousarray(recv_off, dtype=np.uint64)
+        assert so.size == self.world + 1 and ro.size == self.world + 1
+        self._check(_lib.lib().ghip_comm_exchange_device(self._h, C.c_void_p(d_send), so.ctypes.data_as(C.c_void_p), C.c_void_p(d_recv),
+                                                         ro.ctypes.data_as(C.c_void_p)))
+
     def allgather_pairs(self, pairs: np.ndarray) -> np.ndarray:
         p = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
         out, n = C.c_void_p(), C.c_size_t(0)

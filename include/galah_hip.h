@@ -251,6 +251,11 @@ const char *ghip_comm_transport(const ghip_comm *comm);   /* "rccl", "local-peer
 const char *ghip_comm_last_error(const ghip_comm *comm);
 int ghip_comm_allgather_device(ghip_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
 int ghip_comm_allgather_host(ghip_comm *comm, const void *send, size_t bytes_per_rank, void *recv);
+/* All-to-all-v of device bytes: this rank's bytes [send_off[d], send_off[d+1]) of d_send arrive at rank d's
+ * d_recv + its recv_off[this rank]; recv_off[r+1] - recv_off[r] is what this rank expects from rank r.  Both arrays
+ * hold world + 1 offsets; sender and receiver must agree on every size (GHIP_EINVAL otherwise).  Every rank calls it.
+ * rccl: one ncclSend / ncclRecv per peer in one group; local: peer copies; host-callback: all-gather, keep one's parts. */
+int ghip_comm_exchange_device(ghip_comm *comm, const void *d_send, const uint64_t *send_off, void *d_recv, const uint64_t *recv_off);
 /* the block of rank `rank`: first genome, number of genomes, block size B */
 void ghip_shard_range(size_t n_total, uint32_t rank, uint32_t world, size_t *first, size_t *count, size_t *block);
 /* local = the sketches of this rank's block -> the matrix of all n_total genomes on every rank (N*s*8 bytes, once) */

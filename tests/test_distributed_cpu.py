@@ -56,6 +56,11 @@ def _worker(rank, world, port, q):
         out["nodev"] = "no error"
     except Exception as e:  # noqa: BLE001
         out["nodev"] = type(e).__name__
+    try:
+        comm.exchange_device(0, [0] * (world + 1), 0, [0] * (world + 1))
+        out["nodev_exchange"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["nodev_exchange"] = type(e).__name__
     q.put(out)
     dist.barrier()
     comm.close()
@@ -77,7 +82,7 @@ def test_exchange_logic_over_gloo(world):
     for r, o in enumerate(outs):
         assert o["fixed"] == [[100 * x + y for y in range(5)] for x in range(world)]
         assert o["merged_ok"] and o["ragged_ok"] and o["empty_ok"]
-        assert o["nodev"] == "GalahHipError"
+        assert o["nodev"] == "GalahHipError" and o["nodev_exchange"] == "GalahHipError"
 
 
 def test_single_rank_communicator_needs_no_transport():

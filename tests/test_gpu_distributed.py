@@ -199,6 +199,96 @@ def test_local_transport_threads_equal_single_rank(ctx):
         c.close()
 
 
+def _on_threads(world, fn):
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            out[r] = fn(r)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errs, errs
+    return out
+
+
+def test_exchange_device_ragged_blocks_over_peer_copies(ctx):
+    """ghip_comm_exchange_device: rank r sends (r + 2 * d) % 5 blocks of 1 KiB to rank d (some pairs exchange nothing),
+    every word tagged with sender, receiver and position."""
+    import torch
+
+    import galah_amd
+    from galah_amd.distributed import local_comms
+    world, blk = 4, 256
+    ctxs = [galah_amd.Context(0) for _ in range(world)]
+    comms = local_comms(ctxs)
+    words = lambda r, d: ((r + 2 * d) % 5) * blk
+
+    def run(r):
+        send = torch.cat([torch.arange(words(r, d), dtype=torch.int32, device="cuda") + (r * 16 + d) * 1_000_000 for d in range(world)] +
+                         [torch.zeros(1, dtype=torch.int32, device="cuda")])
+        send_off = np.cumsum([0] + [words(r, d) * 4 for d in range(world)])
+        recv_off = np.cumsum([0] + [words(s, r) * 4 for s in range(world)]) + 64   # (not at the start of the buffer)
+        recv = torch.full((int(recv_off[-1]) // 4 + 16,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        comms[r].exchange_device(send.data_ptr(), send_off, recv.data_ptr(), recv_off)
+        got = recv.cpu().numpy()
+        assert (got[:16] == -1).all() and (got[int(recv_off[-1]) // 4:] == -1).all()
+        for s in range(world):
+            part = got[int(recv_off[s]) // 4: int(recv_off[s + 1]) // 4]
+            assert part.tolist() == (np.arange(words(s, r)) + (s * 16 + r) * 1_000_000).tolist(), (r, s)
+        return True
+
+    assert _on_threads(world, run) == [True] * world
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_index_slices_go_only_where_they_are_wanted(ctx):
+    """ghip_exchange_ani_index over three ranks with a pair list in which genomes are wanted by none, one and two other
+    ranks: the combined index of a rank holds its block plus exactly the foreign genomes its pairs reference, and the ANI
+    of every pair computed on its first genome's rank is that of one index over all genomes."""
+    import galah_amd
+    from galah_amd.distributed import local_comms, shard_range
+    world, n, length, members = 3, 12, 150_000, 12
+    full = ctx.ani_index_build(ctx.genomes_synthetic_range(SEED, members, 0, n, length, 0.03))
+    pl = [(0, 1), (0, 5), (0, 9), (1, 5), (1, 11), (2, 3), (4, 6), (4, 9), (4, 10), (5, 8), (6, 9), (7, 11), (8, 10), (9, 11)]
+    pairs = np.zeros(len(pl), dtype=galah_amd.PAIR_DTYPE)
+    pairs["i"], pairs["j"] = [a for a, _ in pl], [b for _, b in pl]
+    want = ctx.ani_pairs(full, np.array(pl, dtype=np.uint32), 0.15)
+    assert (want > 80).all()
+    ctxs = [galah_amd.Context(0) for _ in range(world)]
+    comms = local_comms(ctxs)
+
+    def run(r):
+        first, count, block = shard_range(n, r, world)
+        local = ctxs[r].ani_index_build(ctxs[r].genomes_synthetic_range(SEED, members, first, count, length, 0.03))
+        idx, ids = comms[r].exchange_ani_index(local, n, pairs)
+        mine = [(a, b) for a, b in pl if a // block == r]
+        foreign = sorted({b for a, b in mine if b // block != r})
+        present = [g for g in range(n) if ids[g] != 0xFFFFFFFF]
+        assert present == sorted(set(range(first, first + count)) | set(foreign)), (r, present)
+        assert [int(ids[g]) for g in foreign] == list(range(count, count + len(foreign)))
+        got = ctxs[r].ani_pairs(idx, np.array([(ids[a], ids[b]) for a, b in mine], dtype=np.uint32), 0.15)
+        return {p: v for p, v in zip(mine, got.tolist())}
+
+    got = {}
+    for part in _on_threads(world, run):
+        got.update(part)
+    assert [got[p] for p in pl] == want.tolist()
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
 def test_single_process_multi_context_driver_on_files(ctx):
     """ghip_cluster_files_multi: files in -> clusters out with several contexts driven by one process equals
     galah_amd.cluster on one context (which the parity suite pins to the oracle)."""
@@ -224,7 +314,8 @@ def test_single_process_multi_context_driver_on_files(ctx):
 
 def _rccl_single_rank(port, q):
     """RCCL refuses two ranks on one device, so a ONE-rank communicator is as far as the transport can be exercised on a
-    one-GPU box: unique id, ncclCommInitRank, ncclAllGather on device and (staged) host payloads, and a whole job."""
+    one-GPU box: unique id, ncclCommInitRank, ncclAllGather on device and (staged) host payloads, ncclSend / ncclRecv,
+    and a whole job."""
     import torch
 
     import galah_amd
@@ -242,6 +333,11 @@ def _rccl_single_rank(port, q):
     comm.allgather_device(src.data_ptr(), dst.data_ptr(), src.numel() * 8)
     ok = bool(torch.equal(src, dst))
     ok = ok and comm.allgather_host(np.float32([1.25, 2.5, 3.75])).tolist() == [[1.25, 2.5, 3.75]]
+    # grouped ncclSend / ncclRecv (to itself: all a one-rank communicator can do): 1000 words from word 24 to word 100
+    dst.zero_()
+    torch.cuda.synchronize()
+    comm.exchange_device(src.data_ptr(), [24 * 8, 1024 * 8], dst.data_ptr(), [100 * 8, 1100 * 8])
+    ok = ok and bool(torch.equal(dst[100:1100], src[24:1024])) and int(dst[:100].abs().sum()) == 0 and int(dst[1100:].abs().sum()) == 0
     pairs = np.zeros(3, dtype=galah_amd.PAIR_DTYPE); pairs["i"] = [1, 2, 3]; pairs["j"] = [4, 5, 6]
     ok = ok and comm.allgather_pairs(pairs).tobytes() == pairs.tobytes()
     job = DereplicationJob(ctx, 0, 1, n_genomes=N, min_ani=np.float32(0.9), ani_threshold=np.float32(95.0), min_af=0.15, comm=comm)
