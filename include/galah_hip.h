@@ -272,7 +272,8 @@ int ghip_allgather_pairs(ghip_comm *comm, const ghip_pair *local, size_t n_local
 /* The ANI index slices a rank needs but does not own (second genomes of pairs whose first genome it owns; `pairs` is
  * the whole list).  *out_index = `local` itself when nothing had to move, else a new handle (free it) = local genomes
  * followed by the foreign genomes THIS rank's pairs reference; out_local_ids[g] = position of global genome g in it,
- * UINT32_MAX if absent.  (Owners offer what any rank needs in one all-gather per array; a rank keeps what it wants.) */
+ * UINT32_MAX if absent.  An owner sends a genome's slices only to the ranks whose pairs reference it
+ * (ghip_comm_exchange_device; the host-callback transport all-gathers the packed slices and a rank keeps its parts). */
 int ghip_exchange_ani_index(ghip_comm *comm, const ghip_ani_index *local, size_t n_total, const ghip_pair *pairs,
                             size_t n_pairs, ghip_ani_index **out_index, uint32_t *out_local_ids /* [n_total] */);
 typedef struct {   /* wall milliseconds of one ghip_distances_and_ani_ranks call on this rank */
