@@ -30,6 +30,27 @@ KERNEL(k_mul_u24, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = se
 KERNEL(k_mad64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(a[c]) : "v"(seed) : "vcc");,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mad64_sgpr, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mad_u64_u32 %0, s[40:41], %1, %1, %0" : "+v"(a[c]) : "v"(seed) : "s40", "s41");,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mad64_rot, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       asm volatile("v_mad_u64_u32 %0, s[40:41], %4, %4, %0\n v_mad_u64_u32 %1, s[42:43], %4, %4, %1\n v_mad_u64_u32 %2, s[44:45], %4, %4, %2\n v_mad_u64_u32 %3, s[46:47], %4, %4, %3"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(seed) : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+       asm volatile("v_mad_u64_u32 %0, s[40:41], %4, %4, %0\n v_mad_u64_u32 %1, s[42:43], %4, %4, %1\n v_mad_u64_u32 %2, s[44:45], %4, %4, %2\n v_mad_u64_u32 %3, s[46:47], %4, %4, %3"
+                    : "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(seed) : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mad64_s0, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) { uint64_t t; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"((uint32_t)a[c]), "s"(seed) : "vcc"); a[c] = t; },
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mad64_s0_sgpr, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) { uint64_t t; asm volatile("v_mad_u64_u32 %0, s[40:41], %1, %2, 0" : "=v"(t) : "v"((uint32_t)a[c]), "s"(seed) : "s40", "s41"); a[c] = t; },
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mul_lo_s, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[c]) : "s"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mad_u32_u24, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
 KERNEL(k_lshl_add64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshl_add_u64 %0, %0, 3, %0" : "+v"(a[c]));,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
@@ -233,6 +254,12 @@ int main() {
     run("v_mul_hi_u32", k_mul_hi, d_out, 1);
     run("v_mul_u32_u24", k_mul_u24, d_out, 1);
     run("v_mad_u64_u32", k_mad64, d_out, 1);
+    run("mad64 sdst=s[40:41]", k_mad64_sgpr, d_out, 1);
+    run("mad64 sdst rotating", k_mad64_rot, d_out, 1);
+    run("mad64 v*s+0 vcc", k_mad64_s0, d_out, 1);
+    run("mad64 v*s+0 sgpr", k_mad64_s0_sgpr, d_out, 1);
+    run("v_mul_lo_u32 v*s", k_mul_lo_s, d_out, 1);
+    run("v_mad_u32_u24", k_mad_u32_u24, d_out, 1);
     run("v_lshl_add_u64", k_lshl_add64, d_out, 1);
     run("v_lshlrev_b64", k_lshl64, d_out, 1);
     run("v_lshrrev_b64", k_lshr64, d_out, 1);
