@@ -51,6 +51,21 @@ KERNEL(k_mul_lo_s, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = s
 KERNEL(k_mad_u32_u24, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[c]) : "v"(seed));,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+// does the cost of a cheap op depend on its neighbours?  8 alignbits and 8 xors per iteration, alternating or grouped
+KERNEL(k_mix_alt, uint32_t a[CHAINS]; uint32_t b[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %2, 7\n v_xor_b32_e32 %1, %1, %2" : "+v"(a[c]), "+v"(b[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mix_grp, uint32_t a[CHAINS]; uint32_t b[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(seed));
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(b[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+// ... and on being independent of it?  one chain: alignbit feeds the xor feeds the next alignbit
+KERNEL(k_mix_dep, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7\n v_xor_b32_e32 %0, %0, %1" : "+v"(a[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mix_dep1, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7\n v_xor_b32_e32 %0, %0, %1" : "+v"(a[0]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
 KERNEL(k_lshl_add64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshl_add_u64 %0, %0, 3, %0" : "+v"(a[c]));,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
@@ -260,6 +275,10 @@ int main() {
     run("mad64 v*s+0 sgpr", k_mad64_s0_sgpr, d_out, 1);
     run("v_mul_lo_u32 v*s", k_mul_lo_s, d_out, 1);
     run("v_mad_u32_u24", k_mad_u32_u24, d_out, 1);
+    run("alignbit,xor alternating", k_mix_alt, d_out, 2);
+    run("alignbit x8 then xor x8", k_mix_grp, d_out, 2);
+    run("alignbit->xor dependent, 8 chains", k_mix_dep, d_out, 2);
+    run("alignbit->xor one chain", k_mix_dep1, d_out, 2);
     run("v_lshl_add_u64", k_lshl_add64, d_out, 1);
     run("v_lshlrev_b64", k_lshl64, d_out, 1);
     run("v_lshrrev_b64", k_lshr64, d_out, 1);
