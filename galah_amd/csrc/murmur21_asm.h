@@ -4,33 +4,40 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
-// x * C mod 2^64: result in v[R0:R1], v[E0:E1] is scratch (gfx950 wants even-aligned 64-bit tuples, so
-// the cross terms are accumulated in their own pair and added to the high word): 3 mads + 1 add.
-#define GHIP_MULC(R0, R1, E0, E1, X0, X1, CLO, CHI)                                     \
-    "v_mad_u64_u32 v[" #E0 ":" #E1 "], vcc, " X1 ", " CLO ", 0\n"                      \
-    "v_mad_u64_u32 v[" #E0 ":" #E1 "], vcc, " X0 ", " CHI ", v[" #E0 ":" #E1 "]\n"     \
-    "v_mad_u64_u32 v[" #R0 ":" #R1 "], vcc, " X0 ", " CLO ", 0\n"                      \
-    "v_add_u32 v" #R1 ", v" #R1 ", v" #E0 "\n"
-#define GHIP_XORSHIFT33(LO, HI) "v_lshrrev_b32 v52, 1, " HI "\n v_xor_b32 " LO ", " LO ", v52\n"
-
+// x * C mod 2^64 = three v_mad_u64_u32 (gfx950 wants even-aligned 64-bit tuples, so the cross terms are accumulated
+// in their own pair) and one add of the cross terms to the high word.
+//
 // MurmurHash3_x64_128(canonical 21-mer, seed).h1 from the table terms A = k1*c1, B = k2*c2,
 // T = rotl(tail*c1,31)*c2 ^ 21.  S1/S2/S3 are the three instructions a non-zero seed adds.
+//
+// Order: the hash is two independent halves (k1 -> h1, k2 -> h2) that meet three times; its 47 instructions are
+// issued with the halves INTERLEAVED -- the six multiplies of a stage stand together, then the two adds, the shifts,
+// the xors -- so that no instruction waits on the one before it.  Worth about 1 % (scripts/ubench/hash_variants, warm
+// clocks: 205-207 SIMD-cycles per wave half after half, 204-205 interleaved, 200 with two evaluations interleaved on
+// top; sketch_kmers 91.5 -> 90.2 ms per 50 Gbases): the SIMD is busy either way, every instruction of this mix costs
+// about 4.3 cycles whatever its class, and the instruction count is what there is to save.
 #define GHIP_MURMUR21_BODY(S1, S2, S3)                                                   \
     "v_alignbit_b32 v48, %[a0], %[a1], 1\n"                                             \
     "v_alignbit_b32 v49, %[a1], %[a0], 1\n" /* rotl(A,31) */                            \
-    GHIP_MULC(40, 41, 42, 43, "v48", "v49", "%[c2lo]", "%[c2hi]")                       \
+    "v_alignbit_b32 v50, %[b1], %[b0], 31\n"                                            \
+    "v_alignbit_b32 v51, %[b0], %[b1], 31\n" /* rotl(B,33) */                           \
+    "v_mad_u64_u32 v[42:43], vcc, v49, %[c2lo], 0\n" /* k1 = rotl(A,31)*c2 -> v[40:41] */ \
+    "v_mad_u64_u32 v[46:47], vcc, v51, %[c1lo], 0\n" /* k2 = rotl(B,33)*c1 -> v[44:45] */ \
+    "v_mad_u64_u32 v[40:41], vcc, v48, %[c2lo], 0\n"                                    \
+    "v_mad_u64_u32 v[44:45], vcc, v50, %[c1lo], 0\n"                                    \
+    "v_mad_u64_u32 v[42:43], vcc, v48, %[c2hi], v[42:43]\n"                             \
+    "v_mad_u64_u32 v[46:47], vcc, v50, %[c1hi], v[46:47]\n"                             \
+    "v_add_u32 v41, v41, v42\n"                                                         \
+    "v_add_u32 v45, v45, v46\n"                                                         \
     S1                                       /* h1 = seed ^ k1 */                       \
+    S3                                       /* h2 = seed ^ k2 */                       \
     "v_alignbit_b32 v48, v40, v41, 5\n"                                                 \
     "v_alignbit_b32 v49, v41, v40, 5\n"     /* rotl(h1,27) */                           \
+    "v_alignbit_b32 v50, v44, v45, 1\n"                                                 \
+    "v_alignbit_b32 v51, v45, v44, 1\n"     /* rotl(h2,31) */                           \
     S2                                       /* h1 += h2 (= seed) */                    \
     "v_lshl_add_u64 v[48:49], v[48:49], 2, v[48:49]\n"                                  \
     "v_lshl_add_u64 v[48:49], v[48:49], 0, %[k52]\n"                                    \
-    "v_alignbit_b32 v50, %[b1], %[b0], 31\n"                                            \
-    "v_alignbit_b32 v51, %[b0], %[b1], 31\n" /* rotl(B,33) */                           \
-    GHIP_MULC(44, 45, 46, 47, "v50", "v51", "%[c1lo]", "%[c1hi]")                       \
-    S3                                       /* h2 = seed ^ k2 */                       \
-    "v_alignbit_b32 v50, v44, v45, 1\n"                                                 \
-    "v_alignbit_b32 v51, v45, v44, 1\n"     /* rotl(h2,31) */                           \
     "v_lshl_add_u64 v[50:51], v[50:51], 0, v[48:49]\n"                                  \
     "v_lshl_add_u64 v[50:51], v[50:51], 2, v[50:51]\n"                                  \
     "v_lshl_add_u64 v[50:51], v[50:51], 0, %[k38]\n"                                    \
@@ -39,17 +46,27 @@
     "v_xor_b32 v50, 21, v50\n"              /* h2 ^= 21 */                              \
     "v_lshl_add_u64 v[48:49], v[48:49], 0, v[50:51]\n"                                  \
     "v_lshl_add_u64 v[50:51], v[50:51], 0, v[48:49]\n"                                  \
-    GHIP_XORSHIFT33("v48", "v49")                                                       \
-    GHIP_MULC(40, 41, 42, 43, "v48", "v49", "%[f1lo]", "%[f1hi]")                       \
-    GHIP_XORSHIFT33("v40", "v41")           /* a = v[40:41]: fmix64(h1) short of its last multiply */ \
-    GHIP_XORSHIFT33("v50", "v51")                                                       \
-    GHIP_MULC(44, 45, 46, 47, "v50", "v51", "%[f1lo]", "%[f1hi]")                       \
-    GHIP_XORSHIFT33("v44", "v45")           /* b = v[44:45]: the same for h2 */         \
+    "v_lshrrev_b32 v52, 1, v49\n"           /* fmix64 of both, short of the last multiply: x ^= x >> 33 */ \
+    "v_lshrrev_b32 v42, 1, v51\n"                                                       \
+    "v_xor_b32 v48, v48, v52\n"                                                         \
+    "v_xor_b32 v50, v50, v42\n"                                                         \
+    "v_mad_u64_u32 v[42:43], vcc, v49, %[f1lo], 0\n" /* x *= f1 */                      \
+    "v_mad_u64_u32 v[46:47], vcc, v51, %[f1lo], 0\n"                                    \
+    "v_mad_u64_u32 v[40:41], vcc, v48, %[f1lo], 0\n"                                    \
+    "v_mad_u64_u32 v[44:45], vcc, v50, %[f1lo], 0\n"                                    \
+    "v_mad_u64_u32 v[42:43], vcc, v48, %[f1hi], v[42:43]\n"                             \
+    "v_mad_u64_u32 v[46:47], vcc, v50, %[f1hi], v[46:47]\n"                             \
+    "v_add_u32 v41, v41, v42\n"                                                         \
+    "v_add_u32 v45, v45, v46\n"                                                         \
+    "v_lshrrev_b32 v52, 1, v41\n"           /* x ^= x >> 33 */                          \
+    "v_lshrrev_b32 v42, 1, v45\n"                                                       \
+    "v_xor_b32 v40, v40, v52\n"             /* a = v[40:41]: fmix64(h1) short of its last multiply */ \
+    "v_xor_b32 v44, v44, v42\n"             /* b = v[44:45]: the same for h2 */         \
     /* a*f2 + b*f2 = (a + b)*f2: ONE multiply gives the high word the filter needs */   \
     "v_lshl_add_u64 v[48:49], v[40:41], 0, v[44:45]\n"                                  \
     "v_mad_u64_u32 v[42:43], vcc, v49, %[f2lo], 0\n"                                    \
-    "v_mad_u64_u32 v[42:43], vcc, v48, %[f2hi], v[42:43]\n"                             \
     "v_mad_u64_u32 v[50:51], vcc, v48, %[f2lo], 0\n"                                    \
+    "v_mad_u64_u32 v[42:43], vcc, v48, %[f2hi], v[42:43]\n"                             \
     "v_add3_u32 %[s1], v51, v42, 1\n"
 
 // The hash is h = fin(a*f2) + fin(b*f2) with fin(x) = x ^ (x >> 33), f2 = 0xc4ceb9fe1a85ec53 and a, b the two halves

@@ -66,6 +66,22 @@ KERNEL(k_mix_dep, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = se
 KERNEL(k_mix_dep1, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %1, 7\n v_xor_b32_e32 %0, %0, %1" : "+v"(a[0]) : "v"(seed));,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+// pairs of cheap ops between expensive ones: independent, or the second using the first's result
+KERNEL(k_mix_ecc, uint32_t a[CHAINS]; uint32_t b[CHAINS]; uint32_t d[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; d[c] = a[c] * 5; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %3, 7\n v_xor_b32_e32 %1, %1, %3\n v_xor_b32_e32 %2, %2, %3" : "+v"(a[c]), "+v"(b[c]), "+v"(d[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c] + d[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mix_ecc_dep, uint32_t a[CHAINS]; uint32_t b[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %2, 7\n v_lshrrev_b32_e32 %1, 1, %0\n v_xor_b32_e32 %0, %0, %1" : "+v"(a[c]), "+v"(b[c]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mix_ecc_dep1, uint32_t a[CHAINS]; uint32_t b[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %2, 7\n v_lshrrev_b32_e32 %1, 1, %0\n v_xor_b32_e32 %0, %0, %1" : "+v"(a[0]), "+v"(b[0]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mix_eecc1, uint32_t a[CHAINS]; uint32_t b[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %2, 7\n v_alignbit_b32 %1, %1, %2, 9\n v_xor_b32_e32 %0, %0, %2\n v_xor_b32_e32 %1, %1, %2" : "+v"(a[0]), "+v"(b[0]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
+KERNEL(k_mix_ecec1, uint32_t a[CHAINS]; uint32_t b[CHAINS]; for (int c = 0; c < CHAINS; c++) { a[c] = seed + c + threadIdx.x; b[c] = a[c] * 3; },
+       _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_alignbit_b32 %0, %0, %2, 7\n v_xor_b32_e32 %0, %0, %2\n v_alignbit_b32 %1, %1, %2, 9\n v_xor_b32_e32 %1, %1, %2" : "+v"(a[0]), "+v"(b[0]) : "v"(seed));,
+       uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c] + b[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
 KERNEL(k_lshl_add64, uint64_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = seed + c + threadIdx.x,
        _Pragma("unroll") for (int c = 0; c < CHAINS; c++) asm volatile("v_lshl_add_u64 %0, %0, 3, %0" : "+v"(a[c]));,
        uint64_t s = 0; for (int c = 0; c < CHAINS; c++) s += a[c]; out[blockIdx.x * blockDim.x + threadIdx.x] = s)
@@ -279,6 +295,11 @@ int main() {
     run("alignbit x8 then xor x8", k_mix_grp, d_out, 2);
     run("alignbit->xor dependent, 8 chains", k_mix_dep, d_out, 2);
     run("alignbit->xor one chain", k_mix_dep1, d_out, 2);
+    run("E C C independent regs", k_mix_ecc, d_out, 3);
+    run("E lshr xor dependent, 8 chains", k_mix_ecc_dep, d_out, 3);
+    run("E lshr xor dependent, one chain", k_mix_ecc_dep1, d_out, 3);
+    run("E E C C two chains (a,b)", k_mix_eecc1, d_out, 4);
+    run("E C E C two chains (a,b)", k_mix_ecec1, d_out, 4);
     run("v_lshl_add_u64", k_lshl_add64, d_out, 1);
     run("v_lshlrev_b64", k_lshl64, d_out, 1);
     run("v_lshrrev_b64", k_lshr64, d_out, 1);
