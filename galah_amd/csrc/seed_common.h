@@ -59,6 +59,7 @@ struct SeedOut {  // where a block's seeds go (kernel argument, by value)
 
 struct SeedLds {  // per-block LDS state; slot-major so that the 64 lanes of a wave write consecutive words
     uint32_t raw[SEED_LANE_CAP][GHIP_SKETCH_THREADS];   // forward code as the pass holds it (see seed_canon)
+    uint32_t list[SEED_WAVES][SEED_LANE_CAP * 64];      // the flush's wave-compacted list of the rowed seeds (seed_block_flush)
     uint32_t ctot[SEED_LDS_CHUNKS];
     uint32_t seg_n[SEGMENTS], seg_base[SEGMENTS];
     uint32_t seg_over[SEGMENTS], seg_cur[SEGMENTS];   // seeds beyond a lane's rows (dense genomes): their number, their cursor
@@ -160,17 +161,42 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
     // seeds with a row of their own in SeedLds::raw (the clamped stores of a lane with more than SEED_LANE_CAP seeds
     // overwrote its last row): they are filed through the block's segment runs; the others, rare, one by one
     const uint32_t rowed = mine <= SEED_LANE_CAP ? mine : SEED_LANE_CAP - 1;
-    // pass 1: canonical code, strand, segment, and the rank in the block's run of that segment (one LDS counter per segment)
-    uint32_t canon_r[SEED_LANE_CAP], place_r[SEED_LANE_CAP];   // place = segment << 28 | strand << 27 | rank
+    // A lane holds 64 / c ~ 0.5 seeds: filing them lane by lane ran the ~55 instructions per seed below three times per
+    // wave (some lane nearly always holds three) for the ~32 seeds of the wave.  The wave first COMPACTS its rowed seeds
+    // into a list -- entry = byte offset of the code in SeedLds::raw << 6 | position bit in the lane's mask -- and then
+    // files one seed per lane: one round for up to 64 seeds.
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *list = sl.list[threadIdx.x >> 6];
+    uint64_t over = sb.mask;   // ends as the positions beyond the rowed ones
+    uint32_t n_wave = 0;       // wave-uniform: seeds in the list
 #pragma unroll
     for (uint32_t i = 0; i < SEED_LANE_CAP; i++) {
-        canon_r[i] = 0; place_r[i] = 0;
-        if (i < rowed) {
+        const bool has = i < rowed;
+        const uint64_t b = __builtin_amdgcn_ballot_w64(has);
+        if (has) {
+            const uint32_t at = n_wave + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            list[at] = ((i * GHIP_SKETCH_THREADS + threadIdx.x) << 8) | (uint32_t)__builtin_ctzll(over);
+            over &= over - 1;
+        }
+        n_wave += (uint32_t)__popcll(b);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // pass 1: canonical code, strand, segment, and the rank in the block's run of that segment (one LDS counter per segment)
+    const uint32_t rel_base = rel0 - threadIdx.x * GHIP_SKETCH_POS_PER_THREAD;   // uniform: a lane's positions start at 64 * thread + this
+    uint32_t canon_r[SEED_LANE_CAP], place_r[SEED_LANE_CAP], rel_r[SEED_LANE_CAP];   // place = segment << 28 | strand << 27 | rank
+#pragma unroll
+    for (uint32_t r = 0; r < SEED_LANE_CAP; r++) {
+        canon_r[r] = 0; place_r[r] = 0; rel_r[r] = 0;
+        if (64u * r + lane < n_wave) {
+            const uint32_t entry = list[64u * r + lane], off = entry >> 6;   // off = 4 * (row * threads + thread)
             uint32_t canon, strand;
-            seed_canon<COMPLEMENTED>(sl.raw[i][threadIdx.x], so.k, canon, strand);
+            seed_canon<COMPLEMENTED>(*reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(&sl.raw[0][0]) + off), so.k, canon, strand);
             const uint32_t seg = code_segment(canon);
-            canon_r[i] = canon;
-            place_r[i] = (seg << 28) | (strand << 27) | atomicAdd(&sl.seg_n[seg], 1u);
+            canon_r[r] = canon;
+            place_r[r] = (seg << 28) | (strand << 27) | atomicAdd(&sl.seg_n[seg], 1u);
+            rel_r[r] = rel_base + ((off & (4u * GHIP_SKETCH_THREADS - 1u)) << 4) + (entry & 63u);   // 64 * thread + bit
         }
     }
     // The seeds that found no row (a lane with more than SEED_LANE_CAP of them: rare at c = 125, the RULE for genomes seeded
@@ -189,8 +215,6 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
         canon = min(f, r);
         strand = r < f ? 1u : 0u;
     };
-    uint64_t over = sb.mask;   // the positions beyond the rowed ones
-    for (uint32_t i = 0; i < rowed; i++) over &= over - 1;
     for (uint64_t m = over; m; m &= m - 1) {
         uint32_t canon, strand;
         code_at(rel0 + (uint32_t)__builtin_ctzll(m), canon, strand);
@@ -203,19 +227,16 @@ __device__ __forceinline__ void seed_block_flush(SeedLds &sl, const SeedOut &so,
         sl.seg_base[threadIdx.x] = c ? atomicAdd(&so.seg_count[(uint64_t)sb.g * SEGMENTS + threadIdx.x], c) : 0u;
     }
     __syncthreads();
-    // pass 2: positions come off the lane's mask in the order the codes were stored
-    uint64_t mask = sb.mask;
+    // pass 2: the lane's list entries again, from registers
 #pragma unroll
-    for (uint32_t i = 0; i < SEED_LANE_CAP; i++) {
-        if (i < rowed) {
-            const uint32_t rel = rel0 + (uint32_t)__builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t at = sb.rem_first + rel, chrel = seed_chunk_of(at, so.chunk_magic);
-            const uint32_t seg = place_r[i] >> 28, idx = sl.seg_base[seg] + (place_r[i] & 0x07ffffffu);
+    for (uint32_t r = 0; r < SEED_LANE_CAP; r++) {
+        if (64u * r + lane < n_wave) {
+            const uint32_t at = sb.rem_first + rel_r[r], chrel = seed_chunk_of(at, so.chunk_magic);
+            const uint32_t seg = place_r[r] >> 28, idx = sl.seg_base[seg] + (place_r[r] & 0x07ffffffu);
             if (idx < sb.scap) {
                 const uint64_t o = sb.sstart + (uint64_t)seg * sb.scap + idx;
-                so.seed_code[o] = canon_r[i];
-                so.seed_loc[o] = seed_loc(sb.ch_first + chrel, (place_r[i] >> 27) & 1u, at - chrel * so.chunk);
+                so.seed_code[o] = canon_r[r];
+                so.seed_loc[o] = seed_loc(sb.ch_first + chrel, (place_r[r] >> 27) & 1u, at - chrel * so.chunk);
             }
             if (chrel < SEED_LDS_CHUNKS) atomicAdd(&sl.ctot[chrel], 1u);
             else atomicAdd(&sb.ctot[sb.ch_first + chrel], 1u);
