@@ -113,6 +113,7 @@ static void ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     ctx->io.shutdown();
     for (auto &b : ctx->pool) hipFree(b.p);
     for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+    if (ctx->pin_buf) hipHostFree(ctx->pin_buf);
     if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
     for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
@@ -159,10 +160,37 @@ int dmalloc(ghip_ctx *ctx, T **p, size_t count) {
     return *p ? GHIP_OK : GHIP_EHIP;
 }
 
+// Copies between pageable host memory and the device go through a pinned bounce buffer from 256 KiB on.  The runtime
+// stages small pageable copies itself; a larger buffer it pins in place, and the NEXT copy or event wait of the process
+// then stalls for 12-30 ms while it is unpinned (measured at 50 000 genomes: the 3.6 MB candidate list coming back made
+// the first ANI round's 360 KB upload take 12-32 ms; scripts/ani_round_overhead.py).  One memcpy at host speed instead.
+constexpr size_t GHIP_PIN_MIN = 256u << 10, GHIP_PIN_MAX = 32u << 20;
+static void *pinned_bounce(ghip_ctx *ctx, size_t bytes) {   // ctx->pin_mu held; nullptr: no pinned memory to be had (the caller copies directly)
+    if (ctx->pin_bytes >= bytes) return ctx->pin_buf;
+    if (ctx->pin_buf) { hipHostFree(ctx->pin_buf); ctx->pin_buf = nullptr; ctx->pin_bytes = 0; }
+    const size_t want = std::min(bytes + bytes / 2, GHIP_PIN_MAX);
+    if (hipHostMalloc(&ctx->pin_buf, want, hipHostMallocDefault) != hipSuccess) { ctx->pin_buf = nullptr; (void)hipGetLastError(); return nullptr; }
+    ctx->pin_bytes = want;
+    return ctx->pin_buf;
+}
+
 template <typename T>
 int h2d(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
     if (count == 0) return GHIP_OK;
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    const size_t bytes = count * sizeof(T);
+    if (bytes >= GHIP_PIN_MIN) {
+        std::lock_guard<std::mutex> pl(ctx->pin_mu);
+        if (void *p = pinned_bounce(ctx, std::min(bytes, GHIP_PIN_MAX))) {
+            for (size_t at = 0; at < bytes; at += GHIP_PIN_MAX) {   // (longer copies: piece by piece)
+                const size_t m = std::min(GHIP_PIN_MAX, bytes - at);
+                memcpy(p, reinterpret_cast<const char *>(src) + at, m);
+                GHIP_HIP_CHECK(ctx, hipMemcpyAsync(reinterpret_cast<char *>(dst) + at, p, m, hipMemcpyHostToDevice, ctx->stream));
+                GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            return GHIP_OK;
+        }
+    }
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // src may be pageable / short-lived
     return GHIP_OK;
 }
@@ -189,7 +217,20 @@ static int stream_sync(ghip_ctx *ctx) {
 template <typename T>
 int d2h(ghip_ctx *ctx, T *dst, const T *src, size_t count) {
     if (count == 0) return GHIP_OK;
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t bytes = count * sizeof(T);
+    if (bytes >= GHIP_PIN_MIN) {
+        std::lock_guard<std::mutex> pl(ctx->pin_mu);
+        if (void *p = pinned_bounce(ctx, std::min(bytes, GHIP_PIN_MAX))) {
+            for (size_t at = 0; at < bytes; at += GHIP_PIN_MAX) {
+                const size_t m = std::min(GHIP_PIN_MAX, bytes - at);
+                GHIP_HIP_CHECK(ctx, hipMemcpyAsync(p, reinterpret_cast<const char *>(src) + at, m, hipMemcpyDeviceToHost, ctx->stream));
+                GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                memcpy(reinterpret_cast<char *>(dst) + at, p, m);
+            }
+            return GHIP_OK;
+        }
+    }
+    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return GHIP_OK;
 }
@@ -220,6 +261,10 @@ double ghip_cpu_quota() {
 // standard deviations and 10 %, the first form, 50 000 genomes of 1 Mb overflowed a handful of their 400 000 segments
 // every time: +33 ms).
 }  // namespace
+
+// the same for the other translation units (comm.cpp): bytes between pageable host memory and the device, synchronous
+int ghip_copy_to_device(ghip_ctx *ctx, void *d_dst, const void *src, size_t bytes) { return h2d(ctx, static_cast<char *>(d_dst), static_cast<const char *>(src), bytes); }
+int ghip_copy_to_host(ghip_ctx *ctx, void *dst, const void *d_src, size_t bytes) { return d2h(ctx, static_cast<char *>(dst), static_cast<const char *>(d_src), bytes); }
 // Seed density of a genome (oracle: go_ani_density): the base density c while the genome holds ~8192 seeds at it, else four
 // times denser, and so on down to every k-mer (125 -> 31 -> 7 -> 1): a 200 kb plasmid or a 5 kb contig carries as many
 // seeds as a genome does, and its ANI is as little noisy (skani's own remedy is --small-genomes = -c 30, chosen by the
@@ -2117,11 +2162,22 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
 // device part of ghip_ani_pairs: res[6 p ..] = M and T of the median-containment chunk, aligned bases of q, aligned chunks,
 // (unused), aligned bases of r
 static int ani_pairs_device(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, size_t n, uint64_t *res) {
+    // GHIP_ANI_DEBUG=1: where the wall time of one call goes (stderr)
+    static const bool dbg = getenv("GHIP_ANI_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ani_pairs %zu] %-22s %8.3f ms\n", n, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     // the context is held for the device part only: the host finish runs next to other callers' launches
     // (calculate_ani arrives from many rayon workers at once, src/clusterer.rs:267-296)
     std::lock_guard<std::mutex> lk(ctx->mu);
+    lap("context lock");
     GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     { const int rcw = ghip_index_wait(ctx, idx); if (rcw) return rcw; }
+    lap("index wait (binning)");
     DeviceFree tmp(ctx);
     uint32_t *d_pairs = nullptr;
     uint64_t *d_out = nullptr;
@@ -2130,11 +2186,15 @@ static int ani_pairs_device(ghip_ctx *ctx, const ghip_ani_index *idx, const uint
     tmp.add(d_pairs);
     if ((rc = dmalloc(ctx, &d_out, 6 * n))) return rc;
     tmp.add(d_out);
+    lap("device buffers");
     if ((rc = h2d(ctx, d_pairs, pairs, 2 * n))) return rc;
+    lap("pairs to device");
     const size_t batch = (size_t)1 << 22;  // 512 threads per pair: keep each dispatch below 2^32 work-items
     for (size_t off = 0; off < n; off += batch)
         if ((rc = ghip_launch_ani_pairs(ctx, idx, pairs + 2 * off, d_pairs + 2 * off, std::min(batch, n - off), d_out + 6 * off))) return rc;
+    lap("launch");
     if ((rc = d2h(ctx, res, d_out, 6 * n))) return rc;
+    lap("kernel + results to host");
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ani_pairs: ") + hipGetErrorString(e)); }
     return GHIP_OK;
 }
@@ -2160,8 +2220,11 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if (!ctx || !idx || !out_ani || (n && !pairs)) return GHIP_EINVAL;
     for (size_t i = 0; i < 2 * n; i++) if (pairs[i] >= idx->n) return ghip_set_error(ctx, GHIP_EINVAL, "genome index out of range");
     if (n == 0) return GHIP_OK;
+    static const bool dbg = getenv("GHIP_ANI_DEBUG") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
     std::vector<uint64_t> res(6 * n);
     { const int rc = ani_pairs_device(ctx, idx, pairs, n, res.data()); if (rc) return rc; }
+    const auto t_dev = std::chrono::steady_clock::now();
     // the f64 pow and the two-decimal rounding stay on the host (glibc's pow is what the oracle's parity is defined
     // by): ~70 ns per pair, spread over threads from 20 000 pairs on (below that spawning costs more than it saves)
     auto finish_range = [&](size_t p0, size_t p1) {
@@ -2191,6 +2254,8 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
         ctx->io.run((int)workers, [&](int w) { finish_range(std::min(n, (size_t)w * per), std::min(n, ((size_t)w + 1) * per)); });
         ctx->ingest_mu.unlock();
     } else parallel_ranges(n, 12500, 16, finish_range);
+    if (dbg) fprintf(stderr, "[ani_pairs %zu] device part %.3f ms, host finish %.3f ms\n", n, std::chrono::duration<double, std::milli>(t_dev - t_in).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count());
     return GHIP_OK;
 }
 

@@ -295,11 +295,10 @@ int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv) {
         if (!ds.p || !dr.p) return cerr_(c, GHIP_EHIP, "out of device memory for a host collective");
         std::vector<uint8_t> hr(padded * c->world);
         COMM_HIP(c, hipSetDevice(ctx->device));
-        COMM_HIP(c, hipMemcpyAsync(ds.p, send, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (ghip_copy_to_device(ctx, ds.p, send, bytes) != GHIP_OK) return cerr_(c, GHIP_EHIP, "host collective: upload failed");
         int rc = allgather_device(c, ds.p, dr.p, padded);
         if (rc) return rc;
-        COMM_HIP(c, hipMemcpyAsync(hr.data(), dr.p, hr.size(), hipMemcpyDeviceToHost, ctx->stream));
-        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        if (ghip_copy_to_host(ctx, hr.data(), dr.p, hr.size()) != GHIP_OK) return cerr_(c, GHIP_EHIP, "host collective: download failed");
         for (uint32_t r = 0; r < c->world; r++) memcpy((char *)recv + (size_t)r * bytes, hr.data() + (size_t)r * padded, bytes);
         return GHIP_OK;
     }
@@ -591,7 +590,7 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
             if (e == hipSuccess && cnt > cap) ok = false;   // cannot happen (one candidate per owned pair at most): the dense share then
             if (e == hipSuccess && ok) {
                 host.resize(cnt);
-                if (cnt) e = hipMemcpy(host.data(), d_out, cnt * sizeof(ghip_pair), hipMemcpyDeviceToHost);
+                if (cnt && ghip_copy_to_host(ctx, host.data(), d_out, cnt * sizeof(ghip_pair)) != GHIP_OK) e = hipErrorUnknown;
             }
         }
         hipStreamSynchronize(ctx->stream);

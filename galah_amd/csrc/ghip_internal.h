@@ -88,6 +88,10 @@ struct ghip_ctx {
     std::vector<pinned_slot> ingest_slots;
     uint8_t *ingest_stage = nullptr;   // one device allocation behind all the slots' staging areas (pinned_slot::d point into it)
     size_t ingest_stage_bytes = 0;
+    // pinned bounce buffer of the larger host<->device copies (api.cpp h2d / d2h), kept and grown on demand
+    void *pin_buf = nullptr;
+    size_t pin_bytes = 0;
+    std::mutex pin_mu;
     ghip_io_pool io;
     std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
     hipStream_t copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -96,6 +100,9 @@ struct ghip_ctx {
     bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };
 
+// synchronous copies between pageable host memory and the device on the context's stream (pinned bounce buffer from 256 KiB: api.cpp)
+int ghip_copy_to_device(ghip_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int ghip_copy_to_host(ghip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes);  // nullptr on failure (ctx->err set); thread-safe
 void ghip_pool_free(ghip_ctx *ctx, void *p);         // thread-safe; the caller has made sure nothing in flight uses p
 
