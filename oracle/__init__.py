@@ -112,6 +112,8 @@ def lib():
     L.go_ani_sketch_density.argtypes = [C.c_void_p]
     L.go_ani_pair_detail.restype = C.c_float
     L.go_ani_pair_detail.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    L.go_ani_pair_mode.restype = C.c_float
+    L.go_ani_pair_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.go_ani_pair.restype = C.c_float
     L.go_ani_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = L
@@ -354,6 +356,17 @@ def ani_pair_detail(q: AniSketch, r: AniSketch, min_af: float = 0.15):
     afq, afr = C.c_float(0), C.c_float(0)
     d = (C.c_uint64 * 6)()
     ani = lib().go_ani_pair_detail(q._h, r._h, np.float32(min_af), C.byref(afq), C.byref(afr), d)
+    return float(ani), float(afq.value), float(afr.value), [int(x) for x in d]
+
+
+CHAIN, CHAIN_SPAN, AGG_WMEDIAN, AGG_POOLED, BAND_SPAN, BAND_SUB = 0, 1, 2, 4, 8, 16   # BAND_SUB | D << 8
+
+
+def ani_pair_mode(q: AniSketch, r: AniSketch, flags: int, min_af: float = 0.15):
+    """EXPERIMENTAL estimator variants (measurement only, scripts/ani_chain_vs_band.py): same return as ani_pair_detail."""
+    afq, afr = C.c_float(0), C.c_float(0)
+    d = (C.c_uint64 * 6)()
+    ani = lib().go_ani_pair_mode(q._h, r._h, np.float32(min_af), flags, C.byref(afq), C.byref(afr), d)
     return float(ani), float(afq.value), float(afr.value), [int(x) for x in d]
 
 

@@ -118,6 +118,12 @@ float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_f
 float go_ani_pair_detail(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r,
                          uint64_t detail[6]);
 
+/* EXPERIMENTAL (measurement only, scripts/ani_chain_vs_band.py): ordered colinear chain / span denominators / other
+ * aggregates in place of the frozen band vote; flags: 1 chain with span denominators (0: chain, whole-chunk denominators),
+ * 2 T-weighted median, 4 pooled, 8 band vote with span denominators.  See galah_oracle_ani.c. */
+float go_ani_pair_mode(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, int flags, float *af_q, float *af_r,
+                       uint64_t detail[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,3 +303,282 @@ float go_ani_pair_detail(const go_ani_sketch *q, const go_ani_sketch *r, float m
 float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, float *af_q, float *af_r) {
     return go_ani_pair_detail(q, r, min_af_fraction, af_q, af_r, NULL);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * EXPERIMENTAL second mode (round 4; measurement only -- scripts/ani_chain_vs_band.py; nothing in the product or in the
+ * frozen golden uses it): the ORDERED COLINEAR CHAIN of Shaw & Yu 2023 in place of the band vote, and/or denominators
+ * limited to the SPAN a chunk's matches cover.  Restated from the paper's description (skani's source is not here):
+ *   anchors of a chunk  = (seed a of x in the chunk, seed b of y) with equal codes, at the pair's density; at most
+ *                         GO_CHAIN_MAX_OCC anchors per x seed (a more repetitive seed is ignored, as skani does)
+ *   orientation groups  : o = strand_a ^ strand_b; u = o ? -pos_b : pos_b, so that a colinear run ascends in (pos_a, u)
+ *   chain DP            : anchors sorted by (o, pos_a, u); f(i) = 100 + max(0, max_j f(j) - |(u_i-u_j) - (x_i-x_j)|) over the
+ *                         GO_CHAIN_LOOKBACK predecessors j of the same orientation with x_j < x_i and u_j < u_i  (gap cost
+ *                         = the diagonal shift in bases, one anchor = 100: a 100-base indel costs one anchor)
+ *   chains of a chunk   : best end first, back-tracked until a used anchor; kept when it holds >= 3 distinct x seeds and
+ *                         its x span does not overlap a kept chain's (several contigs / a rearrangement inside a chunk)
+ *   M_c                 = distinct x seeds of the kept chains
+ *   T_c                 = GO_CHAIN_SPAN: x seeds (pair density) with first <= pos <= last of each kept chain, and the
+ *                         aligned bases are the spans'; otherwise the chunk's total and the chunk's bases (as the band vote)
+ *   GO_BAND_SPAN        : the BAND VOTE's matches with span denominators: M_c as the frozen definition, T_c = the chunk's
+ *                         seeds between the first and the last seed that voted for a qualifying band
+ *   aggregate           : GO_AGG_MEDIAN lower median over the shorter genome's aligned chunks (the frozen rule),
+ *                         GO_AGG_WMEDIAN the same weighted by T_c, GO_AGG_POOLED sum M / sum T
+ */
+#define GO_CHAIN_MAX_OCC 32
+#define GO_CHAIN_LOOKBACK 50
+enum { GO_CHAIN_SPAN = 1, GO_AGG_WMEDIAN = 2, GO_AGG_POOLED = 4, GO_BAND_SPAN = 8, GO_BAND_SUB = 16 /* closing distance D in bits 8..11 */ };
+
+typedef struct { int64_t x, u; uint32_t o, a; } chain_anchor;
+static int cmp_anchor(const void *pa, const void *pb) {
+    const chain_anchor *a = (const chain_anchor *)pa, *b = (const chain_anchor *)pb;
+    if (a->o != b->o) return (a->o > b->o) - (a->o < b->o);
+    if (a->x != b->x) return (a->x > b->x) - (a->x < b->x);
+    return (a->u > b->u) - (a->u < b->u);
+}
+typedef struct { int64_t f; uint32_t i; } chain_end;
+static int cmp_end(const void *pa, const void *pb) {
+    const chain_end *a = (const chain_end *)pa, *b = (const chain_end *)pb;
+    if (a->f != b->f) return (a->f < b->f) - (a->f > b->f);   /* descending score */
+    return (a->i > b->i) - (a->i < b->i);
+}
+
+/* chunks of x against y: appends the aligned chunks' (M, T) when listed, adds the aligned bases */
+static void chain_direction(const go_ani_sketch *x, const go_ani_sketch *y, uint32_t thr, int flags, int listed,
+                            chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
+    size_t a0 = 0;
+    chain_anchor *an = NULL; size_t cap = 0;
+    for (uint32_t c = 0; c < x->n_chunks; c++) {
+        size_t a1 = a0;
+        while (a1 < x->n && x->chunk_id[a1] == c) a1++;
+        size_t n = 0, tc_full = 0;
+        for (size_t a = a0; a < a1; a++) {
+            if (x->sel[a] >= thr) continue;
+            tc_full++;
+            const uint32_t code = (uint32_t)x->h[a];
+            size_t lo = lower_bound_code(y->sorted, y->n, code), hi = lo, occ = 0;
+            while (hi < y->n && y->sorted[hi].code == code) { if (y->sel[y->sorted[hi].idx] < thr) occ++; hi++; }
+            if (occ == 0 || occ > GO_CHAIN_MAX_OCC) continue;
+            for (size_t e = lo; e < hi; e++) {
+                const uint32_t b = y->sorted[e].idx;
+                if (y->sel[b] >= thr) continue;
+                if (n == cap) { cap = cap ? 2 * cap : 1024; an = (chain_anchor *)realloc(an, cap * sizeof(*an)); }
+                const uint32_t o = (uint32_t)(x->strand[a] ^ y->strand[b]);
+                an[n].x = x->pos[a]; an[n].u = o ? -(int64_t)y->pos[b] : (int64_t)y->pos[b]; an[n].o = o; an[n].a = (uint32_t)a; n++;
+            }
+        }
+        uint64_t mc = 0, tc = 0, bases = 0;
+        if (n >= GO_ANI_MIN_COLINEAR) {
+            qsort(an, n, sizeof(*an), cmp_anchor);
+            int64_t *f = (int64_t *)malloc(n * sizeof(int64_t));
+            int32_t *prev = (int32_t *)malloc(n * sizeof(int32_t));
+            uint8_t *used = (uint8_t *)calloc(n, 1);
+            chain_end *ends = (chain_end *)malloc(n * sizeof(chain_end));
+            for (size_t i = 0; i < n; i++) {
+                int64_t best = 0; int32_t bp = -1;
+                for (size_t back = 1; back <= GO_CHAIN_LOOKBACK && back <= i; back++) {
+                    const size_t j = i - back;
+                    if (an[j].o != an[i].o) break;
+                    if (an[j].x >= an[i].x || an[j].u >= an[i].u) continue;
+                    int64_t dd = (an[i].u - an[j].u) - (an[i].x - an[j].x);
+                    if (dd < 0) dd = -dd;
+                    const int64_t cand = f[j] - dd;
+                    if (cand > best) { best = cand; bp = (int32_t)j; }
+                }
+                f[i] = 100 + best; prev[i] = bp;
+                ends[i].f = f[i]; ends[i].i = (uint32_t)i;
+            }
+            qsort(ends, n, sizeof(chain_end), cmp_end);
+            int64_t (*kept)[2] = (int64_t (*)[2])malloc(n * sizeof(int64_t[2]));
+            size_t nk = 0;
+            for (size_t e = 0; e < n; e++) {
+                int32_t i = (int32_t)ends[e].i;
+                if (used[i]) continue;
+                int64_t last = an[i].x, first = last;
+                uint64_t seeds = 0; uint32_t prev_a = UINT32_MAX;
+                for (; i >= 0 && !used[i]; i = prev[i]) { used[i] = 1; first = an[i].x; if (an[i].a != prev_a) { seeds++; prev_a = an[i].a; } }
+                if (seeds < GO_ANI_MIN_COLINEAR) continue;
+                int overlap = 0;
+                for (size_t z = 0; z < nk; z++) if (first <= kept[z][1] && kept[z][0] <= last) { overlap = 1; break; }
+                if (overlap) continue;
+                kept[nk][0] = first; kept[nk][1] = last; nk++;
+                mc += seeds;
+                if (flags & GO_CHAIN_SPAN) {
+                    for (size_t a = a0; a < a1; a++) if (x->sel[a] < thr && (int64_t)x->pos[a] >= first && (int64_t)x->pos[a] <= last) tc++;
+                    bases += (uint64_t)(last - first) + x->k;
+                }
+            }
+            free(f); free(prev); free(used); free(ends); free(kept);
+        }
+        if (!(flags & GO_CHAIN_SPAN)) {
+            tc = tc_full;
+            uint64_t lo = (uint64_t)c * x->chunk, hi = lo + x->chunk;
+            if (hi > x->length) hi = x->length;
+            bases = hi - lo;
+        }
+        if (mc > tc) mc = tc;
+        if (tc >= 1 && mc >= GO_ANI_MIN_COLINEAR && mc * 10000 >= 510 * tc) {
+            if (listed) { out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++; }
+            *aligned_bases += bases;
+        }
+        a0 = a1;
+    }
+    free(an);
+}
+
+/* the band vote's matches with span denominators (GO_BAND_SPAN) */
+static void band_span_direction(const go_ani_sketch *x, const go_ani_sketch *y, uint32_t thr, int swap, int listed,
+                                chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
+    uint32_t *mask = (uint32_t *)calloc(x->n + 1, sizeof(uint32_t));
+    for (size_t a = 0; a < x->n; a++) {
+        if (x->sel[a] >= thr) continue;
+        const uint32_t code = (uint32_t)x->h[a];
+        for (size_t e = lower_bound_code(y->sorted, y->n, code); e < y->n && y->sorted[e].code == code; e++) {
+            const uint32_t b = y->sorted[e].idx;
+            if (y->sel[b] >= thr) continue;
+            const uint32_t o = (uint32_t)(x->strand[a] ^ y->strand[b]);
+            /* the band of the frozen definition is stated for (q, r); x may be r */
+            const uint32_t pq = swap ? y->pos[b] : x->pos[a], pr = swap ? x->pos[a] : y->pos[b];
+            const uint32_t band = o ? (((pr + pq) >> GO_ANI_BAND_SHIFT) & 7u) | 8u
+                                    : ((2u * (pr - pq) + 1u + (1u << GO_ANI_BAND_SHIFT)) >> (GO_ANI_BAND_SHIFT + 1)) & 7u;
+            mask[a] |= 1u << band;
+        }
+    }
+    size_t a0 = 0;
+    for (uint32_t c = 0; c < x->n_chunks; c++) {
+        size_t a1 = a0;
+        while (a1 < x->n && x->chunk_id[a1] == c) a1++;
+        uint32_t v[GO_ANI_SLOTS] = {0};
+        for (size_t a = a0; a < a1; a++) if (mask[a]) v[(mask[a] & (mask[a] - 1)) ? GO_ANI_BANDS : (uint32_t)__builtin_ctz(mask[a])]++;
+        uint64_t mc = 0; uint32_t good = 0;
+        for (uint32_t b = 0; b < GO_ANI_BANDS; b++) if (v[b] >= GO_ANI_MIN_COLINEAR) { mc += v[b]; good |= 1u << b; }
+        if (mc) {
+            mc += v[GO_ANI_BANDS];
+            int64_t first = -1, last = -1;
+            for (size_t a = a0; a < a1; a++) if (mask[a] && !(mask[a] & (mask[a] - 1)) && (mask[a] & good)) { if (first < 0) first = x->pos[a]; last = x->pos[a]; }
+            uint64_t tc = 0, m2 = 0;
+            for (size_t a = a0; a < a1; a++) if (x->sel[a] < thr && (int64_t)x->pos[a] >= first && (int64_t)x->pos[a] <= last) {
+                tc++;
+                if (mask[a] && ((mask[a] & (mask[a] - 1)) || (mask[a] & good))) m2++;   /* matches inside the span only */
+            }
+            mc = m2;
+            if (tc >= 1 && mc * 10000 >= 510 * tc) {
+                if (listed) { out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++; }
+                *aligned_bases += (uint64_t)(last - first) + x->k;
+            }
+        }
+        a0 = a1;
+    }
+    free(mask);
+}
+
+/* GO_BAND_SUB: the band vote's matches; a chunk is cut into sub-blocks of 2^t positions (t the smallest with (chunk-1) >> t <= 15:
+ * 2048 at chunk 20000); a sub-block is SUPPORTED when one of its seeds has an anchor; runs of at most D unsupported sub-blocks
+ * between supported ones, or between a supported one and the chunk's edge, are filled in; T_c and the aligned bases count the
+ * supported and filled sub-blocks only -- a fully covered chunk keeps its whole denominator (no span-end bias), an uncovered
+ * stretch of more than D sub-blocks leaves it. */
+static void band_sub_direction(const go_ani_sketch *x, const go_ani_sketch *y, uint32_t thr, int swap, uint32_t D, int listed,
+                               chunk_frac *out, size_t *n_out, uint64_t *aligned_bases) {
+    uint32_t *mask = (uint32_t *)calloc(x->n + 1, sizeof(uint32_t));
+    uint32_t t = 0;
+    while (((x->chunk - 1) >> t) > 15) t++;
+    for (size_t a = 0; a < x->n; a++) {
+        if (x->sel[a] >= thr) continue;
+        const uint32_t code = (uint32_t)x->h[a];
+        for (size_t e = lower_bound_code(y->sorted, y->n, code); e < y->n && y->sorted[e].code == code; e++) {
+            const uint32_t b = y->sorted[e].idx;
+            if (y->sel[b] >= thr) continue;
+            const uint32_t o = (uint32_t)(x->strand[a] ^ y->strand[b]);
+            const uint32_t pq = swap ? y->pos[b] : x->pos[a], pr = swap ? x->pos[a] : y->pos[b];
+            const uint32_t band = o ? (((pr + pq) >> GO_ANI_BAND_SHIFT) & 7u) | 8u
+                                    : ((2u * (pr - pq) + 1u + (1u << GO_ANI_BAND_SHIFT)) >> (GO_ANI_BAND_SHIFT + 1)) & 7u;
+            mask[a] |= 1u << band;
+        }
+    }
+    size_t a0 = 0;
+    for (uint32_t c = 0; c < x->n_chunks; c++) {
+        size_t a1 = a0;
+        while (a1 < x->n && x->chunk_id[a1] == c) a1++;
+        uint32_t v[GO_ANI_SLOTS] = {0}, tsb[16] = {0}, sup = 0;
+        for (size_t a = a0; a < a1; a++) {
+            if (x->sel[a] >= thr) continue;
+            const uint32_t sb = (x->pos[a] - c * x->chunk) >> t;
+            tsb[sb]++;
+            if (mask[a]) { v[(mask[a] & (mask[a] - 1)) ? GO_ANI_BANDS : (uint32_t)__builtin_ctz(mask[a])]++; sup |= 1u << sb; }
+        }
+        uint64_t lo = (uint64_t)c * x->chunk, hi = lo + x->chunk;
+        if (hi > x->length) hi = x->length;
+        const uint32_t nsb = (uint32_t)(((hi - lo) - 1) >> t) + 1;
+        uint64_t mc = 0;
+        for (uint32_t b = 0; b < GO_ANI_BANDS; b++) if (v[b] >= GO_ANI_MIN_COLINEAR) mc += v[b];
+        if (mc) {
+            mc += v[GO_ANI_BANDS];
+            /* closing: fill runs of <= D unsupported sub-blocks bounded by supported ones or the chunk's edges */
+            uint32_t closed = sup;
+            for (uint32_t s0 = 0; s0 < nsb;) {
+                if (sup >> s0 & 1u) { s0++; continue; }
+                uint32_t s1 = s0;
+                while (s1 < nsb && !(sup >> s1 & 1u)) s1++;
+                if (s1 - s0 <= D) for (uint32_t z = s0; z < s1; z++) closed |= 1u << z;
+                s0 = s1;
+            }
+            uint64_t tc = 0, bases = 0;
+            for (uint32_t z = 0; z < nsb; z++) if (closed >> z & 1u) {
+                tc += tsb[z];
+                uint64_t b0 = lo + ((uint64_t)z << t), b1 = b0 + (1ull << t);
+                if (b1 > hi) b1 = hi;
+                bases += b1 - b0;
+            }
+            if (mc > tc) mc = tc;
+            if (tc >= 1 && mc * 10000 >= 510 * tc) {
+                if (listed) { out[*n_out].m = mc; out[*n_out].t = tc; (*n_out)++; }
+                *aligned_bases += bases;
+            }
+        }
+        a0 = a1;
+    }
+    free(mask);
+}
+
+float go_ani_pair_mode(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, int flags, float *af_q, float *af_r,
+                       uint64_t detail[6]) {
+    uint64_t bq = 0, br = 0;
+    size_t n = 0;
+    const uint32_t c_pair = q->c > r->c ? q->c : r->c, thr = UINT32_MAX / c_pair;
+    chunk_frac *fr = (chunk_frac *)malloc(((size_t)q->n_chunks + r->n_chunks + 1) * sizeof(chunk_frac));
+    if (flags & GO_BAND_SUB) {
+        band_sub_direction(q, r, thr, 0, (uint32_t)(flags >> 8) & 15u, q->length <= r->length, fr, &n, &bq);
+        band_sub_direction(r, q, thr, 1, (uint32_t)(flags >> 8) & 15u, r->length <= q->length, fr, &n, &br);
+    } else if (flags & GO_BAND_SPAN) {
+        band_span_direction(q, r, thr, 0, q->length <= r->length, fr, &n, &bq);
+        band_span_direction(r, q, thr, 1, r->length <= q->length, fr, &n, &br);
+    } else {
+        chain_direction(q, r, thr, flags, q->length <= r->length, fr, &n, &bq);
+        chain_direction(r, q, thr, flags, r->length <= q->length, fr, &n, &br);
+    }
+    double afq = q->length ? (double)bq / (double)q->length : 0.0;
+    double afr = r->length ? (double)br / (double)r->length : 0.0;
+    if (af_q) *af_q = (float)afq;
+    if (af_r) *af_r = (float)afr;
+    if (detail) { detail[0] = detail[1] = 0; detail[2] = n; detail[3] = bq; detail[4] = br; detail[5] = c_pair; }
+    if (n == 0) { free(fr); return 0.0f; }
+    chunk_frac med;
+    if (flags & GO_AGG_POOLED) {
+        med.m = med.t = 0;
+        for (size_t e = 0; e < n; e++) { med.m += fr[e].m; med.t += fr[e].t; }
+    } else {
+        qsort(fr, n, sizeof(chunk_frac), cmp_frac);
+        if (flags & GO_AGG_WMEDIAN) {
+            uint64_t tot = 0, run = 0; size_t e = 0;
+            for (size_t z = 0; z < n; z++) tot += fr[z].t;
+            for (; e < n; e++) { run += fr[e].t; if (2 * run >= tot) break; }
+            med = fr[e < n ? e : n - 1];
+        } else med = fr[(n - 1) / 2];
+    }
+    free(fr);
+    if (detail) { detail[0] = med.m; detail[1] = med.t; }
+    if (afq < (double)min_af_fraction && afr < (double)min_af_fraction) return 0.0f;
+    double ani = 100.0 * pow((double)med.m / (double)med.t, 1.0 / (double)q->k);
+    char txt[64];
+    snprintf(txt, sizeof txt, "%.2f", ani);
+    return strtof(txt, NULL);
+}

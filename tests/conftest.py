@@ -70,8 +70,9 @@ def random_sketches(rng, n, s, shared_groups=0, min_len=None):
     return hashes, lens
 
 
-def fasta_records(name: str):
-    """(names, upper-cased sequences as uint8 arrays) of a multi-record fixture."""
+def fasta_records(name: str, full_names: bool = False):
+    """(names, upper-cased sequences as uint8 arrays) of a multi-record fixture; full_names: the whole header line (galah's
+    contig names are the record ids needletail yields, spaces included -- tests/test_cmdline.rs:583-587)."""
     import gzip
     names, seqs, cur = [], [], []
     with gzip.open(fasta(name), "rt") as f:
@@ -80,7 +81,7 @@ def fasta_records(name: str):
             if line.startswith(">"):
                 if names:
                     seqs.append("".join(cur))
-                names.append(line[1:].split()[0])
+                names.append(line[1:] if full_names else line[1:].split()[0])
                 cur = []
             elif line:
                 cur.append(line)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Freezes the build-defined ANI estimator (oracle/galah_oracle_ani.c; skani's own floats are unpinned):
 writes tests/golden/ani_golden.json = for every pair of the fixture genomes under tests/golden/fasta (copies of the
-reference's tests/data FASTA files, see make_golden.py) and every pair of the records of contigs_specific.fna
-(tests/test_cmdline.rs:482-505), what the oracle computes at min_aligned_fraction 0.15 (galah's default, src/lib.rs:78):
+reference's tests/data FASTA files, see make_golden.py), every pair of the records of contigs_specific.fna
+(tests/test_cmdline.rs:482-505) and (round 4, "anchor_contig_pairs") every pair of the records of contigs.fna + contigs_extra.fna
++ contigs_rep_bug.fna (:461-480, :546-567, :570-609), what the oracle computes at min_aligned_fraction 0.15 (galah's default, src/lib.rs:78):
 
     M, T            matched / total seeds of the lower-median chunk
     chunks          aligned chunks of both directions
@@ -48,8 +49,17 @@ def build():
     # a record's stream is its bases followed by one 'N' (what the ingest makes of a one-record file)
     csk = [oracle.AniSketch.from_bytes(np.concatenate([s, np.frombuffer(b"N", dtype=np.uint8)])) for s in cs]
     contigs = {n: {"length": int(s.length), "density": int(s.density), "seeds": int(s.nseeds)} for n, s in zip(cn, csk)}
+    # round 4: the records of the reference's other three contig fixtures (tests/test_cmdline.rs:461-480, 546-567, 570-609)
+    an, as_ = [], []
+    for f in ("contigs", "contigs_extra", "contigs_rep_bug"):
+        n, s = fasta_records(f, full_names=True)
+        an += n
+        as_ += s
+    ask = [oracle.AniSketch.from_bytes(np.concatenate([s, np.frombuffer(b"N", dtype=np.uint8)])) for s in as_]
+    anchors = {n: {"length": int(s.length), "density": int(s.density), "seeds": int(s.nseeds)} for n, s in zip(an, ask)}
     return {"k": 15, "c": 125, "chunk": 20000, "min_aligned_fraction": MIN_AF, "source": "oracle-derived (no reference float exists)",
-            "genomes": genomes, "genome_pairs": rows_of(GENOMES, sk), "contigs": contigs, "contig_pairs": rows_of(cn, csk)}
+            "genomes": genomes, "genome_pairs": rows_of(GENOMES, sk), "contigs": contigs, "contig_pairs": rows_of(cn, csk),
+            "anchor_contigs": anchors, "anchor_contig_pairs": rows_of(an, ask)}
 
 
 if __name__ == "__main__":

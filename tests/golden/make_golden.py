@@ -42,7 +42,10 @@ GENOMES = {
     "abisko_S2M16": "abisko4/73.20110800_S2M.16.fna",
 }
 # multi-record files whose RECORDS the reference clusters (--cluster-contigs); copied as data, not sketched here
-CONTIG_FILES = {"contigs_specific": "contigs/contigs_specific.fna"}   # tests/test_cmdline.rs:482-505
+CONTIG_FILES = {"contigs_specific": "contigs/contigs_specific.fna",   # tests/test_cmdline.rs:482-505
+                "contigs": "contigs/contigs.fna",                     # :461-480 (--large-contigs), :546-567 with contigs_extra
+                "contigs_extra": "contigs/contigs_extra.fna",         # :546-567 (--small-contigs)
+                "contigs_rep_bug": "contigs/contigs_rep_bug.fna"}     # :570-588 (--large-contigs), :591-609 (--small-contigs)
 PAIRS = [("set1_1mbp", "set1_500kb"), ("abisko_S1X13", "abisko_S2D19"), ("abisko_S1X13", "abisko_S3X12"),
          ("abisko_S1X13", "abisko_S2D13"), ("abisko_S2D19", "abisko_S3X12"), ("abisko_S2D19", "abisko_S2D13"),
          ("abisko_S3X12", "abisko_S2D13"), ("antonio_MAG52", "antonio_MAG189"), ("set2_1mbp", "set2_half"),

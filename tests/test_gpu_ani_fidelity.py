@@ -59,6 +59,57 @@ def test_device_equals_the_ani_golden_file(ctx, ani_golden):
     idx = ctx.ani_index_build(g, ani_golden["k"], ani_golden["c"], ani_golden["chunk"])
     _check_rows(ctx, idx, cn, ani_golden["contig_pairs"], ani_golden["min_aligned_fraction"])
     idx.free(); g.free()
+    # round 4: the records of the reference's other three contig fixtures
+    an, as_ = [], []
+    for f in ("contigs", "contigs_extra", "contigs_rep_bug"):
+        n, s = fasta_records(f, full_names=True)
+        an += n
+        as_ += s
+    assert an == list(ani_golden["anchor_contigs"])
+    g = ctx.genomes_from_host([np.concatenate([s, np.frombuffer(b"N", dtype=np.uint8)]) for s in as_])
+    idx = ctx.ani_index_build(g, ani_golden["k"], ani_golden["c"], ani_golden["chunk"])
+    _check_rows(ctx, idx, an, ani_golden["anchor_contig_pairs"], ani_golden["min_aligned_fraction"])
+    idx.free(); g.free()
+
+
+def _contig_flow_hip(ctx, files, base_c):
+    """every record a genome: sketch + ANI index on the device, finch precluster at 90 %, ANI of every precluster pair,
+    host clusterer at 95 % -- the flow of tests/test_gpu_parity.py::test_reference_contig_expectation_through_hip"""
+    names, seqs = [], []
+    for f in files:
+        n, s = fasta_records(f, full_names=True)
+        names += n
+        seqs += s
+    g = ctx.genomes_from_host(seqs)
+    sk, idx = ctx.sketch_and_index(g, 21, 1000, 0, 15, base_c, 20000)
+    pairs = ctx.precluster(sk, np.float32(0.9))
+    pi = np.stack([pairs["i"], pairs["j"]], axis=1).astype(np.uint32)
+    ani = ctx.ani_pairs(idx, pi, 0.15)
+    got = galah_amd.cluster_pairs(len(seqs), pairs, np.float32(95.0), ani)
+    native = ctx.cluster_index(idx, len(seqs), pairs, np.float32(95.0), 0.15)   # lazy rounds inside the library
+    assert native[0] == got
+    sk.free(); idx.free(); g.free()
+    return names, {(int(a), int(b)): float(v) for (a, b), v in zip(pi, ani)}, got
+
+
+def test_reference_contig_anchors_through_hip(ctx):
+    """tests/test_cmdline.rs:461-480 (contigs.fna, --large-contigs) and :546-567 (contigs.fna + contigs_extra.fna,
+    --small-contigs) on the device path: the expected clusters, at the base density of either flag."""
+    for files, want in ((["contigs"], [[0, 1], [2], [3]]), (["contigs", "contigs_extra"], [[0, 1, 4], [2], [3]])):
+        for base_c in (125, 30):
+            names, ani, got = _contig_flow_hip(ctx, files, base_c)
+            assert sorted(sorted(c) for c in got) == want and got[0][0] == 0, (files, base_c, got)
+            assert all(v == 100.0 for v in ani.values())   # the family members are copies of the contig
+
+
+def test_reference_contig_anchor_rep_bug_through_hip(ctx):
+    """tests/test_cmdline.rs:570-588 / :591-609: contigs_rep_bug.fna has two expected answers (skani -c 125: one cluster of
+    three; -c 30: NODE_1070 apart).  The device reproduces the oracle -- 95.94 / 92.35 / 96.21 at either base density, clusters
+    [[0], [2, 1]] -- which is NEITHER of them (tests/test_oracle_golden.py has the analysis)."""
+    for base_c in (125, 30):
+        names, ani, got = _contig_flow_hip(ctx, ["contigs_rep_bug"], base_c)
+        assert [round(ani[k], 2) for k in ((0, 1), (0, 2), (1, 2))] == [95.94, 92.35, 96.21]
+        assert got == [[0], [2, 1]]
 
 
 # (length, independent pairs per identity, |mean error| bound, largest single error bound) in ANI points, for true

@@ -179,6 +179,72 @@ def test_ani_golden_file_is_what_the_oracle_computes():
     assert got["genome_pairs"] == want["genome_pairs"]
     assert got["contig_pairs"] == want["contig_pairs"]
     assert len(want["genome_pairs"]) == 91 and len(want["contig_pairs"]) == 36
+    # round 4: the records of contigs.fna + contigs_extra.fna + contigs_rep_bug.fna (added keys; nothing above changed)
+    assert got["anchor_contigs"] == want["anchor_contigs"] and got["anchor_contig_pairs"] == want["anchor_contig_pairs"]
+    assert len(want["anchor_contig_pairs"]) == 28
+
+
+# The reference's remaining contig membership expectations (all of them held by skani: `skani triangle` at -c 125 for
+# --large-contigs, -c 30 for --small-contigs; src/skani.rs:414-484), in record order with every record a genome.
+#   tests/test_cmdline.rs:461-480  contigs.fna, --large-contigs            {13024, 13024_2} {50844} {37820}
+#   :546-567  contigs.fna + contigs_extra.fna, --small-contigs             {13024, _2, _3} {50844} {37820}
+#   :570-588  contigs_rep_bug.fna, --large-contigs                         {k141_313035, k141_401621, NODE_1070}
+#   :591-609  contigs_rep_bug.fna, --small-contigs                         {k141_313035, k141_401621} {NODE_1070}
+CONTIG_ANCHORS = [(["contigs"], 125, [[0, 1], [2], [3]]), (["contigs", "contigs_extra"], 30, [[0, 1, 4], [2], [3]])]
+REP_BUG_EXPECTED = {125: [[0, 1, 2]], 30: [[0, 1], [2]]}
+# what the build-defined estimator gives for contigs_rep_bug.fna at EITHER base density (all three records, 28-42 kb, are
+# seeded with every 15-mer by the per-genome rule): the representatives of the --small-contigs answer, k141_401621 with the
+# other one -- NEITHER of the reference's two answers
+REP_BUG_GOT = [[0], [2, 1]]
+
+
+def _contig_flow(files, base_c):
+    from conftest import fasta_records
+    names, seqs = [], []
+    for f in files:
+        n, s = fasta_records(f, full_names=True)
+        names += n
+        seqs += s
+    sk = [oracle.sketch_bytes(s, 21, 1000, 0) for s in seqs]
+    n = len(seqs)
+    cache = oracle.Cache()
+    for i in range(n):
+        for j in range(i + 1, n):
+            c, t = oracle.raw_distance(sk[i], sk[j])
+            ani = oracle.mash_ani(c, t, 21)
+            if ani >= float(np.float32(0.9)):
+                cache.insert((i, j), np.float32(ani))
+    stop = np.frombuffer(b"N", dtype=np.uint8)
+    dense = [oracle.AniSketch.from_bytes(np.concatenate([s, stop]), 15, base_c, 20000) for s in seqs]
+    return names, dense, oracle.cluster(n, cache, 95.0, lambda a, b: oracle.ani_pair(dense[a], dense[b], 0.15)[0])
+
+
+def test_reference_contig_anchors_contigs_and_contigs_extra():
+    for files, base_c, want in CONTIG_ANCHORS:
+        for c in (base_c, 125, 30):   # the per-genome density makes the caller's base density immaterial at these lengths
+            names, dense, got = _contig_flow(files, c)
+            assert all(d.density == 1 for d in dense)
+            assert sorted(sorted(x) for x in got) == want, (files, c, got)
+            assert got[0][0] == 0 and names[0] == "73.20110600_S2D.10_contig_13024"   # the representative the reference prints first
+
+
+def test_reference_contig_anchor_rep_bug_is_reproduced_by_neither_density():
+    """contigs_rep_bug.fna has TWO expected answers in the reference (skani -c 125: one cluster of three; -c 30: NODE_1070
+    apart) -- skani's own estimate of ANI(k141_313035, NODE_1070) straddles 95 % with its seed density.  The build-defined
+    estimator gives 92.35 at every base density (both records are seeded with every 15-mer): chunk 0 of the 28 kb contig holds
+    8 kb without a homologue in NODE_1070 and 4 kb at ~93 %, and the lower median of TWO chunks is the diluted one (an ordered
+    chain with span-limited denominators -- scripts/ani_chain_vs_band.py -- gives 94.95, pooled 95.96: the pair sits on the
+    threshold under every form).  So the representatives are the --small-contigs answer's, but k141_401621 (95.94 to
+    k141_313035, 96.21 to NODE_1070) joins NODE_1070 where skani keeps it with k141_313035: NEITHER expectation is reproduced,
+    and this test pins exactly that (anchor table) instead of a tuned pass."""
+    for c in (125, 30):
+        names, dense, got = _contig_flow(["contigs_rep_bug"], c)
+        assert names[0].startswith("k141_313035 flag=1") and names[2].startswith("NODE_1070")
+        assert got == REP_BUG_GOT
+        assert sorted(sorted(x) for x in got) != REP_BUG_EXPECTED[125] and sorted(sorted(x) for x in got) != REP_BUG_EXPECTED[30]
+        assert sorted(x[0] for x in got) == sorted(x[0] for x in REP_BUG_EXPECTED[30])   # the representatives of --small-contigs
+        a = {(i, j): oracle.ani_pair(dense[i], dense[j], 0.15)[0] for i in range(3) for j in range(i + 1, 3)}
+        assert [round(a[k], 2) for k in ((0, 1), (0, 2), (1, 2))] == [95.94, 92.35, 96.21]
 
 
 def _finch_plus_ani(names, thr, min_af):
