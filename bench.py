@@ -24,6 +24,7 @@ At N = 1 the same process then also reports every other BASELINE configuration (
   configs4_50k_quality_order  configs[4]: 50 000 x 5 Mb (94 GB resident), CheckM2-style qualities, Parks2020_reduced order
   configs3_contigs            configs[3]: 100 000 contigs of 2-20 kb, FASTA files in -> clusters out (small sketches)
   wall_clock                  BASELINE metric 2: 1 000 genome FASTA files in -> clusters out (plain and gzip)
+  wall_clock_10k              the same at the north-star size: 10 000 x 5 Mb FASTA files (51 GB) in -> clusters out
   skani                       run-time probe for a `skani` binary (GHIP_SKANI_BIN or PATH; ANI parity is unpinned without one)
   pmc_live                    HBM bytes / VALU instructions per launch of the dominant kernels, measured by child runs
 
@@ -383,60 +384,111 @@ def configs3_leg(args, ctx):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def wall_clock(args, ctx):
-    """BASELINE metric 2 (`galah cluster`: src/cluster_argument_parsing.rs:545-716 is files in -> clusters out): the
-    configs[1] genomes (1 000 x 5 Mb) written as 80-column FASTA (plain and gzip level 1), then
-    galah_amd.cluster(paths, FinchPreclusterer, HipAniClusterer) timed first-call and warm."""
+def wall_clock(args, ctx, n_species=100, with_gz=True, repeats=3):
+    """BASELINE metric 2 (`galah cluster`: src/cluster_argument_parsing.rs:545-716 is files in -> clusters out): n_species x
+    members genomes of args.length bp written as 80-column FASTA (plain; gzip level 1 at the configs[1] size), then
+    galah_amd.cluster(paths, FinchPreclusterer, HipAniClusterer) timed first-call and warm.  n_species = 1 000 is the
+    north-star size (10 000 x 5 Mb = 51 GB of files): ingest and the fused sketch pass overlap batch by batch inside
+    ghip_sketch_and_index_files; reported beside the wall time: the ingest alone, the box's host-to-device rate and the floor
+    it sets for the 2-bit form, the GPU's busy share (HIP-event kernel time / wall), and what is left above
+    max(ingest alone, resident compute)."""
+    import queue
+    import threading
     import zlib
     from concurrent.futures import ThreadPoolExecutor
 
     import galah_amd
 
-    n = 100 * args.members
-    d, base = _scratch_dir(n * (args.length + args.length // 80 + 64) * 1.4)
+    n = n_species * args.members
+    d, base = _scratch_dir(n * (args.length + args.length // 80 + 64) * (1.4 if with_gz else 1.08) + (2 << 30))
     if d is None:
-        return {"skipped": "no scratch directory with room for the genome files"}
+        return {"skipped": f"no scratch directory with room for {n} genome files of {args.length} bp"}
     try:
-        g = ctx.genomes_synthetic(args.seed, 100, args.members, args.length, args.sub_rate)
         t0 = time.perf_counter()
-        seqs = [g.to_host(i) for i in range(n)]   # to_host goes through the one context: serial
-        del g
-
-        def write(i):
-            data = _fasta_bytes(seqs[i], f"genome{i}")
-            p = os.path.join(d, f"g{i:05d}.fna")
-            with open(p, "wb") as f:
-                f.write(data)
-            co = zlib.compressobj(1, zlib.DEFLATED, 31)  # gzip container, level 1
-            with open(p + ".gz", "wb") as f:
-                f.write(co.compress(data) + co.flush())
-            return p
-
         threads = min(64, os.cpu_count() or 1)   # what the ingest may use: plain files take ~1.25 x the CPU quota of them, gzip 1.5 x
-        with ThreadPoolExecutor(threads) as ex:
-            paths = list(ex.map(write, range(n)))
-        del seqs
+        paths = [os.path.join(d, f"g{i:05d}.fna") for i in range(n)]
+
+        def write(i, seq):
+            data = _fasta_bytes(seq, f"genome{i}")
+            with open(paths[i], "wb") as f:
+                f.write(data)
+            if with_gz:
+                co = zlib.compressobj(1, zlib.DEFLATED, 31)  # gzip container, level 1
+                with open(paths[i] + ".gz", "wb") as f:
+                    f.write(co.compress(data) + co.flush())
+
+        # genomes leave the device in blocks of 100 species (to_host goes through the one context: serial) while the
+        # writer threads format and write the previous ones -- at most ~2 x `threads` sequences wait in memory
+        work: "queue.Queue" = queue.Queue(maxsize=2 * threads)
+        errors = []
+
+        def writer():
+            while True:
+                item = work.get()
+                if item is None:
+                    return
+                try:
+                    write(*item)
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+
+        pool = [threading.Thread(target=writer) for _ in range(min(threads, 32))]
+        for t in pool:
+            t.start()
+        for sp0 in range(0, n_species, 100):
+            cnt = min(100, n_species - sp0) * args.members
+            g = ctx.genomes_synthetic_range(args.seed, args.members, sp0 * args.members, cnt, args.length, args.sub_rate)
+            for i in range(cnt):
+                work.put((sp0 * args.members + i, g.to_host(i)))
+            g.free()
+        for _ in pool:
+            work.put(None)
+        for t in pool:
+            t.join()
+        if errors:
+            raise errors[0]
         t_write = time.perf_counter() - t0
         gz = [p + ".gz" for p in paths]
-        out = {"workload": f"{n} FASTA files x {args.length} bp (80 columns) in {base}", "genomes": n, "io_threads": threads,
+        out = {"workload": f"{n} FASTA files x {args.length} bp (80 columns) in {base}"
+                           + (" = the north-star size, files in -> clusters out" if n == GENOMES_1GPU else ""), "genomes": n, "io_threads": threads,
                "files_written_s": t_write, "plain_bytes": sum(os.path.getsize(p) for p in paths),
-               "gz_bytes": sum(os.path.getsize(p) for p in gz)}
+               "gz_bytes": sum(os.path.getsize(p) for p in gz) if with_gz else None}
 
         def run(ps):
             pre = galah_amd.FinchPreclusterer(float(parse_percentage(args.precluster_ani)), args.sketch_size, args.kmer, ctx=ctx, io_threads=threads)
             cl = galah_amd.HipAniClusterer(float(parse_percentage(args.ani)) * 100.0, float(parse_percentage(args.min_aligned_fraction)),
                                            ctx=ctx, io_threads=threads)
+            ctx.profile_reset()
             t0 = time.perf_counter()
             clusters = galah_amd.cluster(ps, pre, cl)
-            return time.perf_counter() - t0, clusters
+            dt = time.perf_counter() - t0
+            ctx.synchronize()
+            busy = sum(v[1] for v in ctx.kernel_stats().values()) * 1e-3   # seconds of kernel time (HIP events) inside the call
+            return dt, clusters, busy
 
-        t_first, c0 = run(paths)
-        t_warm, c1 = min((run(paths) for _ in range(3)), key=lambda x: x[0])
-        t_gz, c2 = min((run(gz) for _ in range(2)), key=lambda x: x[0])
-        assert c0 == c1 == c2, "clusters differ between runs / between plain and gzip input"
+        ctx.profile(True)
+        t_first, c0, _ = run(paths)
+        t_warm, c1, busy = min((run(paths) for _ in range(repeats)), key=lambda x: x[0])
+        assert c0 == c1, "clusters differ between runs"
+        t_gz = None
+        if with_gz:
+            t_gz, c2, _ = min((run(gz) for _ in range(2)), key=lambda x: x[0])
+            assert c0 == c2, "clusters differ between plain and gzip input"
         t0 = time.perf_counter()
         gg = ctx.genomes_from_files(paths, threads)
         t_ingest = time.perf_counter() - t0
+        # the same genomes once resident: what the kernels alone take (sketch + seeds, pairs, lazy ANI, clusterer)
+        import galah_amd.distributed as gd
+        job = gd.DereplicationJob(ctx, 0, 1, n_genomes=n, kmer=args.kmer, sketch_size=args.sketch_size, min_ani=parse_percentage(args.precluster_ani),
+                                  ani_threshold=np.float32(parse_percentage(args.ani) * np.float32(100.0)),
+                                  min_af=float(parse_percentage(args.min_aligned_fraction)), lazy_ani=True)
+        job.genomes = gg
+        job.step()
+        t0 = time.perf_counter()
+        res = job.step()
+        t_resident = time.perf_counter() - t0
+        assert res["clusters"] == c0, "files -> clusters differs from the resident step over the same genomes"
+        job = res = None
         gg.free()
         # the box's own host-to-device rate (one pinned 1 GiB copy, second run): what the ingest can at best approach
         import torch
@@ -450,17 +502,23 @@ def wall_clock(args, ctx):
             torch.cuda.synchronize()
             h2d = max(h2d, (1 << 30) / (time.perf_counter() - t0) / 1e9)
         del src, dst
+        pcie_floor = (n * args.length / 4) / (h2d * 1e9)
         out.update({"plain_first_call_s": t_first, "plain_s": t_warm, "gz_s": t_gz, "clusters": len(c0),
                     "ingest_only_s": t_ingest, "ingest_GBps": out["plain_bytes"] / t_ingest / 1e9,
-                    # the ingest ships 2-bit codes, which ARE the resident form (GHIP_INGEST=ascii ships one byte per base and
-                    # packs on the device): the floor of what actually crosses PCIe, and -- for reference -- of the file bytes
-                    "pcie_form": "2-bit codes copied straight into place + the runs of the other bytes (GHIP_INGEST=ascii: one byte per base, packed on the device)",
+                    # the ingest ships 2-bit codes, which ARE the resident form (ghip_options.ingest_form = ASCII ships one byte per
+                    # base and packs on the device): the floor of what actually crosses PCIe, and -- for reference -- of the file bytes
+                    "pcie_form": "2-bit codes copied straight into place + the runs of the other bytes (ingest_form ASCII: one byte per base, packed on the device)",
                     "h2d_pinned_GBps": h2d, "pcie_bytes_shipped": n * args.length // 4,
-                    "pcie_floor_s": (n * args.length / 4) / (h2d * 1e9),
+                    "pcie_floor_s": pcie_floor,
                     "pcie_floor_if_ascii_s": out["plain_bytes"] / (h2d * 1e9),
-                    "plain_s_minus_pcie_floor_ms": (t_warm - (n * args.length / 4) / (h2d * 1e9)) * 1e3,
+                    "plain_s_minus_pcie_floor_ms": (t_warm - pcie_floor) * 1e3,
                     "host_cgroup_cpu_quota": cpu_quota(),   # what bounds the ingest now: read + parse + pack ~1 CPU-second per 5 GB
                     "after_ingest_s": t_warm - t_ingest,
+                    # where the wall time goes: the ingest alone (read + parse + pack + PCIe), the kernels alone on resident genomes,
+                    # the GPU's busy share of the warm run, and what the overlap leaves above the larger of the two
+                    "resident_step_s": t_resident, "gpu_kernel_s": busy, "gpu_busy_fraction": busy / t_warm,
+                    "plain_s_minus_max_ingest_compute_ms": (t_warm - max(t_ingest, t_resident, pcie_floor)) * 1e3,
+                    "overlap": "ghip_sketch_and_index_files ingests plain inputs above 1 GiB in pieces next to the fused sketch pass of the piece before",
                     "pairs_per_s_end_to_end": n * (n - 1) // 2 / t_warm,
                     "genomes_per_s_end_to_end": n / t_warm})
         return out
@@ -648,7 +706,9 @@ def main_single(args, ctx, json_fd):
         legs.append(("configs1_1k", configs1))
     if not args.no_extras:
         legs += [("configs4_50k_quality_order", lambda: configs4_leg(args, ctx)), ("configs3_contigs", lambda: configs3_leg(args, ctx)),
-                 ("wall_clock", lambda: wall_clock(args, ctx)), ("skani", lambda: skani_probe(ctx))]
+                 ("wall_clock", lambda: wall_clock(args, ctx)),
+                 ("wall_clock_10k", lambda: wall_clock(args, ctx, n_species=GENOMES_1GPU // args.members, with_gz=False, repeats=2)),
+                 ("skani", lambda: skani_probe(ctx))]
 
         def live():
             t = pmc_live()

@@ -14,8 +14,8 @@ from .finch import FinchPreclusterer, distances
 from .ani import HipAniClusterer
 from .clusterer import GalahClusterer, cluster
 from .quality import parks2020_reduced_score, quality_order_parks2020_reduced
-from ._lib import GalahHipError, PAIR_DTYPE
+from ._lib import GalahHipError, PAIR_DTYPE, get_options, set_options
 
 __all__ = ["SortedPairGenomeDistanceCache", "Context", "cluster_pairs", "cluster_pairs_lazy", "device_count", "fasta_stream", "FinchPreclusterer",
            "distances", "HipAniClusterer", "cluster", "GalahClusterer", "GalahHipError", "PAIR_DTYPE", "parks2020_reduced_score",
-           "quality_order_parks2020_reduced"]
+           "quality_order_parks2020_reduced", "get_options", "set_options"]

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GHIP_LIB_OVERRIDE") or os.path.join(_HERE, "libgalah_
 PAIR_DTYPE = np.dtype([("i", "<u4"), ("j", "<u4"), ("common", "<u4"), ("total", "<u4"), ("ani", "<f4")])
 
 GHIP_OK = 0
-ERROR_NAMES = {1: "GHIP_EINVAL", 2: "GHIP_EIO", 3: "GHIP_EHIP", 4: "GHIP_ENOMEM", 5: "GHIP_EUNSUPPORTED", 6: "GHIP_ECALLBACK"}
+ERROR_NAMES = {1: "GHIP_EINVAL", 2: "GHIP_EIO", 3: "GHIP_EHIP", 4: "GHIP_ENOMEM", 5: "GHIP_EUNSUPPORTED", 6: "GHIP_ECALLBACK", 7: "GHIP_EPEER"}
 
 ANI_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
 ANI_BATCH_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_float))
@@ -32,6 +32,8 @@ _vp, _sz, _u32, _u64, _f32, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint6
 _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "ghip_abi_version": (_int, []),
+    "ghip_get_options": (_int, [_vp, _vp]),
+    "ghip_set_options": (_int, [_vp, _vp]),
     "ghip_device_count": (_int, []),
     "ghip_init": (_int, [_int, _pp]),
     "ghip_destroy": (None, [_vp]),
@@ -104,6 +106,11 @@ SIGNATURES = {
     "ghip_exchange_ani_index": (_int, [_vp, _vp, _sz, _vp, _sz, _pp, _vp]),
     "ghip_distances_and_ani_ranks": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _f32, _u32, _u32, _u32, _f32, _pp, _pp,
                                             C.POINTER(_sz), _pp, _vp]),
+    "ghip_cluster_ranks": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _f32, _u32, _u32, _u32, _f32, _vp, _f32, _pp, _pp, C.POINTER(_sz), _pp,
+                                  C.POINTER(_sz), _pp, _vp]),
+    "ghip_cluster_index_comm": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _f32, _f32, _pp, _pp, C.POINTER(_sz), _vp]),
+    "ghip_comm_agree": (_int, [_vp, _int]),
+    "ghip_comm_context": (_vp, [_vp]),
     "ghip_cluster_files_multi": (_int, [_pp, _u32, C.POINTER(C.c_char_p), _sz, _u32, _u32, _f32, _f32, _f32, _u32, _int, _pp, _pp,
                                         C.POINTER(_sz)]),
     "ghip_cluster": (_int, [_sz, _vp, _sz, _vp, _int, _f32, ANI_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz)]),
@@ -120,6 +127,50 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 class RankTimes(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("sketch_ms", "allgather_sketches_ms", "pairs_ms", "allgather_pairs_ms",
                                           "exchange_ani_index_ms", "ani_pairs_ms", "gather_ani_ms")] + [("pairs_compared", C.c_uint64)]
+
+
+class ClusterTimes(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("sketch_ms", "allgather_sketches_ms", "pairs_ms", "allgather_pairs_ms", "exchange_ani_index_ms",
+                                          "ani_rounds_ms", "cluster_host_ms")] + \
+               [(k, C.c_uint64) for k in ("pairs_compared", "ani_pairs_asked", "ani_pairs_here", "lazy_rounds")]
+
+
+# ghip_options (include/galah_hip.h): every switch of the library, per context
+OPTION_FIELDS = ("struct_size", "pair_form", "join_ranks", "ingest_form", "ingest_groups", "io_threads_plain", "io_threads_gz", "copy_streams",
+                 "use_libdeflate", "pipeline_pieces", "overlap_binning", "lazy_flush_below", "cluster_threads", "ani_force_general",
+                 "ani_tall_below", "debug", "pair_debug", "fault_stage", "fault_rank")
+PAIR_FORMS = {"auto": 0, "join": 1, "probe": 2, "merge": 3}
+JOIN_RANKS = {"hash": 0, "records": 1, "replicate": 2}
+INGEST_FORMS = {"packed": 0, "ascii": 1, "pageable": 2, "two-phase": 3}
+FAULT_STAGES = {"none": 0, "sketch": 1, "pairs_stage1": 2, "pairs_stage2": 3, "index_pack": 4, "ani_round": 5}
+_OPTION_ENUMS = {"pair_form": PAIR_FORMS, "join_ranks": JOIN_RANKS, "ingest_form": INGEST_FORMS, "fault_stage": FAULT_STAGES}
+
+
+class Options(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in OPTION_FIELDS]
+
+
+def get_options(ctx_handle=None) -> dict:
+    """The options of a context (None: the process-wide defaults, seeded once from the GHIP_* environment)."""
+    o = Options()
+    check(lib().ghip_get_options(ctx_handle, C.byref(o)), ctx_handle)
+    return {k: int(getattr(o, k)) for k in OPTION_FIELDS if k != "struct_size"}
+
+
+def set_options(ctx_handle=None, **fields) -> dict:
+    """ghip_set_options: change the named fields (enumerations by name or number); returns the previous values of those
+    fields, so that `old = set_options(h, pair_form="join"); ...; set_options(h, **old)` restores them."""
+    o = Options()
+    check(lib().ghip_get_options(ctx_handle, C.byref(o)), ctx_handle)
+    old = {}
+    for k, v in fields.items():
+        if k not in OPTION_FIELDS or k == "struct_size":
+            raise KeyError(f"ghip_options has no field {k!r}")
+        old[k] = int(getattr(o, k))
+        setattr(o, k, _OPTION_ENUMS[k][v] if isinstance(v, str) else int(v))
+    o.struct_size = C.sizeof(Options)
+    check(lib().ghip_set_options(ctx_handle, C.byref(o)), ctx_handle)
+    return old
 
 
 class AniLayout(C.Structure):

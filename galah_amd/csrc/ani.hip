@@ -671,7 +671,7 @@ int ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32
     uint32_t fast_chunks = 1;
     bool small_fast = false, small_gen = false;   // some genome small enough for the wide rounds (their offset table costs LDS)
     size_t n_gen = 0;
-    const bool force_general = getenv("GHIP_ANI_FORCE_GENERAL") != nullptr;   // measurement aid: every pair through the general form
+    const bool force_general = ctx->opt.ani_force_general != 0;   // measurement aid: every pair through the general form
     for (size_t p = 0; p < n_pairs; p++) {
         const uint32_t q = pairs[2 * p], r = pairs[2 * p + 1], nch = nch_of(q) + nch_of(r);
         n_gen += (force_general || idx->seed_thr[q] != idx->seed_thr[r] || nch > GHIP_ANI_LDS_PAIR_CHUNKS) ? 1 : 0;
@@ -685,8 +685,7 @@ int ghip_launch_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32
     const size_t n_fast = n_pairs - n_gen;
     // 16 waves per pair while there are fewer pairs than CUs (GHIP_ANI_TALL_BELOW; 0 = never).  Measured, 8 -> 16 waves:
     // 8 pairs 0.133 -> 0.095 ms, 96 pairs 0.168 -> 0.122, but 384 pairs 0.192 -> 0.235 and 1 536 pairs 0.44 -> 0.64.
-    const char *tb = getenv("GHIP_ANI_TALL_BELOW");   // (read per launch: the tests switch it)
-    const size_t tall_below = tb ? (size_t)strtoull(tb, nullptr, 10) : (size_t)200;
+    const size_t tall_below = ctx->opt.ani_tall_below;   // (ghip_options: the tests switch it)
     DeviceFree_ tmp{ctx, {}};
     uint32_t *d_sel = nullptr;
     if (n_gen) {   // the two selections, one upload: [fast..., general...]

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <thread>
 
+#include <sys/stat.h>
+
 #include "ghip_internal.h"
 
 int ghip_read_fasta_streams(const char *const *paths, size_t n, int threads,
@@ -426,6 +428,77 @@ int upload_streams(ghip_ctx *ctx, ghip_genomes *g, hipStream_t st, const std::fu
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------ options
+namespace {
+std::mutex g_opt_mu;
+bool g_opt_ready = false;
+ghip_options g_opt{};
+
+ghip_options options_from_environment() {
+    ghip_options o{};
+    o.struct_size = sizeof(ghip_options);
+    auto is = [](const char *v, const char *w) { return v && !strcmp(v, w); };
+    auto num = [](const char *name, uint32_t dflt) { const char *e = getenv(name); return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : dflt; };
+    auto set = [](const char *name) { const char *e = getenv(name); return e != nullptr; };
+    const char *pk = getenv("GHIP_PAIR_KERNEL"), *jr = getenv("GHIP_JOIN_RANKS"), *ing = getenv("GHIP_INGEST"), *pl = getenv("GHIP_PIPELINE");
+    const char *nl = getenv("GHIP_NO_LIBDEFLATE");
+    o.pair_form = is(pk, "join") ? GHIP_PAIR_JOIN : is(pk, "probe") ? GHIP_PAIR_PROBE : is(pk, "merge") ? GHIP_PAIR_MERGE : GHIP_PAIR_AUTO;
+    o.join_ranks = is(jr, "records") ? GHIP_JOIN_RECORDS : is(jr, "replicate") ? GHIP_JOIN_REPLICATE : GHIP_JOIN_HASH;
+    o.ingest_form = is(ing, "ascii") ? GHIP_INGEST_ASCII : is(ing, "pageable") ? GHIP_INGEST_PAGEABLE : is(ing, "two-phase") ? GHIP_INGEST_TWO_PHASE : GHIP_INGEST_PACKED;
+    o.ingest_groups = set("GHIP_INGEST_NO_GROUPS") ? 0 : 1;
+    o.io_threads_plain = num("GHIP_INGEST_THREADS_PLAIN", 0);
+    o.io_threads_gz = num("GHIP_INGEST_THREADS_GZ", 0);
+    o.copy_streams = std::min(4u, std::max(1u, num("GHIP_COPY_STREAMS", 2)));
+    o.use_libdeflate = (nl && *nl && *nl != '0') ? 0 : 1;
+    o.pipeline_pieces = is(pl, "0") ? 0 : 1;
+    o.overlap_binning = set("GHIP_NO_OVERLAP") ? 0 : 1;
+    o.lazy_flush_below = num("GHIP_LAZY_FLUSH_BELOW", 512);
+    o.cluster_threads = num("GHIP_CLUSTER_THREADS", 0);
+    o.ani_force_general = set("GHIP_ANI_FORCE_GENERAL") ? 1 : 0;
+    o.ani_tall_below = num("GHIP_ANI_TALL_BELOW", 200);
+    o.debug = (set("GHIP_INGEST_DEBUG") ? GHIP_DEBUG_INGEST : 0) | (set("GHIP_PRECLUSTER_DEBUG") ? GHIP_DEBUG_PRECLUSTER : 0) |
+              (set("GHIP_COMM_DEBUG") ? GHIP_DEBUG_COMM : 0) | (set("GHIP_CLUSTER_DEBUG") ? GHIP_DEBUG_CLUSTER : 0) | (set("GHIP_ANI_DEBUG") ? GHIP_DEBUG_ANI : 0);
+    o.pair_debug = num("GHIP_PAIR_DEBUG", 0);
+    return o;
+}
+
+// the fields a caller's (possibly shorter, older) struct holds are taken; out-of-range values are refused
+int merge_options(ghip_options &dst, const ghip_options *src) {
+    if (!src || src->struct_size < 2 * sizeof(uint32_t) || src->struct_size % sizeof(uint32_t)) return GHIP_EINVAL;
+    ghip_options o = dst;
+    memcpy(&o, src, std::min<size_t>(src->struct_size, sizeof(ghip_options)));
+    o.struct_size = sizeof(ghip_options);
+    if (o.pair_form > GHIP_PAIR_MERGE || o.join_ranks > GHIP_JOIN_REPLICATE || o.ingest_form > GHIP_INGEST_TWO_PHASE || o.copy_streams < 1 ||
+        o.copy_streams > 4 || o.fault_stage > GHIP_FAULT_ANI_ROUND)
+        return GHIP_EINVAL;
+    dst = o;
+    return GHIP_OK;
+}
+}  // namespace
+
+ghip_options ghip_process_options() {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (!g_opt_ready) { g_opt = options_from_environment(); g_opt_ready = true; }
+    return g_opt;
+}
+
+extern "C" int ghip_get_options(const ghip_ctx *ctx, ghip_options *out) {
+    if (!out) return GHIP_EINVAL;
+    *out = ctx ? ctx->opt : ghip_process_options();
+    return GHIP_OK;
+}
+
+extern "C" int ghip_set_options(ghip_ctx *ctx, const ghip_options *opt) {
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        const int rc = merge_options(ctx->opt, opt);
+        return rc ? ghip_set_error(ctx, rc, "ghip_set_options: a field is out of range or struct_size is wrong") : GHIP_OK;
+    }
+    (void)ghip_process_options();   // the environment first
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    return merge_options(g_opt, opt);
+}
+
 // ------------------------------------------------------------------------------------ context
 extern "C" int ghip_abi_version(void) { return GHIP_ABI_VERSION; }
 
@@ -444,6 +517,7 @@ extern "C" int ghip_init(int device, ghip_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return ghip_set_error(nullptr, GHIP_EHIP, "hipSetDevice failed");
     ghip_ctx *ctx = new ghip_ctx();
     ctx->device = device;
+    ctx->opt = ghip_process_options();
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return ghip_set_error(nullptr, GHIP_EHIP, "hipStreamCreate failed");
@@ -634,9 +708,10 @@ extern "C" int ghip_genomes_from_files(ghip_ctx *ctx, const char *const *paths, 
 static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t n, int io_threads, const uint64_t *known_caps,
                                    ghip_genomes **out) {
     if (!ctx || !out || (n && !paths)) return GHIP_EINVAL;
-    if (getenv("GHIP_INGEST") && !strcmp(getenv("GHIP_INGEST"), "two-phase"))
+    const ghip_options opt = ctx->opt;
+    if (opt.ingest_form == GHIP_INGEST_TWO_PHASE)
         return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);
-    const bool dbg = getenv("GHIP_INGEST_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(opt, GHIP_DEBUG_INGEST);
     const auto w0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<uint64_t> cap(n);
@@ -658,10 +733,7 @@ static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size
         // not START before the kernels of batch b had finished: the two alternated instead of overlapping.)
         std::lock_guard<std::mutex> ingest_lk(ctx->ingest_mu);
         GHIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        if (ctx->n_copy_streams == 0) {
-            const char *e = getenv("GHIP_COPY_STREAMS");
-            ctx->n_copy_streams = std::min(4, std::max(1, e ? atoi(e) : 2));
-        }
+        if (ctx->n_copy_streams == 0) ctx->n_copy_streams = (int)std::min(4u, std::max(1u, opt.copy_streams));
         for (int x = 0; x < ctx->n_copy_streams; x++) {
             hipStream_t &cs = ctx->copy_stream[x];
             if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; (void)hipGetLastError(); }
@@ -690,22 +762,21 @@ static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size
         // 154 / 123 / 142 / 150 ms with 8 / 12 / 16 / 24 threads.  gzip input is inflate-bound (CPU): every thread the
         // caller offers is used, up to ~1.5x the CPUs the process may actually use (below).
         {
-            const char *mt = getenv("GHIP_INGEST_THREADS_PLAIN");
+            const uint32_t mt = opt.io_threads_plain;
             // (the ASCII form is PCIe-bound: a dozen readers; the packed form ships a quarter of the bytes and is bound
             // by the CPUs the process may use -- 1 000 x 5 Mb on the 16-CPU-quota boxes: 127 / 90 / 78 / 74 / 86 / 94 ms
             // with 8 / 12 / 16 / 20 / 24 / 32 readers)
-            const char *form = getenv("GHIP_INGEST");
-            const bool ascii_form = form && (!strcmp(form, "ascii") || !strcmp(form, "pageable"));
+            const bool ascii_form = opt.ingest_form == GHIP_INGEST_ASCII || opt.ingest_form == GHIP_INGEST_PAGEABLE;
             const double q = ghip_cpu_quota();
-            const int plain_cap = mt ? std::max(1, atoi(mt)) : (ascii_form ? 12 : (q > 0 ? std::max(8, (int)(q * 1.25 + 0.5)) : 16));
+            const int plain_cap = mt ? (int)mt : (ascii_form ? 12 : (q > 0 ? std::max(8, (int)(q * 1.25 + 0.5)) : 16));
             if (n_gz == 0) threads = std::min(threads, plain_cap);
             else {
                 // ... of the CPUs the process may actually use: under a cgroup quota (the GPU boxes: 256 logical CPUs, 16
                 // CPUs' worth of time) threads beyond ~1.5x the quota only get throttled -- 1 000 gzip files: 0.58 s with
                 // 64 threads, 0.42-0.47 s with 16-32
-                const char *gt = getenv("GHIP_INGEST_THREADS_GZ");
+                const uint32_t gt = opt.io_threads_gz;
                 const double quota = ghip_cpu_quota();
-                const int gz_cap = gt ? std::max(1, atoi(gt)) : (quota > 0 ? std::max(8, (int)(quota * 1.5 + 0.5)) : threads);
+                const int gz_cap = gt ? (int)gt : (quota > 0 ? std::max(8, (int)(quota * 1.5 + 0.5)) : threads);
                 threads = std::min(threads, gz_cap);
             }
         }
@@ -733,11 +804,10 @@ static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size
         // everything when GHIP_INGEST=pageable) take blocking pageable copies.
         constexpr size_t GHIP_PINNED_SLOT_MAX = 24u << 20;
         constexpr size_t GHIP_PINNED_SLOTS = 32;
-        const char *ing = getenv("GHIP_INGEST");
-        bool use_pinned = !(ing && !strcmp(ing, "pageable"));
+        bool use_pinned = opt.ingest_form != GHIP_INGEST_PAGEABLE;
         for (int x = 0; x < ctx->n_copy_streams; x++) use_pinned = use_pinned && ctx->copy_stream[x];
         // (the packed form stages a quarter of the bytes: streams of up to four times the size go through the slots)
-        const bool packed_wanted = use_pinned && !(ing && !strcmp(ing, "ascii"));
+        const bool packed_wanted = use_pinned && opt.ingest_form != GHIP_INGEST_ASCII;
         // (a slot holds the largest file -- or, where the files are small, a group of them: 4 Mbases, see `units` below)
         uint64_t sum_cap = 0;
         for (size_t i = 0; i < n; i++) sum_cap += cap[i] + 2 * GHIP_TAIL_PAD;
@@ -819,7 +889,7 @@ static int genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size
         {
             constexpr uint64_t SMALL_FILE = 256u << 10, GROUP_BASES = 4u << 20;
             constexpr size_t GROUP_FILES = 512;
-            const bool grouping = packed_mode && n_slots && !getenv("GHIP_INGEST_NO_GROUPS");
+            const bool grouping = packed_mode && n_slots && opt.ingest_groups;
             for (size_t i = 0; i < n;) {
                 size_t j = i + 1;
                 if (grouping && cap[i] <= SMALL_FILE) {
@@ -1230,11 +1300,21 @@ extern "C" int ghip_sketches_load_named(ghip_ctx *ctx, const char *path, ghip_sk
     std::vector<uint32_t> l;
     std::vector<uint64_t> h;
     std::string blob;
+    std::string why = "not a sketch matrix file: ";
     if (ok) {
-        l.resize(n); h.resize(n * (size_t)s); blob.resize(nb);
+        // the header's counts are believed only when the FILE is exactly as long as they say (a truncated or
+        // corrupt header could ask for terabytes before the checksum was ever looked at), and an allocation that still fails
+        // is an error code, not an exception through the C boundary
+        struct stat st;
+        const uint64_t header = 8 + 4 + 4 + (v2 ? 8 : 0) + 8 + (v2 ? 8 : 0);
+        const uint64_t want = header + 4 * n + 8 * n * (uint64_t)s + nb + (v2 ? 8 : 0);
+        if (fstat(fileno(f), &st) != 0 || (uint64_t)st.st_size != want) { ok = false; why = "sketch matrix file is truncated or its header is damaged (size): "; }
+    }
+    if (ok) {
+        try { l.resize(n); h.resize(n * (size_t)s); blob.resize(nb); }
+        catch (const std::exception &) { fclose(f); return ghip_set_error(ctx, GHIP_ENOMEM, std::string("out of host memory loading ") + path); }
         ok = get(f, c, l.data(), 4 * l.size()) && get(f, c, h.data(), 8 * h.size()) && get(f, c, &blob[0], nb);
     }
-    std::string why = "not a sketch matrix file: ";
     if (ok && v2) {
         uint64_t sum = 0;
         ok = fread(&sum, 8, 1, f) == 1 && sum == c.h;
@@ -1558,13 +1638,13 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
     //   probe (pairs_probe.hip)  dense, cuckoo sets in LDS; s <= 1024
     //   merge (pairs.hip)        dense, 64-way merge path; s > 1024, or a sketch holds 2^64-1 / a cuckoo insertion failed
     // GHIP_PAIR_KERNEL=join|probe|merge forces a form (join still declines what it cannot do).
-    const char *force = getenv("GHIP_PAIR_KERNEL");
+    const uint32_t force = ctx->opt.pair_form;
     // (sketches too long for LDS tiles, s > 4096, go to the join whatever n is: the dense form left for them reads global memory)
-    const bool want_join = !dense_share && (force ? !strcmp(force, "join") : (n >= GHIP_JOIN_MIN_N || s > 4096));
-    bool use_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
+    const bool want_join = !dense_share && (force != GHIP_PAIR_AUTO ? force == GHIP_PAIR_JOIN : (n >= GHIP_JOIN_MIN_N || s > 4096));
+    bool use_probe = s <= 1024 && force != GHIP_PAIR_MERGE;
     bool probe_checked = false;
 
-    const bool dbg_laps = getenv("GHIP_PRECLUSTER_DEBUG") != nullptr;   // host laps of the stage on stderr
+    const bool dbg_laps = ghip_dbg(ctx->opt, GHIP_DEBUG_PRECLUSTER);   // host laps of the stage on stderr
     auto lap_t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg_laps) return;
@@ -1672,7 +1752,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
                 (rc = dmalloc(ctx, &sub.d_hashes, G.size() * (size_t)s)) || (tmp.add(sub.d_hashes), false) ||
                 (rc = dmalloc(ctx, &sub.d_lens, G.size())) || (tmp.add(sub.d_lens), false)) return rc;
             ghip_launch_gather_rows(ctx, sk->d_hashes, sk->d_lens, d_G, G.size(), s, sub.d_hashes, sub.d_lens);
-            bool sub_probe = s <= 1024 && !(force && !strcmp(force, "merge"));
+            bool sub_probe = s <= 1024 && force != GHIP_PAIR_MERGE;
             if (sub_probe) {
                 if ((rc = prepare_probe(ctx, &sub))) return rc;
                 tmp.add(sub.d_tables); tmp.add(sub.d_tags); tmp.add(sub.d_row_start);
@@ -1730,8 +1810,7 @@ extern "C" int ghip_precluster_ranks(ghip_ctx *ctx, const ghip_sketches *sk, flo
     // Default: the pair work is SHARDED -- dense forms by tile, the join form by (i + j) mod world at record emission
     // (its element stage, one pass over all N*s hashes, runs on every rank).  GHIP_JOIN_RANKS=replicate makes every
     // rank run the whole join and keep the whole list instead (no candidate exchange; DESIGN.md section 6 has both timings).
-    const char *mode = getenv("GHIP_JOIN_RANKS");
-    const bool replicate = world > 1 && mode && !strcmp(mode, "replicate");
+    const bool replicate = world > 1 && ctx->opt.join_ranks == GHIP_JOIN_REPLICATE;
     return precluster_impl(ctx, sk, min_ani, rank, world, replicate, 0, out_pairs, out_n, out_replicated);
 }
 
@@ -1967,7 +2046,7 @@ extern "C" int ghip_sketch_and_index(ghip_ctx *ctx, const ghip_genomes *g, uint3
         rc = sketch_genomes_locked(ctx, g, k, s, seed, nullptr, &sk);
         if (!rc) rc = index_seed_standalone(ctx, g, idx, cap);
     }
-    if (!rc) rc = index_finish(ctx, idx, getenv("GHIP_NO_OVERLAP") == nullptr);   // the binning overlaps the caller's pair stage
+    if (!rc) rc = index_finish(ctx, idx, ctx->opt.overlap_binning != 0);   // the binning overlaps the caller's pair stage
     if (rc) { if (sk) free_sketches_locked(sk); free_index_locked(idx); return rc; }
     *out_sk = sk;
     *out_idx = idx;
@@ -2007,8 +2086,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
         // (gzip input is inflate-bound on the host: cutting it into pieces only adds eight load-imbalanced tails)
         size_t n_gz = 0;
         for (size_t i = 0; i < n; i++) { const size_t l = strlen(paths[i]); n_gz += (l > 3 && !strcmp(paths[i] + l - 3, ".gz")) ? 1 : 0; }
-        const char *pl = getenv("GHIP_PIPELINE");
-        if (!(pl && !strcmp(pl, "0")) && n_gz == 0 && total_bytes > (1ull << 30))
+        if (ctx->opt.pipeline_pieces && n_gz == 0 && total_bytes > (1ull << 30))
             piece = std::min<uint64_t>(batch_bases, std::max<uint64_t>(total_bytes / 4 + 1, 512ull << 20));
     }
     std::vector<std::pair<size_t, size_t>> ranges;
@@ -2163,7 +2241,7 @@ extern "C" int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *pat
 // (unused), aligned bases of r
 static int ani_pairs_device(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs, size_t n, uint64_t *res) {
     // GHIP_ANI_DEBUG=1: where the wall time of one call goes (stderr)
-    static const bool dbg = getenv("GHIP_ANI_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_ANI);
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg) return;
@@ -2220,7 +2298,7 @@ extern "C" int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const ui
     if (!ctx || !idx || !out_ani || (n && !pairs)) return GHIP_EINVAL;
     for (size_t i = 0; i < 2 * n; i++) if (pairs[i] >= idx->n) return ghip_set_error(ctx, GHIP_EINVAL, "genome index out of range");
     if (n == 0) return GHIP_OK;
-    static const bool dbg = getenv("GHIP_ANI_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_ANI);
     const auto t_in = std::chrono::steady_clock::now();
     std::vector<uint64_t> res(6 * n);
     { const int rc = ani_pairs_device(ctx, idx, pairs, n, res.data()); if (rc) return rc; }

@@ -44,7 +44,8 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
                         uint64_t *out_requested, ghip_ctx *pool_ctx = nullptr) {
     if (!out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
     if (n_pairs && !pairs) return GHIP_EINVAL;
-    const bool dbg = getenv("GHIP_CLUSTER_DEBUG") != nullptr;
+    const ghip_options opt = pool_ctx ? pool_ctx->opt : ghip_process_options();
+    const bool dbg = ghip_dbg(opt, GHIP_DEBUG_CLUSTER);
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[cluster] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; } };
     if (out_requested) *out_requested = 0;
@@ -112,7 +113,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
             else { ani_state[e] = 2; ani_val[e] = pair_ani[e]; }
         }
     }
-    bool aborted = false;  // the callback returned < 0: the host's calculate_ani failed (a Rust panic, a Python exception)
+    std::atomic<bool> aborted{false};  // the callback returned < 0: the host's calculate_ani failed (a Rust panic, a Python exception)
     std::vector<uint8_t> is_rep(n, 0);       // indexed by genome
     if (batch_cb && !skip_clusterer && !pair_ani && n_pairs) {
         // ---- lazy ANI in batches.  The greedy rules only ever look at edges that touch a REPRESENTATIVE (candidate
@@ -129,8 +130,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
         // A round costs the callee one launch's latency however few edges it holds (ani_pairs: ~0.25 ms for anything up
         // to ~800 pairs), so a SHORT round is topped up (below): a short edge list is thereby asked for whole in its
         // first round, and the tail of a long one is one round instead of several tiny ones.
-        size_t flush_below = 512;
-        if (const char *e = getenv("GHIP_LAZY_FLUSH_BELOW")) flush_below = (size_t)strtoull(e, nullptr, 10);
+        const size_t flush_below = opt.lazy_flush_below;
         for (;;) {
             req.clear();
             for (size_t s = 0; s < nsets; s++) {
@@ -286,7 +286,8 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
     {
         // threads only where they pay (spawning one costs ~30 us): ranges of >= 2 000 genomes, at most 8 workers
         size_t workers = ani_cb ? 1 : std::min<size_t>({(size_t)8, n / 2000, (size_t)std::max(1u, std::thread::hardware_concurrency())});
-        if (const char *e = getenv("GHIP_CLUSTER_THREADS")) workers = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));
+        // (a callback back-end stays on ONE thread whatever the option says: the host's calculate_ani need not be re-entrant)
+        if (opt.cluster_threads && !ani_cb) workers = opt.cluster_threads;
         workers = std::max<size_t>(1, std::min(workers, nsets));
         std::vector<std::vector<uint64_t>> ends(workers);
         if (workers == 1) run_range(0, nsets, ends[0]);
@@ -356,31 +357,85 @@ struct IndexAni {
     const ghip_pair *by_genome;        // the caller's pair list (genome indices)
     const uint32_t *orig;              // sorted edge -> index into by_genome (null: identity)
     float min_af;
-    std::vector<uint32_t> buf;
-    uint64_t rounds = 0, ns_ani = 0;
+    // several ranks (ghip_cluster_index_comm): a request is answered by the rank that owns the pair's FIRST genome (where
+    // ghip_exchange_ani_index put the slices it needs); local_ids maps genome -> position in this rank's index
+    ghip_comm *comm = nullptr;
+    const uint32_t *local_ids = nullptr;
+    size_t block = 0;
+    uint32_t rank = 0, world = 1;
+    std::vector<uint32_t> buf, mine_at;
+    std::vector<float> vals;
+    std::vector<uint8_t> send, got;
+    std::vector<uint64_t> sizes, cursor;
+    uint64_t rounds = 0, ns_ani = 0, asked_here = 0;
     int rc = GHIP_OK;
 };
 int index_ani_batch(void *user, const uint32_t *edge, size_t n, float *out) {
     IndexAni *s = static_cast<IndexAni *>(user);
     const auto t0 = std::chrono::steady_clock::now();
-    s->buf.resize(2 * n);
-    for (size_t x = 0; x < n; x++) {
-        const ghip_pair &p = s->by_genome[s->orig ? s->orig[edge[x]] : edge[x]];
-        s->buf[2 * x] = p.i; s->buf[2 * x + 1] = p.j;
+    auto pair_of = [&](size_t x) -> const ghip_pair & { return s->by_genome[s->orig ? s->orig[edge[x]] : edge[x]]; };
+    auto id = [&](uint32_t g) { return s->local_ids ? s->local_ids[g] : g; };
+    if (s->world == 1) {
+        s->buf.resize(2 * n);
+        for (size_t x = 0; x < n; x++) { const ghip_pair &p = pair_of(x); s->buf[2 * x] = id(p.i); s->buf[2 * x + 1] = id(p.j); }
+        s->rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), n, s->min_af, out, nullptr);
+        s->asked_here += n;
+    } else {
+        // The round's requests are the same list on every rank (the clusterer is deterministic and every rank runs it):
+        // each rank answers the requests it owns, one variable-length gather -- sizes known to all, so ONE collective --
+        // carries every rank's answers behind a status word, and every rank files them in request order.  A rank whose
+        // launch failed says so in that word: all ranks leave the round together.
+        s->buf.clear(); s->mine_at.clear();
+        s->sizes.assign(s->world, sizeof(uint32_t));
+        for (size_t x = 0; x < n; x++) {
+            const ghip_pair &p = pair_of(x);
+            const size_t owner = p.i / s->block;
+            s->sizes[owner] += sizeof(float);
+            if (owner == s->rank) { s->buf.push_back(id(p.i)); s->buf.push_back(id(p.j)); s->mine_at.push_back((uint32_t)x); }
+        }
+        const size_t mine = s->mine_at.size();
+        s->vals.assign(mine, 0.0f);
+        int local_rc = GHIP_OK;
+        for (size_t x = 0; x < 2 * mine && !local_rc; x++)
+            if (s->buf[x] == UINT32_MAX) local_rc = ghip_set_error(s->ctx, GHIP_EINVAL, "a requested pair's genome is not in this rank's ANI index");
+        if (!local_rc && mine) local_rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), mine, s->min_af, s->vals.data(), nullptr);
+        if (!local_rc && ghip_comm_fault(s->comm, GHIP_FAULT_ANI_ROUND)) local_rc = ghip_set_error(s->ctx, GHIP_EHIP, "injected fault: ANI round");
+        s->asked_here += mine;
+        s->send.resize(sizeof(uint32_t) + mine * sizeof(float));
+        const uint32_t status = (uint32_t)local_rc;
+        memcpy(s->send.data(), &status, sizeof(status));
+        if (mine) memcpy(s->send.data() + sizeof(uint32_t), s->vals.data(), mine * sizeof(float));
+        int rc = ghip_comm_gatherv_known(s->comm, s->send.data(), s->send.size(), s->sizes, s->got);
+        if (!rc) {
+            s->cursor.assign(s->world, 0);
+            uint64_t at = 0;
+            for (uint32_t r = 0; r < s->world && !rc; r++) {
+                uint32_t st;
+                memcpy(&st, s->got.data() + at, sizeof(st));
+                if (st) rc = r == s->rank ? local_rc : ghip_set_error(s->ctx, GHIP_EPEER, "rank " + std::to_string(r) + " failed in a lazy ANI round (code " + std::to_string(st) + ")");
+                s->cursor[r] = at + sizeof(uint32_t);
+                at += s->sizes[r];
+            }
+            if (!rc)
+                for (size_t x = 0; x < n; x++) {
+                    const size_t owner = pair_of(x).i / s->block;
+                    memcpy(&out[x], s->got.data() + s->cursor[owner], sizeof(float));
+                    s->cursor[owner] += sizeof(float);
+                }
+        }
+        s->rc = rc ? rc : local_rc;
     }
-    s->rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), n, s->min_af, out, nullptr);
     s->rounds++;
     s->ns_ani += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return s->rc == GHIP_OK ? 0 : 1;
 }
-}  // namespace
 
-extern "C" int ghip_cluster_index(ghip_ctx *ctx, const ghip_ani_index *idx, size_t n, const ghip_pair *pairs, size_t n_pairs,
-                                  const uint32_t *order, float ani_threshold, float min_aligned_fraction,
-                                  uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats) {
+int cluster_index_impl(ghip_ctx *ctx, ghip_comm *comm, const ghip_ani_index *idx, const uint32_t *local_ids, size_t n, const ghip_pair *pairs,
+                       size_t n_pairs, const uint32_t *order, float ani_threshold, float min_aligned_fraction, uint32_t **out_members,
+                       uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats, size_t n_stats) {
     if (!ctx || !out_members || !out_offsets || !out_n_clusters || (n_pairs && (!pairs || !idx))) return GHIP_EINVAL;
     const auto t0 = std::chrono::steady_clock::now();
-    if (out_stats) memset(out_stats, 0, 4 * sizeof(uint64_t));
+    if (out_stats) memset(out_stats, 0, n_stats * sizeof(uint64_t));
     for (size_t e = 0; e < n_pairs; e++)
         if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return ghip_set_error(ctx, GHIP_EINVAL, "pair list names a genome out of range");
     std::vector<ghip_pair> sorted;
@@ -422,13 +477,44 @@ extern "C" int ghip_cluster_index(ghip_ctx *ctx, const ghip_ani_index *idx, size
         orig.swap(ix);
     }
     IndexAni st{ctx, idx, pairs, orig.empty() ? nullptr : orig.data(), min_aligned_fraction};
+    if (comm) {
+        size_t first, count;
+        st.comm = comm; st.rank = ghip_comm_rank(comm); st.world = ghip_comm_world(comm);
+        ghip_shard_range(n, st.rank, st.world, &first, &count, &st.block);
+    }
+    st.local_ids = local_ids;
     uint64_t asked = 0;
     const int rc = cluster_impl(n, sorted.empty() ? pairs : sorted.data(), n_pairs, nullptr, 0, ani_threshold, nullptr,
                                 n_pairs ? index_ani_batch : nullptr, &st, out_members, out_offsets, out_n_clusters, &asked, ctx);
     if (out_stats) {
         out_stats[0] = asked; out_stats[1] = st.rounds; out_stats[2] = st.ns_ani;
         out_stats[3] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (n_stats > 4) out_stats[4] = st.asked_here;
     }
-    if (rc == GHIP_ECALLBACK && st.rc != GHIP_OK) return st.rc;   // the ANI launch failed: its own code and message
+    if (rc == GHIP_ECALLBACK && st.rc != GHIP_OK) return st.rc;   // the ANI launch failed (here or on a peer): its own code and message
     return rc;
+}
+}  // namespace
+
+extern "C" int ghip_cluster_index(ghip_ctx *ctx, const ghip_ani_index *idx, size_t n, const ghip_pair *pairs, size_t n_pairs,
+                                  const uint32_t *order, float ani_threshold, float min_aligned_fraction,
+                                  uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats) {
+    return cluster_index_impl(ctx, nullptr, idx, nullptr, n, pairs, n_pairs, order, ani_threshold, min_aligned_fraction, out_members, out_offsets,
+                              out_n_clusters, out_stats, 4);
+}
+
+// The same on several ranks (src/clusterer.rs:194-204, 276-296, 377-405: the reference asks lazily, and so does every world
+// size here): EVERY rank calls it with the same pair list and runs the same deterministic clusterer; a round's requests are
+// dealt to the ranks that own the pairs' first genomes (`idx` = what ghip_exchange_ani_index returned on this rank,
+// `local_ids` its genome -> position map) and come back in one variable-length gather per round.  Every rank returns the
+// same clusters.  out_stats[5] = pairs asked (all ranks), rounds, ns in the rounds, ns in all, pairs THIS rank computed.
+extern "C" int ghip_cluster_index_comm(ghip_comm *comm, const ghip_ani_index *idx, const uint32_t *local_ids, size_t n,
+                                       const ghip_pair *pairs, size_t n_pairs, const uint32_t *order, float ani_threshold,
+                                       float min_aligned_fraction, uint32_t **out_members, uint64_t **out_offsets,
+                                       size_t *out_n_clusters, uint64_t *out_stats) {
+    if (!comm) return GHIP_EINVAL;
+    ghip_ctx *ctx = ghip_comm_context(comm);
+    if (!ctx) return GHIP_EINVAL;
+    return ghip_comm_note_error(comm, cluster_index_impl(ctx, comm, idx, local_ids, n, pairs, n_pairs, order, ani_threshold, min_aligned_fraction,
+                                                         out_members, out_offsets, out_n_clusters, out_stats, 5));
 }

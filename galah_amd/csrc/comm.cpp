@@ -36,6 +36,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;   // optional
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
@@ -56,6 +57,7 @@ Rccl &rccl() {
         x.GroupStart = (decltype(x.GroupStart))dlsym(x.handle, "ncclGroupStart");
         x.GroupEnd = (decltype(x.GroupEnd))dlsym(x.handle, "ncclGroupEnd");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
+        x.CommAbort = (decltype(x.CommAbort))dlsym(x.handle, "ncclCommAbort");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
         if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.Send || !x.Recv || !x.GroupStart || !x.GroupEnd || !x.CommDestroy ||
             !x.GetErrorString)
@@ -97,6 +99,8 @@ struct ghip_comm {
     uint32_t rank = 0, world = 1;
     Transport transport = T_SELF;
     ncclComm_t nccl = nullptr;
+    bool agreed_failure = false;   // the error a call is returning was agreed by every rank (agree(), exchange 1 of the pair stage): the caller must not agree on it again
+    bool dead = false;   // an RCCL call failed: the communicator was aborted, every later collective returns an error at once
     LocalGroup *group = nullptr;
     ghip_allgather_fn fn = nullptr;
     void *user = nullptr;
@@ -114,6 +118,20 @@ int cerr_(ghip_comm *c, int code, const std::string &msg) {
     if (c->ctx) ghip_set_error(c->ctx, code, msg);
     if (c->group) c->group->fail();
     return code;
+}
+
+// an RCCL call itself failed: the communicator is unusable.  Abort it (peers blocked on this rank inside RCCL are released
+// by their own error path rather than waiting for a collective this rank will never join) and refuse every later call.
+int rccl_failed(ghip_comm *c, const char *what, ncclResult_t r) {
+    const std::string msg = std::string(what) + ": " + rccl().GetErrorString(r);
+    if (c->nccl && rccl().CommAbort) { rccl().CommAbort(c->nccl); c->nccl = nullptr; }
+    c->dead = true;
+    return cerr_(c, GHIP_EHIP, msg);
+}
+
+// tests of the error paths: ghip_options.fault_stage / fault_rank make one rank fail at a named point
+bool fault_here(const ghip_comm *c, uint32_t stage) {
+    return c->ctx && c->ctx->opt.fault_stage == stage && c->ctx->opt.fault_rank == c->rank;
 }
 
 struct PoolBuf {  // device scratch from the context's pool
@@ -150,8 +168,9 @@ int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t byte
         COMM_HIP(c, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         return GHIP_OK;
     case T_RCCL: {
+        if (c->dead) return cerr_(c, GHIP_EHIP, "the RCCL communicator was aborted by an earlier failure");
         ncclResult_t r = rccl().AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream);
-        if (r != ncclSuccess) return cerr_(c, GHIP_EHIP, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+        if (r != ncclSuccess) return rccl_failed(c, "ncclAllGather", r);
         COMM_HIP(c, hipStreamSynchronize(ctx->stream));
         return GHIP_OK;
     }
@@ -190,6 +209,7 @@ int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t byte
 }
 
 int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv);
+int agree(ghip_comm *c, int status, const char *what);
 
 // All-to-all-v of device bytes: my bytes [send_off[d], send_off[d + 1]) of d_send arrive at rank d's d_recv + its
 // recv_off[me]; recv_off[r + 1] - recv_off[r] is what I expect from rank r (both arrays hold world + 1 offsets, and the
@@ -212,6 +232,7 @@ int exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, 
         COMM_HIP(c, hipStreamSynchronize(ctx->stream));
         return GHIP_OK;
     case T_RCCL: {
+        if (c->dead) return cerr_(c, GHIP_EHIP, "the RCCL communicator was aborted by an earlier failure");
         ncclResult_t r = rccl().GroupStart();
         for (uint32_t p = 0; p < world && r == ncclSuccess; p++) {
             if (sends(p)) r = rccl().Send((const char *)d_send + send_off[p], sends(p), ncclUint8, (int)p, c->nccl, ctx->stream);
@@ -219,7 +240,7 @@ int exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, 
         }
         const ncclResult_t e = rccl().GroupEnd();
         if (r == ncclSuccess) r = e;
-        if (r != ncclSuccess) return cerr_(c, GHIP_EHIP, std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(r));
+        if (r != ncclSuccess) return rccl_failed(c, "ncclSend/ncclRecv", r);
         COMM_HIP(c, hipStreamSynchronize(ctx->stream));
         return GHIP_OK;
     }
@@ -250,18 +271,23 @@ int exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, 
         int rc = allgather_host(c, send_off, (size_t)(world + 1) * sizeof(uint64_t), all_off.data());
         if (rc) return rc;
         uint64_t m = 0;
+        bool mismatch = false;   // (reported AFTER the device collective below: the peers enter it whatever this rank finds)
         for (uint32_t r = 0; r < world; r++) {
             const uint64_t *o = &all_off[(size_t)r * (world + 1)];
             m = std::max(m, o[world] - o[0]);
-            if (o[me + 1] - o[me] != recvs(r)) return cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects");
+            if (o[me + 1] - o[me] != recvs(r)) mismatch = true;
         }
-        if (m == 0) return GHIP_OK;
+        if (m == 0) return mismatch ? cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects") : GHIP_OK;
         m = (m + 15) / 16 * 16;
         PoolBuf sb(ctx, m), rb(ctx, m * world);
-        if (!sb.p || !rb.p) return cerr_(c, GHIP_EHIP, "out of device memory for the exchange");
-        if (send_off[world] > send_off[0])
-            COMM_HIP(c, hipMemcpyAsync(sb.p, (const char *)d_send + send_off[0], send_off[world] - send_off[0], hipMemcpyDeviceToDevice, ctx->stream));
+        // a rank that cannot take part says so in a status word first: nobody enters the device collective alone
+        int mine = (!sb.p || !rb.p) ? GHIP_EHIP : GHIP_OK;
+        if (!mine && send_off[world] > send_off[0] &&
+            hipMemcpyAsync(sb.p, (const char *)d_send + send_off[0], send_off[world] - send_off[0], hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            mine = GHIP_EHIP;
+        if ((rc = agree(c, mine, "staging the exchange"))) return rc;
         if ((rc = allgather_device(c, sb.p, rb.p, m))) return rc;
+        if (mismatch) return cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects");
         for (uint32_t r = 0; r < world; r++) {
             const uint64_t *o = &all_off[(size_t)r * (world + 1)];
             if (recvs(r)) COMM_HIP(c, hipMemcpyAsync((char *)d_recv + recv_off[r], (const char *)rb.p + (size_t)r * m + (o[me] - o[0]), recvs(r), hipMemcpyDeviceToDevice, ctx->stream));
@@ -329,13 +355,43 @@ int allgatherv_host(ghip_comm *c, const void *send, size_t bytes, std::vector<ui
     return GHIP_OK;
 }
 
+// Phase boundary: every rank contributes its status (GHIP_OK or the code of what failed on it); all return together --
+// GHIP_OK when every rank is fine, its own code on a rank that failed, GHIP_EPEER on the others.  A rank that fails between
+// two collectives therefore never leaves its peers waiting in the next one: they meet it here first.  (One small host
+// all-gather: ~0.05 ms over RCCL.)
+int agree(ghip_comm *c, int status, const char *what) {
+    if (c->world == 1) return status;
+    std::vector<int32_t> all(c->world, 0);
+    const int32_t mine = status;
+    const int rc = allgather_host(c, &mine, sizeof(mine), all.data());
+    if (rc) return rc;
+    if (status) { c->agreed_failure = true; return status; }
+    for (uint32_t r = 0; r < c->world; r++)
+        if (all[r]) return c->agreed_failure = true, cerr_(c, GHIP_EPEER, std::string("rank ") + std::to_string(r) + " failed at: " + what + " (code " + std::to_string(all[r]) + ")");
+    return GHIP_OK;
+}
+
 double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 }  // namespace
 
+int ghip_comm_gatherv_known(ghip_comm *c, const void *send, size_t bytes, std::vector<uint64_t> &sizes, std::vector<uint8_t> &out) {
+    return allgatherv_host(c, send, bytes, out, sizes, true);
+}
+bool ghip_comm_fault(const ghip_comm *c, uint32_t stage) { return fault_here(c, stage); }
+int ghip_comm_note_error(ghip_comm *c, int rc) {
+    if (rc && c && c->ctx) c->err = ghip_last_error(c->ctx);
+    return rc;
+}
+
 // ================================================================================================ C ABI
+extern "C" int ghip_comm_agree(ghip_comm *c, int status) {
+    if (!c) return GHIP_EINVAL;
+    return agree(c, status, "a phase of the host's own");
+}
+
 extern "C" int ghip_comm_unique_id(uint8_t id[GHIP_UNIQUE_ID_BYTES]) {
     if (!id) return GHIP_EINVAL;
     static_assert(GHIP_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
@@ -409,6 +465,7 @@ extern "C" void ghip_comm_destroy(ghip_comm *c) {
     delete c;
 }
 
+extern "C" ghip_ctx *ghip_comm_context(const ghip_comm *c) { return c ? c->ctx : nullptr; }
 extern "C" uint32_t ghip_comm_rank(const ghip_comm *c) { return c ? c->rank : 0; }
 extern "C" uint32_t ghip_comm_world(const ghip_comm *c) { return c ? c->world : 0; }
 extern "C" const char *ghip_comm_transport(const ghip_comm *c) {
@@ -457,14 +514,17 @@ extern "C" int ghip_allgather_sketches(ghip_comm *c, const ghip_sketches *local,
     const uint32_t s = local->s;
     const size_t rows = block * c->world;
     PoolBuf sendh(ctx, block * (size_t)s * 8), sendl(ctx, block * 4), recvh(ctx, rows * (size_t)s * 8), recvl(ctx, rows * 4);
-    if (!sendh.p || !sendl.p || !recvh.p || !recvl.p) return cerr_(c, GHIP_EHIP, "out of device memory for the sketch all-gather");
-    COMM_HIP(c, hipSetDevice(ctx->device));
-    if (count < block) {  // padding rows: empty sketches (never read: the matrix is cut at n_total)
-        COMM_HIP(c, hipMemsetAsync((char *)sendh.p + count * (size_t)s * 8, 0xff, (block - count) * (size_t)s * 8, ctx->stream));
-        COMM_HIP(c, hipMemsetAsync((char *)sendl.p + count * 4, 0, (block - count) * 4, ctx->stream));
+    // everything that can fail on this rank alone happens before the status word; the two collectives follow it
+    int rc = GHIP_OK;
+    if (!sendh.p || !sendl.p || !recvh.p || !recvl.p) rc = cerr_(c, GHIP_EHIP, "out of device memory for the sketch all-gather");
+    if (!rc && hipSetDevice(ctx->device) != hipSuccess) rc = cerr_(c, GHIP_EHIP, "hipSetDevice failed");
+    if (!rc && count < block) {  // padding rows: empty sketches (never read: the matrix is cut at n_total)
+        if (hipMemsetAsync((char *)sendh.p + count * (size_t)s * 8, 0xff, (block - count) * (size_t)s * 8, ctx->stream) != hipSuccess ||
+            hipMemsetAsync((char *)sendl.p + count * 4, 0, (block - count) * 4, ctx->stream) != hipSuccess)
+            rc = cerr_(c, GHIP_EHIP, "sketch all-gather: hipMemsetAsync failed");
     }
-    int rc = count ? ghip_sketches_copy_into(ctx, local, sendh.p, sendl.p) : GHIP_OK;
-    if (rc) return cerr_(c, rc, std::string("sketch all-gather: ") + ghip_last_error(ctx));   // (tells the peers of a LOCAL group)
+    if (!rc && count && (rc = ghip_sketches_copy_into(ctx, local, sendh.p, sendl.p))) rc = cerr_(c, rc, std::string("sketch all-gather: ") + ghip_last_error(ctx));
+    if ((rc = agree(c, rc, "packing the sketch block"))) return rc;
     if ((rc = allgather_device(c, sendh.p, recvh.p, block * (size_t)s * 8))) return rc;
     if ((rc = allgather_device(c, sendl.p, recvl.p, block * 4))) return rc;
     ghip_sketches *full = nullptr;
@@ -522,14 +582,16 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
     ghip_ctx *ctx = c->ctx;
     if (!ctx) return GHIP_EINVAL;
     *out_pairs = nullptr; *out_n = 0; *out_replicated = 0;
+    c->agreed_failure = false;
     const size_t n = sk->n;
     const uint32_t s = sk->s, world = c->world, rank = c->rank;
-    const char *force = getenv("GHIP_PAIR_KERNEL"), *mode = getenv("GHIP_JOIN_RANKS");
-    const bool want = world > 1 && !(mode && (!strcmp(mode, "replicate") || !strcmp(mode, "records"))) &&
-                      (force ? !strcmp(force, "join") : (n >= GHIP_JOIN_MIN_N || s > 4096)) && (uint64_t)n * s < (1ull << 32) && n >= 2;
+    // (the options are per context: ranks of one job are expected to hold the same pair_form / join_ranks)
+    const uint32_t force = ctx->opt.pair_form, mode = ctx->opt.join_ranks;
+    const bool want = world > 1 && mode == GHIP_JOIN_HASH &&
+                      (force != GHIP_PAIR_AUTO ? force == GHIP_PAIR_JOIN : (n >= GHIP_JOIN_MIN_N || s > 4096)) && (uint64_t)n * s < (1ull << 32) && n >= 2;
     if (!want) return ghip_precluster_ranks(ctx, sk, min_ani, rank, world, out_pairs, out_n, out_replicated);
 
-    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_COMM);
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) { fprintf(stderr, "[precluster_comm rank %u] %s %.3f ms\n", rank, what, ms_since(t0)); t0 = std::chrono::steady_clock::now(); } };
     // ---- stage 1: my share of the hashes -> partial common per sharing pair
@@ -539,11 +601,12 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
     int rc = GHIP_OK;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        COMM_HIP(c, hipSetDevice(ctx->device));
-        rc = ghip_pair_filter_prepare(ctx, s, sk->k, min_ani);
+        if (hipSetDevice(ctx->device) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "hipSetDevice failed");   // (a flag of exchange 1, like every error of stage 1)
+        if (!rc) rc = ghip_pair_filter_prepare(ctx, s, sk->k, min_ani);
         floor = ctx->cmin.floor;
         // (min_ani <= 0: pairs without a common hash qualify -- the dense forms; the same verdict on every rank)
         if (!rc && floor != 0 && floor != 0xffffu) rc = ghip_pairs_join_partials(ctx, sk->d_hashes, sk->d_lens, n, s, rank, world, &d_ent, &n_ent, &status, &rec_total);
+        if (!rc && fault_here(c, GHIP_FAULT_PAIRS_STAGE1)) rc = ghip_set_error(ctx, GHIP_EHIP, "injected fault: pair stage 1");
     }
     struct Freer { ghip_ctx *ctx; void *&p; ~Freer() { if (p) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->stream); ghip_pool_free(ctx, p); } } } freer{ctx, d_ent};
     lap("stage 1 (partials)");
@@ -551,21 +614,24 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
     uint64_t mine3[3] = {(uint64_t)(rc ? 3 : status), rec_total, n_ent};
     std::vector<uint64_t> all3(3 * (size_t)world);
     const int rc_x = allgather_host(c, mine3, sizeof(mine3), all3.data());
-    if (rc) return rc;
     if (rc_x) return rc_x;
+    if (rc) { c->agreed_failure = true; return ghip_comm_note_error(c, rc); }   // (the peers read flag 3 in exchange 1: they return too)
     uint64_t any = 0, records = 0, m = 0;
     for (uint32_t r = 0; r < world; r++) { any |= all3[3 * r]; records += all3[3 * r + 1]; m = std::max<uint64_t>(m, all3[3 * r + 2]); }
     const uint64_t P = (uint64_t)n * (n - 1) / 2;
     // a dense pass costs ~1 ns per pair, a record ~0.3 ns: beyond 4 records per pair the dense kernel is the better tool
     if (any || records > 4 * P + (1u << 20) || records >= (1ull << 31) || m * world >= (1ull << 31))
-        return (any & 2) ? cerr_(c, GHIP_EHIP, "a peer rank failed in the pair stage") : ghip_precluster_ranks(ctx, sk, min_ani, rank, world, out_pairs, out_n, out_replicated);
+        return (any & 2) ? (c->agreed_failure = true, cerr_(c, GHIP_EPEER, "a peer rank failed in the pair stage (stage 1)")) : ghip_precluster_ranks(ctx, sk, min_ani, rank, world, out_pairs, out_n, out_replicated);
     lap("exchange 1");
-    // ---- exchange 2: the entries of every rank (blocks padded to the longest with key = 2^64 - 1)
+    // ---- exchange 2: the entries of every rank (blocks padded to the longest with key = 2^64 - 1).  Its buffers can only be
+    // sized now; a rank that cannot get them says so in a status word before anyone enters the device collective.
     const size_t block = std::max<uint64_t>(m, 1) * GHIP_JOIN_ENTRY_BYTES;
     PoolBuf sb(ctx, block), rb(ctx, block * world);
-    if (!sb.p || !rb.p) return cerr_(c, GHIP_EHIP, "out of device memory for the partial-count exchange");
-    COMM_HIP(c, hipMemsetAsync(sb.p, 0xff, block, ctx->stream));
-    if (n_ent) COMM_HIP(c, hipMemcpyAsync(sb.p, d_ent, (size_t)n_ent * GHIP_JOIN_ENTRY_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!sb.p || !rb.p) rc = cerr_(c, GHIP_EHIP, "out of device memory for the partial-count exchange");
+    if (!rc && (hipMemsetAsync(sb.p, 0xff, block, ctx->stream) != hipSuccess ||
+                (n_ent && hipMemcpyAsync(sb.p, d_ent, (size_t)n_ent * GHIP_JOIN_ENTRY_BYTES, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)))
+        rc = cerr_(c, GHIP_EHIP, "partial-count exchange: staging failed");
+    if ((rc = agree(c, rc, "staging the partial-count exchange"))) return rc;
     if ((rc = allgather_device(c, sb.p, rb.p, block))) return rc;
     lap("exchange 2");
     // ---- stage 2: the pairs I own
@@ -583,6 +649,7 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
         hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream);
         lap("stage 2 set-up");
         if (e == hipSuccess) rc = ghip_pairs_join_finish(ctx, rb.p, n_all, n_all, sk->d_hashes, sk->d_lens, s, ctx->cmin.d_cmin, floor, rank, world, d_out, d_count, cap, &ok);
+        if (e == hipSuccess && !rc && fault_here(c, GHIP_FAULT_PAIRS_STAGE2)) rc = ghip_set_error(ctx, GHIP_EHIP, "injected fault: pair stage 2");
         lap("stage 2 kernels");
         if (e == hipSuccess && !rc && ok) {
             e = hipMemcpyAsync(&cnt, d_count, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream);
@@ -635,7 +702,9 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     size_t first, count, block;
     ghip_shard_range(n_total, me, world, &first, &count, &block);
     if (local->n != count) return cerr_(c, GHIP_EINVAL, "local ANI index does not match this rank's block");
-    { std::lock_guard<std::mutex> lk(ctx->mu); if (ghip_index_wait(ctx, local) != GHIP_OK) return cerr_(c, GHIP_EHIP, "ANI index kernels failed"); }
+    int rc = GHIP_OK;
+    { std::lock_guard<std::mutex> lk(ctx->mu); if (ghip_index_wait(ctx, local) != GHIP_OK) rc = cerr_(c, GHIP_EHIP, "ANI index kernels failed"); }
+    if (!rc && fault_here(c, GHIP_FAULT_INDEX_PACK)) rc = cerr_(c, GHIP_EHIP, "injected fault: ANI index pack");
     for (size_t g = 0; g < n_total; g++) out_local_ids[g] = UINT32_MAX;
     for (size_t g = 0; g < count; g++) out_local_ids[first + g] = (uint32_t)g;
     // second genomes of pairs that span two ranks: wants[g] = the ranks (bit d of word d / 64) whose pairs reference g
@@ -643,11 +712,12 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     std::vector<uint64_t> wants(n_total * W, 0);
     bool any = false;
     for (size_t x = 0; x < n_pairs; x++) {
-        if (pairs[x].i >= n_total || pairs[x].j >= n_total) return cerr_(c, GHIP_EINVAL, "pair index out of range");
+        if (pairs[x].i >= n_total || pairs[x].j >= n_total) return cerr_(c, GHIP_EINVAL, "pair index out of range");   // (the list is the same on every rank: all return)
         const size_t d = pairs[x].i / block;
         if (d != pairs[x].j / block) { wants[pairs[x].j * W + d / 64] |= 1ull << (d % 64); any = true; }
     }
-    if (!any || world == 1) { *out_index = const_cast<ghip_ani_index *>(local); return GHIP_OK; }
+    if (world == 1) { if (rc) return rc; *out_index = const_cast<ghip_ani_index *>(local); return GHIP_OK; }
+    if (!any) { if ((rc = agree(c, rc, "the ANI index"))) return rc; *out_index = const_cast<ghip_ani_index *>(local); return GHIP_OK; }
     auto wanted_by = [&](size_t g, uint32_t d) { return (wants[g * W + d / 64] >> (d % 64)) & 1; };
     std::vector<uint32_t> needed;   // exchanged genomes, ascending: the same list on every rank
     for (size_t g = 0; g < n_total; g++) {
@@ -666,7 +736,8 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
         }
     std::vector<uint8_t> meta_all;
     std::vector<uint64_t> meta_sizes;
-    int rc = allgatherv_host(c, meta.data(), meta.size() * 8, meta_all, meta_sizes);
+    if ((rc = agree(c, rc, "the ANI index"))) return rc;
+    rc = allgatherv_host(c, meta.data(), meta.size() * 8, meta_all, meta_sizes);
     if (rc) return rc;
     const size_t n_recv = meta_all.size() / 24;
     if (n_recv != needed.size()) return cerr_(c, GHIP_EINVAL, "ranks disagree on the genomes to exchange");
@@ -702,29 +773,34 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
         {local->d_bin_start, &lbin, &cbin, nullptr},
         {local->d_chunk_total, &local->chunk_start, &cchunk, nullptr},
     };
-    COMM_HIP(c, hipSetDevice(ctx->device));
     std::vector<void *> owned;
-    auto drop = [&]() { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->stream); for (void *p : owned) ghip_pool_free(ctx, p); };
-    // every early return below goes through fail(): the peers are told (LOCAL: the group's flag; the others learn it at
-    // their next collective) and the combined arrays go back to the pool
-    auto fail = [&](int code, const std::string &msg) { drop(); return cerr_(c, code, msg); };
-    std::vector<uint64_t> runs, send_off(world + 1), recv_off(world + 1);
-    for (int fi = 0; fi < 4; fi++) {
+    auto drop = [&]() { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->stream); for (void *p : owned) ghip_pool_free(ctx, p); owned.clear(); };
+    // Phase 1 (local work only): the combined arrays, the local parts copied into them, and per array the slices every
+    // destination wants packed back to back.  Whatever fails here fails on this rank alone, so it is remembered, not
+    // returned: the status word after the phase takes every rank out together.  Phase 2: the four all-to-all-v exchanges.
+    struct Packed { void *send = nullptr; std::vector<uint64_t> send_off, recv_off; };
+    Packed packed[4];
+    std::vector<uint64_t> runs;
+    auto fail = [&](int code, const std::string &msg) { if (!rc) rc = cerr_(c, code, msg); };
+    if (hipSetDevice(ctx->device) != hipSuccess) fail(GHIP_EHIP, "hipSetDevice failed");
+    for (int fi = 0; fi < 4 && !rc; fi++) {
         Field &f = fields[fi];
+        Packed &pk = packed[fi];
+        pk.send_off.assign(world + 1, 0); pk.recv_off.assign(world + 1, 0);
         PoolBuf dst(ctx, std::max<uint64_t>((*f.cstart)[nc], 1) * 4);
-        if (!dst.p) return fail(GHIP_EHIP, "out of device memory for the combined ANI index");
+        if (!dst.p) { fail(GHIP_EHIP, "out of device memory for the combined ANI index"); break; }
         f.dst = static_cast<uint32_t *>(dst.release());
         owned.push_back(f.dst);
         // local part: one copy
         const uint64_t lbytes = (*f.lstart)[count] * 4;
         hipError_t e = lbytes ? hipMemcpyAsync(f.dst, f.src, lbytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
-        if (e != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
+        if (e != hipSuccess) { fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e)); break; }
         // what I send: per destination, the slices of my genomes it wants, packed back to back (consecutive genomes are
         // one run: they are neighbours in the index arrays)
         runs.clear();
         uint64_t at = 0;
         for (uint32_t d = 0; d < world; d++) {
-            send_off[d] = at * 4;
+            pk.send_off[d] = at * 4;
             if (d == me) continue;
             uint64_t prev_end = ~0ull;
             for (size_t l = 0; l < count; l++) {
@@ -737,28 +813,39 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
                 at += n;
             }
         }
-        send_off[world] = at * 4;
+        pk.send_off[world] = at * 4;
         // what I receive: my wanted genomes, owner by owner, land behind the local part in the combined layout
         {
             size_t w = 0;
             uint64_t got = 0;
             for (uint32_t r = 0; r < world; r++) {
-                recv_off[r] = got * 4;
+                pk.recv_off[r] = got * 4;
                 for (; w < wanted.size() && needed[wanted[w]] / block == r; w++) got += (*f.cstart)[count + w + 1] - (*f.cstart)[count + w];
             }
-            recv_off[world] = got * 4;
-            if (w != wanted.size() || got != (*f.cstart)[nc] - (*f.cstart)[count]) return fail(GHIP_EINVAL, "ANI index exchange: sizes do not add up");
+            pk.recv_off[world] = got * 4;
+            if (w != wanted.size() || got != (*f.cstart)[nc] - (*f.cstart)[count]) { fail(GHIP_EINVAL, "ANI index exchange: sizes do not add up"); break; }
         }
         PoolBuf sb(ctx, std::max<uint64_t>(at, 1) * 4), dr(ctx, std::max<size_t>(runs.size(), 1) * sizeof(uint64_t));
-        if (!sb.p || !dr.p) return fail(GHIP_EHIP, "out of device memory for the ANI index exchange");
+        if (!sb.p || !dr.p) { fail(GHIP_EHIP, "out of device memory for the ANI index exchange"); break; }
         if (!runs.empty()) {
             e = hipMemcpyAsync(dr.p, runs.data(), runs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (`runs` is pageable and reused by the next array)
-            if (e != hipSuccess) return fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e));
+            if (e != hipSuccess) { fail(GHIP_EHIP, std::string("ANI index exchange: ") + hipGetErrorString(e)); break; }
             ghip_launch_copy_runs(ctx->stream, f.src, static_cast<uint32_t *>(sb.p), static_cast<const uint64_t *>(dr.p), runs.size() / 3);
         }
-        if ((rc = exchange_device(c, sb.p, send_off.data(), (char *)f.dst + (*f.cstart)[count] * 4, recv_off.data()))) { drop(); return rc; }
-        // (exchange_device returns with the stream idle: sb and dr go back to the pool)
+        pk.send = sb.release();
+        owned.push_back(pk.send);
+        // (dr goes back to the pool here: its destructor waits for the stream, i.e. for copy_runs)
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) fail(GHIP_EHIP, "ANI index exchange: packing failed");
+    if ((rc = agree(c, rc, "packing the ANI index slices"))) { drop(); return rc; }
+    for (int fi = 0; fi < 4; fi++) {
+        Field &f = fields[fi];
+        if ((rc = exchange_device(c, packed[fi].send, packed[fi].send_off.data(), (char *)f.dst + (*f.cstart)[count] * 4, packed[fi].recv_off.data()))) { drop(); return rc; }
+    }
+    {   // the send buffers go back to the pool (exchange_device returns with the stream idle); the combined arrays stay
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (int fi = 0; fi < 4; fi++) { ghip_pool_free(ctx, packed[fi].send); owned.erase(std::find(owned.begin(), owned.end(), packed[fi].send)); }
     }
     ghip_ani_index *idx = nullptr;
     rc = ghip_ani_index_wrap_device(ctx, nc, local->k, local->c, local->chunk, glen.data(), cap.data(), cnt.data(), fields[0].dst,
@@ -770,8 +857,68 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
 }
 
 // ------------------------------------------------------------------------------------------------ one whole pass
+namespace {
+// What both whole-pass entry points share: sketch + seed this rank's block, gather the sketch matrix, the pair stage and its
+// gather, the ANI index slices.  A STATUS WORD is agreed at every phase boundary whose phase can fail on one rank alone
+// (sketching, the pair stage's second half): no rank walks into the next collective without the others.
+struct RankPass {
+    ghip_sketches *sk_l = nullptr, *sk = nullptr;
+    ghip_ani_index *idx_l = nullptr, *idx = nullptr;
+    ghip_pair *all = nullptr;
+    size_t n_all = 0, first = 0, count = 0, block = 0;
+    std::vector<uint32_t> local_ids;
+    bool keep_sketches = false;
+    ~RankPass() {
+        if (sk && sk != sk_l && !keep_sketches) ghip_sketches_free(sk);
+        if (sk_l && !(keep_sketches && sk == sk_l)) ghip_sketches_free(sk_l);
+        if (idx && idx != idx_l) ghip_ani_index_free(idx);
+        if (idx_l) ghip_ani_index_free(idx_l);
+    }
+};
+
+int rank_pass_front(ghip_comm *c, const ghip_genomes *local, size_t n_total, uint32_t k, uint32_t s, uint64_t seed, float min_ani,
+                    uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, RankPass &p, ghip_rank_times &tm) {
+    ghip_ctx *ctx = c->ctx;
+    c->agreed_failure = false;
+    ghip_shard_range(n_total, c->rank, c->world, &p.first, &p.count, &p.block);
+    if (local->n != p.count) return cerr_(c, GHIP_EINVAL, "local genome count does not match this rank's block");
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](double &slot) { slot += ms_since(t0); t0 = std::chrono::steady_clock::now(); };
+    int rc = ghip_sketch_and_index(ctx, local, k, s, seed, ani_k, ani_c, ani_chunk, &p.sk_l, &p.idx_l);
+    if (!rc && fault_here(c, GHIP_FAULT_SKETCH)) rc = ghip_set_error(ctx, GHIP_EHIP, "injected fault: sketch");
+    if (rc && c->group) c->group->fail();
+    if ((rc = agree(c, ghip_comm_note_error(c, rc), "sketching"))) return rc;
+    lap(tm.sketch_ms);
+    if (c->world == 1) p.sk = p.sk_l;
+    else if ((rc = ghip_allgather_sketches(c, p.sk_l, n_total, &p.sk))) return rc;
+    lap(tm.allgather_sketches_ms);
+    int replicated = 0;
+    ghip_pair *mine = nullptr;
+    size_t n_mine = 0;
+    rc = ghip_precluster_comm(c, p.sk, min_ani, &mine, &n_mine, &replicated);
+    // (an error the pair stage agreed on inside -- exchange 1, the staging of exchange 2 -- is held by every rank already;
+    // anything else is this rank's own and is agreed here)
+    if (rc && c->agreed_failure) return rc;
+    if (rc && c->group) c->group->fail();
+    if ((rc = agree(c, ghip_comm_note_error(c, rc), "the pair stage"))) { ghip_free(mine); return rc; }
+    tm.pairs_compared = ghip_last_pairs_compared(ctx);
+    lap(tm.pairs_ms);
+    if (c->world == 1 || replicated) { p.all = mine; p.n_all = n_mine; }
+    else {
+        rc = ghip_allgather_pairs(c, mine, n_mine, &p.all, &p.n_all);
+        ghip_free(mine);
+        if (rc) return rc;
+    }
+    lap(tm.allgather_pairs_ms);
+    p.local_ids.resize(std::max<size_t>(n_total, 1));
+    if ((rc = ghip_exchange_ani_index(c, p.idx_l, n_total, p.all, p.n_all, &p.idx, p.local_ids.data()))) { ghip_free(p.all); p.all = nullptr; return rc; }
+    lap(tm.exchange_ani_index_ms);
+    return GHIP_OK;
+}
+}  // namespace
+
 // FinchPreclusterer::distances + the batched ClusterDistanceFinder::calculate_ani of one dereplication job, on this
-// rank's block of genomes; every rank returns the same (pairs, ani).
+// rank's block of genomes, EVERY precluster pair's ANI (eager); every rank returns the same (pairs, ani).
 extern "C" int ghip_distances_and_ani_ranks(ghip_comm *c, const ghip_genomes *local, size_t n_total, uint32_t k, uint32_t s,
                                             uint64_t seed, float min_ani, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk,
                                             float min_aligned_fraction, ghip_pair **out_pairs, float **out_ani, size_t *out_n,
@@ -782,73 +929,80 @@ extern "C" int ghip_distances_and_ani_ranks(ghip_comm *c, const ghip_genomes *lo
     *out_pairs = nullptr; *out_ani = nullptr; *out_n = 0;
     if (out_sketches) *out_sketches = nullptr;
     ghip_rank_times tm{};
-    size_t first, count, block;
-    ghip_shard_range(n_total, c->rank, c->world, &first, &count, &block);
-    if (local->n != count) return cerr_(c, GHIP_EINVAL, "local genome count does not match this rank's block");
+    RankPass p;
+    int rc = rank_pass_front(c, local, n_total, k, s, seed, min_ani, ani_k, ani_c, ani_chunk, p, tm);
+    if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](double &slot) { slot += ms_since(t0); t0 = std::chrono::steady_clock::now(); };
-
-    ghip_sketches *sk_l = nullptr, *sk = nullptr;
-    ghip_ani_index *idx_l = nullptr, *idx = nullptr;
-    ghip_pair *mine = nullptr, *all = nullptr;
-    size_t n_mine = 0, n_all = 0;
-    std::vector<uint32_t> local_ids;
-    float *ani = nullptr;
-    auto cleanup = [&]() {
-        if (sk && sk != sk_l && !(out_sketches && *out_sketches == sk)) ghip_sketches_free(sk);
-        if (sk_l && !(out_sketches && *out_sketches == sk_l)) ghip_sketches_free(sk_l);
-        if (idx && idx != idx_l) ghip_ani_index_free(idx);
-        if (idx_l) ghip_ani_index_free(idx_l);
-        if (mine && mine != all) ghip_free(mine);
-    };
-    int rc = ghip_sketch_and_index(ctx, local, k, s, seed, ani_k, ani_c, ani_chunk, &sk_l, &idx_l);
-    if (rc) { if (c->group) c->group->fail(); cleanup(); return rc; }
-    lap(tm.sketch_ms);
-    if (c->world == 1) sk = sk_l;
-    else if ((rc = ghip_allgather_sketches(c, sk_l, n_total, &sk))) { cleanup(); return rc; }
-    lap(tm.allgather_sketches_ms);
-    int replicated = 0;
-    rc = ghip_precluster_comm(c, sk, min_ani, &mine, &n_mine, &replicated);
-    if (rc) { if (c->group) c->group->fail(); cleanup(); return rc; }
-    tm.pairs_compared = ghip_last_pairs_compared(ctx);
-    lap(tm.pairs_ms);
-    if (c->world == 1 || replicated) { all = mine; n_all = n_mine; }
-    else if ((rc = ghip_allgather_pairs(c, mine, n_mine, &all, &n_all))) { cleanup(); return rc; }
-    lap(tm.allgather_pairs_ms);
-    local_ids.resize(std::max<size_t>(n_total, 1));
-    if ((rc = ghip_exchange_ani_index(c, idx_l, n_total, all, n_all, &idx, local_ids.data()))) { cleanup(); if (all) ghip_free(all); return rc; }
-    lap(tm.exchange_ani_index_ms);
+    ghip_pair *all = p.all;
+    const size_t n_all = p.n_all, block = p.block;
     // my share: the pairs whose first genome I own -- a consecutive run of the (i, j)-sorted list
     size_t lo = 0, hi = 0;
     {
-        auto owner = [&](const ghip_pair &p) { return p.i / block; };
-        lo = std::partition_point(all, all + n_all, [&](const ghip_pair &p) { return owner(p) < c->rank; }) - all;
-        hi = std::partition_point(all, all + n_all, [&](const ghip_pair &p) { return owner(p) <= c->rank; }) - all;
+        auto owner = [&](const ghip_pair &q) { return q.i / block; };
+        lo = std::partition_point(all, all + n_all, [&](const ghip_pair &q) { return owner(q) < c->rank; }) - all;
+        hi = std::partition_point(all, all + n_all, [&](const ghip_pair &q) { return owner(q) <= c->rank; }) - all;
     }
     std::vector<uint32_t> pi(2 * (hi - lo));
-    for (size_t x = lo; x < hi; x++) { pi[2 * (x - lo)] = local_ids[all[x].i]; pi[2 * (x - lo) + 1] = local_ids[all[x].j]; }
+    for (size_t x = lo; x < hi; x++) { pi[2 * (x - lo)] = p.local_ids[all[x].i]; pi[2 * (x - lo) + 1] = p.local_ids[all[x].j]; }
     std::vector<float> ani_mine(hi - lo);
-    if (hi > lo && (rc = ghip_ani_pairs(ctx, idx, pi.data(), hi - lo, min_aligned_fraction, ani_mine.data(), nullptr))) {
-        if (c->group) c->group->fail();
-        cleanup(); ghip_free(all); return rc;
-    }
+    rc = hi > lo ? ghip_ani_pairs(ctx, p.idx, pi.data(), hi - lo, min_aligned_fraction, ani_mine.data(), nullptr) : GHIP_OK;
+    if (!rc && fault_here(c, GHIP_FAULT_ANI_ROUND)) rc = ghip_set_error(ctx, GHIP_EHIP, "injected fault: ANI share");
+    if (rc && c->group) c->group->fail();
+    if ((rc = agree(c, ghip_comm_note_error(c, rc), "the ANI shares"))) { ghip_free(all); return rc; }
     lap(tm.ani_pairs_ms);
-    ani = (float *)malloc(std::max<size_t>(n_all, 1) * sizeof(float));
-    if (!ani) { cleanup(); ghip_free(all); return cerr_(c, GHIP_ENOMEM, "out of host memory for the ANI values"); }
+    float *ani = (float *)malloc(std::max<size_t>(n_all, 1) * sizeof(float));
+    if ((rc = agree(c, ani ? GHIP_OK : GHIP_ENOMEM, "the ANI values' host buffer"))) { ghip_free(all); free(ani); return rc; }
     if (c->world == 1) { if (n_all) memcpy(ani, ani_mine.data(), n_all * sizeof(float)); }
     else {  // the ranks' runs are consecutive in rank order: a variable-length gather IS the whole array
         std::vector<uint8_t> got;
         std::vector<uint64_t> sizes(c->world, 0);   // every rank can count every rank's run from the list: one collective less
         for (size_t x = 0; x < n_all; x++) sizes[all[x].i / block] += sizeof(float);
-        if ((rc = allgatherv_host(c, ani_mine.data(), ani_mine.size() * sizeof(float), got, sizes, true))) { cleanup(); ghip_free(all); free(ani); return rc; }
-        if (got.size() != n_all * sizeof(float)) { cleanup(); ghip_free(all); free(ani); return cerr_(c, GHIP_EINVAL, "ANI gather: sizes do not add up"); }
+        if ((rc = allgatherv_host(c, ani_mine.data(), ani_mine.size() * sizeof(float), got, sizes, true))) { ghip_free(all); free(ani); return rc; }
+        if (got.size() != n_all * sizeof(float)) { ghip_free(all); free(ani); return cerr_(c, GHIP_EINVAL, "ANI gather: sizes do not add up"); }
         if (n_all) memcpy(ani, got.data(), got.size());
     }
     lap(tm.gather_ani_ms);
-    if (out_sketches) *out_sketches = sk;
-    cleanup();
+    if (out_sketches) { *out_sketches = p.sk; p.keep_sketches = true; }
     *out_pairs = all; *out_ani = ani; *out_n = n_all;
     if (times) *times = tm;
+    return GHIP_OK;
+}
+
+// clusterer::cluster of one dereplication job over the ranks (src/clusterer.rs:14-152 with the finch preclusterer and the
+// batched ANI clusterer): the same front, then the LAZY rounds of the native clusterer with each round's requests dealt
+// to the ranks (ghip_cluster_index_comm) -- the algorithm one rank runs (ghip_cluster_index), for every world size.  Every
+// rank returns the same clusters (and, when asked, the same pair list).  order (nullable): galah's quality order.
+extern "C" int ghip_cluster_ranks(ghip_comm *c, const ghip_genomes *local, size_t n_total, uint32_t k, uint32_t s, uint64_t seed,
+                                  float min_ani, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, float min_aligned_fraction,
+                                  const uint32_t *order, float ani_threshold, uint32_t **out_members, uint64_t **out_offsets,
+                                  size_t *out_n_clusters, ghip_pair **out_pairs /* nullable */, size_t *out_n_pairs /* nullable */,
+                                  ghip_sketches **out_sketches /* nullable */, ghip_cluster_times *times /* nullable */) {
+    if (!c || !local || !out_members || !out_offsets || !out_n_clusters) return GHIP_EINVAL;
+    ghip_ctx *ctx = c->ctx;
+    if (!ctx) return GHIP_EINVAL;
+    *out_members = nullptr; *out_offsets = nullptr; *out_n_clusters = 0;
+    if (out_pairs) *out_pairs = nullptr;
+    if (out_n_pairs) *out_n_pairs = 0;
+    if (out_sketches) *out_sketches = nullptr;
+    ghip_rank_times tm{};
+    RankPass p;
+    int rc = rank_pass_front(c, local, n_total, k, s, seed, min_ani, ani_k, ani_c, ani_chunk, p, tm);
+    if (rc) return rc;
+    uint64_t st[5] = {0, 0, 0, 0, 0};
+    const bool identity = p.idx == p.idx_l;   // nothing was exchanged: the local index serves global ids only on one rank
+    rc = ghip_cluster_index_comm(c, p.idx, (identity && c->world == 1) ? nullptr : p.local_ids.data(), n_total, p.all, p.n_all, order, ani_threshold,
+                                 min_aligned_fraction, out_members, out_offsets, out_n_clusters, st);
+    if (rc) { ghip_free(p.all); return ghip_comm_note_error(c, rc); }
+    if (times) {
+        times->sketch_ms = tm.sketch_ms; times->allgather_sketches_ms = tm.allgather_sketches_ms; times->pairs_ms = tm.pairs_ms;
+        times->allgather_pairs_ms = tm.allgather_pairs_ms; times->exchange_ani_index_ms = tm.exchange_ani_index_ms;
+        times->ani_rounds_ms = (double)st[2] * 1e-6; times->cluster_host_ms = (double)(st[3] - st[2]) * 1e-6;
+        times->pairs_compared = tm.pairs_compared; times->ani_pairs_asked = st[0]; times->ani_pairs_here = st[4]; times->lazy_rounds = st[1];
+    }
+    if (out_sketches) { *out_sketches = p.sk; p.keep_sketches = true; }
+    if (out_pairs) { *out_pairs = p.all; if (out_n_pairs) *out_n_pairs = p.n_all; }
+    else { if (out_n_pairs) *out_n_pairs = p.n_all; ghip_free(p.all); }
     return GHIP_OK;
 }
 

@@ -56,8 +56,13 @@ struct ghip_io_pool {
     void shutdown();
 };
 
+// process-wide default options: the environment, read once (api.cpp); ghip_set_options(NULL, ..) replaces them
+ghip_options ghip_process_options();
+inline bool ghip_dbg(const ghip_options &o, uint32_t bit) { return (o.debug & bit) != 0; }
+
 struct ghip_ctx {
     int device = 0;
+    ghip_options opt{};   // copied from the process-wide defaults at ghip_init; ghip_set_options(ctx, ..)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // work that overlaps the main stream's next stage (the deferred ani_bin); made on first use
@@ -179,6 +184,11 @@ struct ghip_ani_index {
     mutable hipEvent_t bin_done = nullptr;
     mutable std::vector<void *> bin_scratch;
 };
+// comm.cpp, for the lazy ANI rounds of cluster.cpp: variable-length host all-gather whose sizes every rank already knows
+// (one collective; out = the blocks in rank order); whether options.fault_stage names `stage` on this rank
+int ghip_comm_gatherv_known(ghip_comm *c, const void *send, size_t bytes, std::vector<uint64_t> &sizes, std::vector<uint8_t> &out);
+bool ghip_comm_fault(const ghip_comm *c, uint32_t stage);
+int ghip_comm_note_error(ghip_comm *c, int rc);   // rc != 0: the context's last error text becomes the communicator's too; returns rc
 int ghip_index_wait(ghip_ctx *ctx, const ghip_ani_index *idx);   // ctx->mu held; returns an error if the deferred kernel failed
 
 #define GHIP_ANI_BIN_BITS 14

@@ -66,8 +66,6 @@ struct LibDeflate {
     void (*release)(void *) = nullptr;
     int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
     LibDeflate() {
-        const char *off = getenv("GHIP_NO_LIBDEFLATE");
-        if (off && *off && *off != '0') return;
         void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
@@ -80,7 +78,7 @@ struct LibDeflate {
 // All members of the gzip image `raw` into dst (sized from the last member's ISIZE, doubled while a member lacks room).
 bool gunzip_libdeflate(const std::vector<uint8_t> &raw, std::vector<uint8_t> &dst, size_t isize) {
     static const LibDeflate lib;
-    if (!lib.alloc) return false;
+    if (!lib.alloc || !ghip_process_options().use_libdeflate) return false;   // (process-wide: the parser has no context)
     void *d = lib.alloc();
     if (!d) return false;
     dst.resize(std::max<size_t>(isize, 1 << 16));
@@ -409,13 +407,25 @@ bool ghip_slurp(const char *path, std::vector<uint8_t> &buf) { return slurp(path
 // is replaced by one 'N', so a plain file's stream is no longer than the file; for a single-member gzip the
 // trailer holds the uncompressed size (mod 2^32).  0 = unknown (unreadable; the parse reports the error).
 uint64_t ghip_stream_capacity_hint(const char *path) {
-    {   // a name that does not end in ".gz": the file size bounds the stream -- one system call instead of five.  (A gzip
-        // file without the extension then outgrows its hint; the ingest notices and takes the two-phase form.)
+    {   // a name that does not end in ".gz": the file size bounds the stream -- one system call instead of five.  But a gzip
+        // file WITHOUT the extension must not pass for plain text where it matters: the hint also cuts the batches and pieces
+        // of ghip_sketch_and_index_files, which would exceed their byte budget by the compression ratio.  Files
+        // above 256 KiB therefore get their first two bytes read (gzip: 1f 8b); small files are grouped by size, cost
+        // nothing to under-estimate (the ingest notices and takes the two-phase form) and keep the stat-only path -- the
+        // 100 000-contig workload makes 100 000 of these calls.
         const size_t l = strlen(path);
         if (!(l > 3 && !strcmp(path + l - 3, ".gz"))) {
             struct stat st;
             if (stat(path, &st) != 0) return 0;
-            return (uint64_t)st.st_size + 1;
+            bool gzip_magic = false;
+            if (st.st_size > (256 << 10)) {
+                if (FILE *f0 = fopen(path, "rb")) {
+                    unsigned char m[2] = {0, 0};
+                    gzip_magic = fread(m, 1, 2, f0) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+                    fclose(f0);
+                }
+            }
+            if (!gzip_magic) return (uint64_t)st.st_size + 1;
         }
     }
     FILE *f = fopen(path, "rb");

@@ -287,7 +287,7 @@ void ghip_launch_pairs(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *
     const unsigned grid = (unsigned)std::min<uint64_t>(my_tiles, 1u << 21);  // x 1024 threads < 2^32 work-items
     hipLaunchKernelGGL(pair_intersect_tile_kernel, dim3(grid), dim3(PAIR_THREADS), lds_bytes,
                        ctx->stream, d_hashes, d_lens, (uint32_t)n, s, s_pad, sp, pt, nt, n_tilepairs, rank,
-                       world, row_lo, d_cmin, d_out, d_count, cap, getenv("GHIP_PAIR_DEBUG") ? atoi(getenv("GHIP_PAIR_DEBUG")) : 0);
+                       world, row_lo, d_cmin, d_out, d_count, cap, (int)ctx->opt.pair_debug);
     ghip_prof_end(ctx);
 }
 

@@ -628,7 +628,7 @@ template <typename Src>
 int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_t total_t, uint32_t n_valid_bound, uint32_t bits2,
               bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */) {
     const uint32_t nb = 256u << bits2;
-    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_COMM);
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "    [partition] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
     uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256);   // hist1 | start1 | cursor1
@@ -886,7 +886,7 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 8 * sizeof(uint32_t), ctx->stream));
     ghip_prof_begin(ctx, "pair_join");
     auto done = [&](int rc) { ghip_prof_end(ctx); return rc; };
-    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_COMM);
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) { hipStreamSynchronize(ctx->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  [join_partials] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
     uint64_t *ek = nullptr; uint32_t *ev = nullptr, *d_estart = nullptr;
@@ -946,7 +946,7 @@ int ghip_pairs_join_finish(ghip_ctx *ctx, const void *d_all, uint32_t n_all, uin
                            uint32_t s, const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
                            unsigned long long *d_count, uint64_t cap, bool *ok) {
     *ok = false;
-    const bool dbg = getenv("GHIP_COMM_DEBUG") != nullptr;
+    const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_COMM);
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  [join_finish] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
     struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};

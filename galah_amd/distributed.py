@@ -203,6 +203,61 @@ class Comm:
         times["_pairs_compared"] = int(tm.pairs_compared)
         return pairs, ani, times, (Sketches(self.ctx, sk) if want_sketches else None)
 
+    def cluster_ranks(self, genomes, n_total: int, kmer: int, sketch_size: int, min_ani, ani_k: int, ani_c: int, ani_chunk: int,
+                      min_af: float, ani_threshold, order=None, want_pairs: bool = True, want_sketches: bool = False):
+        """ghip_cluster_ranks: the whole pass with the LAZY ANI rounds of the native clusterer dealt over the ranks -- the
+        algorithm one rank runs, for every world size.  Every rank gets the same result.
+        -> (clusters, pairs or None, stage milliseconds + counters, gathered Sketches or None)."""
+        from .engine import ClusterList, Sketches
+        L = _lib.lib()
+        members, offsets, nc = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        pp, npairs, sk = C.c_void_p(), C.c_size_t(0), C.c_void_p()
+        tm = _lib.ClusterTimes()
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+            assert order.shape == (n_total,)
+        self._check(L.ghip_cluster_ranks(self._h, genomes._h, n_total, kmer, sketch_size, 0, np.float32(min_ani), ani_k, ani_c, ani_chunk,
+                                         np.float32(min_af), order.ctypes.data if order is not None else None, np.float32(ani_threshold),
+                                         C.byref(members), C.byref(offsets), C.byref(nc), C.byref(pp) if want_pairs else None,
+                                         C.byref(npairs), C.byref(sk) if want_sketches else None, C.byref(tm)))
+        try:
+            off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), shape=(nc.value + 1,)).copy()
+            mem = np.ctypeslib.as_array(C.cast(members, C.POINTER(C.c_uint32)), shape=(max(int(off[-1]), 1),)).copy()
+        finally:
+            L.ghip_free(members)
+            L.ghip_free(offsets)
+        pairs = _take(pp, npairs.value, PAIR_DTYPE) if want_pairs else None
+        times = {k: (float(getattr(tm, k)) if k.endswith("_ms") else int(getattr(tm, k))) for k, _ in _lib.ClusterTimes._fields_}
+        times["n_pairs"] = int(npairs.value)
+        return ClusterList(mem, off), pairs, times, (Sketches(self.ctx, sk) if want_sketches else None)
+
+    def cluster_index(self, idx, local_ids, n_total: int, pairs: np.ndarray, ani_threshold, min_af: float = 0.15, order=None):
+        """ghip_cluster_index_comm (every rank calls it with the same pair list): -> (clusters, stats)."""
+        from .engine import ClusterList
+        L = _lib.lib()
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        ids = None if local_ids is None else np.ascontiguousarray(local_ids, dtype=np.uint32)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+        members, offsets, nc = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        stats = np.zeros(5, dtype=np.uint64)
+        self._check(L.ghip_cluster_index_comm(self._h, idx._h if idx is not None else None, ids.ctypes.data if ids is not None else None, n_total,
+                                              pairs.ctypes.data, pairs.shape[0], order.ctypes.data if order is not None else None,
+                                              np.float32(ani_threshold), np.float32(min_af), C.byref(members), C.byref(offsets), C.byref(nc),
+                                              stats.ctypes.data))
+        try:
+            off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), shape=(nc.value + 1,)).copy()
+            mem = np.ctypeslib.as_array(C.cast(members, C.POINTER(C.c_uint32)), shape=(max(int(off[-1]), 1),)).copy()
+        finally:
+            L.ghip_free(members)
+            L.ghip_free(offsets)
+        return ClusterList(mem, off), {"asked": int(stats[0]), "rounds": int(stats[1]), "ani_ms": float(stats[2]) * 1e-6,
+                                       "total_ms": float(stats[3]) * 1e-6, "asked_here": int(stats[4])}
+
+    def agree(self, status: int = 0):
+        """ghip_comm_agree: raises on every rank when any rank passes a non-zero status."""
+        self._check(_lib.lib().ghip_comm_agree(self._h, int(status)))
+
     def close(self):
         if self._h:
             _lib.lib().ghip_comm_destroy(self._h)
@@ -292,10 +347,11 @@ class DereplicationJob:
         self.min_ani, self.ani_threshold, self.min_af = np.float32(min_ani), np.float32(ani_threshold), float(min_af)
         self.comm = comm if comm is not None else make_comm(ctx, rank, world, backend)
         self.first, self.count, self.block = shard_range(n_genomes, rank, world)
-        # one rank: ask the clusterer's ANI lazily, in batches, only for the pairs the greedy rules look at
-        # (ghip_cluster_lazy) -- what the reference does one `skani dist` at a time; several ranks compute every
-        # precluster pair's ANI in parallel shares instead (ghip_distances_and_ani_ranks)
-        self.lazy_ani = lazy_ani and world == 1
+        # lazy_ani: the clusterer's ANI is asked for lazily, in batches, only for the pairs the greedy rules look at -- what the
+        # reference does one `skani dist` at a time (src/clusterer.rs:194-204, 377-405) -- by the native clusterer, for EVERY
+        # world size (ghip_cluster_ranks: a round's requests are dealt to the ranks).  Otherwise every precluster pair's ANI is
+        # computed in parallel shares (ghip_distances_and_ani_ranks) and rank 0 clusters from the values.
+        self.lazy_ani = lazy_ani
         self.last_pairs_asked = 0
         self.genomes = None
         self._stage: Dict[str, float] = {}
@@ -310,7 +366,7 @@ class DereplicationJob:
         representative.  Sketches, pairs and ANI are computed where the genomes lie; the pair list is re-indexed and re-sorted
         before the greedy clusterer, whose clusters then hold positions in `order`."""
         order = np.asarray(order, dtype=np.int64)
-        assert self.world == 1 and sorted(order.tolist()) == list(range(self.n))
+        assert self.lazy_ani and sorted(order.tolist()) == list(range(self.n))
         self.order = order.astype(np.uint32)
 
     def load_synthetic(self, seed: int, members: int, length: int, sub_rate: float):
@@ -335,24 +391,22 @@ class DereplicationJob:
         return self._full.to_host()
 
     def _step_lazy(self) -> Dict:
-        t0 = time.perf_counter()
-        sk, idx = self.ctx.sketch_and_index(self.genomes, self.kmer, self.s, 0, self.ani_k, self.ani_c, self.ani_chunk)
-        t1 = time.perf_counter()
-        pairs = self.ctx.precluster(sk, self.min_ani)
-        self.last_pairs_compared = self.ctx.last_pairs_compared
-        t2 = time.perf_counter()
-        # clusterer::cluster in native code (ghip_cluster_index): the lazy rounds are answered by the resident ANI index;
-        # with a quality order the clusterer sees the genomes in that order and the clusters hold positions in it
-        clusters, st = self.ctx.cluster_index(idx, self.n, pairs, self.ani_threshold, self.min_af, self.order)
-        t3 = time.perf_counter()
-        idx.free()
-        self._full = sk
-        self.last_pairs_asked = st["asked"]
-        for k, v in (("sketch", t1 - t0), ("pairs", t2 - t1), ("ani_pairs", st["ani_ms"] * 1e-3), ("host_cluster", t3 - t2 - st["ani_ms"] * 1e-3)):
-            self._stage[k] = self._stage.get(k, 0.0) + v * 1e3
+        # clusterer::cluster in native code (ghip_cluster_ranks): sketch + seed, (gather), pair stage, (gather, index slices),
+        # then the lazy rounds answered by the resident ANI index on the rank that owns each pair; with a quality order the
+        # clusterer sees the genomes in that order and the clusters hold positions in it.  Every rank returns the same clusters.
+        clusters, pairs, tm, self._full = self.comm.cluster_ranks(self.genomes, self.n, self.kmer, self.s, self.min_ani, self.ani_k, self.ani_c,
+                                                                 self.ani_chunk, self.min_af, self.ani_threshold, self.order,
+                                                                 want_pairs=True, want_sketches=True)
+        self.last_pairs_compared = tm["pairs_compared"]
+        self.last_pairs_asked = tm["ani_pairs_asked"]
+        for k, v in (("sketch", tm["sketch_ms"]), ("allgather_sketches", tm["allgather_sketches_ms"]), ("pairs", tm["pairs_ms"]),
+                     ("allgather_pairs", tm["allgather_pairs_ms"]), ("exchange_ani_index", tm["exchange_ani_index_ms"]),
+                     ("ani_pairs", tm["ani_rounds_ms"]), ("host_cluster", tm["cluster_host_ms"])):
+            if self.world > 1 or k in ("sketch", "pairs", "ani_pairs", "host_cluster"):
+                self._stage[k] = self._stage.get(k, 0.0) + v
         self._steps += 1
         return {"n_pairs": len(pairs), "n_clusters": len(clusters), "clusters": clusters, "pairs": pairs, "pair_ani": None,
-                "ani_pairs_asked": st["asked"], "lazy_rounds": st["rounds"]}
+                "ani_pairs_asked": tm["ani_pairs_asked"], "ani_pairs_here": tm["ani_pairs_here"], "lazy_rounds": tm["lazy_rounds"]}
 
     def step(self) -> Dict:
         if self._full is not None:

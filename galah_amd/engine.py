@@ -4,6 +4,7 @@ Plumbing only -- every call goes straight to libgalah_hip.so; nothing here compu
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -151,6 +152,22 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # ---- options (ghip_options: what the GHIP_* environment variables only seed the defaults of)
+    def options(self) -> Dict[str, int]:
+        return _lib.get_options(self._h)
+
+    def set_options(self, **fields) -> Dict[str, int]:
+        """Change the named ghip_options fields of THIS context; returns their previous values."""
+        return _lib.set_options(self._h, **fields)
+
+    @contextlib.contextmanager
+    def with_options(self, **fields):
+        old = self.set_options(**fields)
+        try:
+            yield self
+        finally:
+            self.set_options(**old)
 
     # ---- plumbing
     def set_stream(self, hip_stream: Optional[int]):

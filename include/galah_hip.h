@@ -34,8 +34,9 @@ extern "C" {
 #define GHIP_ENOMEM 4   /* host allocation failure */
 #define GHIP_EUNSUPPORTED 5 /* mode the finch back-end refuses (src/finch.rs:14-15,26-41) */
 #define GHIP_ECALLBACK 6    /* the ANI callback of ghip_cluster returned < 0 (its calculate_ani failed) */
+#define GHIP_EPEER 7        /* multi-rank call: ANOTHER rank failed; every rank returns together (the failing one with its own code) */
 
-#define GHIP_ABI_VERSION 1
+#define GHIP_ABI_VERSION 2   /* 2: ghip_options, ghip_comm_agree, ghip_cluster_index_comm, ghip_cluster_ranks */
 
 typedef struct ghip_ctx ghip_ctx;           /* one per (process, GPU) */
 typedef struct ghip_genomes ghip_genomes;   /* normalised base streams resident in HBM */
@@ -61,6 +62,45 @@ int ghip_set_stream(ghip_ctx *ctx, void *hip_stream);
 int ghip_synchronize(ghip_ctx *ctx);
 /* Async device-to-device copy on the ctx stream (moves index arrays into exchange buffers). */
 int ghip_memcpy_d2d(ghip_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes);
+
+/* ---------------------------------------------------------------- options
+ * Every switch the library has, as a struct set PER CONTEXT (round 4; until then 28 getenv sites inside the library, which a
+ * Rust host cannot set per call and which are not thread-safe against setenv).  The environment variables named below are
+ * read ONCE, when the process-wide defaults are first needed, and only seed those defaults; a context copies the defaults
+ * at ghip_init; ghip_set_options(ctx, ..) changes one context, ghip_set_options(NULL, ..) the process-wide defaults (what
+ * the context-less entry points -- ghip_cluster*, ghip_fasta_stream -- and later ghip_init calls use).  Set struct_size =
+ * sizeof(ghip_options); a shorter struct from an older host sets the fields it has.  Call with no other call of the
+ * context in flight. */
+enum { GHIP_PAIR_AUTO = 0, GHIP_PAIR_JOIN = 1, GHIP_PAIR_PROBE = 2, GHIP_PAIR_MERGE = 3 };       /* GHIP_PAIR_KERNEL=join|probe|merge */
+enum { GHIP_JOIN_HASH = 0, GHIP_JOIN_RECORDS = 1, GHIP_JOIN_REPLICATE = 2 };                     /* GHIP_JOIN_RANKS=records|replicate */
+enum { GHIP_INGEST_PACKED = 0, GHIP_INGEST_ASCII = 1, GHIP_INGEST_PAGEABLE = 2, GHIP_INGEST_TWO_PHASE = 3 };  /* GHIP_INGEST=ascii|pageable|two-phase */
+enum { GHIP_DEBUG_INGEST = 1, GHIP_DEBUG_PRECLUSTER = 2, GHIP_DEBUG_COMM = 4, GHIP_DEBUG_CLUSTER = 8, GHIP_DEBUG_ANI = 16 };  /* GHIP_*_DEBUG: host laps on stderr */
+/* where ghip_options.fault_stage makes rank fault_rank fail (tests of the multi-rank error paths; 0 = never) */
+enum { GHIP_FAULT_NONE = 0, GHIP_FAULT_SKETCH = 1, GHIP_FAULT_PAIRS_STAGE1 = 2, GHIP_FAULT_PAIRS_STAGE2 = 3, GHIP_FAULT_INDEX_PACK = 4,
+       GHIP_FAULT_ANI_ROUND = 5 };
+typedef struct ghip_options {
+    uint32_t struct_size;       /* sizeof(ghip_options) of the caller */
+    uint32_t pair_form;         /* GHIP_PAIR_*: form of the pair stage (AUTO: by n and s; JOIN still declines what it cannot do) */
+    uint32_t join_ranks;        /* GHIP_JOIN_*: how several ranks share the join (HASH: hash-sharded, the default) */
+    uint32_t ingest_form;       /* GHIP_INGEST_*: how file bytes reach the device (PACKED: 2-bit codes + runs, the default) */
+    uint32_t ingest_groups;     /* 1 (default): small files are ingested in groups; 0: one by one   (GHIP_INGEST_NO_GROUPS) */
+    uint32_t io_threads_plain;  /* reader threads for plain files, 0 = from the CPU quota   (GHIP_INGEST_THREADS_PLAIN) */
+    uint32_t io_threads_gz;     /* inflating threads, 0 = from the CPU quota                (GHIP_INGEST_THREADS_GZ) */
+    uint32_t copy_streams;      /* 1..4 host-to-device copy streams of the ingest, default 2 (GHIP_COPY_STREAMS) */
+    uint32_t use_libdeflate;    /* 1 (default): libdeflate when the host has it; 0: zlib     (GHIP_NO_LIBDEFLATE) */
+    uint32_t pipeline_pieces;   /* 1 (default): plain inputs above 1 GiB are ingested in pieces next to the kernels (GHIP_PIPELINE=0) */
+    uint32_t overlap_binning;   /* 1 (default): ani_bin runs on the side stream next to the pair stage (GHIP_NO_OVERLAP) */
+    uint32_t lazy_flush_below;  /* a lazy ANI round of fewer requests asks for everything still open, default 512 (GHIP_LAZY_FLUSH_BELOW) */
+    uint32_t cluster_threads;   /* worker threads of the host clusterer, 0 = by size         (GHIP_CLUSTER_THREADS) */
+    uint32_t ani_force_general; /* 1: every pair through the general ani_pairs form (measurement aid) (GHIP_ANI_FORCE_GENERAL) */
+    uint32_t ani_tall_below;    /* pair lists shorter than this run 16 waves per pair, default 200 (GHIP_ANI_TALL_BELOW) */
+    uint32_t debug;             /* GHIP_DEBUG_* bits */
+    uint32_t pair_debug;        /* merge-path kernel's debug selector (GHIP_PAIR_DEBUG) */
+    uint32_t fault_stage;       /* GHIP_FAULT_*: tests only */
+    uint32_t fault_rank;
+} ghip_options;
+int ghip_get_options(const ghip_ctx *ctx /* NULL: the process-wide defaults */, ghip_options *out);
+int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const ghip_options *opt);
 
 /* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:
  * "sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_tile", "ani_seeds", "ani_bin",
@@ -288,6 +328,37 @@ int ghip_distances_and_ani_ranks(ghip_comm *comm, const ghip_genomes *local, siz
                                  uint64_t seed, float min_ani_fraction, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk,
                                  float min_aligned_fraction, ghip_pair **out_pairs, float **out_ani_percent, size_t *out_n,
                                  ghip_sketches **out_sketches, ghip_rank_times *times /* nullable */);
+/* The same front, then clusterer::cluster (src/clusterer.rs:14-152) with the LAZY batched ANI rounds of ghip_cluster_index dealt
+ * over the ranks -- what one rank runs, for every world size: only the pairs the greedy rules look at are computed
+ * (src/clusterer.rs:194-204, 276-296, 377-405), each by the rank that owns its first genome, one variable-length gather per
+ * round.  Every rank runs the (deterministic) host clusterer and returns the same clusters as ghip_cluster does; order
+ * (nullable) = galah's quality order, as in ghip_cluster_index.  out_pairs / out_sketches nullable (free with ghip_free /
+ * ghip_sketches_free).  A failure on one rank takes every rank out of the call together (that rank with its own code, the
+ * others with GHIP_EPEER): a status word is agreed at every phase boundary. */
+typedef struct {   /* wall milliseconds of one ghip_cluster_ranks call on this rank */
+    double sketch_ms, allgather_sketches_ms, pairs_ms, allgather_pairs_ms, exchange_ani_index_ms, ani_rounds_ms, cluster_host_ms;
+    uint64_t pairs_compared;    /* genome pairs this rank's pair stage was responsible for */
+    uint64_t ani_pairs_asked;   /* precluster pairs whose ANI the clusterer asked for (all ranks together) */
+    uint64_t ani_pairs_here;    /* ... of which this rank computed */
+    uint64_t lazy_rounds;
+} ghip_cluster_times;
+int ghip_cluster_ranks(ghip_comm *comm, const ghip_genomes *local, size_t n_total, uint32_t k, uint32_t s, uint64_t seed,
+                       float min_ani_fraction, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, float min_aligned_fraction,
+                       const uint32_t *order, float ani_threshold_percent, uint32_t **out_members, uint64_t **out_offsets,
+                       size_t *out_n_clusters, ghip_pair **out_pairs, size_t *out_n_pairs, ghip_sketches **out_sketches,
+                       ghip_cluster_times *times);
+/* The lazy rounds alone, for a host that strings the phases itself: EVERY rank calls it with the same pair list; idx /
+ * local_ids = what ghip_exchange_ani_index returned on this rank (local_ids NULL: positions are genome ids).
+ * out_stats[5] = pairs asked, rounds, ns in the rounds, ns in all, pairs this rank computed. */
+int ghip_cluster_index_comm(ghip_comm *comm, const ghip_ani_index *idx, const uint32_t *local_ids, size_t n_genomes,
+                            const ghip_pair *pairs, size_t n_pairs, const uint32_t *order, float ani_threshold_percent,
+                            float min_aligned_fraction, uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters,
+                            uint64_t *out_stats);
+/* Phase boundary of a host that strings the phases itself: every rank passes GHIP_OK or the code of what failed on it; all
+ * return together -- GHIP_OK, the rank's own code, or GHIP_EPEER.  (The entry points above do this between their phases.) */
+int ghip_comm_agree(ghip_comm *comm, int status);
+ghip_ctx *ghip_comm_context(const ghip_comm *comm);
+
 /* Files in -> clusters out on `world` GPUs driven by ONE process (what galah's `cluster` does, src/clusterer.rs:14-152
  * with the finch preclusterer and the batched ANI clusterer): one thread per context ingests and sketches its block of
  * the file list, the exchanges above run over peer copies, the greedy clusterer runs on the caller's thread.

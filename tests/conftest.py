@@ -49,6 +49,24 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def opts(ctx):
+    """opts(field=value, ...): set ghip_options fields of the session's context for one test (restored afterwards) -- how the
+    tests pick a form of a stage, instead of the GHIP_* environment variables that only seed the defaults."""
+    saved = ctx.options()
+    yield lambda **kw: ctx.set_options(**kw)
+    ctx.set_options(**saved)
+
+
+@pytest.fixture
+def process_opts():
+    """The same for the process-wide defaults (what the context-less entry points use: ghip_cluster*, ghip_fasta_stream)."""
+    import galah_amd
+    saved = galah_amd.get_options()
+    yield lambda **kw: galah_amd.set_options(None, **kw)
+    galah_amd.set_options(None, **saved)
+
+
 def random_sketches(rng, n, s, shared_groups=0, min_len=None):
     """Random strictly-ascending u64 sketches; members of a group share a fraction of hashes."""
     hashes = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)

@@ -89,10 +89,14 @@ int main(int argc, char **argv) {
         // a round this short is topped up with every edge still open (one batch); with that off the HIP clusterer is asked lazily:
         // genome 0 is the representative, only its 3 edges are ever looked at
         CHECK(galah::last_ani_pairs_requested() == 6);
-        setenv("GHIP_LAZY_FLUSH_BELOW", "0", 1);
+        ghip_options opt;   // (ghip_cluster_lazy has no context: the process-wide options)
+        CHECK(ghip_get_options(nullptr, &opt) == GHIP_OK && opt.struct_size == sizeof(ghip_options) && opt.lazy_flush_below == 512);
+        opt.lazy_flush_below = 0;
+        CHECK(ghip_set_options(nullptr, &opt) == GHIP_OK);
         CHECK((sorted(galah::cluster(abisko, pre, cl)) == std::vector<std::vector<size_t>>{{0, 1, 2, 3}}));
         CHECK(galah::last_ani_pairs_requested() == 3);
-        unsetenv("GHIP_LAZY_FLUSH_BELOW");
+        opt.lazy_flush_below = 512;
+        CHECK(ghip_set_options(nullptr, &opt) == GHIP_OK);
         // the library entry (GalahClusterer, src/cluster_argument_parsing.rs:108-115,1514-1530): same call, same clusters
         galah::GalahClusterer gc;
         gc.genome_fasta_paths = abisko; gc.preclusterer = &pre; gc.clusterer = &cl;

@@ -47,8 +47,8 @@ for rnd in range(rounds):
                 fh.write(blob)
             paths.append(path)
         want = [galah_amd.fasta_stream(p) for p in paths]
-        form = str(rng.choice(["pipelined", "pipelined", "ascii", "pageable", "two-phase"]))
-        os.environ["GHIP_INGEST"] = form
+        form = str(rng.choice(["packed", "packed", "ascii", "pageable", "two-phase"]))
+        ctx.set_options(ingest_form=form)
         g = ctx.genomes_from_files(paths, int(rng.integers(1, 9)))
         for i, p in enumerate(paths):
             got = g.to_host(i).tobytes()
@@ -60,5 +60,5 @@ for rnd in range(rounds):
         g.free()
     finally:
         shutil.rmtree(d, ignore_errors=True)
-os.environ.pop("GHIP_INGEST", None)
+ctx.set_options(ingest_form="packed")
 print(f"fuzz ok: {rounds} rounds, {checked} files checked")

@@ -29,7 +29,7 @@ for r in range(rounds):
     want = oracle.distances_from_sketches(hashes, lens, thr, threads=16)
     sk = ctx.sketches_from_host(hashes, lens, 21)
     for form in ("probe", "merge", "join"):
-        os.environ["GHIP_PAIR_KERNEL"] = form
+        ctx.set_options(pair_form=form)
         got = ctx.precluster(sk, thr)
         assert got.tobytes() == want.tobytes(), (r, form, n, s, groups, min_len, float(thr))
         world = int(rng.choice([2, 3, 5]))

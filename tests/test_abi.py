@@ -2,6 +2,7 @@
 without a GPU, and its host clusterer (ghip_cluster, no GPU involved) matches the oracle."""
 import os
 import re
+import subprocess
 import sys
 
 import numpy as np
@@ -23,7 +24,7 @@ def test_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in galah_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert L.ghip_abi_version() == 1
+    assert L.ghip_abi_version() == 2
 
 
 @pytest.mark.skipif(galah_amd.device_count() > 0, reason="only meaningful without a GPU")
@@ -219,6 +220,39 @@ def test_gunzip_paths_agree(tmp_path):
     assert got["dense.fna.gz"].startswith("3000001 ")
 
 
+def test_options_struct_round_trip_and_environment_seed():
+    """ghip_options (include/galah_hip.h): the process-wide defaults are seeded from the GHIP_* environment ONCE; fields are set
+    by struct (per context on a GPU box -- tests/test_gpu_*; here the process-wide copy, no GPU needed); a shorter struct from
+    an older host sets the fields it has; out-of-range values are refused."""
+    import ctypes as C
+    from galah_amd import _lib
+    L = _lib.lib()
+    code = ("import galah_amd; o = galah_amd.get_options(); "
+            "print(o['pair_form'], o['join_ranks'], o['ingest_form'], o['lazy_flush_below'], o['use_libdeflate'], o['debug'], o['copy_streams'])")
+    env = dict(os.environ, GHIP_PAIR_KERNEL="merge", GHIP_JOIN_RANKS="records", GHIP_INGEST="two-phase", GHIP_LAZY_FLUSH_BELOW="33",
+               GHIP_NO_LIBDEFLATE="1", GHIP_COMM_DEBUG="1", GHIP_COPY_STREAMS="9", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["3", "1", "3", "33", "0", "4", "4"], (r.stdout, r.stderr)
+    saved = galah_amd.get_options()
+    try:
+        old = galah_amd.set_options(None, pair_form="join", lazy_flush_below=7, fault_stage="ani_round", fault_rank=2)
+        now = galah_amd.get_options()
+        assert (now["pair_form"], now["lazy_flush_below"], now["fault_stage"], now["fault_rank"]) == (1, 7, 5, 2)
+        assert old == {k: saved[k] for k in old}
+        short = (C.c_uint32 * 3)(12, 2, 2)      # struct_size = 12: only pair_form and join_ranks
+        assert L.ghip_set_options(None, short) == 0
+        now = galah_amd.get_options()
+        assert (now["pair_form"], now["join_ranks"], now["lazy_flush_below"]) == (2, 2, 7)
+        for bad in ({"pair_form": 9}, {"join_ranks": 3}, {"ingest_form": 4}, {"copy_streams": 0}, {"fault_stage": 6}):
+            with pytest.raises(galah_amd.GalahHipError):
+                galah_amd.set_options(None, **bad)
+        assert L.ghip_set_options(None, (C.c_uint32 * 1)(4)) == 1 and L.ghip_set_options(None, None) == 1 and L.ghip_get_options(None, None) == 1
+        assert galah_amd.get_options() == now      # a refused struct changes nothing
+    finally:
+        galah_amd.set_options(None, **saved)
+    assert galah_amd.get_options() == saved
+
+
 def test_unrelated_genomes_are_singletons_without_an_ani_source():
     """No precluster pair at all (a set of unrelated genomes): singleton clusters, and no ANI source is needed --
     the C++ mirror passes NULL for both pair_ani and the callback then (include/galah_hip.hpp)."""
@@ -254,13 +288,13 @@ def test_ani_callback_exception_propagates():
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_lazy_batched_clusterer_equals_full(seed, monkeypatch):
+def test_lazy_batched_clusterer_equals_full(seed, process_opts):
     """ghip_cluster_lazy asks only for precluster pairs that touch a representative, in rounds -- and returns the
     clusters of the oracle's run of the reference's greedy algorithm with every ANI known.  (A round of fewer than
-    GHIP_LAZY_FLUSH_BELOW = 512 requests is topped up with everything the open preclusters lack -- a round costs the GPU
+    ghip_options.lazy_flush_below = 512 requests is topped up with everything the open preclusters lack -- a round costs the GPU
     callee a launch's latency; here: off, default, and so large that the first round asks for everything.)"""
     all_at_once = seed % 2 == 1
-    monkeypatch.setenv("GHIP_LAZY_FLUSH_BELOW", "1000000" if all_at_once else ("0" if seed % 4 == 0 else "12"))
+    process_opts(lazy_flush_below=1000000 if all_at_once else (0 if seed % 4 == 0 else 12))
     rng = np.random.default_rng(100 + seed)
     n = int(rng.integers(5, 160))
     pairs = _random_graph(rng, n, rng.uniform(0.2, 0.95), int(rng.integers(1, 9)))

@@ -61,6 +61,15 @@ def _worker(rank, world, port, q):
         out["nodev_exchange"] = "no error"
     except Exception as e:  # noqa: BLE001
         out["nodev_exchange"] = type(e).__name__
+    # phase boundary (ghip_comm_agree): all fine -> nobody raises; the last rank reports a failure -> EVERY rank raises
+    # together, that rank with its own code, the others with GHIP_EPEER naming it; the communicator stays usable
+    comm.agree(0)
+    try:
+        comm.agree(3 if rank == world - 1 else 0)
+        out["agree"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["agree"] = str(e)
+    out["after_agree"] = comm.allgather_host(np.int64([rank])).ravel().tolist()
     q.put(out)
     dist.barrier()
     comm.close()
@@ -83,6 +92,9 @@ def test_exchange_logic_over_gloo(world):
         assert o["fixed"] == [[100 * x + y for y in range(5)] for x in range(world)]
         assert o["merged_ok"] and o["ragged_ok"] and o["empty_ok"]
         assert o["nodev"] == "GalahHipError" and o["nodev_exchange"] == "GalahHipError"
+        assert o["agree"].startswith("GHIP_EHIP" if r == world - 1 else "GHIP_EPEER"), o["agree"]
+        assert r == world - 1 or f"rank {world - 1} failed" in o["agree"]
+        assert o["after_agree"] == list(range(world))
 
 
 def test_single_rank_communicator_needs_no_transport():

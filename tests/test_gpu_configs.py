@@ -381,7 +381,7 @@ def test_bench_line_contract():
             assert len(d["per_rank"]) == 2 and d["config"]["transport"] == "host-callback"
 
 
-def test_ingest_of_a_large_file_in_every_form(ctx, tmp_path, monkeypatch):
+def test_ingest_of_a_large_file_in_every_form(ctx, tmp_path, opts):
     """A 30 Mb genome (above the 24 MB an ASCII staging slot holds, inside what a packed one does) next to a small one:
     the resident stream is the same whichever way it travelled -- packed through a slot, as it is through a slot or a
     blocking copy, or by the two-phase form."""
@@ -397,8 +397,8 @@ def test_ingest_of_a_large_file_in_every_form(ctx, tmp_path, monkeypatch):
         p.write_bytes(b">contig1 x\n" + lines[: len(lines) // 2] + b">contig2\n" + lines[len(lines) // 2:])
         paths.append(str(p))
     want = [galah_amd.fasta_stream(p)[0].tobytes() for p in paths]
-    for form in ("pipelined", "ascii", "pageable", "two-phase"):
-        monkeypatch.setenv("GHIP_INGEST", form)
+    for form in ("packed", "ascii", "pageable", "two-phase"):
+        opts(ingest_form=form)
         g = ctx.genomes_from_files(paths, 4)
         for i in range(2):
             assert g.to_host(i).tobytes() == want[i], (form, i)

@@ -163,7 +163,7 @@ def test_ani_pairs_vs_oracle(ctx):
     assert all(v == 0.0 for v in diff)                # unrelated genomes fail the aligned-fraction gate
 
 
-def test_ani_pairs_both_workgroup_shapes(ctx, monkeypatch):
+def test_ani_pairs_both_workgroup_shapes(ctx, opts):
     """Short pair lists run 16 waves per pair, long ones 8 (ani.hip): the same values either way -- on genomes of very
     different sizes (rounds of 64 bins and of 1024), with sparse and dense seeds."""
     g = ctx.genomes_synthetic(4, 3, 4, 700_000, 0.03)
@@ -172,13 +172,13 @@ def test_ani_pairs_both_workgroup_shapes(ctx, monkeypatch):
         n = len(genomes)
         idx = ctx.ani_index_build(genomes, 15, c, 20000)
         pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.uint32)
-        monkeypatch.setenv("GHIP_ANI_TALL_BELOW", "0")
+        opts(ani_tall_below=0)
         want, want_af = ctx.ani_pairs(idx, pairs, 0.15, want_af=True)
         assert (want > 90).sum() >= n
-        monkeypatch.setenv("GHIP_ANI_TALL_BELOW", "1000000")
+        opts(ani_tall_below=1000000)
         got, got_af = ctx.ani_pairs(idx, pairs, 0.15, want_af=True)
         assert np.array_equal(got, want) and np.array_equal(got_af, want_af), c
-        monkeypatch.delenv("GHIP_ANI_TALL_BELOW")
+        opts(ani_tall_below=200)
         for m in (1, 3, 90, len(pairs)):
             assert np.array_equal(ctx.ani_pairs(idx, pairs[:m], 0.15), want[:m]), m
         idx.free()
@@ -261,9 +261,9 @@ def test_cluster_end_to_end_vs_oracle(ctx):
         assert sorted(x for c in got for x in c) == list(range(len(paths)))
 
 
-def test_merge_path_kernel_also_matches_oracle(ctx, monkeypatch):
+def test_merge_path_kernel_also_matches_oracle(ctx, opts):
     """The 64-way merge-path kernel (fallback form of pair_intersect_tile) on the same inputs."""
-    monkeypatch.setenv("GHIP_PAIR_KERNEL", "merge")
+    opts(pair_form="merge")
     for n, s, min_len, thr in ((37, 1000, None, 0.9), (130, 256, 1, 0.8), (64, 1000, 1, 0.0)):
         rng = np.random.default_rng(n * 7 + s)
         hashes, lens = random_sketches(rng, n, s, shared_groups=5, min_len=min_len)
@@ -329,6 +329,21 @@ def test_sketch_matrix_save_load_against_the_oracle(ctx, tmp_path):
     open(bad, "wb").write(bytes(raw))
     with pytest.raises(galah_amd.GalahHipError, match="damaged"):
         ctx.sketches_load(bad)
+    # a truncated file, and a header whose counts ask for terabytes: refused by SIZE before anything is
+    # allocated -- an error code, never std::bad_alloc through the C boundary
+    open(bad, "wb").write(bytes(raw[: len(raw) - 4096]))
+    with pytest.raises(galah_amd.GalahHipError, match="truncated"):
+        ctx.sketches_load(bad)
+    huge = bytearray(open(p, "rb").read())
+    huge[24:32] = struct.pack("<Q", (1 << 32) - 1)          # n: 4 294 967 295 rows of 1 000 hashes = 34 TB
+    open(bad, "wb").write(bytes(huge))
+    with pytest.raises(galah_amd.GalahHipError, match="GHIP_EIO"):
+        ctx.sketches_load(bad)
+    huge = bytearray(open(p, "rb").read())
+    huge[32:40] = struct.pack("<Q", (1 << 40) - 1)          # names: 1 TB
+    open(bad, "wb").write(bytes(huge))
+    with pytest.raises(galah_amd.GalahHipError, match="GHIP_EIO"):
+        ctx.sketches_load(bad)
     open(bad, "wb").write(b">not a matrix\nACGT\n")
     with pytest.raises(galah_amd.GalahHipError, match="not a sketch matrix"):
         ctx.sketches_load(bad)
@@ -341,13 +356,13 @@ def test_sketch_matrix_save_load_against_the_oracle(ctx, tmp_path):
 
 
 @pytest.mark.parametrize("form", [None, "merge", "join"])
-def test_incremental_dereplication_on_a_saved_matrix(ctx, tmp_path, monkeypatch, form):
+def test_incremental_dereplication_on_a_saved_matrix(ctx, tmp_path, opts, form):
     """docs/preludes/cluster_prelude.md:13-15's workflow without re-sketching: a first run over 8 of the reference's fixture
     genomes persists its sketch matrix; a second run names the matrix and 6 NEW files, reads and sketches only those, runs
     the pair stage on the (new x all) rectangle and -- given the first run's pairs -- returns the cache a full run over all
     14 files produces, checked against oracle.distances; in every form of the pair stage."""
     if form:
-        monkeypatch.setenv("GHIP_PAIR_KERNEL", form)
+        opts(pair_form=form)
     paths = [fasta(n) for n in FIXTURE_GENOMES]
     old, new = paths[:8], paths[8:]
     full = oracle.distances(paths, np.float32(0.9))
@@ -370,7 +385,7 @@ def test_incremental_dereplication_on_a_saved_matrix(ctx, tmp_path, monkeypatch,
         galah_amd.FinchPreclusterer(0.9, 500, 21, ctx=ctx).distances_incremental(m1, new)
 
 
-def test_sketch_sizes_beyond_the_lds_tiles(ctx, monkeypatch):
+def test_sketch_sizes_beyond_the_lds_tiles(ctx, opts):
     """num_kmers has no bound in the reference (src/finch.rs:55-61): s = 10 000 -- candidate lists sorted in global memory,
     the pair stage through the inverted index, and through the global-memory dense kernel where the join declines
     (threshold 0, an empty sketch) or is switched off -- sketches and pair lists against the oracle."""
@@ -384,11 +399,10 @@ def test_sketch_sizes_beyond_the_lds_tiles(ctx, monkeypatch):
         assert lens[i] == len(o) and np.array_equal(hashes[i, : lens[i]], o), i
     assert lens[0] == s and lens[6] == 0
     for thr, form in ((0.9, None), (0.0, None), (0.9, "merge"), (0.95, "merge")):
-        if form:
-            monkeypatch.setenv("GHIP_PAIR_KERNEL", form)
+        opts(pair_form=form or "auto")
         got = ctx.precluster(sk, np.float32(thr))
         assert got.tobytes() == oracle.distances_from_sketches(hashes, lens, np.float32(thr)).tobytes(), (thr, form)
-        monkeypatch.delenv("GHIP_PAIR_KERNEL", raising=False)
+        opts(pair_form="auto")
     assert len(ctx.precluster(sk, np.float32(0.9))) >= 6   # the members of a species pair up (and the empty sketch with everything: NaN quirk)
     with pytest.raises(galah_amd.GalahHipError, match="65535"):
         ctx.sketch_genomes(g, 21, 70_000, 0)
@@ -537,11 +551,11 @@ def test_every_seed_of_dirty_streams(ctx, c):
             start += int(cap[i])
 
 
-def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
+def test_join_form_of_the_pair_stage_matches_oracle(ctx, opts):
     """The inverted-index form (pairs_join.hip; automatic from N >= 1200) forced on small inputs: same bytes as
     the oracle's pair loop, whole and sharded; and the inputs it must decline (threshold 0, empty sketches)
     still give the dense kernels' answer."""
-    monkeypatch.setenv("GHIP_PAIR_KERNEL", "join")
+    opts(pair_form="join")
     ctx.profile(True)
     for n, s, min_len, thr, groups in ((37, 1000, None, 0.9, 5), (130, 256, 1, 0.8, 5), (300, 1000, 700, 0.9, 40),
                                        (64, 1000, 1, 0.0, 5), (2, 1000, None, 0.9, 1)):
@@ -566,7 +580,7 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
                 merged = np.sort(np.concatenate(parts), order=["i", "j"])
                 assert merged.tobytes() == want.tobytes()
                 # the multi-rank entry point: by default the join form is sharded too (records only of the rank's
-                # (i + j) mod world pairs); with GHIP_JOIN_RANKS=replicate it hands every rank the whole list
+                # (i + j) mod world pairs); with join_ranks = replicate it hands every rank the whole list
                 parts, compared = [], 0
                 for r in range(world):
                     part, replicated = ctx.precluster_ranks(sk, np.float32(thr), r, world)
@@ -575,14 +589,14 @@ def test_join_form_of_the_pair_stage_matches_oracle(ctx, monkeypatch):
                     parts.append(part)
                 assert compared == n * (n - 1) // 2
                 assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes()
-                monkeypatch.setenv("GHIP_JOIN_RANKS", "replicate")
+                opts(join_ranks="replicate")
                 compared = 0
                 for r in range(world):
                     whole, replicated = ctx.precluster_ranks(sk, np.float32(thr), r, world)
                     compared += ctx.last_pairs_compared
                     assert replicated and whole.tobytes() == want.tobytes()
                 assert compared == n * (n - 1) // 2
-                monkeypatch.delenv("GHIP_JOIN_RANKS")
+                opts(join_ranks="hash")
         else:  # declined: the dense forms give each rank its share
             parts = []
             for r in range(3):
@@ -760,7 +774,7 @@ def test_batched_files_entry_point_equals_one_batch(ctx):
     assert np.array_equal(h4, h1) and np.array_equal(l4, l1)
 
 
-def test_ingest_forms_agree(ctx, tmp_path, monkeypatch):
+def test_ingest_forms_agree(ctx, tmp_path, opts):
     """Plain, gzip and multi-member gzip files (whose trailer under-reports the stream, forcing the two-phase
     ingest), CRLF line ends, no final newline, an empty file, lower case and IUPAC codes: same sketches and
     statistics as the oracle, in the pipelined and in the two-phase form."""
@@ -795,8 +809,8 @@ def test_ingest_forms_agree(ctx, tmp_path, monkeypatch):
     for p in paths[1:5]:
         assert np.array_equal(oracle.sketch_file(p), want_sk[0])   # all forms hold the same records
     streams = {}
-    for form in ("pipelined", "ascii", "two-phase"):   # pipelined = 2-bit packed over PCIe, expanded on the device
-        monkeypatch.setenv("GHIP_INGEST", form)
+    for form in ("packed", "ascii", "two-phase"):   # packed = 2-bit codes over PCIe, copied into place on the device
+        opts(ingest_form=form)
         g = ctx.genomes_from_files(paths, 3)
         hashes, lens = ctx.sketch_genomes(g, 21, 1000, 0).to_host()
         for i, p in enumerate(paths):
@@ -878,6 +892,32 @@ def test_cluster_on_the_resident_index_native_rounds(ctx):
     look_o = {(int(p["i"]), int(p["j"])): float(v) for p, v in zip(re, every_o)}
     assert got_o == oracle.cluster(n, oracle.Cache.from_pairs(re), float(thr), lambda a, b: look_o[(min(a, b), max(a, b))])
     assert sorted(x for c in got_o for x in c) == list(range(n))
+    # with `order` the edges are renumbered to positions but their ANI is asked for as (p.i, p.j) in GENOME order,
+    # where the reference's calculate_ani takes (representative, genome) of the sorted list.  That is only right while the ANI
+    # kernel is exactly symmetric -- so: (1) the same clusters as a run over the PHYSICALLY re-ordered genome list (its own
+    # sketches, index, pair list, no `order`), and (2) ani(q, r) == ani(r, q) bit for bit, also for a pair of mixed density
+    streams = [g.to_host(int(x)) for x in order]
+    g2 = ctx.genomes_from_host(streams)
+    sk2, idx2 = ctx.sketch_and_index(g2, 21, 1000, 0)
+    pairs2 = ctx.precluster(sk2, np.float32(0.9))
+    assert pairs2.tobytes() == re.tobytes()      # the renumbered, re-sorted list IS the pair list of the re-ordered genomes
+    got_p, st_p = ctx.cluster_index(idx2, n, pairs2, thr, 0.15)
+    assert got_p == got_o and st_p["asked"] == st_o["asked"]
+    assert np.array_equal(ctx.ani_pairs(idx, pi[:, ::-1].copy(), 0.15), every)
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    small, big = acgt[rng.integers(0, 4, 300_000)], acgt[rng.integers(0, 4, 2_000_000)]
+    cp = small.copy()
+    hit = rng.random(len(cp)) < 0.03
+    cp[hit] = acgt[(np.searchsorted(acgt, cp[hit]) + rng.integers(1, 4, size=int(hit.sum()))) % 4]
+    big[500_000:800_000] = cp
+    gm = ctx.genomes_from_host([small, big])
+    im = ctx.ani_index_build(gm)
+    fwd = ctx.ani_pairs(im, np.array([[0, 1]], dtype=np.uint32), 0.15)
+    rev = ctx.ani_pairs(im, np.array([[1, 0]], dtype=np.uint32), 0.15)
+    assert fwd[0] == rev[0] and 96.0 < fwd[0] < 98.0
+    for h in (sk2, idx2, g2, im, gm):
+        h.free()
     # no pairs: every genome its own cluster, no index needed
     assert ctx.cluster_index(None, 3, np.zeros(0, dtype=galah_amd.PAIR_DTYPE), thr)[0] == [[0], [1], [2]]
     with pytest.raises(galah_amd.GalahHipError):
