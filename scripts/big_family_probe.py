@@ -21,7 +21,7 @@ lens = np.full(n, s, dtype=np.uint32)
 ctx = galah_amd.Context(0)
 sk = ctx.sketches_from_host(hashes, lens, 21)
 for form in ("default", "probe"):
-    if form == "probe": os.environ["GHIP_PAIR_KERNEL"] = "probe"
+    if form == "probe": ctx.set_options(pair_form="probe")
     p = ctx.precluster(sk, np.float32(0.9))
     ctx.synchronize(); t0 = time.perf_counter(); p = ctx.precluster(sk, np.float32(0.9)); ctx.synchronize()
     print("%-8s n=%d family=%d: %d pairs listed in %.1f ms" % (form, n, fam, len(p), (time.perf_counter() - t0) * 1e3))

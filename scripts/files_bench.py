@@ -38,11 +38,11 @@ for rep in range(int(os.environ.get("GHIP_FILES_BENCH_REPS", "2")) * len(thread_
     T = thread_list[rep % len(thread_list)]
     if os.environ.get("GHIP_FILES_BENCH_PLAIN_CAPS"):   # sweep the reader cap for plain files
         caps = os.environ["GHIP_FILES_BENCH_PLAIN_CAPS"].split(",")
-        os.environ["GHIP_INGEST_THREADS_PLAIN"] = caps[rep % len(caps)]
-        print("plain cap", os.environ["GHIP_INGEST_THREADS_PLAIN"], end="  ")
+        ctx.set_options(io_threads_plain=int(caps[rep % len(caps)]))
+        print("plain cap", caps[rep % len(caps)], end="  ")
     if os.environ.get("GHIP_FILES_BENCH_ALTERNATE"):   # A/B of the batch pipeline inside one process
-        os.environ["GHIP_PIPELINE"] = "1" if rep % 2 == 0 else "0"
-        print("GHIP_PIPELINE =", os.environ["GHIP_PIPELINE"], end="  ")
+        ctx.set_options(pipeline_pieces=1 if rep % 2 == 0 else 0)
+        print("pipeline_pieces =", 1 if rep % 2 == 0 else 0, end="  ")
     t0 = time.perf_counter()
     gg = ctx.genomes_from_files(paths, T)
     t_ingest = time.perf_counter() - t0

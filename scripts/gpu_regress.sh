@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -5
 python tests/fuzz_ani.py 120 3 2>&1 | tail -1
-GHIP_ANI_TALL_BELOW=0 python tests/fuzz_ani.py 120 4 2>&1 | tail -1
+python tests/fuzz_ani.py 120 4 --tall-below 0 2>&1 | tail -1
 python tests/fuzz_sketch.py 40 3 2>&1 | tail -1
 python tests/fuzz_ingest.py 60 3 2>&1 | tail -1
 galah_amd/csrc/build/test_host_mirror tests/golden/fasta 2>&1 | tail -2

@@ -30,7 +30,7 @@ def best(fn, reps=3):
     return out, t * 1e3
 
 res = {"n": n, "pairs": n * (n - 1) // 2}
-os.environ["GHIP_PAIR_KERNEL"] = "join"
+ctx.set_options(pair_form="join")
 whole, t = best(lambda: ctx.precluster(sk, np.float32(0.9)))
 res["join_whole_ms"] = t; res["candidates"] = len(whole)
 shares, ts = [], []
@@ -121,7 +121,7 @@ res["join_hash_share_of_8_ms"] = {"min": min(tls), "max": max(tls), "per_rank": 
 allp = np.concatenate(hshares)
 key = (allp["i"].astype(np.uint64) << np.uint64(32)) | allp["j"].astype(np.uint64)
 assert allp[np.argsort(key, kind="stable")].tobytes() == whole.tobytes(), "hash-sharded shares do not add up to the whole list"
-os.environ["GHIP_PAIR_KERNEL"] = "probe"
+ctx.set_options(pair_form="probe")
 _, t = best(lambda: ctx.precluster(sk, np.float32(0.9)), 2)
 res["dense_whole_ms"] = t
 ts = []
@@ -133,5 +133,5 @@ res["dense_tile_share_of_8_ms"] = {"min": min(ts), "max": max(ts)}
 allp = np.concatenate(dshares)
 key = (allp["i"].astype(np.uint64) << np.uint64(32)) | allp["j"].astype(np.uint64)
 assert allp[np.argsort(key, kind="stable")].tobytes() == whole.tobytes()
-del os.environ["GHIP_PAIR_KERNEL"]
+ctx.set_options(pair_form="auto")
 print(json.dumps(res))

@@ -15,6 +15,8 @@ import oracle  # noqa: E402
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = galah_amd.Context(0)
+if "--tall-below" in sys.argv:   # ghip_options.ani_tall_below: 0 = every launch in the 8-wave shape
+    ctx.set_options(ani_tall_below=int(sys.argv[sys.argv.index("--tall-below") + 1]))
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
