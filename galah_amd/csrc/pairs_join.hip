@@ -25,6 +25,7 @@
 // N*s >= 2^32.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 
 #include "ghip_internal.h"
 
@@ -123,9 +124,12 @@ __global__ __launch_bounds__(256) void join_scan256_kernel(const uint32_t *__res
     }
 }
 
+// start1 == nullptr: the CAPACITY form (fused partition) -- first-level bucket d owns slots [d * cap1, (d + 1) * cap1) and
+// the per-digit cursors ARE the counts afterwards: no histogram pass, no scan, no host round trip before the second level.
+// An element beyond its bucket's capacity is dropped and flags bit 3 raised: the caller repeats the join in the exact form.
 template <typename Src>
 __global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const uint32_t *__restrict__ start1,
-                                                                  uint32_t *__restrict__ cursor1,
+                                                                  uint32_t *__restrict__ cursor1, uint32_t cap1, uint32_t *__restrict__ flags,
                                                                   uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
     __shared__ uint32_t h[256], base[256];
     h[threadIdx.x] = 0;
@@ -142,9 +146,20 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const
         }
     }
     __syncthreads();
+    __shared__ uint32_t lim[256];   // capacity form: one past the last slot of the bucket (exact form: no limit)
     {   // one global atomic per digit and block reserves the block's range in that bucket
         const uint32_t c = h[threadIdx.x];
-        base[threadIdx.x] = c ? start1[threadIdx.x] + atomicAdd(&cursor1[threadIdx.x], c) : 0u;
+        uint32_t b = 0, l = 0xffffffffu;
+        if (c) {
+            const uint32_t at = atomicAdd(&cursor1[threadIdx.x], c);
+            if (start1) b = start1[threadIdx.x] + at;
+            else {
+                b = threadIdx.x * cap1 + at;
+                l = (threadIdx.x + 1) * cap1;
+                if (at + c > cap1) atomicOr(flags, 8u);
+            }
+        }
+        base[threadIdx.x] = b; lim[threadIdx.x] = l;
     }
     __syncthreads();
     h[threadIdx.x] = 0;
@@ -154,18 +169,30 @@ __global__ __launch_bounds__(J_THREADS) void join_scatter1_kernel(Src src, const
         if (okmask & (1u << u)) {
             const uint32_t d = digit1(Src::mix(keys[u]));
             const uint32_t pos = base[d] + atomicAdd(&h[d], 1u);
-            out_keys[pos] = keys[u];
-            if (out_vals) out_vals[pos] = vals[u];
+            if (pos < lim[d]) {
+                out_keys[pos] = keys[u];
+                if (out_vals) out_vals[pos] = vals[u];
+            }
         }
     }
+}
+
+// first-level bucket d1 of the intermediate array: [start1[d1], start1[d1 + 1]) in the exact form, the first
+// min(count1[d1], cap1) slots of [d1 * cap1, ...) in the capacity form (count1 != nullptr)
+__device__ __forceinline__ void join_bucket1(const uint32_t *start1, const uint32_t *count1, uint32_t cap1, uint32_t d1, uint32_t &lo, uint32_t &end) {
+    if (count1) { lo = d1 * cap1; end = lo + min(count1[d1], cap1); }
+    else { lo = start1[d1]; end = start1[d1 + 1]; }
 }
 
 // ---- MSD pass 2: inside first-level bucket blockIdx.y, digit = the next bits2 bits --------------------------------
 template <typename Src>
 __global__ __launch_bounds__(J_THREADS) void join_hist2_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ start1,
+                                                               const uint32_t *__restrict__ count1, uint32_t cap1,
                                                                uint32_t bits2, uint32_t *__restrict__ hist2) {
     const uint32_t d1 = blockIdx.y, nd2 = 1u << bits2;
-    const uint32_t lo = start1[d1] + blockIdx.x * J_TILE, end = start1[d1 + 1];
+    uint32_t lo, end;
+    join_bucket1(start1, count1, cap1, d1, lo, end);
+    lo += blockIdx.x * J_TILE;
     if (lo >= end) return;
     const uint32_t hi = min(end, lo + J_TILE);
     __shared__ uint32_t h[J_D2_MAX];
@@ -260,13 +287,90 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_write_kernel(const uint32
     // 32-bit offsets: the host bounds the inputs (n*s < 2^32 elements, < 2^31 records from a 64-bit total)
 }
 
+// The same scan in ONE launch (fused form): per-tile sums, a grid barrier, the write.  The grid is n_tiles <= 256 blocks of
+// 256 threads with no dynamic LDS -- a fraction of what the chip holds at once, so every block is (or becomes, as soon as a
+// co-running kernel's blocks retire) resident and the barrier cannot starve; the tile sums cross the XCDs through
+// agent-scope atomics.  `arrive` is zeroed by the caller (one word per scan of a join call).  hist_b (nullable): a second
+// counter array that is only summed; totals (nullable) = {sum of hist_b, sum of hist} as 64-bit numbers -- what
+// join_totals_kernel delivered in a launch of its own.  The counters are read ONCE (they wait in registers across the barrier).
+__global__ __launch_bounds__(J_THREADS) void join_scan_fused_kernel(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ hist_b,
+                                                                    uint32_t *__restrict__ tile_sum, uint32_t *__restrict__ tile_max,
+                                                                    unsigned long long *__restrict__ tile_sum_b, uint32_t *__restrict__ arrive,
+                                                                    uint32_t n_tiles, uint32_t *__restrict__ start, uint32_t *__restrict__ max_out,
+                                                                    unsigned long long *__restrict__ totals) {
+    __shared__ uint32_t ws[J_WAVES], wm[J_WAVES], ts[256], tm[256];
+    __shared__ unsigned long long wb[J_WAVES];
+    const size_t base = (size_t)blockIdx.x * J_SCAN_TILE + threadIdx.x * J_SCAN_PER;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t v[J_SCAN_PER];
+    uint32_t sum = 0, m = 0;
+    unsigned long long sum_b = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < J_SCAN_PER / 4; q++) {
+        const uint4 x = reinterpret_cast<const uint4 *>(hist + base)[q];
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        sum += x.x + x.y + x.z + x.w;
+        m = max(max(m, max(x.x, x.y)), max(x.z, x.w));
+        if (hist_b) { const uint4 y = reinterpret_cast<const uint4 *>(hist_b + base)[q]; sum_b += (unsigned long long)y.x + y.y + y.z + y.w; }
+    }
+    uint32_t incl = sum;   // inclusive scan of the thread sums over the wave (kept for the write phase)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { m = max(m, (uint32_t)__shfl_xor(m, off, 64)); sum_b += __shfl_xor(sum_b, off, 64); }
+    if (lane == 63u) ws[wave] = incl;
+    if (lane == 0u) { wm[wave] = m; wb[wave] = sum_b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0, x = 0;
+        unsigned long long b = 0;
+        for (uint32_t w = 0; w < J_WAVES; w++) { t += ws[w]; x = max(x, wm[w]); b += wb[w]; }
+        __hip_atomic_store(&tile_sum[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tile_max[blockIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tile_sum_b[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the three stores above are ordered before it
+        while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_tiles) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    ts[threadIdx.x] = threadIdx.x < n_tiles ? __hip_atomic_load(&tile_sum[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    tm[threadIdx.x] = threadIdx.x < n_tiles ? __hip_atomic_load(&tile_max[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t t = 0; t < blockIdx.x; t++) before += ts[t];   // <= 255 LDS broadcasts
+    uint32_t run = before + incl - sum;
+    for (uint32_t w = 0; w < wave; w++) run += ws[w];
+    uint32_t o[J_SCAN_PER];
+#pragma unroll
+    for (uint32_t q = 0; q < J_SCAN_PER; q++) { o[q] = run; run += v[q]; }
+#pragma unroll
+    for (uint32_t q = 0; q < J_SCAN_PER / 4; q++)
+        reinterpret_cast<uint4 *>(start + base)[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long total = 0, total_b = 0;
+        uint32_t x = 0;
+        for (uint32_t t = 0; t < n_tiles; t++) {
+            total += ts[t]; x = max(x, tm[t]);
+            total_b += __hip_atomic_load(&tile_sum_b[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        start[(size_t)n_tiles * J_SCAN_TILE] = (uint32_t)total;   // (32-bit offsets: the host bounds the inputs and declines on a 64-bit total beyond them)
+        if (max_out) *max_out = x;
+        if (totals) { totals[0] = total_b; totals[1] = total; }
+    }
+}
+
 template <typename Src>
 __global__ __launch_bounds__(J_THREADS) void join_scatter2_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                                  const uint32_t *__restrict__ start1, uint32_t bits2,
+                                                                  const uint32_t *__restrict__ start1, const uint32_t *__restrict__ count1, uint32_t cap1,
+                                                                  uint32_t bits2,
                                                                   const uint32_t *__restrict__ start2, uint32_t *__restrict__ cursor2,
                                                                   uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
     const uint32_t d1 = blockIdx.y, nd2 = 1u << bits2;
-    const uint32_t lo = start1[d1] + blockIdx.x * J_TILE, end = start1[d1 + 1];
+    uint32_t lo, end;
+    join_bucket1(start1, count1, cap1, d1, lo, end);
+    lo += blockIdx.x * J_TILE;
     if (lo >= end) return;
     const uint32_t hi = min(end, lo + J_TILE);
     __shared__ uint32_t h[J_D2_MAX], base[J_D2_MAX];
@@ -622,42 +726,95 @@ int scan_counters(ghip_ctx *ctx, std::vector<void *> &owned, const uint32_t *d_h
     return GHIP_OK;
 }
 
+// The fused form of a join call (ghip_options.join_fused): what it needs zeroed, in ONE block cleared by one memset per
+// stage -- the first-level cursors, the second-level histogram and cursors, the arrival words of the single-launch scans.
+constexpr uint32_t J_ARRIVE = 8;
+struct JoinFused {
+    bool on = false;
+    uint32_t *d_arrive = nullptr;   // [J_ARRIVE] one word per fused scan of the call (zeroed with the call's flag words)
+    uint32_t n_arrive = 0;
+    uint32_t *d_flags = nullptr;    // bit 3: a first-level bucket outgrew its capacity
+};
+
+// the same in one launch (join_scan_fused_kernel); d_hist_b / d_totals nullable (the record totals of the counting pass)
+int scan_counters_fused(ghip_ctx *ctx, std::vector<void *> &owned, JoinFused &jf, const uint32_t *d_hist, const uint32_t *d_hist_b, uint32_t nb,
+                        uint32_t *d_start, uint32_t *d_max, unsigned long long *d_totals) {
+    const uint32_t n_tiles = nb / J_SCAN_TILE;
+    if (nb % J_SCAN_TILE || n_tiles == 0 || n_tiles > 256 || jf.n_arrive >= J_ARRIVE) return ghip_set_error(ctx, GHIP_EINVAL, "join: counter array not scannable");
+    uint32_t *d_tile = jalloc<uint32_t>(ctx, owned, 512 + 2 * 256);   // tile sums | tile maxima | 64-bit sums of the second array
+    if (!d_tile) return GHIP_EHIP;
+    hipLaunchKernelGGL(join_scan_fused_kernel, dim3(n_tiles), dim3(J_THREADS), 0, ctx->stream, d_hist, d_hist_b, d_tile, d_tile + 256,
+                       reinterpret_cast<unsigned long long *>(d_tile + 512), jf.d_arrive + jf.n_arrive, n_tiles, d_start, d_max, d_totals);
+    jf.n_arrive++;
+    return GHIP_OK;
+}
+
+// capacity of a first-level bucket in the fused form: the mean load plus slack for what the digit does to it.  Elements
+// (uniform hash bits): Poisson, six standard deviations.  Records: all records of a genome pair share one digit -- a bucket's
+// load is a sum of ~pairs/256 lumps of up to s records each -- half the mean on top, and room for a few whole lumps.
+uint32_t fused_cap1(uint64_t n_valid, bool lumpy, uint32_t lump) {
+    const double mean = (double)n_valid / 256.0;
+    const double cap = lumpy ? 1.5 * mean + 16.0 * (double)lump + 4096.0 : mean + 6.0 * std::sqrt(mean) + 1024.0;
+    return (uint32_t)std::min<double>(((uint64_t)cap + 3) / 4 * 4, (double)(0xffffffffu / 256u));
+}
+
 // Partition `src` (total_t candidate slots, at most n_valid_bound of them valid) into nb = 256 << bits2 buckets.
 // On return keys_out/vals_out hold the elements bucket by bucket and d_start2[nb + 1] the bucket offsets.
+// Exact form: histogram, scan, scatter at both levels (7 launches, one host round trip for the second level's grid).
+// Fused form (jf.on): the first level scatters into fixed-capacity buckets -- no histogram, no scan, no round trip --
+// and the second level's scan is one launch: 4 launches.  Overflow of a capacity raises jf.d_flags bit 3.
 template <typename Src>
 int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_t total_t, uint32_t n_valid_bound, uint32_t bits2,
-              bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */) {
+              bool with_vals, uint64_t **keys_out, uint32_t **vals_out, uint32_t **d_start2_out, uint32_t *d_max /* nullable */,
+              JoinFused *jf = nullptr, bool lumpy = false, uint32_t lump = 0) {
     const uint32_t nb = 256u << bits2;
     const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_COMM);
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "    [partition] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
-    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256);   // hist1 | start1 | cursor1
-    uint32_t *d_hist2 = jalloc<uint32_t>(ctx, owned, 2 * (size_t)nb);     // hist2 | cursor2
+    const bool fused = jf && jf->on;
+    const uint32_t cap1 = fused ? fused_cap1(n_valid_bound, lumpy, lump) : 0u;
+    const size_t n_mid = fused ? (size_t)256 * cap1 : (size_t)n_valid_bound;   // slots of the intermediate (first-level) arrays
+    if (fused && n_mid >= (1ull << 32)) return ghip_set_error(ctx, GHIP_EINVAL, "join: fused partition beyond 2^32 slots");
+    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256 + 2 * (size_t)nb);   // hist1 | start1 | cursor1 | hist2 | cursor2: one block, one memset
     uint32_t *d_start2 = jalloc<uint32_t>(ctx, owned, nb + 1);
-    uint64_t *k1 = jalloc<uint64_t>(ctx, owned, n_valid_bound), *k2 = jalloc<uint64_t>(ctx, owned, n_valid_bound);
-    uint32_t *v1 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
+    uint64_t *k1 = jalloc<uint64_t>(ctx, owned, n_mid), *k2 = jalloc<uint64_t>(ctx, owned, n_valid_bound);
+    uint32_t *v1 = with_vals ? jalloc<uint32_t>(ctx, owned, n_mid) : nullptr;
     uint32_t *v2 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
-    if (!d_hist1 || !d_hist2 || !d_start2 || !k1 || !k2 || (with_vals && (!v1 || !v2))) return GHIP_EHIP;
+    if (!d_hist1 || !d_start2 || !k1 || !k2 || (with_vals && (!v1 || !v2))) return GHIP_EHIP;
     lap("alloc");
-    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_cursor2 = d_hist2 + nb;
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (256 + 257 + 256) * sizeof(uint32_t), ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist2, 0, 2 * (size_t)nb * sizeof(uint32_t), ctx->stream));
+    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_hist2 = d_cursor1 + 256, *d_cursor2 = d_hist2 + nb;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (256 + 257 + 256 + 2 * (size_t)nb) * sizeof(uint32_t), ctx->stream));
     const unsigned tiles = (total_t + J_TILE - 1) / J_TILE;
-    if (tiles) hipLaunchKernelGGL((join_hist1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, d_hist1);
-    hipLaunchKernelGGL(join_scan256_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist1, d_start1);
-    if (tiles) hipLaunchKernelGGL((join_scatter1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, d_start1, d_cursor1, k1, v1);
-    // the second pass runs per first-level bucket: its grid needs the largest bucket
-    uint32_t hist1[256];
-    GHIP_HIP_CHECK(ctx, hipMemcpyAsync(hist1, d_hist1, sizeof(hist1), hipMemcpyDeviceToHost, ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    lap("pass 1 + sync");
-    const uint32_t big = *std::max_element(hist1, hist1 + 256);
-    const unsigned tiles2 = (big + J_TILE - 1) / J_TILE;
-    if (tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, d_start1, bits2, d_hist2);
-    { const int src_ = scan_counters(ctx, owned, d_hist2, nb, d_start2, d_max); if (src_) return src_; }
-    if (tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, d_start1, bits2,
-                                   d_start2, d_cursor2, k2, v2);
-    lap("pass 2 launches");
+    unsigned tiles2 = 0;
+    if (fused) {
+        if (tiles) hipLaunchKernelGGL((join_scatter1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, (const uint32_t *)nullptr, d_cursor1,
+                                      cap1, jf->d_flags, k1, v1);
+        tiles2 = (cap1 + J_TILE - 1) / J_TILE;   // (blocks past a bucket's count leave at once)
+        if (tiles && tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, (const uint32_t *)nullptr,
+                                                (const uint32_t *)d_cursor1, cap1, bits2, d_hist2);
+        { const int src_ = scan_counters_fused(ctx, owned, *jf, d_hist2, nullptr, nb, d_start2, d_max, nullptr); if (src_) return src_; }
+        if (tiles && tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, (const uint32_t *)nullptr,
+                                                (const uint32_t *)d_cursor1, cap1, bits2, d_start2, d_cursor2, k2, v2);
+        lap("fused: 4 launches");
+    } else {
+        if (tiles) hipLaunchKernelGGL((join_hist1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, d_hist1);
+        hipLaunchKernelGGL(join_scan256_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist1, d_start1);
+        if (tiles) hipLaunchKernelGGL((join_scatter1_kernel<Src>), dim3(tiles), dim3(J_THREADS), 0, ctx->stream, src, (const uint32_t *)d_start1, d_cursor1, 0u,
+                                      (uint32_t *)nullptr, k1, v1);
+        // the second pass runs per first-level bucket: its grid needs the largest bucket
+        uint32_t hist1[256];
+        GHIP_HIP_CHECK(ctx, hipMemcpyAsync(hist1, d_hist1, sizeof(hist1), hipMemcpyDeviceToHost, ctx->stream));
+        GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        lap("pass 1 + sync");
+        const uint32_t big = *std::max_element(hist1, hist1 + 256);
+        tiles2 = (big + J_TILE - 1) / J_TILE;
+        if (tiles2) hipLaunchKernelGGL((join_hist2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, (const uint32_t *)d_start1,
+                                       (const uint32_t *)nullptr, 0u, bits2, d_hist2);
+        { const int src_ = scan_counters(ctx, owned, d_hist2, nb, d_start2, d_max); if (src_) return src_; }
+        if (tiles2) hipLaunchKernelGGL((join_scatter2_kernel<Src>), dim3(tiles2, 256), dim3(J_THREADS), 0, ctx->stream, k1, v1, (const uint32_t *)d_start1,
+                                       (const uint32_t *)nullptr, 0u, bits2, d_start2, d_cursor2, k2, v2);
+        lap("pass 2 launches");
+    }
     *keys_out = k2;
     if (vals_out) *vals_out = v2;
     *d_start2_out = d_start2;
@@ -714,7 +871,7 @@ struct JoinBig {   // a caller's means to finish the pairs of very large familie
 static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t enb, uint64_t *ek, uint32_t *ev, const uint32_t *d_estart,
                             uint32_t *d_rcount, uint32_t *d_rstart, uint32_t *d_flags, unsigned long long *d_total, uint32_t rank,
                             uint32_t world, uint32_t row_lo, uint32_t flags[2], unsigned long long totals[2], uint32_t *cap_used,
-                            JoinBig *jb = nullptr) {
+                            JoinBig *jb = nullptr, JoinFused *jf = nullptr) {
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_kernel<false>), elem_pairs_lds(J_ELEM_CAP));
     ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_kernel<true>), elem_pairs_lds(J_ELEM_CAP));
     uint32_t *d_all = jalloc<uint32_t>(ctx, owned, enb);
@@ -738,8 +895,12 @@ static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t 
         if (with_big)
             hipLaunchKernelGGL((join_elem_pairs_big_kernel<false>), dim3(256), dim3(J_THREADS), J_BIG_LDS, ctx->stream, ek, ev, d_estart, d_rcount,
                                (const uint32_t *)nullptr, (uint64_t *)nullptr, d_flags, d_all, rank, world, row_lo, jb->d_big, jb->d_list, jb->d_n);
-        hipLaunchKernelGGL(join_totals_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_all, d_rcount, enb, d_total);
-        int rc = scan_counters(ctx, owned, d_rcount, enb, d_rstart, nullptr);
+        int rc;
+        if (jf && jf->on) rc = scan_counters_fused(ctx, owned, *jf, d_rcount, d_all, enb, d_rstart, nullptr, d_total);   // offsets and both totals in one launch
+        else {
+            hipLaunchKernelGGL(join_totals_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_all, d_rcount, enb, d_total);
+            rc = scan_counters(ctx, owned, d_rcount, enb, d_rstart, nullptr);
+        }
         if (rc) return rc;
         totals[0] = totals[1] = 0;
         GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -767,11 +928,14 @@ void ghip_launch_gather_rows(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
 }
 
 // *used = false: the join form declined (see the file header) and nothing was written; run a dense kernel instead.
-int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
-                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline,
-                    std::vector<uint32_t> *empties, uint8_t *d_big, bool *has_big) {
+// fused: the partitions in their fused form (ghip_options.join_fused); *overflow = a first-level capacity was exceeded -- nothing
+// usable was written, the caller repeats the call in the exact form.
+static int pairs_join_impl(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                           const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
+                           unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline,
+                           std::vector<uint32_t> *empties, uint8_t *d_big, bool *has_big, bool fused, bool *overflow) {
     *used = false;
+    *overflow = false;
     if (has_big) *has_big = false;
     if (late_decline) *late_decline = false;
     if (cmin_floor == 0 || cmin_floor == 0xffffu || n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
@@ -791,17 +955,19 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
         if (n_elem == 0) { *used = true; if (pairs_compared) *pairs_compared = (uint64_t)n * (n - 1) / 2; return GHIP_OK; }   // nothing but empty sketches
     }
     struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
-    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 6);  // [0] flags, [1] largest element bucket, [2..3] u64 records of all ranks, [4..5] of this rank
+    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 6 + J_ARRIVE);  // [0] flags, [1] largest element bucket, [2..3] u64 records of all ranks, [4..5] of this rank, then the fused scans' arrival words
     if (!d_flags) return GHIP_EHIP;
     unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_flags + 2);
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 6 * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, (6 + J_ARRIVE) * sizeof(uint32_t), ctx->stream));
+    JoinFused jf;
+    jf.on = fused; jf.d_arrive = d_flags + 6; jf.d_flags = d_flags;
 
     ghip_prof_begin(ctx, "pair_join");
     // 1. elements -> 65536 hash buckets
     uint64_t *ek = nullptr; uint32_t *ev = nullptr, *d_estart = nullptr;
     ElemSrc es{d_hashes, d_lens, s, (uint32_t)(n * s), 0u, 1u};
     const uint32_t ebits = bits2_for(n_elem, J_BITS2_MIN_ELEM), enb = 256u << ebits;
-    int rc = partition(ctx, own.p, es, es.total, (uint32_t)n_elem, ebits, true, &ek, &ev, &d_estart, d_flags + 1);
+    int rc = partition(ctx, own.p, es, es.total, (uint32_t)n_elem, ebits, true, &ek, &ev, &d_estart, d_flags + 1, &jf);
     if (rc) { ghip_prof_end(ctx); return rc; }
     // 2. records per bucket, their offsets, their number
     uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
@@ -810,7 +976,8 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     unsigned long long totals[2] = {0, 0};   // records of all ranks (what every rank decides on), records of this rank
     JoinBig jb;
     jb.d_big = d_big;
-    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, rank, world, row_lo, flags, totals, &ecap, &jb))) { ghip_prof_end(ctx); return rc; }
+    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, rank, world, row_lo, flags, totals, &ecap, &jb, &jf))) { ghip_prof_end(ctx); return rc; }
+    if (flags[0] & 8u) { *overflow = true; ghip_prof_end(ctx); return GHIP_OK; }   // (fused form) an element bucket of the first level outgrew its capacity
     if (has_big) *has_big = jb.used && (flags[0] & 4u) != 0;
     uint8_t *const big_used = jb.used ? d_big : nullptr;
     const unsigned long long total_rec = totals[0];
@@ -829,7 +996,7 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
     const uint32_t rbits = bits2_for(n_rec), rnb = 256u << rbits;  // ~350 records per sharing pair: few distinct pairs per bucket
-    rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr);
+    rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr, &jf, true, s);
     if (rc) { ghip_prof_end(ctx); return rc; }
     hipLaunchKernelGGL((join_reduce_kernel<false, 0>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
                        (JoinEntry *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s,
@@ -837,6 +1004,11 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     ghip_prof_end(ctx);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags[0] & 8u) {  // (fused form) a record bucket of the first level outgrew its capacity: records were dropped
+        GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+        *overflow = true;
+        return GHIP_OK;
+    }
     if (flags[0] & 2u) {  // a record bucket overflowed its table: discard what was written, let a dense kernel run
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
         // (with world > 1 this decision is this rank's alone -- its own records filled the table -- so the caller must
@@ -859,6 +1031,22 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
     return GHIP_OK;
 }
 
+int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
+                    const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
+                    unsigned long long *d_count, uint64_t cap, uint64_t *pairs_compared, bool *used, bool *late_decline,
+                    std::vector<uint32_t> *empties, uint8_t *d_big, bool *has_big) {
+    bool overflow = false;
+    if (ctx->opt.join_fused) {
+        std::vector<uint32_t> emp;   // (a repeated call must not list the empty sketches twice)
+        const int rc = pairs_join_impl(ctx, d_hashes, d_lens, n, s, d_cmin, cmin_floor, rank, world, row_lo, d_out, d_count, cap, pairs_compared, used,
+                                       late_decline, empties ? &emp : nullptr, d_big, has_big, true, &overflow);
+        if (rc || !overflow) { if (empties) empties->insert(empties->end(), emp.begin(), emp.end()); return rc; }
+        if (d_big) GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_big, 0, n, ctx->stream));   // the marks of the abandoned attempt
+    }
+    return pairs_join_impl(ctx, d_hashes, d_lens, n, s, d_cmin, cmin_floor, rank, world, row_lo, d_out, d_count, cap, pairs_compared, used, late_decline,
+                           empties, d_big, has_big, false, &overflow);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Hash-sharded form for several ranks (comm.cpp: precluster_join_sharded).  The one-rank join's element stage -- one pass
 // over all N*s hashes, three quarters of its time at 10 000 genomes -- does not shrink when the RECORDS are dealt over
@@ -870,9 +1058,11 @@ int ghip_pairs_join(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_l
 // filter and candidate list as in the one-rank form (stage 2: ghip_pairs_join_finish).
 // *status bit 0: this rank declines (an element bucket beyond the LDS stage / a table overflow / more records than fit).
 
-int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s, uint32_t hrank,
-                             uint32_t hworld, void **d_entries_out, uint32_t *n_entries_out, uint32_t *status, unsigned long long *rec_total) {
+static int join_partials_impl(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s, uint32_t hrank,
+                              uint32_t hworld, void **d_entries_out, uint32_t *n_entries_out, uint32_t *status, unsigned long long *rec_total,
+                              bool fused, bool *overflow) {
     *d_entries_out = nullptr; *n_entries_out = 0; *status = 1; *rec_total = 0;
+    *overflow = false;
     if (n < 2 || (uint64_t)n * s >= (1ull << 32)) return GHIP_OK;
     std::vector<uint32_t> lens(n);
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(lens.data(), d_lens, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -880,10 +1070,12 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     uint64_t n_elem = 0;
     for (uint32_t l : lens) { n_elem += l; if (l == 0) return GHIP_OK; }   // an empty sketch pairs with everything (NaN quirk): dense forms only
     struct Owned { ghip_ctx *c; std::vector<void *> p; ~Owned() { for (void *x : p) ghip_pool_free(c, x); } } own{ctx, {}};
-    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 8);  // [0] flags, [1] largest element bucket, [2..3] u64 records found, [4..5] records kept
+    uint32_t *d_flags = jalloc<uint32_t>(ctx, own.p, 8 + J_ARRIVE);  // [0] flags, [1] largest element bucket, [2..3] u64 records found, [4..5] records kept, [8..] arrival words of the fused scans
     if (!d_flags) return GHIP_EHIP;
     unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_flags + 2);
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, 8 * sizeof(uint32_t), ctx->stream));
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, (8 + J_ARRIVE) * sizeof(uint32_t), ctx->stream));
+    JoinFused jf;
+    jf.on = fused; jf.d_arrive = d_flags + 8; jf.d_flags = d_flags;
     ghip_prof_begin(ctx, "pair_join");
     auto done = [&](int rc) { ghip_prof_end(ctx); return rc; };
     const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_COMM);
@@ -895,15 +1087,18 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     // (bucket count as in the one-rank form: a rank's hashes fill 1/hworld of the first-level digits, the buckets below
     // each digit hold what they hold there)
     const uint32_t ebits = bits2_for(n_elem, J_BITS2_MIN_ELEM), enb = 256u << ebits;
-    int rc = partition(ctx, own.p, es, es.total, (uint32_t)mine_bound, ebits, true, &ek, &ev, &d_estart, d_flags + 1);
+    // (fused form: a rank's hashes fill 1/hworld of the first-level buckets, each as full as in the one-rank form -- the
+    // capacity follows from ALL the elements)
+    int rc = partition(ctx, own.p, es, es.total, (uint32_t)mine_bound, ebits, true, &ek, &ev, &d_estart, d_flags + 1, &jf);
     if (rc) return done(rc);
     lap("element partition");
     uint32_t *d_rcount = jalloc<uint32_t>(ctx, own.p, enb), *d_rstart = jalloc<uint32_t>(ctx, own.p, enb + 1);
     if (!d_rcount || !d_rstart) return done(GHIP_EHIP);
     uint32_t flags[2], ecap = 0;
     unsigned long long totals[2] = {0, 0};
-    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, 0u, 1u, 0u, flags, totals, &ecap))) return done(rc);
+    if ((rc = elem_pairs_count(ctx, own.p, enb, ek, ev, d_estart, d_rcount, d_rstart, d_flags, d_total, 0u, 1u, 0u, flags, totals, &ecap, nullptr, &jf))) return done(rc);
     lap("count records");
+    if (flags[0] & 8u) { *overflow = true; return done(GHIP_OK); }
     *rec_total = totals[0];
     if ((flags[0] & 1u) || totals[0] >= (1ull << 31)) return done(GHIP_OK);   // declined (status bit 0 stays set)
     const uint32_t n_rec = (uint32_t)totals[1];
@@ -915,19 +1110,20 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     uint64_t *rk = nullptr; uint32_t *d_pstart = nullptr;
     RecSrc rs{d_rec, n_rec};
     const uint32_t rbits = bits2_for(n_rec), rnb = 256u << rbits;
-    if ((rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr))) return done(rc);
+    if ((rc = partition(ctx, own.p, rs, n_rec, n_rec, rbits, false, &rk, nullptr, &d_pstart, nullptr, &jf, true, s))) return done(rc);
     // pairs per bucket -> their offsets -> the entries, compact and in bucket order (no atomics)
     uint32_t *d_ecount = jalloc<uint32_t>(ctx, own.p, rnb), *d_estart2 = jalloc<uint32_t>(ctx, own.p, rnb + 1);
     if (!d_ecount || !d_estart2) return done(GHIP_EHIP);
     hipLaunchKernelGGL((join_reduce_kernel<false, 1>), dim3(rnb / J_WAVES), dim3(J_THREADS), 0, ctx->stream, rk, (const uint32_t *)nullptr,
                        (JoinEntry *)nullptr, d_ecount, (const uint32_t *)nullptr, d_pstart, d_hashes, d_lens, s, (const uint16_t *)nullptr, 0u, 0u, 1u, 0u,
                        (ghip_pair *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, d_flags, (const uint8_t *)nullptr);
-    if ((rc = scan_counters(ctx, own.p, d_ecount, rnb, d_estart2, nullptr))) return done(rc);
+    if ((rc = fused ? scan_counters_fused(ctx, own.p, jf, d_ecount, nullptr, rnb, d_estart2, nullptr, nullptr) : scan_counters(ctx, own.p, d_ecount, rnb, d_estart2, nullptr))) return done(rc);
     uint32_t f0 = 0, n_ent = 0;
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&f0, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipMemcpyAsync(&n_ent, d_estart2 + rnb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     lap("count entries");
+    if (f0 & 8u) { *overflow = true; return done(GHIP_OK); }   // (fused form) a first-level record bucket outgrew its capacity
     if (f0 & 2u) return done(GHIP_OK);   // a record table overflowed: declined
     JoinEntry *d_ent = (JoinEntry *)ghip_pool_alloc(ctx, (size_t)std::max<uint32_t>(n_ent, 1) * sizeof(JoinEntry));
     if (!d_ent) return done(GHIP_EHIP);
@@ -938,6 +1134,16 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     lap("emit entries");
     *d_entries_out = d_ent; *n_entries_out = n_ent; *status = 0;
     return done(GHIP_OK);
+}
+
+int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s, uint32_t hrank,
+                             uint32_t hworld, void **d_entries_out, uint32_t *n_entries_out, uint32_t *status, unsigned long long *rec_total) {
+    bool overflow = false;
+    if (ctx->opt.join_fused) {
+        const int rc = join_partials_impl(ctx, d_hashes, d_lens, n, s, hrank, hworld, d_entries_out, n_entries_out, status, rec_total, true, &overflow);
+        if (rc || !overflow) return rc;
+    }
+    return join_partials_impl(ctx, d_hashes, d_lens, n, s, hrank, hworld, d_entries_out, n_entries_out, status, rec_total, false, &overflow);
 }
 
 // d_all: the entries of every rank, blocks padded with key = 2^64 - 1.  *ok = false: this rank's tables overflowed (huge

@@ -98,6 +98,9 @@ typedef struct ghip_options {
     uint32_t pair_debug;        /* merge-path kernel's debug selector (GHIP_PAIR_DEBUG) */
     uint32_t fault_stage;       /* GHIP_FAULT_*: tests only */
     uint32_t fault_rank;
+    uint32_t join_fused;        /* 1: the join's partitions in their fused form -- first level into fixed-capacity buckets (no histogram
+                                   pass, no scan, no host round trip), single-launch scans: 12 launches instead of 20; an outgrown
+                                   capacity repeats the call in the exact form.  0: the exact form   (GHIP_JOIN_FUSED) */
 } ghip_options;
 int ghip_get_options(const ghip_ctx *ctx /* NULL: the process-wide defaults */, ghip_options *out);
 int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const ghip_options *opt);

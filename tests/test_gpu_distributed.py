@@ -130,7 +130,7 @@ def test_lazy_ani_on_one_rank_equals_all_pairs(ctx, opts):
             assert asked < len(full["pairs"])       # family of 8: 7 edges to the representative, the other 21 never asked
 
 
-@pytest.mark.parametrize("mode,world", [("shard", 3), ("records", 3), ("replicate", 3), ("shard", 8)])
+@pytest.mark.parametrize("mode,world", [("shard", 3), ("records", 3), ("replicate", 3), ("shard", 8), ("shard_fused", 3)])
 def test_ranks_join_form_equals_single_rank(ctx, mode, world):
     """N = 2100 short genomes on three and on eight ranks (ragged shards): the pair stage takes the join form -- HASH-SHARDED
     (default: every rank partitions 1/world of the hashes, the per-pair partial counts are exchanged, a rank finishes the
@@ -139,7 +139,7 @@ def test_ranks_join_form_equals_single_rank(ctx, mode, world):
     index slices are exchanged too."""
     import oracle
     n, length = 2100, 30_000
-    got = _run(world, n=n, length=length, options={} if mode == "shard" else {"join_ranks": mode})
+    got = _run(world, n=n, length=length, options={} if mode == "shard" else ({"join_fused": 1} if mode == "shard_fused" else {"join_ranks": mode}))
     want, hashes, lens = _single(ctx, n, length)
     _same(got, want, hashes, lens)
     assert got["compared"] == n * (n - 1) // 2          # the ranks' shares partition the triangle

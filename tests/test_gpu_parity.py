@@ -261,6 +261,44 @@ def test_cluster_end_to_end_vs_oracle(ctx):
         assert sorted(x for c in got for x in c) == list(range(len(paths)))
 
 
+def test_join_fused_form_equals_exact_form_and_survives_an_outgrown_capacity(ctx, opts):
+    """ghip_options.join_fused (round 4: 20 -> 12 launches, no host round trip inside a partition): byte-identical pair lists
+    to the exact form and to the oracle at a size where the join is the automatic form (3 000 sketches, families of every
+    size up to 60), whole and as the shares of 3 ranks; and a matrix built to overflow a first-level capacity -- every hash
+    with the same eight digit bits -- raises the overflow flag and is answered by the exact form instead, same bytes."""
+    rng = np.random.default_rng(2024)
+    n, s = 3000, 1000
+    hashes, lens = random_sketches(rng, n, s, shared_groups=120, min_len=600)
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32)
+    assert len(want) > 1000
+    ctx.profile(True)
+    for fused in (0, 1):
+        opts(join_fused=fused)
+        ctx.profile_reset()
+        assert ctx.precluster(sk, np.float32(0.9)).tobytes() == want.tobytes(), fused
+        st = ctx.kernel_stats()
+        assert st["pair_join"][0] > 0 and st["pair_intersect_tile"][0] == 0      # the join form ran and did not decline
+        parts = [ctx.precluster_ranks(sk, np.float32(0.9), r, 3)[0] for r in range(3)]
+        assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes(), fused
+    sk.free()
+    # every hash in ONE first-level bucket: bits 12..19 of the hash are the first digit (pairs_join.hip: ElemSrc::mix)
+    n = 1500
+    hashes, lens = random_sketches(rng, n, 256, shared_groups=60, min_len=200)
+    valid = np.arange(256)[None, :] < lens[:, None]
+    skew = (hashes & ~np.uint64(0xFF000)) | np.uint64(0x5A000)
+    hashes = np.where(valid, skew, hashes)
+    hashes = np.sort(hashes, axis=1)      # (clearing bits may reorder a row; rows stay distinct with overwhelming probability)
+    assert all(len(np.unique(hashes[i, : lens[i]])) == lens[i] for i in range(0, n, 97))
+    sk = ctx.sketches_from_host(hashes, lens, 21)
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32)
+    for fused in (0, 1):
+        opts(join_fused=fused)
+        assert ctx.precluster(sk, np.float32(0.9)).tobytes() == want.tobytes(), fused
+    ctx.profile(False)
+    sk.free()
+
+
 def test_merge_path_kernel_also_matches_oracle(ctx, opts):
     """The 64-way merge-path kernel (fallback form of pair_intersect_tile) on the same inputs."""
     opts(pair_form="merge")
@@ -551,11 +589,13 @@ def test_every_seed_of_dirty_streams(ctx, c):
             start += int(cap[i])
 
 
-def test_join_form_of_the_pair_stage_matches_oracle(ctx, opts):
+@pytest.mark.parametrize("fused", [0, 1])
+def test_join_form_of_the_pair_stage_matches_oracle(ctx, opts, fused):
     """The inverted-index form (pairs_join.hip; automatic from N >= 1200) forced on small inputs: same bytes as
     the oracle's pair loop, whole and sharded; and the inputs it must decline (threshold 0, empty sketches)
-    still give the dense kernels' answer."""
-    opts(pair_form="join")
+    still give the dense kernels' answer.  fused: its partitions in the fused form (ghip_options.join_fused: the first
+    level into fixed-capacity buckets, single-launch scans) -- the same bytes."""
+    opts(pair_form="join", join_fused=fused)
     ctx.profile(True)
     for n, s, min_len, thr, groups in ((37, 1000, None, 0.9, 5), (130, 256, 1, 0.8, 5), (300, 1000, 700, 0.9, 40),
                                        (64, 1000, 1, 0.0, 5), (2, 1000, None, 0.9, 1)):
