@@ -162,6 +162,27 @@ def test_config5_50k_genomes_quality_order_two_stage(ctx):
     oc = oracle.cluster(sub, oracle.Cache.from_pairs(pairs[keep]), 95.0,
                         lambda a, b: float(look[(min(a, b), max(a, b))]))
     assert galah_amd.cluster_pairs(sub, pairs[keep], np.float32(95.0), ani[keep]) == oc
+    # ... and the second stage with the ANI KERNEL (the values above are synthetic): a 3 000-genome
+    # sub-problem of the same shape -- 300 species x 10 of 100 kb, CheckM2-style qualities, Parks2020_reduced order, 90 %
+    # precluster / 95 % ANI -- sketch -> pairs -> the native clusterer's lazy ANI rounds on the resident index, against the
+    # oracle's sketches, pair loop, ANI and greedy clusterer in that order
+    from test_gpu_e2e_scale import MEMBERS, RATE, SEED, oracle_end_to_end
+    n_sp, length = 300, 100_000
+    m = n_sp * MEMBERS
+    q = np.random.default_rng(56)
+    sub_order = galah_amd.quality_order_parks2020_reduced(q.uniform(70, 100, m).astype(np.float32) / np.float32(100),
+                                                          q.uniform(0, 5, m).astype(np.float32) / np.float32(100),
+                                                          q.integers(1, 400, m), q.integers(0, 20000, m))
+    g = ctx.genomes_synthetic(SEED, n_sp, MEMBERS, length, RATE)
+    sk2, idx2 = ctx.sketch_and_index(g, 21, 1000, 0)
+    p2 = ctx.precluster(sk2, np.float32(0.9))
+    got, st = ctx.cluster_index(idx2, m, p2, np.float32(95.0), 0.15, sub_order)
+    oh, ol, op, olook, oclusters = oracle_end_to_end(n_sp, length, order=sub_order)
+    h2, l2 = sk2.to_host()
+    assert np.array_equal(h2, oh) and np.array_equal(l2, ol) and p2.tobytes() == op.tobytes()
+    assert got.tolist() == oclusters and st["asked"] <= len(op)
+    for h in (sk2, idx2, g):
+        h.free()
 
 
 def test_config2_full_length_genomes_sample_vs_oracle(ctx):
