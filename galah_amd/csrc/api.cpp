@@ -459,6 +459,7 @@ ghip_options options_from_environment() {
     o.debug = (set("GHIP_INGEST_DEBUG") ? GHIP_DEBUG_INGEST : 0) | (set("GHIP_PRECLUSTER_DEBUG") ? GHIP_DEBUG_PRECLUSTER : 0) |
               (set("GHIP_COMM_DEBUG") ? GHIP_DEBUG_COMM : 0) | (set("GHIP_CLUSTER_DEBUG") ? GHIP_DEBUG_CLUSTER : 0) | (set("GHIP_ANI_DEBUG") ? GHIP_DEBUG_ANI : 0);
     o.pair_debug = num("GHIP_PAIR_DEBUG", 0);
+    o.probe_arranged = num("GHIP_PROBE_ARRANGED", 0);   // (likewise off until measured)
     o.join_fused = num("GHIP_JOIN_FUSED", 0);   // (off until a GPU run has shown it byte-identical and faster: profiles/r04*)
     return o;
 }
@@ -1163,7 +1164,7 @@ extern "C" int ghip_genomes_to_host(ghip_ctx *ctx, const ghip_genomes *g, size_t
 static void free_sketches_locked(ghip_sketches *sk) {  // ctx->mu held
     ghip_ctx *ctx = sk->ctx;
     if (sk->owned) { ghip_pool_free(ctx, sk->d_hashes); ghip_pool_free(ctx, sk->d_lens); }
-    ghip_pool_free(ctx, sk->d_tables); ghip_pool_free(ctx, sk->d_tags); ghip_pool_free(ctx, sk->d_row_start);
+    ghip_pool_free(ctx, sk->d_tables); ghip_pool_free(ctx, sk->d_tags); ghip_pool_free(ctx, sk->d_row_start); ghip_pool_free(ctx, sk->d_arranged);
     ctx->live_handles--;
     delete sk;
 }
@@ -1496,8 +1497,11 @@ static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
     if ((rc = dmalloc(ctx, &sk->d_tags, sk->n * slots))) return rc;
     if ((rc = dmalloc(ctx, &d_flags, 1))) return rc;
     DeviceFree tmp(ctx); tmp.add(d_flags);
+    // the arranged form (ghip_options.probe_arranged, fixed for the life of the matrix's tables): constrained second bucket,
+    // B rows dealt to the lanes by bucket residue
+    if (ctx->opt.probe_arranged && (rc = dmalloc(ctx, &sk->d_arranged, sk->n * ghip_probe_arranged_slots(sk->s)))) return rc;
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
-    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, sk->d_tags, d_flags);
+    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, sk->d_tags, d_flags, sk->d_arranged);
     sk->n_work = ghip_probe_work_rows(sk->n, ctx->num_cus, &sk->probe_cb, sk->row_start);
     if ((rc = dmalloc(ctx, &sk->d_row_start, sk->row_start.size()))) return rc;
     if ((rc = h2d(ctx, sk->d_row_start, sk->row_start.data(), sk->row_start.size()))) return rc;
@@ -1698,7 +1702,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if (joined) {
         } else if (use_probe) {
             ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, sk->d_tags, n, s, sk->probe_cb, sk->d_row_start,
-                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap);
+                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, sk->d_arranged);
             compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, drank, dworld);
         } else if (s <= 4096) {
             ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, &compared);
@@ -1756,7 +1760,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
             bool sub_probe = s <= 1024 && force != GHIP_PAIR_MERGE;
             if (sub_probe) {
                 if ((rc = prepare_probe(ctx, &sub))) return rc;
-                tmp.add(sub.d_tables); tmp.add(sub.d_tags); tmp.add(sub.d_row_start);
+                tmp.add(sub.d_tables); tmp.add(sub.d_tags); tmp.add(sub.d_row_start); if (sub.d_arranged) tmp.add(sub.d_arranged);
                 sub_probe = sub.probe_flags == 0;
             }
             const uint64_t Ps = (uint64_t)G.size() * (G.size() - 1) / 2;
@@ -1770,7 +1774,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
                 uint64_t unused = 0;
                 if (sub_probe)
                     ghip_launch_pairs_probe(ctx, sub.d_hashes, sub.d_lens, sub.d_tables, sub.d_tags, sub.n, s, sub.probe_cb, sub.d_row_start,
-                                            (uint32_t)(sub.row_start.size() - 1), sub.n_work, d_cmin, 0, 1, 0, d_sub, d_count, scap);
+                                            (uint32_t)(sub.row_start.size() - 1), sub.n_work, d_cmin, 0, 1, 0, d_sub, d_count, scap, sub.d_arranged);
                 else if (s <= 4096) ghip_launch_pairs(ctx, sub.d_hashes, sub.d_lens, sub.n, s, d_cmin, 0, 1, 0, d_sub, d_count, scap, &unused);
                 else ghip_launch_pairs_global(ctx, sub.d_hashes, sub.d_lens, sub.n, s, d_cmin, 0, 1, 0, d_sub, d_count, scap, &unused);
                 unsigned long long cnt = 0;

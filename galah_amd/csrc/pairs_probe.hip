@@ -37,7 +37,18 @@ constexpr int PROBE_THREADS = PROBE_WAVES * 64;
 constexpr uint64_t EMPTY = ~0ull;
 
 __device__ __forceinline__ uint32_t bucket1(uint64_t x, uint32_t mask) { return (uint32_t)x & mask; }
-__device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask) { return (uint32_t)(x >> 20) & mask; }
+// ARR (the arranged form, ghip_options.probe_arranged): the second cuckoo choice keeps the first one's low four bucket bits.
+// A bucket is 8 bytes of tags, a ds_read_b64 conflicts when two lanes of a 32-lane group read different addresses of one
+// bank PAIR = bucket mod 32; with both choices of an element in the same residue class mod 16 (and, half the time, mod 32)
+// a B row whose elements are dealt to the lanes by the residue of their first bucket reads both buckets of every element
+// almost without conflicts (pair_arrange_kernel below).  Classes mod 16 rather than 32: a class is then a cuckoo table of
+// buckets / 16 >= 16 buckets of its own, and an insertion that cannot be placed stays as unlikely as in the free form
+// (mod 32 a class of a 1000-hash sketch holds 31 +- 5.6 hashes in 64 slots: an overfull class every few thousand sketches).
+template <bool ARR>
+__device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask) {
+    const uint32_t free2 = (uint32_t)(x >> 20) & mask;
+    return (ARR && mask > 15u) ? ((free2 & ~15u) | ((uint32_t)x & 15u)) : free2;   // (tables of <= 16 buckets keep the free choice)
+}
 // 31 bits of the hash that neither bucket index can use (bits 10..19 and 30..50; s <= 1024: at most 10-bit indices) under a
 // presence bit: an empty slot's tag (0) matches nothing
 __device__ __forceinline__ uint32_t tag_of(uint64_t x) {
@@ -48,6 +59,7 @@ __device__ __forceinline__ uint32_t tag_of(uint64_t x) {
 // pair_table_build: one 256-thread block per sketch, cuckoo insertion with 64-bit LDS atomics.
 // flags: bit 0 = some sketch contains 2^64-1, bit 1 = an insertion did not converge.
 // ---------------------------------------------------------------------------------------------
+template <bool ARR>
 __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *__restrict__ hashes,
                                                                const uint32_t *__restrict__ lens, uint32_t s,
                                                                uint32_t buckets, uint64_t *__restrict__ tables,
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *_
             const unsigned long long y = atomicExch(&tab[2 * b + (rnd >> 31)], x);
             x = y;
             if (x == EMPTY) { placed = true; break; }  // a concurrent eviction freed the slot
-            const uint32_t b1 = bucket1(x, mask), b2 = bucket2(x, mask);
+            const uint32_t b1 = bucket1(x, mask), b2 = bucket2<ARR>(x, mask);
             b = (b == b1) ? b2 : b1;
         }
         if (!placed) atomicOr(flags, 2u);
@@ -88,6 +100,7 @@ __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *_
 
 // Exact (common, total) of one pair, by the calling wavefront: the B row probes the A-sketch's full 64-bit cuckoo set in
 // global memory (L2) -- the arithmetic of raw_distance (src/finch.rs:74-96 via finch::distance), nothing approximate left.
+template <bool ARR>
 __device__ __forceinline__ uint2 exact_pair(const uint64_t *__restrict__ arow, uint32_t na, const uint64_t *__restrict__ brow,
                                                       uint32_t nb, const uint64_t *__restrict__ table, uint32_t mask, uint32_t lane) {
     const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(table);
@@ -101,7 +114,7 @@ __device__ __forceinline__ uint2 exact_pair(const uint64_t *__restrict__ arow, u
 #pragma unroll
         for (int u = 0; u < 8; u++) x[u] = e0 + 64u * u < nb ? brow[e0 + 64u * u] : 0ull;
 #pragma unroll
-        for (int u = 0; u < 8; u++) { v1[u] = set[bucket1(x[u], mask)]; v2[u] = set[bucket2(x[u], mask)]; }
+        for (int u = 0; u < 8; u++) { v1[u] = set[bucket1(x[u], mask)]; v2[u] = set[bucket2<ARR>(x[u], mask)]; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool have = e0 + 64u * u < nb;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
                 const uint64_t x = (e < nb) ? brow[e] : EMPTY;            // (EMPTY is > every max A: never counted)
                 tg[t] = (e < nb) ? tag_of(x) : 1u;
                 o1[t] = bucket1(x, mask) * 8u;
-                o2[t] = bucket2(x, mask) * 8u;
+                o2[t] = bucket2<false>(x, mask) * 8u;
 #pragma unroll
                 for (uint32_t q = 0; q < PROBE_TA; q++) le[q] += (x <= amax[q]) ? 0x10000u : 0u;
             }
@@ -258,8 +271,153 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
+// The ARRANGED form of the same kernel (ghip_options.probe_arranged).  B rows come from `arranged` (pair_arrange_kernel:
+// NS x 64 slots per sketch, slot t * 64 + lane, 2^64 - 1 = hole) and the second bucket is the constrained one, so the 32
+// lanes of a ds_read_b64 group read 32 different bank pairs.  The loops are turned inside out with respect to the kernel
+// above: a GROUP of four row slots is fetched (the next group travels meanwhile), its tags and bucket offsets are worked
+// out once, and all 8 A-sets are probed with them -- 12 registers of row state instead of 3 NS, so the 20 slots per lane of
+// a 1000-hash row cost no spills (the row-major order of the kernel above, at NT = 20: 29 spilled VGPRs).
+template <int NS>
+__global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void pair_probe_arranged_kernel(
+    const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint32_t *__restrict__ tags,
+    const uint64_t *__restrict__ arranged, uint32_t n, uint32_t s, uint32_t buckets, uint32_t cb, const uint64_t *__restrict__ row_start,
+    uint32_t nta, uint64_t n_work, uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin,
+    ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr uint32_t SET_BYTES = (NS > 6 ? 1024u : 256u) * 8u;
+    constexpr int GROUP = 4;
+    static_assert(NS % GROUP == 0 || NS == 6, "slots per lane");
+    uint64_t *samp = reinterpret_cast<uint64_t *>(smem_raw + PROBE_TA * SET_BYTES);     // [TA][64]
+    uint64_t *a_max = samp + PROBE_TA * 64;                                             // [TA]
+    uint32_t *a_len = reinterpret_cast<uint32_t *>(a_max + PROBE_TA);                   // [TA]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t mask = buckets - 1;
+    const uint32_t hole_off = (lane & 31u & mask) * 8u;   // a hole reads the bucket of its own lane's residue: no conflict with its group
+
+    for (uint64_t blk = blockIdx.x;; blk += gridDim.x) {
+        const uint64_t w = blk * world + rank;
+        if (w >= n_work) return;
+        uint32_t lo = 0, hi = nta;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (row_start[mid] <= w) lo = mid; else hi = mid;
+        }
+        const uint32_t ti = lo;
+        const uint32_t j0 = ti * PROBE_TA + (uint32_t)(w - row_start[ti]) * cb;
+        if ((uint64_t)j0 + cb <= row_lo) continue;
+        __syncthreads();
+        for (uint32_t q = 0; q < PROBE_TA; q++) {
+            const uint32_t g = ti * PROBE_TA + q;
+            const uint4 *src = reinterpret_cast<const uint4 *>(tags + (uint64_t)g * 2 * buckets);
+            uint4 *dst = reinterpret_cast<uint4 *>(smem_raw + q * SET_BYTES);
+            for (uint32_t e = threadIdx.x; e < buckets / 2; e += PROBE_THREADS)
+                dst[e] = (g < n) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (threadIdx.x < PROBE_TA * 64) {
+            const uint32_t q = threadIdx.x >> 6, l = threadIdx.x & 63u;
+            const uint32_t g = ti * PROBE_TA + q;
+            const uint32_t na = (g < n) ? lens[g] : 0u;
+            const uint32_t idx = 16 * l + 15;
+            samp[q * 64 + l] = (idx < na) ? hashes[(uint64_t)g * s + idx] : EMPTY;
+            if (l == 0) { a_len[q] = na; a_max[q] = na ? hashes[(uint64_t)g * s + na - 1] : 0ull; }
+        }
+        __syncthreads();
+
+        uint64_t amax[PROBE_TA];   // wave-uniform: scalar registers
+#pragma unroll
+        for (uint32_t q = 0; q < PROBE_TA; q++) {
+            const uint64_t v = a_max[q];
+            amax[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        }
+        for (uint32_t jj = wave; jj < cb; jj += PROBE_WAVES) {
+            const uint32_t gj = j0 + jj;
+            if (gj >= n || gj <= ti * PROBE_TA || gj < row_lo) continue;
+            const uint32_t nb = lens[gj];
+            const uint64_t *arow = arranged + (uint64_t)gj * (NS * 64) + lane;
+            uint32_t packed[PROBE_TA];   // per A-set: low 16 bits hits, high 16 bits #{b <= max A}
+#pragma unroll
+            for (uint32_t q = 0; q < PROBE_TA; q++) packed[q] = 0;
+            constexpr int NG = (NS + GROUP - 1) / GROUP;
+            uint64_t xn[GROUP];
+#pragma unroll
+            for (int u = 0; u < GROUP; u++) xn[u] = arow[64 * u];
+#pragma unroll 1   // (a real loop: unrolled, the compiler hoists every group's loads and offsets to the top and spills 600 registers)
+            for (int gidx = 0; gidx < NG; gidx++) {
+                uint32_t tg[GROUP], o1[GROUP], o2[GROUP];
+                uint64_t x[GROUP];
+#pragma unroll
+                for (int u = 0; u < GROUP; u++) x[u] = xn[u];
+                if (gidx + 1 < NG) {   // the next group's slots are in flight while this one is probed
+#pragma unroll
+                    for (int u = 0; u < GROUP; u++) xn[u] = ((gidx + 1) * GROUP + u < NS) ? arow[64 * ((gidx + 1) * GROUP + u)] : EMPTY;
+                }
+#pragma unroll
+                for (int u = 0; u < GROUP; u++) {
+                    const bool have = x[u] != EMPTY && gidx * GROUP + u < NS;   // (a sketch holding 2^64 - 1 never gets here: probe_flags)
+                    tg[u] = have ? tag_of(x[u]) : 1u;
+                    o1[u] = have ? bucket1(x[u], mask) * 8u : hole_off;
+                    o2[u] = have ? bucket2<true>(x[u], mask) * 8u : hole_off;
+#pragma unroll
+                    for (uint32_t q = 0; q < PROBE_TA; q++) packed[q] += (have && x[u] <= amax[q]) ? 0x10000u : 0u;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < PROBE_TA; q++) {   // unrolled: a set's base is the immediate offset of its LDS reads
+                    const unsigned char *set = smem_raw + q * SET_BYTES;
+                    uint2 v1[GROUP], v2[GROUP];
+#pragma unroll
+                    for (int u = 0; u < GROUP; u++) {
+                        v1[u] = *reinterpret_cast<const uint2 *>(set + o1[u]);
+                        v2[u] = *reinterpret_cast<const uint2 *>(set + o2[u]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < GROUP; u++) {
+                        const uint32_t t = tg[u];
+                        packed[q] += (uint32_t)(v1[u].x == t) | (uint32_t)(v1[u].y == t) | (uint32_t)(v2[u].x == t) | (uint32_t)(v2[u].y == t);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const uint64_t maxb = nb ? hashes[(uint64_t)gj * s + nb - 1] : 0ull;
+#pragma unroll
+            for (uint32_t q = 0; q < PROBE_TA; q++) {
+                const uint32_t gi = ti * PROBE_TA + q;
+                uint32_t pk = packed[q];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) pk += __shfl_xor(pk, off, 64);
+                if (gi >= gj) continue;   // (wave-uniform; the sets past the diagonal were probed for nothing -- diagonal tiles only)
+                const uint32_t na = a_len[q];
+                const uint64_t maxa = amax[q];
+                const uint32_t common = pk & 0xffffu;
+                uint32_t icnt = 0, jcnt = 0;
+                if (na > 0 && nb > 0) {
+                    if (maxa <= maxb) {
+                        icnt = na; jcnt = pk >> 16;
+                    } else {
+                        jcnt = nb;
+                        const uint32_t full = (uint32_t)__popcll(__ballot(samp[q * 64 + lane] <= maxb));
+                        const uint32_t e = 16 * full + (lane & 15u);
+                        const bool in = lane < 16 && e < na && hashes[(uint64_t)gi * s + e] <= maxb;
+                        icnt = 16 * full + (uint32_t)__popcll(__ballot(in));
+                    }
+                }
+                const uint32_t total = min(icnt + jcnt - min(common, icnt + jcnt), 2u * s + 1u);
+                if (lane == 0 && common >= (uint32_t)cmin[total]) {
+                    unsigned long long idx = atomicAdd(out_count, 1ull);
+                    if (idx < cap) {
+                        ghip_pair r;
+                        r.i = gi; r.j = gj; r.common = common; r.total = total; r.ani = 0.0f;
+                        out[idx] = r;   // provisional: pair_verify_kernel recounts it against the full keys
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Exact (common, total) of every listed pair, one wavefront per pair (exact_pair).  The host's f64 recheck
 // (ghip_pairs_finalize) then drops what only the tags let through.
+template <bool ARR>
 __global__ __launch_bounds__(256) void pair_verify_kernel(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
                                                           const uint64_t *__restrict__ tables, uint32_t s, uint32_t buckets,
                                                           ghip_pair *__restrict__ out, const unsigned long long *__restrict__ out_count,
@@ -268,13 +426,55 @@ __global__ __launch_bounds__(256) void pair_verify_kernel(const uint64_t *__rest
     const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < listed; c += (uint64_t)gridDim.x * 4) {
         const uint32_t gi = out[c].i, gj = out[c].j;
-        const uint2 ex = exact_pair(hashes + (uint64_t)gi * s, lens[gi], hashes + (uint64_t)gj * s, lens[gj],
+        const uint2 ex = exact_pair<ARR>(hashes + (uint64_t)gi * s, lens[gi], hashes + (uint64_t)gj * s, lens[gj],
                                     tables + (uint64_t)gi * 2 * buckets, buckets - 1, lane);
         if (lane == 0) { out[c].common = ex.x; out[c].total = ex.y; }
     }
 }
 
+// One 256-thread block per sketch: the row's hashes dealt to the NT x 64 slots of the arranged form.  A hash whose first
+// bucket has residue r mod 32 goes to lane r of the first or the second 32-lane group (alternating), at the next free
+// step t: every (t, group) -- one LDS cycle of a ds_read_b64 when conflict-free -- then reads 32 different bank pairs.
+// A class holds s / 32 hashes on average and 2 NT slots (NT = 20 for s <= 1024: 40 slots for 31 +- 5.6); the few hashes of
+// an overfull class take any hole (they conflict with that step's rightful lane: time, not correctness).  The order of the
+// atomics is not deterministic; the counts the probe takes do not depend on it.
+template <int NT>
+__global__ __launch_bounds__(256) void pair_arrange_kernel(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, uint32_t s,
+                                                           uint32_t buckets, uint64_t *__restrict__ arranged) {
+    __shared__ unsigned long long slot[NT * 64];
+    __shared__ uint32_t cnt[32], n_over;
+    __shared__ unsigned long long over[NT * 64];
+    const uint32_t g = blockIdx.x, mask = buckets - 1;
+    for (uint32_t i = threadIdx.x; i < NT * 64; i += 256) slot[i] = EMPTY;
+    if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_over = 0;
+    __syncthreads();
+    const uint32_t n = min(lens[g], (uint32_t)(NT * 64));
+    const uint64_t *row = hashes + (uint64_t)g * s;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long x = row[i];
+        const uint32_t r = bucket1(x, mask) & 31u;
+        const uint32_t k = atomicAdd(&cnt[r], 1u);
+        if (k < 2u * NT) slot[(k >> 1) * 64 + (k & 1u) * 32 + r] = x;
+        else over[atomicAdd(&n_over, 1u)] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // (rare and short: the hashes of overfull classes into whatever is free)
+        uint32_t at = 0;
+        for (uint32_t o = 0; o < n_over; o++) {
+            while (at < NT * 64 && slot[at] != EMPTY) at++;
+            if (at < NT * 64) slot[at++] = over[o];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < NT * 64; i += 256) arranged[(uint64_t)g * (NT * 64) + i] = slot[i];
+}
+
 }  // namespace
+
+// slots per sketch of the arranged form: NT x 64 with NT = 6 (s <= 256) or 20 (s <= 1024): 1.25-1.5 x the sketch, so that
+// a residue class (s / 32 hashes on average) fits its 2 NT slots with a standard deviation and a half to spare
+size_t ghip_probe_arranged_slots(uint32_t s) { return (s <= 256 ? 6 : 20) * 64; }
 
 size_t ghip_probe_table_slots(uint32_t s) {
     uint32_t b = 1;
@@ -283,12 +483,19 @@ size_t ghip_probe_table_slots(uint32_t s) {
 }
 
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags) {
+                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags, uint64_t *d_arranged /* nullable: the arranged form */) {
     if (n == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
     ghip_prof_begin(ctx, "pair_table_build");
-    hipLaunchKernelGGL(pair_table_build_kernel, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
-                       ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_tags, d_flags);
+    if (d_arranged) {
+        hipLaunchKernelGGL(pair_table_build_kernel<true>, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
+                           ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_tags, d_flags);
+        if (s <= 256) hipLaunchKernelGGL(pair_arrange_kernel<6>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
+        else hipLaunchKernelGGL(pair_arrange_kernel<20>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
+    } else {
+        hipLaunchKernelGGL(pair_table_build_kernel<false>, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
+                           ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_tags, d_flags);
+    }
     ghip_prof_end(ctx);
 }
 
@@ -326,22 +533,27 @@ uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t PROBE_CB, const std::vector
 void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
                              const uint32_t *d_tags, size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
-                             unsigned long long *d_count, uint64_t cap) {
+                             unsigned long long *d_count, uint64_t cap, const uint64_t *d_arranged /* nullable: tables and rows in the arranged form */) {
     const uint64_t mine = n_work > rank ? (n_work - rank + world - 1) / world : 0;
     if (mine == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
     const size_t lds = (size_t)PROBE_TA * (s <= 256 ? 256 : 1024) * 8 + PROBE_TA * 64 * 8 + PROBE_TA * 8 + PROBE_TA * 4;   // (pair_probe_tile_kernel: SET_BYTES)
-    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<16>), 160 * 1024);
-    ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(pair_probe_tile_kernel<4>), 160 * 1024);
     const unsigned grid = (unsigned)std::min<uint64_t>(mine, GHIP_MAX_GRID);
     ghip_prof_begin(ctx, "pair_intersect_tile");
-    if (s <= 256)
-        hipLaunchKernelGGL(pair_probe_tile_kernel<4>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
-                           d_tags, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
-    else
-        hipLaunchKernelGGL(pair_probe_tile_kernel<16>, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens,
-                           d_tags, (uint32_t)n, s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);
+#define GHIP_PROBE_LAUNCH(KERNEL_, ...)                                                                                                   \
+    do {                                                                                                                                 \
+        ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(KERNEL_), 160 * 1024);                                                   \
+        hipLaunchKernelGGL(KERNEL_, dim3(grid), dim3(PROBE_THREADS), lds, ctx->stream, d_hashes, d_lens, d_tags, __VA_ARGS__ (uint32_t)n, \
+                           s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);                   \
+    } while (0)
+    if (d_arranged) {
+        if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<6>, d_arranged,); else GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<20>, d_arranged,);
+    } else {
+        if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_tile_kernel<4>, ); else GHIP_PROBE_LAUNCH(pair_probe_tile_kernel<16>, );
+    }
+#undef GHIP_PROBE_LAUNCH
     // the listed pairs again, against the full keys (part of the same profiled stage: the list is a few thousand pairs)
-    hipLaunchKernelGGL(pair_verify_kernel, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_out, d_count, cap);
+    if (d_arranged) hipLaunchKernelGGL(pair_verify_kernel<true>, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_out, d_count, cap);
+    else hipLaunchKernelGGL(pair_verify_kernel<false>, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_out, d_count, cap);
     ghip_prof_end(ctx);
 }

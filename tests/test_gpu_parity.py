@@ -299,6 +299,33 @@ def test_join_fused_form_equals_exact_form_and_survives_an_outgrown_capacity(ctx
     sk.free()
 
 
+@pytest.mark.parametrize("n,s,min_len,thr", [(37, 1000, None, 0.9), (260, 1000, 1, 0.9), (130, 256, 1, 0.8), (64, 1000, 1, 0.0), (90, 700, 300, 0.95),
+                                             (50, 12, 1, 0.5), (300, 200, 64, 0.9)])
+def test_probe_kernel_arranged_form_matches_oracle(ctx, opts, n, s, min_len, thr):
+    """ghip_options.probe_arranged (round 4): the dense probe kernel with the second cuckoo choice in the first
+    one's residue class and every B row dealt to the lanes by bucket residue (pairs_probe.hip: pair_arrange_kernel,
+    pair_probe_arranged_kernel) -- the same bytes as the oracle's pair loop and as the free form, whole, as the tile shares
+    of 3 ranks, and on the (new x all) rectangle of an incremental run; sketch sizes on both table sizes (s <= 256 and
+    s <= 1024), ragged rows, a table too small for the constraint (s = 12)."""
+    rng = np.random.default_rng(n * 13 + s)
+    hashes, lens = random_sketches(rng, n, s, shared_groups=6, min_len=min_len)
+    want = oracle.distances_from_sketches(hashes, lens, np.float32(thr))
+    ctx.profile(True)
+    for arranged in (1, 0):
+        opts(pair_form="probe", probe_arranged=arranged)
+        sk = ctx.sketches_from_host(hashes, lens, 21)      # (the form is fixed when a matrix's tables are built: a fresh matrix)
+        ctx.profile_reset()
+        assert ctx.precluster(sk, np.float32(thr)).tobytes() == want.tobytes(), arranged
+        assert ctx.kernel_stats()["pair_intersect_tile"][0] > 0      # the probe kernel ran (no fall-back to the merge path)
+        parts = [ctx.precluster(sk, np.float32(thr), r, 3) for r in range(3)]
+        assert np.sort(np.concatenate(parts), order=["i", "j"]).tobytes() == want.tobytes(), arranged
+        lo = n // 2
+        inc = ctx.precluster_from(sk, lo, np.float32(thr))
+        assert inc.tobytes() == want[want["j"] >= lo].tobytes(), arranged
+        sk.free()
+    ctx.profile(False)
+
+
 def test_merge_path_kernel_also_matches_oracle(ctx, opts):
     """The 64-way merge-path kernel (fallback form of pair_intersect_tile) on the same inputs."""
     opts(pair_form="merge")
