@@ -1015,23 +1015,26 @@ extern "C" int ghip_cluster_files_multi(ghip_ctx *const *ctxs, uint32_t world, c
     int rc = ghip_comm_init_local(ctxs, world, comms.data());
     if (rc) return rc;
     std::vector<int> rcs(world, GHIP_OK);
-    ghip_pair *pairs0 = nullptr;
-    float *ani0 = nullptr;
-    size_t n0 = 0;
+    // every rank runs the whole pass with the lazy ANI rounds of the native clusterer dealt over the devices
+    // (ghip_cluster_ranks: the algorithm one device runs) and ends with the same clusters; rank 0's are handed back
+    uint32_t *members0 = nullptr;
+    uint64_t *offsets0 = nullptr;
+    size_t nc0 = 0;
     auto work = [&](uint32_t r) {
         size_t first, count, block;
         ghip_shard_range(n, r, world, &first, &count, &block);
         ghip_genomes *g = nullptr;
         int e = ghip_genomes_from_files(ctxs[r], paths + first, count, std::max(1, io_threads / (int)world), &g);
         if (e) { comms[r]->group->fail(); rcs[r] = e; return; }
-        ghip_pair *p = nullptr;
-        float *a = nullptr;
-        size_t np = 0;
-        e = ghip_distances_and_ani_ranks(comms[r], g, n, k, s, 0, min_ani, 15, ani_c ? ani_c : 125, 20000, min_af, &p, &a, &np, nullptr, nullptr);
+        uint32_t *m = nullptr;
+        uint64_t *o = nullptr;
+        size_t nc = 0;
+        e = ghip_cluster_ranks(comms[r], g, n, k, s, 0, min_ani, 15, ani_c ? ani_c : 125, 20000, min_af, nullptr, ani_threshold, &m, &o, &nc,
+                               nullptr, nullptr, nullptr, nullptr);
         ghip_genomes_free(g);
         rcs[r] = e;
-        if (e == GHIP_OK && r == 0) { pairs0 = p; ani0 = a; n0 = np; }
-        else { ghip_free(p); ghip_free(a); }
+        if (e == GHIP_OK && r == 0) { members0 = m; offsets0 = o; nc0 = nc; }
+        else { ghip_free(m); ghip_free(o); }
     };
     std::vector<std::thread> pool;
     for (uint32_t r = 1; r < world; r++) pool.emplace_back(work, r);
@@ -1040,7 +1043,7 @@ extern "C" int ghip_cluster_files_multi(ghip_ctx *const *ctxs, uint32_t world, c
     // report the rank that actually failed, not the peers its failure released from a collective
     int culprit = -1;
     for (uint32_t r = 0; r < world && culprit < 0; r++)
-        if (rcs[r] && !strstr(ghip_last_error(ctxs[r]), "a peer rank failed")) culprit = (int)r;
+        if (rcs[r] && rcs[r] != GHIP_EPEER && !strstr(ghip_last_error(ctxs[r]), "a peer rank failed")) culprit = (int)r;
     for (uint32_t r = 0; r < world && culprit < 0; r++) if (rcs[r]) culprit = (int)r;
     if (culprit >= 0) {
         rc = rcs[culprit];
@@ -1048,9 +1051,7 @@ extern "C" int ghip_cluster_files_multi(ghip_ctx *const *ctxs, uint32_t world, c
         ghip_set_error(ctxs[0], rc, msg);
     }
     for (uint32_t r = 0; r < world; r++) ghip_comm_destroy(comms[r]);
-    if (rc) { ghip_free(pairs0); ghip_free(ani0); return rc; }
-    rc = ghip_cluster(n, pairs0, n0, ani0, 0, ani_threshold, nullptr, nullptr, out_members, out_offsets, out_n_clusters);
-    ghip_free(pairs0);
-    ghip_free(ani0);
-    return rc;
+    if (rc) { ghip_free(members0); ghip_free(offsets0); return rc; }
+    *out_members = members0; *out_offsets = offsets0; *out_n_clusters = nc0;
+    return GHIP_OK;
 }

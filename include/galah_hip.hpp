@@ -467,8 +467,8 @@ struct GalahClusterer {
 // ---------------------------------------------------------------------------------------------------------------
 // The same `cluster` on SEVERAL GPUs driven by this one process (galah's CLI is a single process): one context and one
 // thread per device, genomes in contiguous blocks, sketch matrix all-gathered by peer copies over xGMI, pair work dealt
-// over the devices, ANI where a pair's first genome lives, greedy clusterer on the caller's thread
-// (ghip_cluster_files_multi).  Same clusters as cluster(genomes, FinchPreclusterer, HipAniClusterer) on one device.
+// over the devices, the native clusterer's lazy ANI rounds with each round's pairs computed where their first genome lives
+// (ghip_cluster_files_multi -> ghip_cluster_ranks: the algorithm one device runs).  Same clusters as cluster(genomes, FinchPreclusterer, HipAniClusterer) on one device.
 inline std::vector<std::vector<size_t>> cluster_multi_gpu(const std::vector<std::shared_ptr<HipContext>> &hips,
                                                           const std::vector<std::string> &genomes, const FinchPreclusterer &pre,
                                                           const HipAniClusterer &cl) {
