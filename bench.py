@@ -606,7 +606,7 @@ def pmc_live():
     if not exe:
         return None
     groups = {"sketch_kmers": ("sketch_kmers21_kernel", True), "pair_join": (r"join_\w+_kernel", False), "sketch_select": ("sketch_select_kernel", False),
-              "ani_pairs": ("ani_pairs_kernel", False), "ani_bin": ("ani_bin_kernel", False), "pair_intersect_tile": ("pair_probe_tile_kernel", False)}   # label regex, FETCH x2?
+              "ani_pairs": ("ani_pairs_kernel", False), "ani_bin": ("ani_bin_kernel", False), "pair_intersect_tile": (r"pair_probe_(tile|arranged)_kernel", False)}   # label regex, FETCH x2?
     out = {g: {} for g in groups}
     d = tempfile.mkdtemp(prefix="ghip_pmc_", dir="/tmp")
     child_steps = 3   # 1 warm-up + 2 timed

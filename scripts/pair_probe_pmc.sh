@@ -17,7 +17,7 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k = "pair_probe_tile" if "pair_probe_tile" in r["Kernel_Name"] else ("pair_verify" if "pair_verify" in r["Kernel_Name"] else None)
+        k = "pair_probe_tile" if ("pair_probe_tile" in r["Kernel_Name"] or "pair_probe_arranged" in r["Kernel_Name"]) else ("pair_verify" if "pair_verify" in r["Kernel_Name"] else None)
         if k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 for k, d in out.items():
