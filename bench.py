@@ -513,6 +513,7 @@ def wall_clock(args, ctx, n_species=100, with_gz=True, repeats=3):
         assert res["clusters"] == c0, "files -> clusters differs from the resident step over the same genomes"
         job = res = None
         gg.free()
+        ctx.profile(False)
         # the box's own host-to-device rate (one pinned 1 GiB copy, second run): what the ingest can at best approach
         import torch
         src = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()

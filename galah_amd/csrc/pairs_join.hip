@@ -754,7 +754,8 @@ int scan_counters_fused(ghip_ctx *ctx, std::vector<void *> &owned, JoinFused &jf
 // load is a sum of ~pairs/256 lumps of up to s records each -- half the mean on top, and room for a few whole lumps.
 uint32_t fused_cap1(uint64_t n_valid, bool lumpy, uint32_t lump) {
     const double mean = (double)n_valid / 256.0;
-    const double cap = lumpy ? 1.5 * mean + 16.0 * (double)lump + 4096.0 : mean + 6.0 * std::sqrt(mean) + 1024.0;
+    // (records at 10 000 genomes: ~176 pairs of ~350 +- 200 records per bucket -> sigma ~ 5 400 on a mean of 61 600: this is 7 sigma)
+    const double cap = lumpy ? 1.5 * mean + 8.0 * (double)lump + 2048.0 : mean + 6.0 * std::sqrt(mean) + 1024.0;
     return (uint32_t)std::min<double>(((uint64_t)cap + 3) / 4 * 4, (double)(0xffffffffu / 256u));
 }
 
@@ -883,6 +884,7 @@ static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t 
         ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_big_kernel<false>), J_BIG_LDS);
         ghip_ensure_dyn_lds(ctx, reinterpret_cast<const void *>(join_elem_pairs_big_kernel<true>), J_BIG_LDS);
     }
+    uint32_t sticky = 0;   // flag bits that must survive the reset between the two attempts: bit 3, a fused partition's overflow
     for (uint32_t cap : {J_ELEM_SMALL, J_ELEM_CAP}) {
         *cap_used = cap;
         // only the last attempt may hand buckets to the block kernel and long runs to the caller's dense pass
@@ -906,7 +908,9 @@ static int elem_pairs_count(ghip_ctx *ctx, std::vector<void *> &owned, uint32_t 
         GHIP_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         GHIP_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         GHIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (!(flags[0] & 1u) || cap == J_ELEM_CAP) break;
+        sticky |= flags[0] & 8u;
+        flags[0] |= sticky;
+        if (sticky || !(flags[0] & 1u) || cap == J_ELEM_CAP) break;   // (an overflow ends the call: the caller repeats it in the exact form)
         // a bucket did not fit the small stage (flags[1] = the largest one): once more, with the full stage
         if (flags[1] > J_ELEM_CAP && !(jb && jb->d_big)) break;   // no stage holds it: the caller declines
         GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));

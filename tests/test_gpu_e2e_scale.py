@@ -106,7 +106,7 @@ def test_10k_genomes_end_to_end_against_the_oracle(ctx, quality_order):
     assert np.array_equal(got_l, lens) and np.array_equal(got_h, hashes)
     assert res["pairs"].tobytes() == pairs.tobytes() and len(pairs) >= 40_000
     assert res["clusters"].tolist() == clusters
-    assert 1_500 < len(clusters) < 5_000 and res["ani_pairs_asked"] < len(pairs)
+    assert 1_000 < len(clusters) < 9_000 and res["ani_pairs_asked"] < len(pairs)
     # the device's ANI values (the lazy rounds keep theirs inside the library): a sample through ghip_ani_pairs
     sk, idx = ctx.sketch_and_index(job.genomes, 21, 1000, 0)
     sample = pairs[:: max(1, len(pairs) // 600)]
