@@ -93,7 +93,7 @@ struct ghip_ctx {
     std::vector<pinned_slot> ingest_slots;
     uint8_t *ingest_stage = nullptr;   // one device allocation behind all the slots' staging areas (pinned_slot::d point into it)
     size_t ingest_stage_bytes = 0;
-    // pinned bounce buffer of the larger host<->device copies (api.cpp h2d / d2h), kept and grown on demand
+    // pinned bounce buffer of the larger host<->device copies (api_internal.h h2d / d2h), kept and grown on demand
     void *pin_buf = nullptr;
     size_t pin_bytes = 0;
     std::mutex pin_mu;
@@ -288,7 +288,7 @@ int ghip_pairs_join_partials(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
 int ghip_pairs_join_finish(ghip_ctx *ctx, const void *d_all, uint32_t n_all, uint32_t n_mine_bound, const uint64_t *d_hashes, const uint32_t *d_lens,
                            uint32_t s, const uint16_t *d_cmin, uint32_t cmin_floor, uint32_t rank, uint32_t world, ghip_pair *d_out,
                            unsigned long long *d_count, uint64_t cap, bool *ok);
-// pieces of the pair stage shared with it (api.cpp; ctx->mu held by the caller of the first, not needed for the second)
+// pieces of the pair stage shared with it (api_pairs.cpp; ctx->mu held by the caller of the first, not needed for the second)
 int ghip_pair_filter_prepare(ghip_ctx *ctx, uint32_t s, uint32_t k, float min_ani);
 int ghip_pairs_finalize(ghip_ctx *ctx, std::vector<ghip_pair> &host, uint32_t k, float min_ani, size_t n, bool filter_share,
                         uint32_t rank, uint32_t world, ghip_pair **out_pairs, size_t *out_n);

@@ -17,7 +17,7 @@
 // and lists their N - 1 pairs itself.  Large families (many genomes sharing each hash: a hash run beyond J_RUN_MAX
 // genomes, or a bucket beyond the LDS stage) go hybrid: a block per oversized bucket (join_elem_pairs_big_kernel)
 // marks the genomes of the long runs in `big`, the join drops the pairs whose two genomes are both marked, and the
-// caller counts exactly those pairs with a dense kernel over the marked rows (api.cpp, precluster_impl).
+// caller counts exactly those pairs with a dense kernel over the marked rows (api_pairs.cpp, precluster_impl).
 //
 // The join form still declines (the caller then runs a dense kernel over everything) when it would not pay or cannot
 // be exact in its fixed-size buffers: min_ani <= 0 (pairs without a common hash qualify), a bucket beyond J_BIG_CAP
