@@ -19,8 +19,9 @@ static int prepare_probe(ghip_ctx *ctx, ghip_sketches *sk) {
     // the arranged form (ghip_options.probe_arranged, fixed for the life of the matrix's tables): constrained second bucket,
     // B rows dealt to the lanes by bucket residue
     if (ctx->opt.probe_arranged && (rc = dmalloc(ctx, &sk->d_arranged, sk->n * ghip_probe_arranged_slots(sk->s)))) return rc;
+    sk->probe_cbits = ghip_probe_constrained_bits(ctx->opt.probe_arranged, sk->s);
     GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
-    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, sk->d_tags, d_flags, sk->d_arranged);
+    ghip_launch_pair_tables(ctx, sk->d_hashes, sk->d_lens, sk->n, sk->s, sk->d_tables, sk->d_tags, d_flags, sk->d_arranged, sk->probe_cbits);
     sk->n_work = ghip_probe_work_rows(sk->n, ctx->num_cus, &sk->probe_cb, sk->row_start);
     if ((rc = dmalloc(ctx, &sk->d_row_start, sk->row_start.size()))) return rc;
     if ((rc = h2d(ctx, sk->d_row_start, sk->row_start.data(), sk->row_start.size()))) return rc;
@@ -221,7 +222,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
         if (joined) {
         } else if (use_probe) {
             ghip_launch_pairs_probe(ctx, sk->d_hashes, sk->d_lens, sk->d_tables, sk->d_tags, n, s, sk->probe_cb, sk->d_row_start,
-                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, sk->d_arranged);
+                                    (uint32_t)(sk->row_start.size() - 1), sk->n_work, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, sk->d_arranged, sk->probe_cbits);
             compared = ghip_probe_pairs_of_rank(n, sk->probe_cb, sk->row_start, drank, dworld);
         } else if (s <= 4096) {
             ghip_launch_pairs(ctx, sk->d_hashes, sk->d_lens, n, s, d_cmin, drank, dworld, (uint32_t)row_lo, d_out, d_count, cap, &compared);
@@ -293,7 +294,7 @@ static int precluster_impl(ghip_ctx *ctx, const ghip_sketches *sk_in, float min_
                 uint64_t unused = 0;
                 if (sub_probe)
                     ghip_launch_pairs_probe(ctx, sub.d_hashes, sub.d_lens, sub.d_tables, sub.d_tags, sub.n, s, sub.probe_cb, sub.d_row_start,
-                                            (uint32_t)(sub.row_start.size() - 1), sub.n_work, d_cmin, 0, 1, 0, d_sub, d_count, scap, sub.d_arranged);
+                                            (uint32_t)(sub.row_start.size() - 1), sub.n_work, d_cmin, 0, 1, 0, d_sub, d_count, scap, sub.d_arranged, sub.probe_cbits);
                 else if (s <= 4096) ghip_launch_pairs(ctx, sub.d_hashes, sub.d_lens, sub.n, s, d_cmin, 0, 1, 0, d_sub, d_count, scap, &unused);
                 else ghip_launch_pairs_global(ctx, sub.d_hashes, sub.d_lens, sub.n, s, d_cmin, 0, 1, 0, d_sub, d_count, scap, &unused);
                 unsigned long long cnt = 0;

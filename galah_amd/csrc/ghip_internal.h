@@ -153,6 +153,7 @@ struct ghip_sketches {
     uint64_t *d_tables = nullptr;      // [n][2*next_pow2(s)]
     uint32_t *d_tags = nullptr;        // [n][2*next_pow2(s)]: 31-bit tags of the same slots (what the probe kernel keeps in LDS)
     uint64_t *d_arranged = nullptr;    // [n][ghip_probe_arranged_slots(s)]: the rows dealt to lanes by bucket residue (arranged form; else null)
+    uint32_t probe_cbits = 0;          // bucket bits the tables' second cuckoo choice shares with the first (arranged form; 0: free)
     uint64_t *d_row_start = nullptr;   // [nta+1]
     std::vector<uint64_t> row_start;
     uint64_t n_work = 0;
@@ -296,13 +297,14 @@ int ghip_precluster_dense_share(ghip_ctx *ctx, const ghip_sketches *sk, float mi
 size_t ghip_probe_table_slots(uint32_t s);
 size_t ghip_probe_arranged_slots(uint32_t s);
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags, uint64_t *d_arranged);
+                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags, uint64_t *d_arranged, uint32_t cbits);
+uint32_t ghip_probe_constrained_bits(uint32_t option, uint32_t s);
 uint64_t ghip_probe_work_rows(size_t n, int num_cus, uint32_t *cb_out, std::vector<uint64_t> &row_start);
 uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t cb, const std::vector<uint64_t> &row_start, uint32_t rank, uint32_t world);
 void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables, const uint32_t *d_tags,
                              size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
-                             unsigned long long *d_count, uint64_t cap, const uint64_t *d_arranged);
+                             unsigned long long *d_count, uint64_t cap, const uint64_t *d_arranged, uint32_t cbits);
 
 void ghip_launch_ani_seeds(ghip_ctx *ctx, const ghip_genomes *g, uint32_t k, const uint32_t *d_seed_thr, uint32_t chunk,
                            uint32_t *d_seed_code, uint32_t *d_seed_loc, const uint64_t *d_seed_start,

@@ -37,17 +37,24 @@ constexpr int PROBE_THREADS = PROBE_WAVES * 64;
 constexpr uint64_t EMPTY = ~0ull;
 
 __device__ __forceinline__ uint32_t bucket1(uint64_t x, uint32_t mask) { return (uint32_t)x & mask; }
-// ARR (the arranged form, ghip_options.probe_arranged): the second cuckoo choice keeps the first one's low four bucket bits.
-// A bucket is 8 bytes of tags, a ds_read_b64 conflicts when two lanes of a 32-lane group read different addresses of one
-// bank PAIR = bucket mod 32; with both choices of an element in the same residue class mod 16 (and, half the time, mod 32)
-// a B row whose elements are dealt to the lanes by the residue of their first bucket reads both buckets of every element
-// almost without conflicts (pair_arrange_kernel below).  Classes mod 16 rather than 32: a class is then a cuckoo table of
-// buckets / 16 >= 16 buckets of its own, and an insertion that cannot be placed stays as unlikely as in the free form
-// (mod 32 a class of a 1000-hash sketch holds 31 +- 5.6 hashes in 64 slots: an overfull class every few thousand sketches).
-template <bool ARR>
-__device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask) {
+// The arranged form (ghip_options.probe_arranged) CONSTRAINS the second cuckoo choice: it keeps the first one's low `cbits`
+// bucket bits (cbits = 0: the free form).  A bucket is 8 bytes of tags, and a ds_read_b64 is served in two groups of 32 lanes
+// that conflict when two lanes read different addresses of one bank PAIR = bucket mod 32: a B row whose elements are dealt to
+// the lanes by the residue of their FIRST bucket (pair_arrange_kernel) reads its first buckets in one LDS cycle per group, and
+// its second buckets -- 5 - cbits random bank bits left -- in ~3.4 (cbits 0), ~3 (2), ~2.7 (3), 2 (4) instead of ~3.4.
+// How far the constraint can go is a matter of the cuckoo tables, simulated on the CPU (1 000-hash sketches, 2 x 1 024
+// slots, 300 000 tables per form): with cbits = 4 a residue class is a cuckoo table of 64 buckets of its own and 2e-5 of
+// the sketches cannot be placed (each one a fall-back of the whole call to the merge kernel); 3e-6 with cbits = 3; none
+// seen with 2 or 0.  And a constrained second choice EQUAL to the first (probability 2^cbits / buckets instead of 1 /
+// buckets) leaves an element one bucket -- three of those in one bucket cannot be placed (8e-4 of the sketches at cbits = 4
+// until the equal case flips the lowest free bit).  Default: 3 bits for tables of >= 1 024 buckets, 2 below.
+__device__ __forceinline__ uint32_t bucket2(uint64_t x, uint32_t mask, uint32_t cbits) {
     const uint32_t free2 = (uint32_t)(x >> 20) & mask;
-    return (ARR && mask > 15u) ? ((free2 & ~15u) | ((uint32_t)x & 15u)) : free2;   // (tables of <= 16 buckets keep the free choice)
+    const uint32_t lm = (1u << cbits) - 1u;
+    if (cbits == 0 || mask <= 2u * lm) return free2;   // (tables too small for the constraint keep the free choice)
+    uint32_t c = (free2 & ~lm) | ((uint32_t)x & lm);
+    if (c == ((uint32_t)x & mask)) c ^= lm + 1u;        // never the first bucket again
+    return c;
 }
 // 31 bits of the hash that neither bucket index can use (bits 10..19 and 30..50; s <= 1024: at most 10-bit indices) under a
 // presence bit: an empty slot's tag (0) matches nothing
@@ -59,10 +66,9 @@ __device__ __forceinline__ uint32_t tag_of(uint64_t x) {
 // pair_table_build: one 256-thread block per sketch, cuckoo insertion with 64-bit LDS atomics.
 // flags: bit 0 = some sketch contains 2^64-1, bit 1 = an insertion did not converge.
 // ---------------------------------------------------------------------------------------------
-template <bool ARR>
 __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *__restrict__ hashes,
                                                                const uint32_t *__restrict__ lens, uint32_t s,
-                                                               uint32_t buckets, uint64_t *__restrict__ tables,
+                                                               uint32_t buckets, uint32_t cbits, uint64_t *__restrict__ tables,
                                                                uint32_t *__restrict__ tags, uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *tab = reinterpret_cast<unsigned long long *>(smem_raw);
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *_
             const unsigned long long y = atomicExch(&tab[2 * b + (rnd >> 31)], x);
             x = y;
             if (x == EMPTY) { placed = true; break; }  // a concurrent eviction freed the slot
-            const uint32_t b1 = bucket1(x, mask), b2 = bucket2<ARR>(x, mask);
+            const uint32_t b1 = bucket1(x, mask), b2 = bucket2(x, mask, cbits);
             b = (b == b1) ? b2 : b1;
         }
         if (!placed) atomicOr(flags, 2u);
@@ -100,9 +106,8 @@ __global__ __launch_bounds__(256) void pair_table_build_kernel(const uint64_t *_
 
 // Exact (common, total) of one pair, by the calling wavefront: the B row probes the A-sketch's full 64-bit cuckoo set in
 // global memory (L2) -- the arithmetic of raw_distance (src/finch.rs:74-96 via finch::distance), nothing approximate left.
-template <bool ARR>
 __device__ __forceinline__ uint2 exact_pair(const uint64_t *__restrict__ arow, uint32_t na, const uint64_t *__restrict__ brow,
-                                                      uint32_t nb, const uint64_t *__restrict__ table, uint32_t mask, uint32_t lane) {
+                                            uint32_t nb, const uint64_t *__restrict__ table, uint32_t mask, uint32_t cbits, uint32_t lane) {
     const ulonglong2 *set = reinterpret_cast<const ulonglong2 *>(table);
     const uint64_t maxa = na ? arow[na - 1] : 0ull, maxb = nb ? brow[nb - 1] : 0ull;
     uint32_t common = 0, b_le = 0, a_le = 0;
@@ -114,7 +119,7 @@ __device__ __forceinline__ uint2 exact_pair(const uint64_t *__restrict__ arow, u
 #pragma unroll
         for (int u = 0; u < 8; u++) x[u] = e0 + 64u * u < nb ? brow[e0 + 64u * u] : 0ull;
 #pragma unroll
-        for (int u = 0; u < 8; u++) { v1[u] = set[bucket1(x[u], mask)]; v2[u] = set[bucket2<ARR>(x[u], mask)]; }
+        for (int u = 0; u < 8; u++) { v1[u] = set[bucket1(x[u], mask)]; v2[u] = set[bucket2(x[u], mask, cbits)]; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool have = e0 + 64u * u < nb;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
                 const uint64_t x = (e < nb) ? brow[e] : EMPTY;            // (EMPTY is > every max A: never counted)
                 tg[t] = (e < nb) ? tag_of(x) : 1u;
                 o1[t] = bucket1(x, mask) * 8u;
-                o2[t] = bucket2<false>(x, mask) * 8u;
+                o2[t] = bucket2(x, mask, 0u) * 8u;
 #pragma unroll
                 for (uint32_t q = 0; q < PROBE_TA; q++) le[q] += (x <= amax[q]) ? 0x10000u : 0u;
             }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
 template <int NS>
 __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void pair_probe_arranged_kernel(
     const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint32_t *__restrict__ tags,
-    const uint64_t *__restrict__ arranged, uint32_t n, uint32_t s, uint32_t buckets, uint32_t cb, const uint64_t *__restrict__ row_start,
+    const uint64_t *__restrict__ arranged, uint32_t cbits, uint32_t n, uint32_t s, uint32_t buckets, uint32_t cb, const uint64_t *__restrict__ row_start,
     uint32_t nta, uint64_t n_work, uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin,
     ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
                     const bool have = x[u] != EMPTY && gidx * GROUP + u < NS;   // (a sketch holding 2^64 - 1 never gets here: probe_flags)
                     tg[u] = have ? tag_of(x[u]) : 1u;
                     o1[u] = have ? bucket1(x[u], mask) * 8u : hole_off;
-                    o2[u] = have ? bucket2<true>(x[u], mask) * 8u : hole_off;
+                    o2[u] = have ? bucket2(x[u], mask, cbits) * 8u : hole_off;
 #pragma unroll
                     for (uint32_t q = 0; q < PROBE_TA; q++) packed[q] += (have && x[u] <= amax[q]) ? 0x10000u : 0u;
                 }
@@ -417,17 +422,16 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
 
 // Exact (common, total) of every listed pair, one wavefront per pair (exact_pair).  The host's f64 recheck
 // (ghip_pairs_finalize) then drops what only the tags let through.
-template <bool ARR>
 __global__ __launch_bounds__(256) void pair_verify_kernel(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens,
-                                                          const uint64_t *__restrict__ tables, uint32_t s, uint32_t buckets,
+                                                          const uint64_t *__restrict__ tables, uint32_t s, uint32_t buckets, uint32_t cbits,
                                                           ghip_pair *__restrict__ out, const unsigned long long *__restrict__ out_count,
                                                           uint64_t cap) {
     const uint64_t listed = min((uint64_t)*out_count, cap);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < listed; c += (uint64_t)gridDim.x * 4) {
         const uint32_t gi = out[c].i, gj = out[c].j;
-        const uint2 ex = exact_pair<ARR>(hashes + (uint64_t)gi * s, lens[gi], hashes + (uint64_t)gj * s, lens[gj],
-                                    tables + (uint64_t)gi * 2 * buckets, buckets - 1, lane);
+        const uint2 ex = exact_pair(hashes + (uint64_t)gi * s, lens[gi], hashes + (uint64_t)gj * s, lens[gj],
+                                    tables + (uint64_t)gi * 2 * buckets, buckets - 1, cbits, lane);
         if (lane == 0) { out[c].common = ex.x; out[c].total = ex.y; }
     }
 }
@@ -483,20 +487,25 @@ size_t ghip_probe_table_slots(uint32_t s) {
 }
 
 void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, size_t n, uint32_t s,
-                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags, uint64_t *d_arranged /* nullable: the arranged form */) {
+                             uint64_t *d_tables, uint32_t *d_tags, uint32_t *d_flags, uint64_t *d_arranged /* nullable: the arranged form */,
+                             uint32_t cbits /* bucket bits the second cuckoo choice shares with the first (0: free) */) {
     if (n == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
     ghip_prof_begin(ctx, "pair_table_build");
+    hipLaunchKernelGGL(pair_table_build_kernel, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
+                       ctx->stream, d_hashes, d_lens, s, buckets, cbits, d_tables, d_tags, d_flags);
     if (d_arranged) {
-        hipLaunchKernelGGL(pair_table_build_kernel<true>, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
-                           ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_tags, d_flags);
         if (s <= 256) hipLaunchKernelGGL(pair_arrange_kernel<6>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
         else hipLaunchKernelGGL(pair_arrange_kernel<20>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
-    } else {
-        hipLaunchKernelGGL(pair_table_build_kernel<false>, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
-                           ctx->stream, d_hashes, d_lens, s, buckets, d_tables, d_tags, d_flags);
     }
     ghip_prof_end(ctx);
+}
+
+// bucket bits the arranged form constrains (ghip_options.probe_arranged: 0 off, 1 by table size, 2..4 that many bits)
+uint32_t ghip_probe_constrained_bits(uint32_t option, uint32_t s) {
+    if (option == 0) return 0;
+    if (option >= 2) return std::min(option, 4u);
+    return ghip_probe_table_slots(s) / 2 >= 1024 ? 3u : 2u;
 }
 
 // work items: A-tile ti (8 sketches) x chunk of cb B-sketches starting at 8*ti.  cb shrinks for small
@@ -533,7 +542,8 @@ uint64_t ghip_probe_pairs_of_rank(size_t n, uint32_t PROBE_CB, const std::vector
 void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_lens, const uint64_t *d_tables,
                              const uint32_t *d_tags, size_t n, uint32_t s, uint32_t cb, const uint64_t *d_row_start, uint32_t nta, uint64_t n_work,
                              const uint16_t *d_cmin, uint32_t rank, uint32_t world, uint32_t row_lo, ghip_pair *d_out,
-                             unsigned long long *d_count, uint64_t cap, const uint64_t *d_arranged /* nullable: tables and rows in the arranged form */) {
+                             unsigned long long *d_count, uint64_t cap, const uint64_t *d_arranged /* nullable: tables and rows in the arranged form */,
+                             uint32_t cbits) {
     const uint64_t mine = n_work > rank ? (n_work - rank + world - 1) / world : 0;
     if (mine == 0) return;
     const uint32_t buckets = (uint32_t)(ghip_probe_table_slots(s) / 2);
@@ -547,13 +557,12 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
                            s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);                   \
     } while (0)
     if (d_arranged) {
-        if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<6>, d_arranged,); else GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<20>, d_arranged,);
+        if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<6>, d_arranged, cbits,); else GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<20>, d_arranged, cbits,);
     } else {
         if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_tile_kernel<4>, ); else GHIP_PROBE_LAUNCH(pair_probe_tile_kernel<16>, );
     }
 #undef GHIP_PROBE_LAUNCH
     // the listed pairs again, against the full keys (part of the same profiled stage: the list is a few thousand pairs)
-    if (d_arranged) hipLaunchKernelGGL(pair_verify_kernel<true>, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_out, d_count, cap);
-    else hipLaunchKernelGGL(pair_verify_kernel<false>, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_out, d_count, cap);
+    hipLaunchKernelGGL(pair_verify_kernel, dim3(2048), dim3(256), 0, ctx->stream, d_hashes, d_lens, d_tables, s, buckets, d_arranged ? cbits : 0u, d_out, d_count, cap);
     ghip_prof_end(ctx);
 }

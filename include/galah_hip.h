@@ -101,9 +101,10 @@ typedef struct ghip_options {
     uint32_t join_fused;        /* 1: the join's partitions in their fused form -- first level into fixed-capacity buckets (no histogram
                                    pass, no scan, no host round trip), single-launch scans: 12 launches instead of 20; an outgrown
                                    capacity repeats the call in the exact form.  0: the exact form   (GHIP_JOIN_FUSED) */
-    uint32_t probe_arranged;    /* 1: the dense probe kernel's tables and B rows in the arranged form -- second cuckoo choice in the
-                                   first one's residue class, a row's hashes dealt to the lanes by bucket residue: its LDS reads
-                                   (almost) free of bank conflicts.  Takes effect when a matrix's tables are built.  (GHIP_PROBE_ARRANGED) */
+    uint32_t probe_arranged;    /* != 0: the dense probe kernel's B rows dealt to the lanes by bucket residue and the second cuckoo
+                                   choice sharing low bucket bits with the first (1: 3 bits for tables of >= 1 024 buckets, 2 below;
+                                   2..4: that many) -- fewer LDS bank conflicts.  Takes effect when a matrix's tables are built.
+                                   (GHIP_PROBE_ARRANGED) */
 } ghip_options;
 int ghip_get_options(const ghip_ctx *ctx /* NULL: the process-wide defaults */, ghip_options *out);
 int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const ghip_options *opt);

@@ -311,7 +311,7 @@ def test_probe_kernel_arranged_form_matches_oracle(ctx, opts, n, s, min_len, thr
     hashes, lens = random_sketches(rng, n, s, shared_groups=6, min_len=min_len)
     want = oracle.distances_from_sketches(hashes, lens, np.float32(thr))
     ctx.profile(True)
-    for arranged in (1, 0):
+    for arranged in (1, 4, 0):   # by table size (3 bits at 1 024 buckets, 2 below) / 4 constrained bucket bits / the free form
         opts(pair_form="probe", probe_arranged=arranged)
         sk = ctx.sketches_from_host(hashes, lens, 21)      # (the form is fixed when a matrix's tables are built: a fresh matrix)
         ctx.profile_reset()
