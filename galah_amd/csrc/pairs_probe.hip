@@ -280,8 +280,8 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
 // NS x 64 slots per sketch, slot t * 64 + lane, 2^64 - 1 = hole) and the second bucket is the constrained one, so the 32
 // lanes of a ds_read_b64 group read 32 different bank pairs.  The loops are turned inside out with respect to the kernel
 // above: a GROUP of four row slots is fetched (the next group travels meanwhile), its tags and bucket offsets are worked
-// out once, and all 8 A-sets are probed with them -- 12 registers of row state instead of 3 NS, so the 20 slots per lane of
-// a 1000-hash row cost no spills (the row-major order of the kernel above, at NT = 20: 29 spilled VGPRs).
+// out once, and all 8 A-sets are probed with them -- 12 registers of row state instead of 3 NS: 82 VGPRs and no spills (the
+// row-major order of the kernel above holds 128 with 7 spilled at 16 slots per lane).
 template <int NS>
 __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void pair_probe_arranged_kernel(
     const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ lens, const uint32_t *__restrict__ tags,
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
     uint32_t nta, uint64_t n_work, uint32_t rank, uint32_t world, uint32_t row_lo, const uint16_t *__restrict__ cmin,
     ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr uint32_t SET_BYTES = (NS > 6 ? 1024u : 256u) * 8u;
+    constexpr uint32_t SET_BYTES = (NS > 4 ? 1024u : 256u) * 8u;
     constexpr int GROUP = 4;
-    static_assert(NS % GROUP == 0 || NS == 6, "slots per lane");
+    static_assert(NS % GROUP == 0, "slots per lane");
     uint64_t *samp = reinterpret_cast<uint64_t *>(smem_raw + PROBE_TA * SET_BYTES);     // [TA][64]
     uint64_t *a_max = samp + PROBE_TA * 64;                                             // [TA]
     uint32_t *a_len = reinterpret_cast<uint32_t *>(a_max + PROBE_TA);                   // [TA]
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void pair_verify_kernel(const uint64_t *__rest
 // One 256-thread block per sketch: the row's hashes dealt to the NT x 64 slots of the arranged form.  A hash whose first
 // bucket has residue r mod 32 goes to lane r of the first or the second 32-lane group (alternating), at the next free
 // step t: every (t, group) -- one LDS cycle of a ds_read_b64 when conflict-free -- then reads 32 different bank pairs.
-// A class holds s / 32 hashes on average and 2 NT slots (NT = 20 for s <= 1024: 40 slots for 31 +- 5.6); the few hashes of
+// A class holds s / 32 hashes on average and 2 NT slots (NT = 16 for s <= 1024: 32 slots for 31 +- 5.6); the hashes of
 // an overfull class take any hole (they conflict with that step's rightful lane: time, not correctness).  The order of the
 // atomics is not deterministic; the counts the probe takes do not depend on it.
 template <int NT>
@@ -476,9 +476,12 @@ __global__ __launch_bounds__(256) void pair_arrange_kernel(const uint64_t *__res
 
 }  // namespace
 
-// slots per sketch of the arranged form: NT x 64 with NT = 6 (s <= 256) or 20 (s <= 1024): 1.25-1.5 x the sketch, so that
-// a residue class (s / 32 hashes on average) fits its 2 NT slots with a standard deviation and a half to spare
-size_t ghip_probe_arranged_slots(uint32_t s) { return (s <= 256 ? 6 : 20) * 64; }
+// slots per sketch of the arranged form: NS x 64 with NS = 4 (s <= 256) or 16 (s <= 1024) -- no more than the free form's
+// row.  A residue class (s / 32 hashes on average) then overflows its 2 NS slots about as often as not and ~60 of 1 000
+// hashes end up in a lane of another residue; the CPU simulation of the LDS groups (scripts/sim/probe_bank_cycles.py) says
+// that costs less than the extra wave-instructions of a roomier row: 149 LDS cycles per row and A-set at NS = 16, 149 at 18,
+// 153 at 20 (3 constrained bits; 218 for the free form's rows)
+size_t ghip_probe_arranged_slots(uint32_t s) { return (s <= 256 ? 4 : 16) * 64; }
 
 size_t ghip_probe_table_slots(uint32_t s) {
     uint32_t b = 1;
@@ -495,8 +498,8 @@ void ghip_launch_pair_tables(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
     hipLaunchKernelGGL(pair_table_build_kernel, dim3((unsigned)n), dim3(256), 2 * (size_t)buckets * sizeof(uint64_t),
                        ctx->stream, d_hashes, d_lens, s, buckets, cbits, d_tables, d_tags, d_flags);
     if (d_arranged) {
-        if (s <= 256) hipLaunchKernelGGL(pair_arrange_kernel<6>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
-        else hipLaunchKernelGGL(pair_arrange_kernel<20>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
+        if (s <= 256) hipLaunchKernelGGL(pair_arrange_kernel<4>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
+        else hipLaunchKernelGGL(pair_arrange_kernel<16>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_hashes, d_lens, s, buckets, d_arranged);
     }
     ghip_prof_end(ctx);
 }
@@ -557,7 +560,7 @@ void ghip_launch_pairs_probe(ghip_ctx *ctx, const uint64_t *d_hashes, const uint
                            s, buckets, cb, d_row_start, nta, n_work, rank, world, row_lo, d_cmin, d_out, d_count, cap);                   \
     } while (0)
     if (d_arranged) {
-        if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<6>, d_arranged, cbits,); else GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<20>, d_arranged, cbits,);
+        if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<4>, d_arranged, cbits,); else GHIP_PROBE_LAUNCH(pair_probe_arranged_kernel<16>, d_arranged, cbits,);
     } else {
         if (s <= 256) GHIP_PROBE_LAUNCH(pair_probe_tile_kernel<4>, ); else GHIP_PROBE_LAUNCH(pair_probe_tile_kernel<16>, );
     }
