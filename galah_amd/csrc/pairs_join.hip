@@ -776,15 +776,19 @@ int partition(ghip_ctx *ctx, std::vector<void *> &owned, const Src &src, uint32_
     const uint32_t cap1 = fused ? fused_cap1(n_valid_bound, lumpy, lump) : 0u;
     const size_t n_mid = fused ? (size_t)256 * cap1 : (size_t)n_valid_bound;   // slots of the intermediate (first-level) arrays
     if (fused && n_mid >= (1ull << 32)) return ghip_set_error(ctx, GHIP_EINVAL, "join: fused partition beyond 2^32 slots");
-    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, 256 + 257 + 256 + 2 * (size_t)nb);   // hist1 | start1 | cursor1 | hist2 | cursor2: one block, one memset
+    // hist1[256] | start1[257 -> 260] | cursor1[256] | hist2[nb] | cursor2[nb]: one block, one memset.  (start1 is padded to 260
+    // words so that hist2 starts on a 16-byte boundary: the scan kernels read it as uint4)
+    constexpr size_t HEAD = 256 + 260 + 256;
+    static_assert(HEAD % 4 == 0, "hist2 must be 16-byte aligned");
+    uint32_t *d_hist1 = jalloc<uint32_t>(ctx, owned, HEAD + 2 * (size_t)nb);
     uint32_t *d_start2 = jalloc<uint32_t>(ctx, owned, nb + 1);
     uint64_t *k1 = jalloc<uint64_t>(ctx, owned, n_mid), *k2 = jalloc<uint64_t>(ctx, owned, n_valid_bound);
     uint32_t *v1 = with_vals ? jalloc<uint32_t>(ctx, owned, n_mid) : nullptr;
     uint32_t *v2 = with_vals ? jalloc<uint32_t>(ctx, owned, n_valid_bound) : nullptr;
     if (!d_hist1 || !d_start2 || !k1 || !k2 || (with_vals && (!v1 || !v2))) return GHIP_EHIP;
     lap("alloc");
-    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 257, *d_hist2 = d_cursor1 + 256, *d_cursor2 = d_hist2 + nb;
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (256 + 257 + 256 + 2 * (size_t)nb) * sizeof(uint32_t), ctx->stream));
+    uint32_t *d_start1 = d_hist1 + 256, *d_cursor1 = d_hist1 + 256 + 260, *d_hist2 = d_hist1 + HEAD, *d_cursor2 = d_hist2 + nb;
+    GHIP_HIP_CHECK(ctx, hipMemsetAsync(d_hist1, 0, (HEAD + 2 * (size_t)nb) * sizeof(uint32_t), ctx->stream));
     const unsigned tiles = (total_t + J_TILE - 1) / J_TILE;
     unsigned tiles2 = 0;
     if (fused) {
