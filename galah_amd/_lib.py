@@ -109,6 +109,7 @@ SIGNATURES = {
     "ghip_cluster_ranks": (_int, [_vp, _vp, _sz, _u32, _u32, _u64, _f32, _u32, _u32, _u32, _f32, _vp, _f32, _pp, _pp, C.POINTER(_sz), _pp,
                                   C.POINTER(_sz), _pp, _vp]),
     "ghip_cluster_index_comm": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _f32, _f32, _pp, _pp, C.POINTER(_sz), _vp]),
+    "ghip_cluster_lazy_comm": (_int, [_vp, _sz, _vp, _sz, _vp, _f32, ANI_BATCH_CALLBACK, _vp, _pp, _pp, C.POINTER(_sz), _vp]),
     "ghip_comm_agree": (_int, [_vp, _int]),
     "ghip_comm_context": (_vp, [_vp]),
     "ghip_cluster_files_multi": (_int, [_pp, _u32, C.POINTER(C.c_char_p), _sz, _u32, _u32, _f32, _f32, _f32, _u32, _int, _pp, _pp,

@@ -359,6 +359,11 @@ struct IndexAni {
     float min_af;
     // several ranks (ghip_cluster_index_comm): a request is answered by the rank that owns the pair's FIRST genome (where
     // ghip_exchange_ani_index put the slices it needs); local_ids maps genome -> position in this rank's index
+    // a host's own ANI source instead of the device index (ghip_cluster_lazy_comm): called with the edges THIS rank answers,
+    // as indices into the caller's pair list
+    ghip_ani_batch_callback host_cb = nullptr;
+    void *host_user = nullptr;
+    std::vector<uint32_t> mine_edge;
     ghip_comm *comm = nullptr;
     const uint32_t *local_ids = nullptr;
     size_t block = 0;
@@ -375,30 +380,44 @@ int index_ani_batch(void *user, const uint32_t *edge, size_t n, float *out) {
     const auto t0 = std::chrono::steady_clock::now();
     auto pair_of = [&](size_t x) -> const ghip_pair & { return s->by_genome[s->orig ? s->orig[edge[x]] : edge[x]]; };
     auto id = [&](uint32_t g) { return s->local_ids ? s->local_ids[g] : g; };
+    auto edge_of = [&](size_t x) { return s->orig ? s->orig[edge[x]] : edge[x]; };   // index into the caller's pair list
     if (s->world == 1) {
-        s->buf.resize(2 * n);
-        for (size_t x = 0; x < n; x++) { const ghip_pair &p = pair_of(x); s->buf[2 * x] = id(p.i); s->buf[2 * x + 1] = id(p.j); }
-        s->rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), n, s->min_af, out, nullptr);
+        if (s->host_cb) {
+            s->mine_edge.resize(n);
+            for (size_t x = 0; x < n; x++) s->mine_edge[x] = edge_of(x);
+            s->rc = s->host_cb(s->host_user, s->mine_edge.data(), n, out) == 0 ? GHIP_OK : GHIP_ECALLBACK;
+        } else {
+            s->buf.resize(2 * n);
+            for (size_t x = 0; x < n; x++) { const ghip_pair &p = pair_of(x); s->buf[2 * x] = id(p.i); s->buf[2 * x + 1] = id(p.j); }
+            s->rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), n, s->min_af, out, nullptr);
+        }
         s->asked_here += n;
     } else {
         // The round's requests are the same list on every rank (the clusterer is deterministic and every rank runs it):
         // each rank answers the requests it owns, one variable-length gather -- sizes known to all, so ONE collective --
         // carries every rank's answers behind a status word, and every rank files them in request order.  A rank whose
         // launch failed says so in that word: all ranks leave the round together.
-        s->buf.clear(); s->mine_at.clear();
+        s->buf.clear(); s->mine_at.clear(); s->mine_edge.clear();
         s->sizes.assign(s->world, sizeof(uint32_t));
         for (size_t x = 0; x < n; x++) {
             const ghip_pair &p = pair_of(x);
             const size_t owner = p.i / s->block;
             s->sizes[owner] += sizeof(float);
-            if (owner == s->rank) { s->buf.push_back(id(p.i)); s->buf.push_back(id(p.j)); s->mine_at.push_back((uint32_t)x); }
+            if (owner == s->rank) {
+                if (s->host_cb) s->mine_edge.push_back(edge_of(x));
+                else { s->buf.push_back(id(p.i)); s->buf.push_back(id(p.j)); }
+                s->mine_at.push_back((uint32_t)x);
+            }
         }
         const size_t mine = s->mine_at.size();
         s->vals.assign(mine, 0.0f);
         int local_rc = GHIP_OK;
-        for (size_t x = 0; x < 2 * mine && !local_rc; x++)
+        for (size_t x = 0; x < s->buf.size() && !local_rc; x++)
             if (s->buf[x] == UINT32_MAX) local_rc = ghip_set_error(s->ctx, GHIP_EINVAL, "a requested pair's genome is not in this rank's ANI index");
-        if (!local_rc && mine) local_rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), mine, s->min_af, s->vals.data(), nullptr);
+        if (!local_rc && mine) {
+            if (s->host_cb) { if (s->host_cb(s->host_user, s->mine_edge.data(), mine, s->vals.data()) != 0) local_rc = ghip_set_error(s->ctx, GHIP_ECALLBACK, "the host's batched calculate_ani failed on this rank"); }
+            else local_rc = ghip_ani_pairs(s->ctx, s->idx, s->buf.data(), mine, s->min_af, s->vals.data(), nullptr);
+        }
         if (!local_rc && ghip_comm_fault(s->comm, GHIP_FAULT_ANI_ROUND)) local_rc = ghip_set_error(s->ctx, GHIP_EHIP, "injected fault: ANI round");
         s->asked_here += mine;
         s->send.resize(sizeof(uint32_t) + mine * sizeof(float));
@@ -432,8 +451,10 @@ int index_ani_batch(void *user, const uint32_t *edge, size_t n, float *out) {
 
 int cluster_index_impl(ghip_ctx *ctx, ghip_comm *comm, const ghip_ani_index *idx, const uint32_t *local_ids, size_t n, const ghip_pair *pairs,
                        size_t n_pairs, const uint32_t *order, float ani_threshold, float min_aligned_fraction, uint32_t **out_members,
-                       uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats, size_t n_stats) {
-    if (!ctx || !out_members || !out_offsets || !out_n_clusters || (n_pairs && (!pairs || !idx))) return GHIP_EINVAL;
+                       uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats, size_t n_stats,
+                       ghip_ani_batch_callback host_cb = nullptr, void *host_user = nullptr) {
+    // (ctx may be NULL with a host callback: a host-payload communicator has no device)
+    if ((!ctx && !host_cb) || !out_members || !out_offsets || !out_n_clusters || (n_pairs && (!pairs || (!idx && !host_cb)))) return GHIP_EINVAL;
     const auto t0 = std::chrono::steady_clock::now();
     if (out_stats) memset(out_stats, 0, n_stats * sizeof(uint64_t));
     for (size_t e = 0; e < n_pairs; e++)
@@ -483,6 +504,7 @@ int cluster_index_impl(ghip_ctx *ctx, ghip_comm *comm, const ghip_ani_index *idx
         ghip_shard_range(n, st.rank, st.world, &first, &count, &st.block);
     }
     st.local_ids = local_ids;
+    st.host_cb = host_cb; st.host_user = host_user;
     uint64_t asked = 0;
     const int rc = cluster_impl(n, sorted.empty() ? pairs : sorted.data(), n_pairs, nullptr, 0, ani_threshold, nullptr,
                                 n_pairs ? index_ani_batch : nullptr, &st, out_members, out_offsets, out_n_clusters, &asked, ctx);
@@ -517,4 +539,17 @@ extern "C" int ghip_cluster_index_comm(ghip_comm *comm, const ghip_ani_index *id
     if (!ctx) return GHIP_EINVAL;
     return ghip_comm_note_error(comm, cluster_index_impl(ctx, comm, idx, local_ids, n, pairs, n_pairs, order, ani_threshold, min_aligned_fraction,
                                                          out_members, out_offsets, out_n_clusters, out_stats, 5));
+}
+
+// The same rounds with the HOST's ClusterDistanceFinder answering them (the reference's calculate_ani, src/lib.rs:47-55, as the
+// batched callback of ghip_cluster_lazy): every rank calls it with the same pair list and its own callback, which is handed
+// the edges THIS rank answers -- those whose first genome lies in its block of ceil(n / world) genomes -- as indices into
+// `pairs`; one variable-length gather per round; every rank returns the same clusters.  Needs no device: a communicator
+// made by ghip_comm_init_callback(NULL, ...) will do (what tests/test_distributed_cpu.py drives over gloo).
+extern "C" int ghip_cluster_lazy_comm(ghip_comm *comm, size_t n, const ghip_pair *pairs, size_t n_pairs, const uint32_t *order,
+                                      float ani_threshold, ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members,
+                                      uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats) {
+    if (!comm || (n_pairs && !batch_cb)) return GHIP_EINVAL;
+    return ghip_comm_note_error(comm, cluster_index_impl(ghip_comm_context(comm), comm, nullptr, nullptr, n, pairs, n_pairs, order, ani_threshold, 0.0f,
+                                                         out_members, out_offsets, out_n_clusters, out_stats, 5, batch_cb, user));
 }

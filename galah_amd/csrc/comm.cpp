@@ -382,7 +382,7 @@ int ghip_comm_gatherv_known(ghip_comm *c, const void *send, size_t bytes, std::v
 }
 bool ghip_comm_fault(const ghip_comm *c, uint32_t stage) { return fault_here(c, stage); }
 int ghip_comm_note_error(ghip_comm *c, int rc) {
-    if (rc && c && c->ctx) c->err = ghip_last_error(c->ctx);
+    if (rc && c) c->err = ghip_last_error(c->ctx);   // (ctx == NULL: a host-payload communicator -- the thread's context-less error text)
     return rc;
 }
 

@@ -254,6 +254,45 @@ class Comm:
         return ClusterList(mem, off), {"asked": int(stats[0]), "rounds": int(stats[1]), "ani_ms": float(stats[2]) * 1e-6,
                                        "total_ms": float(stats[3]) * 1e-6, "asked_here": int(stats[4])}
 
+    def cluster_lazy(self, n_total: int, pairs: np.ndarray, ani_threshold, ani_of_edges, order=None):
+        """ghip_cluster_lazy_comm: the lazy rounds answered by the host's own batched ANI on every rank -- ani_of_edges(edge
+        indices into `pairs`) -> percent values, called with the edges THIS rank answers.  Every rank calls it with the same
+        pair list.  Needs no device.  -> (clusters, stats)."""
+        from .engine import ClusterList
+        L = _lib.lib()
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+        failure = []
+
+        def _cb(_user, edges, n, out):
+            try:
+                idx = np.ctypeslib.as_array(edges, shape=(n,)).copy()
+                vals = np.ascontiguousarray(ani_of_edges(idx), dtype=np.float32)
+                assert vals.shape == (n,)
+                C.memmove(out, vals.ctypes.data, 4 * n)
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not escape through ctypes
+                failure.append(e)
+                return 1
+
+        cb = _lib.ANI_BATCH_CALLBACK(_cb)
+        members, offsets, nc = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        stats = np.zeros(5, dtype=np.uint64)
+        rc = L.ghip_cluster_lazy_comm(self._h, n_total, pairs.ctypes.data, pairs.shape[0], order.ctypes.data if order is not None else None,
+                                      np.float32(ani_threshold), cb, None, C.byref(members), C.byref(offsets), C.byref(nc), stats.ctypes.data)
+        if rc != 0 and failure:
+            raise failure[0]
+        self._check(rc)
+        try:
+            off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), shape=(nc.value + 1,)).copy()
+            mem = np.ctypeslib.as_array(C.cast(members, C.POINTER(C.c_uint32)), shape=(max(int(off[-1]), 1),)).copy()
+        finally:
+            L.ghip_free(members)
+            L.ghip_free(offsets)
+        return ClusterList(mem, off), {"asked": int(stats[0]), "rounds": int(stats[1]), "ani_ms": float(stats[2]) * 1e-6,
+                                       "total_ms": float(stats[3]) * 1e-6, "asked_here": int(stats[4])}
+
     def agree(self, status: int = 0):
         """ghip_comm_agree: raises on every rank when any rank passes a non-zero status."""
         self._check(_lib.lib().ghip_comm_agree(self._h, int(status)))

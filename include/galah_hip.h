@@ -402,6 +402,14 @@ typedef int (*ghip_ani_batch_callback)(void *user, const uint32_t *edge_index, s
 int ghip_cluster_lazy(size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, float ani_threshold,
                       ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members, uint64_t **out_offsets,
                       size_t *out_n_clusters, uint64_t *out_pairs_requested);
+/* The same rounds answered by the HOST's ClusterDistanceFinder (the batched callback of ghip_cluster_lazy) on every rank: each
+ * rank's callback gets the edges that rank answers -- first genome in its block of ceil(n / world) genomes -- as indices into
+ * `pairs`.  Needs no device (a communicator of ghip_comm_init_callback(NULL, ..) will do).  out_stats[5] = pairs asked (all ranks),
+ * rounds, ns in the rounds, ns in all, pairs this rank answered.  A callback failing on one rank takes every rank out together. */
+int ghip_cluster_lazy_comm(ghip_comm *comm, size_t n_genomes, const ghip_pair *pairs, size_t n_pairs, const uint32_t *order,
+                           float ani_threshold_percent, ghip_ani_batch_callback batch_cb, void *user, uint32_t **out_members,
+                           uint64_t **out_offsets, size_t *out_n_clusters, uint64_t *out_stats);
+
 
 /* clusterer::cluster with the resident ANI index as the ClusterDistanceFinder (src/clusterer.rs:56-152 driven by
  * SkaniClusterer::calculate_ani, src/skani.rs:718-788), whole in native code: ghip_cluster_lazy's rounds answered by

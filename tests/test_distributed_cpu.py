@@ -32,6 +32,19 @@ def _share(rank, world, n=200, seed=3):
     return allp, mine
 
 
+def _graph(n, seed):
+    """A random precluster graph with families (the same on every rank) and a deterministic ANI per edge."""
+    rng = np.random.default_rng(seed)
+    fam = rng.integers(0, n // 6, size=n)
+    rows = sorted({(int(a), int(b)) for a in range(n) for b in range(a + 1, n) if fam[a] == fam[b]} |
+                  {(int(min(a, b)), int(max(a, b))) for a, b in rng.integers(0, n, size=(60, 2)) if a != b})
+    pairs = np.zeros(len(rows), dtype=PAIR_DTYPE)
+    for x, (i, j) in enumerate(rows):
+        pairs[x] = (i, j, 500, 1500, np.float32(0.9 + ((i * 31 + j * 17) % 100) / 1000.0))
+    table = (np.float32(93.0) + ((pairs["i"] * 7 + pairs["j"] * 13) % 50).astype(np.float32) / np.float32(10)).astype(np.float32)
+    return n, pairs, table
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -70,6 +83,32 @@ def _worker(rank, world, port, q):
     except Exception as e:  # noqa: BLE001
         out["agree"] = str(e)
     out["after_agree"] = comm.allgather_host(np.int64([rank])).ravel().tolist()
+    # the clusterer's lazy ANI rounds dealt over the ranks with the HOST's batched ANI answering (ghip_cluster_lazy_comm): the
+    # dealing, the per-round gather behind a status word and the filing in request order are what the GPU ranks run
+    # (ghip_cluster_index_comm shares the code); here the "ANI" is a table every rank can compute
+    n, pairs, table = _graph(200, 11)
+    answered = []
+
+    def ani_of(edges):
+        answered.append(len(edges))
+        assert all(int(pairs["i"][e]) // ((n + world - 1) // world) == rank for e in edges)   # only the edges this rank owns
+        return table[edges]
+
+    for order in (None, np.random.default_rng(4).permutation(n)):
+        clusters, st = comm.cluster_lazy(n, pairs, np.float32(95.0), ani_of, order)
+        key = "lazy" if order is None else "lazy_order"
+        out[key] = {"clusters": clusters.tolist(), "asked": st["asked"], "rounds": st["rounds"], "asked_here": st["asked_here"]}
+    # a callback that fails on ONE rank: that rank raises its own exception, the others GHIP_EPEER -- nobody hangs
+    def bad(edges):
+        if rank == world - 1:
+            raise ValueError("calculate_ani failed here")
+        return table[edges]
+    try:
+        comm.cluster_lazy(n, pairs, np.float32(95.0), bad)
+        out["lazy_fail"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["lazy_fail"] = f"{type(e).__name__}: {e}"
+    out["after_fail"] = comm.allgather_host(np.int64([rank])).ravel().tolist()
     q.put(out)
     dist.barrier()
     comm.close()
@@ -95,6 +134,30 @@ def test_exchange_logic_over_gloo(world):
         assert o["agree"].startswith("GHIP_EHIP" if r == world - 1 else "GHIP_EPEER"), o["agree"]
         assert r == world - 1 or f"rank {world - 1} failed" in o["agree"]
         assert o["after_agree"] == list(range(world))
+    # the lazy rounds over the ranks == one rank's ghip_cluster_lazy == the oracle's clusterer with every ANI known
+    import galah_amd
+    import oracle
+    n, pairs, table = _graph(200, 11)
+    want, asked = galah_amd.cluster_pairs_lazy(n, pairs, np.float32(95.0), lambda e: table[e])
+    look = {(int(p["i"]), int(p["j"])): float(v) for p, v in zip(pairs, table)}
+    assert want == oracle.cluster(n, oracle.Cache.from_pairs(pairs), 95.0, lambda a, b: look[(min(a, b), max(a, b))])
+    order = np.random.default_rng(4).permutation(n)
+    rank_of = np.empty(n, np.int64)
+    rank_of[order] = np.arange(n)
+    re = pairs.copy()
+    a, b = rank_of[pairs["i"]], rank_of[pairs["j"]]
+    re["i"], re["j"] = np.minimum(a, b), np.maximum(a, b)
+    perm = np.lexsort((re["j"], re["i"]))
+    look_o = {(int(p["i"]), int(p["j"])): float(v) for p, v in zip(re[perm], table[perm])}
+    want_o = oracle.cluster(n, oracle.Cache.from_pairs(re[perm]), 95.0, lambda x, y: look_o[(min(x, y), max(x, y))])
+    for o in outs:
+        assert o["lazy"]["clusters"] == want and o["lazy"]["asked"] == asked and o["lazy"]["rounds"] >= 1
+        assert o["lazy_order"]["clusters"] == want_o
+    assert sum(o["lazy"]["asked_here"] for o in outs) == asked and sum(1 for o in outs if o["lazy"]["asked_here"]) >= 2
+    assert all(o["lazy"]["clusters"] == outs[0]["lazy"]["clusters"] for o in outs)
+    for r, o in enumerate(outs):
+        assert (o["lazy_fail"].startswith("ValueError") if r == world - 1 else "GHIP_EPEER" in o["lazy_fail"]), o["lazy_fail"]
+        assert o["after_fail"] == list(range(world))
 
 
 def test_single_rank_communicator_needs_no_transport():
