@@ -98,6 +98,16 @@ public:
     HipContext &operator=(const HipContext &) = delete;
     ghip_ctx *get() const { return ctx_; }
     std::string last_error() const { return ghip_last_error(ctx_); }
+    // ghip_options of this context (every switch of the library; the GHIP_* environment only seeds the defaults, once)
+    ghip_options options() const {
+        ghip_options o{};
+        ghip_get_options(ctx_, &o);
+        return o;
+    }
+    void set_options(ghip_options o) {
+        o.struct_size = sizeof(ghip_options);
+        if (ghip_set_options(ctx_, &o) != GHIP_OK) throw std::runtime_error("ghip_set_options: " + last_error());
+    }
 
 private:
     ghip_ctx *ctx_ = nullptr;
