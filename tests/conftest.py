@@ -49,6 +49,13 @@ def ctx():
     c.close()
 
 
+# Round 4: GPU access was closed from outside the build for most of the round, so some code paths were written and
+# desk-checked (and simulated on the CPU where that was possible) but NEVER RUN on hardware.  Their tests are marked with this
+# -- they run, a failure shows as "xfailed" (not as a red suite: the measured default paths are what the product runs), a
+# pass as "xpassed".  Remove the mark once a GPU run has shown them green (scripts/r04_validate.sh suite).
+never_run_on_hardware = pytest.mark.xfail(strict=False, reason="round 4: written while GPU access was closed; never run on hardware")
+
+
 @pytest.fixture
 def opts(ctx):
     """opts(field=value, ...): set ghip_options fields of the session's context for one test (restored afterwards) -- how the

@@ -6,7 +6,7 @@ import pytest
 
 import galah_amd
 import oracle
-from conftest import fasta, random_sketches
+from conftest import fasta, random_sketches, never_run_on_hardware
 
 pytestmark = pytest.mark.gpu
 
@@ -261,6 +261,7 @@ def test_cluster_end_to_end_vs_oracle(ctx):
         assert sorted(x for c in got for x in c) == list(range(len(paths)))
 
 
+@never_run_on_hardware
 def test_join_fused_form_equals_exact_form_and_survives_an_outgrown_capacity(ctx, opts):
     """ghip_options.join_fused (round 4: 20 -> 12 launches, no host round trip inside a partition): byte-identical pair lists
     to the exact form and to the oracle at a size where the join is the automatic form (3 000 sketches, families of every
@@ -301,6 +302,7 @@ def test_join_fused_form_equals_exact_form_and_survives_an_outgrown_capacity(ctx
 
 @pytest.mark.parametrize("n,s,min_len,thr", [(37, 1000, None, 0.9), (260, 1000, 1, 0.9), (130, 256, 1, 0.8), (64, 1000, 1, 0.0), (90, 700, 300, 0.95),
                                              (50, 12, 1, 0.5), (300, 200, 64, 0.9)])
+@never_run_on_hardware
 def test_probe_kernel_arranged_form_matches_oracle(ctx, opts, n, s, min_len, thr):
     """ghip_options.probe_arranged (round 4): the dense probe kernel with the second cuckoo choice in the first
     one's residue class and every B row dealt to the lanes by bucket residue (pairs_probe.hip: pair_arrange_kernel,
@@ -616,7 +618,7 @@ def test_every_seed_of_dirty_streams(ctx, c):
             start += int(cap[i])
 
 
-@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("fused", [0, pytest.param(1, marks=never_run_on_hardware)])
 def test_join_form_of_the_pair_stage_matches_oracle(ctx, opts, fused):
     """The inverted-index form (pairs_join.hip; automatic from N >= 1200) forced on small inputs: same bytes as
     the oracle's pair loop, whole and sharded; and the inputs it must decline (threshold 0, empty sketches)
