@@ -166,6 +166,19 @@ def test_single_rank_communicator_needs_no_transport():
     allp, _ = _share(0, 1)
     assert comm.allgather_pairs(allp).tobytes() == allp.tobytes()
     assert comm.allgather_host(np.float32([1.5, 2.5])).tolist() == [[1.5, 2.5]]
+    comm.agree(0)
+    # the lazy rounds with the host's ANI on a one-rank communicator == ghip_cluster_lazy, for a few random graphs and orders
+    import galah_amd
+    for seed in range(6):
+        n, pairs, table = _graph(60 + 37 * seed, seed)
+        want, asked = galah_amd.cluster_pairs_lazy(n, pairs, np.float32(95.0), lambda e: table[e])
+        got, st = comm.cluster_lazy(n, pairs, np.float32(95.0), lambda e: table[e])
+        assert got == want and st["asked"] == asked == st["asked_here"]
+        order = np.random.default_rng(seed).permutation(n)
+        got_o, _ = comm.cluster_lazy(n, pairs, np.float32(95.0), lambda e: table[e], order)
+        assert sorted(x for c in got_o for x in c) == list(range(n)) and len(got_o) >= 1
+    with pytest.raises(ValueError):
+        comm.cluster_lazy(n, pairs, np.float32(95.0), lambda e: (_ for _ in ()).throw(ValueError("boom")))
 
 
 def test_shard_ranges_cover_and_tiles_partition():
