@@ -770,7 +770,7 @@ def main_single(args, ctx, json_fd):
                 for g in out["kernels"]:
                     if g != dom and t.get(g, {}).get("hbm_bytes_per_step") is not None:
                         out["kernels"][g]["pmc_hbm_bytes_per_launch"] = t[g]["hbm_bytes_per_step"] / per_step[g]
-                        if g == "pair_join" and "bytes_the_join_must_move" in out["kernels"][g]:
+                        if g == "pair_join" and "bytes" in out["kernels"][g].get("bytes_the_join_must_move", {}):
                             out["kernels"][g]["traffic_over_must_move"] = (out["kernels"][g]["pmc_hbm_bytes_per_launch"]
                                                                            / out["kernels"][g]["bytes_the_join_must_move"]["bytes"])
                             out["kernels"][g]["dispatches_per_launch"] = t[g].get("dispatches_per_step", 0) / per_step[g]
