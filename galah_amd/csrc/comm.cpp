@@ -361,10 +361,23 @@ int allgatherv_host(ghip_comm *c, const void *send, size_t bytes, std::vector<ui
 // all-gather: ~0.05 ms over RCCL.)
 int agree(ghip_comm *c, int status, const char *what) {
     if (c->world == 1) return status;
+    if (c->transport == T_LOCAL && status) {
+        // one process, a thread per rank: the group's flag IS the status word -- the peers' barrier returns with it; this rank
+        // keeps its own code and message (a failed group stays failed: it is made per call, ghip_cluster_files_multi)
+        c->group->fail();
+        c->agreed_failure = true;
+        return status;
+    }
     std::vector<int32_t> all(c->world, 0);
     const int32_t mine = status;
     const int rc = allgather_host(c, &mine, sizeof(mine), all.data());
-    if (rc) return rc;
+    if (rc) {
+        if (c->transport == T_LOCAL && c->group->failed.load()) {
+            c->agreed_failure = true;
+            return cerr_(c, GHIP_EPEER, std::string("a peer rank failed at: ") + what);
+        }
+        return rc;
+    }
     if (status) { c->agreed_failure = true; return status; }
     for (uint32_t r = 0; r < c->world; r++)
         if (all[r]) return c->agreed_failure = true, cerr_(c, GHIP_EPEER, std::string("rank ") + std::to_string(r) + " failed at: " + what + " (code " + std::to_string(all[r]) + ")");
