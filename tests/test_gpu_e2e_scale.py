@@ -14,11 +14,24 @@ import oracle
 SEED, MEMBERS, RATE = 42, 10, 0.0253
 
 
+_FRONT = {}   # (n_species, length, min_ani, min_af) -> sketches, pairs, ANI table: the order only changes the clustering
+
+
 def oracle_end_to_end(n_species, length, order=None, threads=None, min_ani=0.9, thr=95.0, min_af=0.15):
     """The whole path on the CPU oracle: (hashes, lens, pairs, {(i, j): ANI} of every precluster pair, clusters).  With
     `order` (order[x] = the genome that comes x-th) the clusterer sees the genomes in that order and the clusters hold
     positions -- what ghip_cluster_index / ghip_cluster_ranks return."""
     threads = threads or min(32, os.cpu_count() or 1)
+    n = n_species * MEMBERS
+    key = (n_species, length, min_ani, min_af)
+    if key not in _FRONT:
+        _FRONT.clear()   # (one workload's tables at a time: the 10 000-genome one is 80 MB of sketches)
+        _FRONT[key] = _oracle_front(n_species, length, threads, min_ani, min_af)
+    hashes, lens, pairs, look = _FRONT[key]
+    return hashes, lens, pairs, look, _oracle_clusters(n, pairs, look, order, thr)
+
+
+def _oracle_front(n_species, length, threads, min_ani, min_af):
     n = n_species * MEMBERS
     with ThreadPoolExecutor(threads) as ex:
         # (ctypes releases the GIL inside the oracle's C functions)
@@ -47,6 +60,10 @@ def oracle_end_to_end(n_species, length, order=None, threads=None, min_ani=0.9, 
         for part in ex.map(batch, range(n_species)):
             look.update(part)
     assert len(look) == len(pairs)
+    return hashes, lens, pairs, look
+
+
+def _oracle_clusters(n, pairs, look, order, thr):
     if order is None:
         clusters = oracle.cluster(n, oracle.Cache.from_pairs(pairs), thr, lambda a, b: look[(min(a, b), max(a, b))])
     else:
@@ -59,7 +76,7 @@ def oracle_end_to_end(n_species, length, order=None, threads=None, min_ani=0.9, 
         re = re[np.lexsort((re["j"], re["i"]))]
         clusters = oracle.cluster(n, oracle.Cache.from_pairs(re), thr,
                                   lambda x, y: look[(min(int(order[x]), int(order[y])), max(int(order[x]), int(order[y])))])
-    return hashes, lens, pairs, look, clusters
+    return clusters
 
 
 def test_oracle_harness_is_self_consistent():
