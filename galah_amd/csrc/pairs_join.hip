@@ -750,12 +750,14 @@ int scan_counters_fused(ghip_ctx *ctx, std::vector<void *> &owned, JoinFused &jf
 }
 
 // capacity of a first-level bucket in the fused form: the mean load plus slack for what the digit does to it.  Elements
-// (uniform hash bits): Poisson, six standard deviations.  Records: all records of a genome pair share one digit -- a bucket's
+// (uniform hash bits, but EQUAL hashes travel together: the ~6 members of a species that keep an ancestral k-mer put six
+// elements into one bucket -- the load's variance is ~4x a Poisson's on the bench's genomes): twelve Poisson standard
+// deviations, i.e. six of the real ones.  Records: all records of a genome pair share one digit -- a bucket's
 // load is a sum of ~pairs/256 lumps of up to s records each -- half the mean on top, and room for a few whole lumps.
 uint32_t fused_cap1(uint64_t n_valid, bool lumpy, uint32_t lump) {
     const double mean = (double)n_valid / 256.0;
     // (records at 10 000 genomes: ~176 pairs of ~350 +- 200 records per bucket -> sigma ~ 5 400 on a mean of 61 600: this is 7 sigma)
-    const double cap = lumpy ? 1.5 * mean + 8.0 * (double)lump + 2048.0 : mean + 6.0 * std::sqrt(mean) + 1024.0;
+    const double cap = lumpy ? 1.5 * mean + 8.0 * (double)lump + 2048.0 : mean + 12.0 * std::sqrt(mean) + 1024.0;
     return (uint32_t)std::min<double>(((uint64_t)cap + 3) / 4 * 4, (double)(0xffffffffu / 256u));
 }
 
