@@ -253,6 +253,17 @@ def test_options_struct_round_trip_and_environment_seed():
     assert galah_amd.get_options() == saved
 
 
+def test_probe_model_shares_the_kernels_bucket_and_tag_functions(tmp_path):
+    """tests/cpp/test_probe_model.cpp: a host-side model of the dense probe form's arranged variant built on the SAME
+    bucket / tag functions the kernels compile (galah_amd/csrc/probe_common.h): every hash in one of its two buckets for
+    0 / 2 / 3 / 4 constrained bits, arranged rows are permutations, the tag probe lists a superset and the full-key recount
+    is exact.  (No GPU: the kernel code itself is covered by the -m gpu parity tests.)"""
+    exe = str(tmp_path / "test_probe_model")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_probe_model.cpp")], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "probe model ok" in r.stdout, r.stdout[-2000:]
+
+
 def test_unrelated_genomes_are_singletons_without_an_ani_source():
     """No precluster pair at all (a set of unrelated genomes): singleton clusters, and no ANI source is needed --
     the C++ mirror passes NULL for both pair_ani and the callback then (include/galah_hip.hpp)."""
