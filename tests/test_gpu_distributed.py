@@ -77,6 +77,9 @@ def _worker(rank, world, port, q, n=N, length=LENGTH, options=None, min_ani=0.9,
     ctx.close()
 
 
+_FAULT_HUNG = []   # fault cases that had to be killed: one hang is reported, the rest of the fault cases are not started
+
+
 def _run(world, **kw):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
@@ -86,18 +89,23 @@ def _run(world, **kw):
         p.start()
     import queue
     try:
-        # (a fault run that hangs must cost two minutes, not the suite: its ranks are killed)
+        # (a fault run that hangs must cost three minutes, not the suite: its ranks are killed, and the fault cases after it
+        # do not start -- _FAULT_HUNG)
         # (the first answer also waits for the ranks to start and run a clean pass; the others follow it within seconds)
-        got = [q.get(timeout=300 if r == 0 else 120) for r in range(world)] if kw.get("fault") is not None else q.get(timeout=900)
+        got = [q.get(timeout=180 if r == 0 else 60) for r in range(world)] if kw.get("fault") is not None else q.get(timeout=900)
     except queue.Empty:
         for p in procs:
             p.terminate()
+        if kw.get("fault") is not None:
+            _FAULT_HUNG.append(kw["fault"])
         raise AssertionError("a rank did not come back in time (hang)")
     for p in procs:
-        p.join(timeout=120 if kw.get("fault") is not None else 300)
+        p.join(timeout=60 if kw.get("fault") is not None else 300)
         if p.exitcode is None:
             for x in procs:
                 x.terminate()
+            if kw.get("fault") is not None:
+                _FAULT_HUNG.append(kw["fault"])
             raise AssertionError("a rank did not exit (hang)")
         assert p.exitcode == 0
     return got
@@ -190,6 +198,8 @@ def test_a_failing_rank_takes_every_rank_out_together(stage, lazy):
     one (RCCL and host-callback transports).  A status word is now agreed at every phase boundary: rank 1 of 3 is made to
     fail at each stage in turn (ghip_options.fault_stage) -- every rank returns an error within seconds, the failing rank
     with its own message and the others with GHIP_EPEER naming it, and the communicator serves a clean pass afterwards."""
+    if _FAULT_HUNG:
+        pytest.xfail(f"fault case {_FAULT_HUNG[0]} hung and was killed: not starting another")
     n, length = (2100, 30_000) if stage.startswith("pairs") else (60, 60_000)   # (the hash-sharded join has the two pair stages)
     got = dict((r, (msg, dt)) for r, msg, dt in _run(3, n=n, length=length, lazy=lazy, fault=(stage, 1)))
     assert sorted(got) == [0, 1, 2]
