@@ -348,6 +348,29 @@ def _fasta_bytes(seq: np.ndarray, name: str) -> bytes:
     return f">{name} synthetic\n".encode() + body
 
 
+def _ram_backed_room(d="/dev/shm"):
+    """Bytes of files a RAM-backed directory may take without endangering the box: tmpfs pages are the container's memory, so
+    the bound is HALF of the smallest of -- the tmpfs' free space, the host's MemAvailable, the memory cgroup's headroom
+    (v2 memory.max - memory.current, or v1's limit - usage).  (A tmpfs reports its own size limit, often most of the RAM,
+    whatever the cgroup allows: filling it would have the kernel kill the bench.)"""
+    room = [shutil.disk_usage(d).free]
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                room.append(int(line.split()[1]) * 1024)
+    except Exception:  # noqa: BLE001
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(lim).read().strip()
+            if m != "max" and int(m) < (1 << 60):
+                room.append(int(m) - int(open(cur).read().strip()))
+        except Exception:  # noqa: BLE001
+            pass
+    return max(0, min(room)) // 2
+
+
 def _scratch_dir(need_bytes):
     import tempfile
     base = next((d for d in ("/dev/shm", "/tmp") if os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes), None)
@@ -428,8 +451,9 @@ def wall_clock(args, ctx, n_species=100, with_gz=True, repeats=3):
     per_genome = (args.length + args.length // 80 + 64) * (1.4 if with_gz else 1.08)
     asked_species = n_species
     if n_species > 100 and os.path.isdir("/dev/shm"):
-        # the north-star size wants 55 GB of RAM-backed files: take what /dev/shm holds (in whole blocks of 100 species), never a disk
-        room = int((shutil.disk_usage("/dev/shm").free * 0.9 - (2 << 30)) / (per_genome * args.members))
+        # the north-star size wants 55 GB of RAM-backed files: take what /dev/shm may hold (half of the memory the container
+        # has left -- _ram_backed_room -- in whole blocks of 100 species), never a disk
+        room = int((_ram_backed_room("/dev/shm") - (2 << 30)) / (per_genome * args.members))
         n_species = min(n_species, room // 100 * 100)
         if n_species < 200:
             return {"skipped": f"/dev/shm has no room for {200 * args.members} genome files of {args.length} bp"}
@@ -776,12 +800,17 @@ def main_single(args, ctx, json_fd):
                             out["kernels"][g]["dispatches_per_launch"] = t[g].get("dispatches_per_step", 0) / per_step[g]
             return t if t is not None else "rocprofv3 not on PATH: roofline.traffic stays null (roofline.recorded_traffic has the committed figure)"
         legs.append(("pmc_live", live))
+    # legs whose size has not run on hardware yet (GPU access closed before round 4 could): an assertion inside one is
+    # REPORTED in the line (parity_failure) instead of taking the measured headline with it
+    unproven = {"wall_clock_10k"}
     for name, fn in legs:
         t0 = time.perf_counter()
         try:
             out[name] = fn()
-        except AssertionError:
-            raise   # a parity failure is a failure of the bench
+        except AssertionError as e:
+            if name not in unproven:
+                raise   # a parity failure is a failure of the bench
+            out[name] = {"error": "ASSERTION FAILED: " + repr(e), "parity_failure": True}
         except Exception as e:  # an extra leg (e.g. no room for 94 GB) must not cost the headline
             out[name] = {"error": repr(e)}
         if isinstance(out[name], dict):
