@@ -356,3 +356,54 @@ def test_cluster_list_behaves_like_the_list_of_lists():
     with pytest.raises(IndexError):
         ClusterList(mem, off)[3]
     assert len(ClusterList(np.zeros(1, np.uint32), np.zeros(1, np.uint64))) == 0
+
+
+def test_every_options_keyword_the_gpu_tests_bench_and_scripts_use_is_a_field_with_a_legal_value():
+    """The GPU tests, bench.py and the scripts pick forms through ghip_options keywords; a misspelt field or enumeration name
+    would only show on the GPU box.  Here: every literal keyword of every opts(...) / set_options(...) / with_options(...) /
+    process_opts(...) call and every `options={...}` / `options=dict(...)` literal in those files goes through
+    ghip_set_options on the process-wide defaults (no device needed)."""
+    import ast
+    import glob
+
+    import galah_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tests", "*.py")) + glob.glob(os.path.join(root, "scripts", "*.py")) +
+                   glob.glob(os.path.join(root, "galah_amd", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
+    setters = {"opts", "set_options", "with_options", "process_opts"}
+    seen = []
+
+    def literal(node):
+        try:
+            return ast.literal_eval(node)
+        except Exception:  # noqa: BLE001 -- a computed value: only the field name can be checked
+            return None
+
+    for path in files:
+        tree = ast.parse(open(path).read(), path)
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            name = node.func.attr if isinstance(node.func, ast.Attribute) else getattr(node.func, "id", None)
+            kws = []
+            if name in setters:
+                kws = [(k.arg, literal(k.value)) for k in node.keywords if k.arg]
+            for k in node.keywords:   # options={...} / options=dict(...) handed to a worker or a job
+                if k.arg == "options":
+                    if isinstance(k.value, ast.Dict):
+                        kws += [(literal(a), literal(b)) for a, b in zip(k.value.keys, k.value.values)]
+                    elif isinstance(k.value, ast.Call) and getattr(k.value.func, "id", None) == "dict":
+                        kws += [(q.arg, literal(q.value)) for q in k.value.keywords if q.arg]
+            seen += [(os.path.relpath(path, root), node.lineno, a, b) for a, b in kws if isinstance(a, str)]
+    assert len(seen) >= 30, seen
+    saved = galah_amd.get_options()
+    try:
+        for path, line, field, value in seen:
+            assert field in galah_amd._lib.OPTION_FIELDS and field != "struct_size", f"{path}:{line}: ghip_options has no field {field!r}"
+            if value is not None:
+                try:
+                    galah_amd.set_options(None, **{field: value})
+                except Exception as e:  # noqa: BLE001
+                    raise AssertionError(f"{path}:{line}: {field}={value!r} is refused: {e!r}")
+    finally:
+        galah_amd.set_options(None, **{k: v for k, v in saved.items() if k != "struct_size"})
