@@ -24,6 +24,23 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
+# The -m gpu suite is run with -x at round end: the parity tests proper come first, the multi-process tests after them, and
+# whatever has not run on hardware yet (never_run_on_hardware below) last -- an early stop then costs the least evidence.
+_GPU_FILE_ORDER = ["test_gpu_parity", "test_gpu_ani_fidelity", "test_gpu_configs", "test_abi", "test_gpu_host_mirror", "test_gpu_e2e_scale",
+                   "test_gpu_distributed"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        unproven = any(m.name == "xfail" and "never run on hardware" in str(m.kwargs.get("reason", "")) for m in item.iter_markers())
+        is_gpu = any(m.name == "gpu" for m in item.iter_markers())
+        if not is_gpu:
+            return (0, 0)   # the CPU suite keeps its order
+        return (2 if unproven else 1, _GPU_FILE_ORDER.index(mod) if mod in _GPU_FILE_ORDER else len(_GPU_FILE_ORDER))
+    items.sort(key=key)   # (stable: the order inside a file stays)
+
+
 def fasta(name: str) -> str:
     return os.path.join(GOLDEN, "fasta", name + ".fna.gz")
 

@@ -11,6 +11,7 @@ import pytest
 
 import galah_amd
 import oracle
+from conftest import never_run_on_hardware
 from galah_amd import PAIR_DTYPE
 
 pytestmark = pytest.mark.gpu
@@ -162,10 +163,14 @@ def test_config5_50k_genomes_quality_order_two_stage(ctx):
     oc = oracle.cluster(sub, oracle.Cache.from_pairs(pairs[keep]), 95.0,
                         lambda a, b: float(look[(min(a, b), max(a, b))]))
     assert galah_amd.cluster_pairs(sub, pairs[keep], np.float32(95.0), ani[keep]) == oc
-    # ... and the second stage with the ANI KERNEL (the values above are synthetic): a 3 000-genome
-    # sub-problem of the same shape -- 300 species x 10 of 100 kb, CheckM2-style qualities, Parks2020_reduced order, 90 %
-    # precluster / 95 % ANI -- sketch -> pairs -> the native clusterer's lazy ANI rounds on the resident index, against the
-    # oracle's sketches, pair loop, ANI and greedy clusterer in that order
+
+
+@never_run_on_hardware
+def test_config5_second_stage_through_the_ani_kernel_on_3000_genomes(ctx):
+    """configs[4]'s second stage with the ANI KERNEL (the values in the test above are synthetic): a
+    3 000-genome sub-problem of the same shape -- 300 species x 10 of 100 kb, CheckM2-style qualities, Parks2020_reduced
+    order, 90 % precluster / 95 % ANI -- sketch -> pairs -> the native clusterer's lazy ANI rounds on the resident index,
+    against the oracle's sketches, pair loop, ANI and greedy clusterer in that order."""
     from test_gpu_e2e_scale import MEMBERS, RATE, SEED, oracle_end_to_end
     n_sp, length = 300, 100_000
     m = n_sp * MEMBERS

@@ -169,7 +169,12 @@ def test_ranks_join_form_equals_single_rank(ctx, mode, world):
         assert got["stages"]["allgather_pairs"] < 0.5   # nothing to gather
 
 
-@pytest.mark.parametrize("world,n,length,order_seed", [(2, N, LENGTH, None), (3, 2100, 30_000, None), (8, 100, 60_000, None), (3, 300, 40_000, 17), (4, 3, 80_000, None)])
+@pytest.mark.parametrize("world,n,length,order_seed", [(2, N, LENGTH, None), (3, 2100, 30_000, None),
+                                                       # (the first two ran on hardware -- profiles/r04b_pytest_distributed_partial.txt;
+                                                       # the 8-rank case ran into an assertion of the test, since corrected)
+                                                       pytest.param(8, 100, 60_000, None, marks=never_run_on_hardware),
+                                                       pytest.param(3, 300, 40_000, 17, marks=never_run_on_hardware),
+                                                       pytest.param(4, 3, 80_000, None, marks=never_run_on_hardware)])
 def test_lazy_native_clusterer_over_the_ranks_equals_one_rank(ctx, world, n, length, order_seed):
     """ghip_cluster_ranks (the verdict's item: N > 1 runs the algorithm N = 1 runs): the lazy rounds of the native clusterer
     with each round's requests dealt to the rank that owns the pair's first genome, one variable-length gather per round.
@@ -375,6 +380,7 @@ def test_index_slices_go_only_where_they_are_wanted(ctx):
         c.close()
 
 
+@never_run_on_hardware   # (since ghip_cluster_files_multi runs ghip_cluster_ranks: the lazy rounds over the in-process transport)
 def test_single_process_multi_context_driver_on_files(ctx):
     """ghip_cluster_files_multi: files in -> clusters out with several contexts driven by one process equals
     galah_amd.cluster on one context (which the parity suite pins to the oracle)."""

@@ -10,6 +10,7 @@ import pytest
 
 import galah_amd
 import oracle
+from conftest import never_run_on_hardware
 
 SEED, MEMBERS, RATE = 42, 10, 0.0253
 
@@ -99,6 +100,7 @@ def test_oracle_harness_is_self_consistent():
 
 
 @pytest.mark.gpu
+@never_run_on_hardware
 @pytest.mark.parametrize("quality_order", [False, True])
 def test_10k_genomes_end_to_end_against_the_oracle(ctx, quality_order):
     """10 000 x 200 kb (1 000 species x 10, ~95 % ANI: the north-star's shape at a CPU-affordable length): every sketch, the
