@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "unproven: not yet green on hardware in its present form; ordered last, fails red")
     # a fresh checkout has no built artefacts (they are git-ignored): build what the tests load -- the C-ABI library,
     # the C++ host-mirror test program and the oracle -- exactly as __graft_entry__.build() does
     import subprocess
@@ -33,7 +34,7 @@ _GPU_FILE_ORDER = ["test_gpu_parity", "test_gpu_ani_fidelity", "test_gpu_configs
 def pytest_collection_modifyitems(config, items):
     def key(item):
         mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
-        unproven = any(m.name == "xfail" and "never run on hardware" in str(m.kwargs.get("reason", "")) for m in item.iter_markers())
+        unproven = any(m.name == "unproven" for m in item.iter_markers())
         is_gpu = any(m.name == "gpu" for m in item.iter_markers())
         if not is_gpu:
             return (0, 0)   # the CPU suite keeps its order
@@ -70,7 +71,7 @@ def ctx():
 # desk-checked (and simulated on the CPU where that was possible) but NEVER RUN on hardware.  Their tests are marked with this
 # -- they run, a failure shows as "xfailed" (not as a red suite: the measured default paths are what the product runs), a
 # pass as "xpassed".  Remove the mark once a GPU run has shown them green (scripts/r04_validate.sh suite).
-never_run_on_hardware = pytest.mark.xfail(strict=False, reason="round 4: written while GPU access was closed; never run on hardware")
+never_run_on_hardware = pytest.mark.unproven   # ordering only (these run last): a failure is a red suite
 
 
 @pytest.fixture
