@@ -12,8 +12,18 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+EMU = os.environ.get("GALAH_TEST_EMU") == "1"
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libgalah_hip_emu.so")
+if EMU:
+    # tests/test_emu.py (and scripts/emu_suite.sh) run GPU tests in a child process against the library's sources compiled for
+    # the host over the wave64 emulator (tests/emu/).  Only the test harness knows this switch: galah_amd never reads it.
+    from galah_amd import _lib as _galah_lib
+    _galah_lib.LIB_PATH = EMU_LIB
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "emu: small enough to also run under the CPU emulator (tests/emu); selected by tests/test_emu.py")
     config.addinivalue_line("markers", "unproven: not yet green on hardware in its present form; ordered last, fails red")
     # a fresh checkout has no built artefacts (they are git-ignored): build what the tests load -- the C-ABI library,
     # the C++ host-mirror test program and the oracle -- exactly as __graft_entry__.build() does
