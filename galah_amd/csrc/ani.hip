@@ -506,7 +506,14 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
     // cross-multiplication.  Every member of the median's tie group holds the same fraction: the smallest
     // (m, t) of the group is reported.
     constexpr uint32_t KEY_CAP = sizeof(st_code) / sizeof(double);
-    if (n <= KEY_CAP) {
+    if (n < GHIP_ANI_POOL_BELOW) {
+        // too few chunks for a median (of two it is the minimum): the pooled count over them (oracle: GO_ANI_POOL_BELOW)
+        if (threadIdx.x == 0 && n) {
+            unsigned long long pm = 0, pt = 0;
+            for (uint32_t e = 0; e < n; e++) { pm += list[e] >> 32; pt += list[e] & 0xffffffffull; }
+            red[4] = (pm << 32) | pt;   // (at most eight chunks of at most 32 768 seeds each: the sums stay in their halves)
+        }
+    } else if (n <= KEY_CAP) {
         // (key, entry) pairs sorted in LDS by an ascending-only bitonic network (positions >= n act as +infinity without
         // being stored: pairs_join.hip has the same network) -- ~45 block-wide exchange steps for the ~500 aligned chunks
         // of two 5 Mb genomes, where counting every entry's rank against every other took 500 steps per thread and a

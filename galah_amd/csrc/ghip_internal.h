@@ -200,6 +200,7 @@ int ghip_index_wait(ghip_ctx *ctx, const ghip_ani_index *idx);   // ctx->mu held
                                        // 160 KiB LDS next to the 28 KiB seed stage; a pair above it takes the kernel form with its votes in global memory
 #define GHIP_ANI_MAX_CHUNKS 65535u     // per genome: a seed's chunk is a 16-bit field (1.3 Gb at the default 20 kb chunk)
 #define GHIP_ANI_SEEDS_WANTED 8192u    // ghip_ani_density: a genome shorter than this many seeds' worth of bases is seeded four times denser
+#define GHIP_ANI_POOL_BELOW 9u          // a pair with fewer aligned chunks than this is estimated from their pooled counts, not their median
 #define GHIP_ANI_MAX_CHUNK_LEN 32768u  // a seed's offset in its chunk is a 15-bit field
 
 int ghip_set_error(ghip_ctx *ctx, int code, const std::string &msg);

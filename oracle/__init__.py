@@ -114,6 +114,8 @@ def lib():
     L.go_ani_pair_detail.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.go_ani_pair_mode.restype = C.c_float
     L.go_ani_pair_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    L.go_ani_pair_pool_below.restype = C.c_float
+    L.go_ani_pair_pool_below.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.go_ani_pair.restype = C.c_float
     L.go_ani_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = L
@@ -367,6 +369,14 @@ def ani_pair_mode(q: AniSketch, r: AniSketch, flags: int, min_af: float = 0.15):
     afq, afr = C.c_float(0), C.c_float(0)
     d = (C.c_uint64 * 6)()
     ani = lib().go_ani_pair_mode(q._h, r._h, np.float32(min_af), flags, C.byref(afq), C.byref(afr), d)
+    return float(ani), float(afq.value), float(afr.value), [int(x) for x in d]
+
+
+def ani_pair_pool_below(q: AniSketch, r: AniSketch, pool_below: int, min_af: float = 0.15):
+    """MEASUREMENT ONLY (scripts/ani_few_chunks.py): ani_pair_detail with another pooling limit."""
+    afq, afr = C.c_float(0), C.c_float(0)
+    d = (C.c_uint64 * 6)()
+    ani = lib().go_ani_pair_pool_below(q._h, r._h, np.float32(min_af), pool_below, C.byref(afq), C.byref(afr), d)
     return float(ani), float(afq.value), float(afr.value), [int(x) for x in d]
 
 

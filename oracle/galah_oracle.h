@@ -111,6 +111,8 @@ uint64_t go_ani_sketch_length(const go_ani_sketch *s);
 uint32_t go_ani_density(uint64_t len, uint32_t c);
 uint32_t go_ani_sketch_density(const go_ani_sketch *s);
 /* returns ANI in PERCENT (skani's unit, src/skani.rs:203-209), 0.0 when AF < min_af */
+float go_ani_pair_pool_below(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction, uint32_t pool_below, float *af_q,
+                             float *af_r, uint64_t detail[6]);   /* measurement only */
 float go_ani_pair(const go_ani_sketch *q, const go_ani_sketch *r, float min_af_fraction,
                   float *af_q, float *af_r);
 /* the same, plus the integers behind the value: detail = {M, T of the median chunk, aligned chunks, aligned bases of q,

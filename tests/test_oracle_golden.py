@@ -193,9 +193,8 @@ def test_ani_golden_file_is_what_the_oracle_computes():
 CONTIG_ANCHORS = [(["contigs"], 125, [[0, 1], [2], [3]]), (["contigs", "contigs_extra"], 30, [[0, 1, 4], [2], [3]])]
 REP_BUG_EXPECTED = {125: [[0, 1, 2]], 30: [[0, 1], [2]]}
 # what the build-defined estimator gives for contigs_rep_bug.fna at EITHER base density (all three records, 28-42 kb, are
-# seeded with every 15-mer by the per-genome rule): the representatives of the --small-contigs answer, k141_401621 with the
-# other one -- NEITHER of the reference's two answers
-REP_BUG_GOT = [[0], [2, 1]]
+# seeded with every 15-mer by the per-genome rule): the --small-contigs answer (:591-609), since round 5 (few-chunk pooling)
+REP_BUG_GOT = [[0, 1], [2]]
 
 
 def _contig_flow(files, base_c):
@@ -228,23 +227,27 @@ def test_reference_contig_anchors_contigs_and_contigs_extra():
             assert got[0][0] == 0 and names[0] == "73.20110600_S2D.10_contig_13024"   # the representative the reference prints first
 
 
-def test_reference_contig_anchor_rep_bug_is_reproduced_by_neither_density():
-    """contigs_rep_bug.fna has TWO expected answers in the reference (skani -c 125: one cluster of three; -c 30: NODE_1070
-    apart) -- skani's own estimate of ANI(k141_313035, NODE_1070) straddles 95 % with its seed density.  The build-defined
-    estimator gives 92.35 at every base density (both records are seeded with every 15-mer): chunk 0 of the 28 kb contig holds
-    8 kb without a homologue in NODE_1070 and 4 kb at ~93 %, and the lower median of TWO chunks is the diluted one (an ordered
-    chain with span-limited denominators -- scripts/ani_chain_vs_band.py -- gives 94.95, pooled 95.96: the pair sits on the
-    threshold under every form).  So the representatives are the --small-contigs answer's, but k141_401621 (95.94 to
-    k141_313035, 96.21 to NODE_1070) joins NODE_1070 where skani keeps it with k141_313035: NEITHER expectation is reproduced,
-    and this test pins exactly that (anchor table) instead of a tuned pass."""
+def test_reference_contig_anchor_rep_bug_gives_the_small_contigs_answer():
+    """contigs_rep_bug.fna has TWO expected answers in the reference (skani -c 125, :570-588: one cluster of three; -c 30,
+    :591-609: NODE_1070 apart) -- skani's own estimate of ANI(k141_313035, NODE_1070) straddles 95 % with its seed density.
+    All three records (28-42 kb) are seeded with every 15-mer by the per-genome rule, so the build-defined estimator has ONE
+    answer at either base density, and since round 5 it is the --small-contigs one: with fewer than nine aligned chunks the
+    pooled counts replace the lower median (of two chunks that was the minimum: chunk 0 of the 28 kb contig holds 8 kb
+    without a homologue in NODE_1070 and pulled the pair to 92.35, and k141_401621 to NODE_1070's side -- NEITHER answer;
+    profiles/r05_ani_few_chunks.txt has the measurement the change rests on).  Pooled: 96.37 / 94.18 / 96.27 --
+    k141_401621 stays with k141_313035, NODE_1070 (94.18 < 95) is its own representative.  The --large-contigs answer
+    needs the pair above 95, which skani reaches only through the noise of its sparser seeding: documented as not
+    reproducible (anchor table)."""
     for c in (125, 30):
         names, dense, got = _contig_flow(["contigs_rep_bug"], c)
         assert names[0].startswith("k141_313035 flag=1") and names[2].startswith("NODE_1070")
-        assert got == REP_BUG_GOT
-        assert sorted(sorted(x) for x in got) != REP_BUG_EXPECTED[125] and sorted(sorted(x) for x in got) != REP_BUG_EXPECTED[30]
-        assert sorted(x[0] for x in got) == sorted(x[0] for x in REP_BUG_EXPECTED[30])   # the representatives of --small-contigs
+        assert got == REP_BUG_GOT and got == REP_BUG_EXPECTED[30]   # representative first, members in the reference's order
+        assert sorted(sorted(x) for x in got) != REP_BUG_EXPECTED[125]
         a = {(i, j): oracle.ani_pair(dense[i], dense[j], 0.15)[0] for i in range(3) for j in range(i + 1, 3)}
-        assert [round(a[k], 2) for k in ((0, 1), (0, 2), (1, 2))] == [95.94, 92.35, 96.21]
+        assert [round(a[k], 2) for k in ((0, 1), (0, 2), (1, 2))] == [96.37, 94.18, 96.27]
+        # the rule it replaced, still reachable for measurement: the lower median of the two chunks
+        m = {(i, j): oracle.ani_pair_pool_below(dense[i], dense[j], 0, 0.15)[0] for i in range(3) for j in range(i + 1, 3)}
+        assert [round(m[k], 2) for k in ((0, 1), (0, 2), (1, 2))] == [95.94, 92.35, 96.21]
 
 
 def _finch_plus_ani(names, thr, min_af):
