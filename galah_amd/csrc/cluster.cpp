@@ -457,15 +457,27 @@ int cluster_index_impl(ghip_ctx *ctx, ghip_comm *comm, const ghip_ani_index *idx
     if ((!ctx && !host_cb) || !out_members || !out_offsets || !out_n_clusters || (n_pairs && (!pairs || (!idx && !host_cb)))) return GHIP_EINVAL;
     const auto t0 = std::chrono::steady_clock::now();
     if (out_stats) memset(out_stats, 0, n_stats * sizeof(uint64_t));
-    for (size_t e = 0; e < n_pairs; e++)
-        if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) return ghip_set_error(ctx, GHIP_EINVAL, "pair list names a genome out of range");
+    int rc_in = GHIP_OK;
+    for (size_t e = 0; e < n_pairs && !rc_in; e++)
+        if (pairs[e].i >= n || pairs[e].j >= n || pairs[e].i == pairs[e].j) rc_in = ghip_set_error(ctx, GHIP_EINVAL, "pair list names a genome out of range");
+    if (order && n_pairs && !rc_in) {
+        std::vector<uint8_t> seen(n, 0);
+        for (size_t x = 0; x < n && !rc_in; x++) {
+            if (order[x] >= n || seen[order[x]]) rc_in = ghip_set_error(ctx, GHIP_EINVAL, "order is not a permutation of the genomes");
+            else seen[order[x]] = 1;
+        }
+    }
+    // several ranks: the rounds below are collectives whose sizes follow from lazy_flush_below and from the arguments -- the
+    // ranks meet first, with their settings and with what each made of its arguments (ghip_comm_agree: GHIP_EINVAL on every
+    // rank when the settings differ, GHIP_EPEER on the peers of a rank that rejects its arguments)
+    if (comm && ghip_comm_world(comm) > 1) rc_in = ghip_comm_agree(comm, rc_in);
+    if (rc_in) return rc_in;
     std::vector<ghip_pair> sorted;
     std::vector<uint32_t> orig;
     if (order && n_pairs) {
         std::vector<uint32_t> rank_of(n, UINT32_MAX);
         for (size_t x = 0; x < n; x++) {
-            if (order[x] >= n || rank_of[order[x]] != UINT32_MAX) return ghip_set_error(ctx, GHIP_EINVAL, "order is not a permutation of the genomes");
-            rank_of[order[x]] = (uint32_t)x;
+            rank_of[order[x]] = (uint32_t)x;   // (a permutation: checked above)
         }
         uint32_t bits = 1;
         while (((uint64_t)1 << bits) < n) bits++;

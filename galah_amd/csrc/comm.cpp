@@ -115,7 +115,7 @@ namespace {
 
 int cerr_(ghip_comm *c, int code, const std::string &msg) {
     c->err = msg;
-    if (c->ctx) ghip_set_error(c->ctx, code, msg);
+    ghip_set_error(c->ctx, code, msg);   // (no context: the thread's context-less error text, what ghip_comm_note_error reads back)
     if (c->group) c->group->fail();
     return code;
 }
@@ -271,23 +271,24 @@ int exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, 
         int rc = allgather_host(c, send_off, (size_t)(world + 1) * sizeof(uint64_t), all_off.data());
         if (rc) return rc;
         uint64_t m = 0;
-        bool mismatch = false;   // (reported AFTER the device collective below: the peers enter it whatever this rank finds)
+        bool mismatch = false;
         for (uint32_t r = 0; r < world; r++) {
             const uint64_t *o = &all_off[(size_t)r * (world + 1)];
             m = std::max(m, o[world] - o[0]);
             if (o[me + 1] - o[me] != recvs(r)) mismatch = true;
         }
-        if (m == 0) return mismatch ? cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects") : GHIP_OK;
+        // a rank that cannot take part -- no staging memory, or a peer offers it another size than it expects -- says so in a
+        // status word first: nobody enters the device collective alone, nobody leaves the exchange alone
+        int mine = mismatch ? cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects") : GHIP_OK;
+        if (m == 0) return agree(c, mine, "an empty exchange");
         m = (m + 15) / 16 * 16;
         PoolBuf sb(ctx, m), rb(ctx, m * world);
-        // a rank that cannot take part says so in a status word first: nobody enters the device collective alone
-        int mine = (!sb.p || !rb.p) ? GHIP_EHIP : GHIP_OK;
+        if (!mine && (!sb.p || !rb.p)) mine = cerr_(c, GHIP_EHIP, "out of device memory for staging the exchange");
         if (!mine && send_off[world] > send_off[0] &&
             hipMemcpyAsync(sb.p, (const char *)d_send + send_off[0], send_off[world] - send_off[0], hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-            mine = GHIP_EHIP;
+            mine = cerr_(c, GHIP_EHIP, "staging the exchange: copy failed");
         if ((rc = agree(c, mine, "staging the exchange"))) return rc;
         if ((rc = allgather_device(c, sb.p, rb.p, m))) return rc;
-        if (mismatch) return cerr_(c, GHIP_EINVAL, "exchange: a peer offers a different size than this rank expects");
         for (uint32_t r = 0; r < world; r++) {
             const uint64_t *o = &all_off[(size_t)r * (world + 1)];
             if (recvs(r)) COMM_HIP(c, hipMemcpyAsync((char *)d_recv + recv_off[r], (const char *)rb.p + (size_t)r * m + (o[me] - o[0]), recvs(r), hipMemcpyDeviceToDevice, ctx->stream));
@@ -355,10 +356,21 @@ int allgatherv_host(ghip_comm *c, const void *send, size_t bytes, std::vector<ui
     return GHIP_OK;
 }
 
-// Phase boundary: every rank contributes its status (GHIP_OK or the code of what failed on it); all return together --
-// GHIP_OK when every rank is fine, its own code on a rank that failed, GHIP_EPEER on the others.  A rank that fails between
-// two collectives therefore never leaves its peers waiting in the next one: they meet it here first.  (One small host
-// all-gather: ~0.05 ms over RCCL.)
+// The settings that decide WHICH collectives a call issues and with what sizes: pair_form / join_ranks choose between the
+// hash-sharded join (two exchanges) and ghip_precluster_ranks (none); lazy_flush_below shapes a lazy round's request list and
+// with it the sizes every rank derives for the round's gather.  They are per context (ghip_options), so nothing but a
+// collective can show that the ranks hold the same: the word travels with every status word.
+uint32_t settings_word(const ghip_comm *c) {
+    const ghip_options o = c->ctx ? c->ctx->opt : ghip_process_options();
+    uint32_t h = 2166136261u;
+    for (uint32_t v : {o.pair_form, o.join_ranks, o.lazy_flush_below}) { h ^= v; h *= 16777619u; }
+    return h;
+}
+
+// Phase boundary: every rank contributes its status (GHIP_OK or the code of what failed on it) and its settings word; all
+// return together -- GHIP_OK when every rank is fine, its own code on a rank that failed, GHIP_EPEER on the others,
+// GHIP_EINVAL on every rank when the settings words differ.  A rank that fails between two collectives therefore never
+// leaves its peers waiting in the next one: they meet it here first.  (One small host all-gather: ~0.05 ms over RCCL.)
 int agree(ghip_comm *c, int status, const char *what) {
     if (c->world == 1) return status;
     if (c->transport == T_LOCAL && status) {
@@ -368,8 +380,9 @@ int agree(ghip_comm *c, int status, const char *what) {
         c->agreed_failure = true;
         return status;
     }
-    std::vector<int32_t> all(c->world, 0);
-    const int32_t mine = status;
+    struct Word { int32_t status; uint32_t settings; };
+    std::vector<Word> all(c->world, Word{0, 0});
+    const Word mine{status, settings_word(c)};
     const int rc = allgather_host(c, &mine, sizeof(mine), all.data());
     if (rc) {
         if (c->transport == T_LOCAL && c->group->failed.load()) {
@@ -380,7 +393,14 @@ int agree(ghip_comm *c, int status, const char *what) {
     }
     if (status) { c->agreed_failure = true; return status; }
     for (uint32_t r = 0; r < c->world; r++)
-        if (all[r]) return c->agreed_failure = true, cerr_(c, GHIP_EPEER, std::string("rank ") + std::to_string(r) + " failed at: " + what + " (code " + std::to_string(all[r]) + ")");
+        if (all[r].status) return c->agreed_failure = true, cerr_(c, GHIP_EPEER, std::string("rank ") + std::to_string(r) + " failed at: " + what + " (code " + std::to_string(all[r].status) + ")");
+    for (uint32_t r = 1; r < c->world; r++)
+        if (all[r].settings != all[0].settings) {
+            c->agreed_failure = true;
+            // (cerr_ fails a LOCAL group: the group is made per call, and every rank of it returns this error)
+            return cerr_(c, GHIP_EINVAL, std::string("the ranks hold different ghip_options (pair_form / join_ranks / lazy_flush_below decide the collectives "
+                                                     "of a call and must be the same on every rank): rank ") + std::to_string(r) + " differs from rank 0, seen at: " + what);
+        }
     return GHIP_OK;
 }
 
@@ -598,7 +618,9 @@ extern "C" int ghip_precluster_comm(ghip_comm *c, const ghip_sketches *sk, float
     c->agreed_failure = false;
     const size_t n = sk->n;
     const uint32_t s = sk->s, world = c->world, rank = c->rank;
-    // (the options are per context: ranks of one job are expected to hold the same pair_form / join_ranks)
+    // pair_form / join_ranks are per context and decide below whether this rank enters exchange 1 at all: the ranks meet
+    // first and compare them (GHIP_EINVAL on every rank when they differ)
+    if (world > 1) { const int rc0 = agree(c, GHIP_OK, "the pair stage's settings"); if (rc0) return rc0; }
     const uint32_t force = ctx->opt.pair_form, mode = ctx->opt.join_ranks;
     const bool want = world > 1 && mode == GHIP_JOIN_HASH &&
                       (force != GHIP_PAIR_AUTO ? force == GHIP_PAIR_JOIN : (n >= GHIP_JOIN_MIN_N || s > 4096)) && (uint64_t)n * s < (1ull << 32) && n >= 2;
@@ -852,10 +874,16 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     }
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) fail(GHIP_EHIP, "ANI index exchange: packing failed");
     if ((rc = agree(c, rc, "packing the ANI index slices"))) { drop(); return rc; }
+    // the four exchanges are collectives: a rank whose own copy fails inside one still enters the remaining ones (its peers
+    // do), remembers the first error, and the status word behind them takes every rank out together
+    int first_rc = GHIP_OK;
     for (int fi = 0; fi < 4; fi++) {
         Field &f = fields[fi];
-        if ((rc = exchange_device(c, packed[fi].send, packed[fi].send_off.data(), (char *)f.dst + (*f.cstart)[count] * 4, packed[fi].recv_off.data()))) { drop(); return rc; }
+        rc = exchange_device(c, packed[fi].send, packed[fi].send_off.data(), (char *)f.dst + (*f.cstart)[count] * 4, packed[fi].recv_off.data());
+        if (rc && (c->agreed_failure || c->dead)) { drop(); return rc; }   // agreed inside (every rank returns) / the communicator is gone
+        if (rc && !first_rc) first_rc = rc;
     }
+    if ((rc = agree(c, first_rc, "the ANI index exchanges"))) { drop(); return rc; }
     {   // the send buffers go back to the pool (exchange_device returns with the stream idle); the combined arrays stay
         std::lock_guard<std::mutex> lk(ctx->mu);
         for (int fi = 0; fi < 4; fi++) { ghip_pool_free(ctx, packed[fi].send); owned.erase(std::find(owned.begin(), owned.end(), packed[fi].send)); }
@@ -863,7 +891,11 @@ extern "C" int ghip_exchange_ani_index(ghip_comm *c, const ghip_ani_index *local
     ghip_ani_index *idx = nullptr;
     rc = ghip_ani_index_wrap_device(ctx, nc, local->k, local->c, local->chunk, glen.data(), cap.data(), cnt.data(), fields[0].dst,
                                     fields[1].dst, fields[2].dst, fields[3].dst, &idx);
-    if (rc) { drop(); if (c->group) c->group->fail(); return rc; }
+    if ((rc = agree(c, ghip_comm_note_error(c, rc), "wrapping the combined ANI index"))) {
+        if (idx) { idx->owned = false; ghip_ani_index_free(idx); }   // (the handle alone: the arrays are still in `owned`)
+        drop();
+        return rc;
+    }
     idx->owned = true;   // the combined arrays belong to the handle
     *out_index = idx;
     return GHIP_OK;

@@ -362,7 +362,10 @@ int ghip_cluster_index_comm(ghip_comm *comm, const ghip_ani_index *idx, const ui
                             float min_aligned_fraction, uint32_t **out_members, uint64_t **out_offsets, size_t *out_n_clusters,
                             uint64_t *out_stats);
 /* Phase boundary of a host that strings the phases itself: every rank passes GHIP_OK or the code of what failed on it; all
- * return together -- GHIP_OK, the rank's own code, or GHIP_EPEER.  (The entry points above do this between their phases.) */
+ * return together -- GHIP_OK, the rank's own code, or GHIP_EPEER.  (The entry points above do this between their phases.)
+ * The word also carries the settings that decide a call's collectives (ghip_options.pair_form, join_ranks,
+ * lazy_flush_below): when the ranks hold different ones, every rank returns GHIP_EINVAL -- here, at the head of
+ * ghip_precluster_comm and of the lazy rounds, and at every phase boundary of the whole-pass entry points. */
 int ghip_comm_agree(ghip_comm *comm, int status);
 ghip_ctx *ghip_comm_context(const ghip_comm *comm);
 

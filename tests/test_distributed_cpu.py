@@ -109,6 +109,37 @@ def _worker(rank, world, port, q):
     except Exception as e:  # noqa: BLE001
         out["lazy_fail"] = f"{type(e).__name__}: {e}"
     out["after_fail"] = comm.allgather_host(np.int64([rank])).ravel().tolist()
+    # settings that decide the collectives: ONE rank holds another lazy_flush_below -- its rounds would ask for other
+    # request lists, i.e. other gather sizes.  Every rank gets GHIP_EINVAL at the head of the rounds; with the setting
+    # restored the same call runs.  (A host-payload communicator has no context: the process-wide options are its settings.)
+    import galah_amd
+    saved = galah_amd.get_options()
+    if rank == world - 1:
+        galah_amd.set_options(None, lazy_flush_below=saved["lazy_flush_below"] + 7)
+    try:
+        comm.cluster_lazy(n, pairs, np.float32(95.0), lambda e: table[e])
+        out["settings"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["settings"] = str(e)
+    try:
+        comm.agree(0)
+        out["settings_agree"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["settings_agree"] = str(e)
+    galah_amd.set_options(None, **saved)
+    comm.agree(0)
+    out["after_settings"] = comm.cluster_lazy(n, pairs, np.float32(95.0), lambda e: table[e])[0].tolist()
+    # ONE rank passes a pair list that names a genome out of range: it gets its own GHIP_EINVAL, its peers GHIP_EPEER -- nobody
+    # is left waiting in the first round's gather
+    bad_pairs = pairs.copy()
+    if rank == 0:
+        bad_pairs["j"][3] = n + 5
+    try:
+        comm.cluster_lazy(n, bad_pairs, np.float32(95.0), lambda e: table[e])
+        out["bad_args"] = "no error"
+    except Exception as e:  # noqa: BLE001
+        out["bad_args"] = str(e)
+    out["after_bad_args"] = comm.allgather_host(np.int64([rank])).ravel().tolist()
     q.put(out)
     dist.barrier()
     comm.close()
@@ -158,6 +189,11 @@ def test_exchange_logic_over_gloo(world):
     for r, o in enumerate(outs):
         assert (o["lazy_fail"].startswith("ValueError") if r == world - 1 else "GHIP_EPEER" in o["lazy_fail"]), o["lazy_fail"]
         assert o["after_fail"] == list(range(world))
+        assert o["settings"].startswith("GHIP_EINVAL") and "different ghip_options" in o["settings"], o["settings"]
+        assert o["settings_agree"].startswith("GHIP_EINVAL"), o["settings_agree"]
+        assert o["after_settings"] == want
+        assert o["bad_args"].startswith("GHIP_EINVAL" if r == 0 else "GHIP_EPEER"), o["bad_args"]
+        assert o["after_bad_args"] == list(range(world))
 
 
 def test_single_rank_communicator_needs_no_transport():
