@@ -139,7 +139,8 @@ class ClusterTimes(C.Structure):
 # ghip_options (include/galah_hip.h): every switch of the library, per context
 OPTION_FIELDS = ("struct_size", "pair_form", "join_ranks", "ingest_form", "ingest_groups", "io_threads_plain", "io_threads_gz", "copy_streams",
                  "use_libdeflate", "pipeline_pieces", "overlap_binning", "lazy_flush_below", "cluster_threads", "ani_force_general",
-                 "ani_tall_below", "debug", "pair_debug", "fault_stage", "fault_rank", "join_fused", "probe_arranged")
+                 "ani_tall_below", "debug", "pair_debug", "fault_stage", "fault_rank", "join_fused", "probe_arranged",
+                 "comm_timeout_ms")
 PAIR_FORMS = {"auto": 0, "join": 1, "probe": 2, "merge": 3}
 JOIN_RANKS = {"hash": 0, "records": 1, "replicate": 2}
 INGEST_FORMS = {"packed": 0, "ascii": 1, "pageable": 2, "two-phase": 3}

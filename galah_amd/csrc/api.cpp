@@ -184,6 +184,7 @@ ghip_options options_from_environment() {
               (set("GHIP_COMM_DEBUG") ? GHIP_DEBUG_COMM : 0) | (set("GHIP_CLUSTER_DEBUG") ? GHIP_DEBUG_CLUSTER : 0) | (set("GHIP_ANI_DEBUG") ? GHIP_DEBUG_ANI : 0);
     o.pair_debug = num("GHIP_PAIR_DEBUG", 0);
     o.probe_arranged = num("GHIP_PROBE_ARRANGED", 0);   // (likewise off until measured)
+    o.comm_timeout_ms = num("GHIP_COMM_TIMEOUT_MS", 60000);
     o.join_fused = num("GHIP_JOIN_FUSED", 0);   // (off until a GPU run has shown it byte-identical and faster: profiles/r04*)
     return o;
 }

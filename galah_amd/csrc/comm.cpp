@@ -37,6 +37,7 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;   // optional
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;   // optional
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
@@ -44,9 +45,16 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r = [] {
         Rccl x;
+        // GHIP_RCCL_LIBRARY: the RCCL build to use, by path (a site's own build; the test suite's stand-in) -- the names below
+        // resolve to whatever librccl the process has mapped already
+        const char *chosen = getenv("GHIP_RCCL_LIBRARY");
+        if (chosen && *chosen) {
+            x.handle = dlopen(chosen, RTLD_NOW | RTLD_GLOBAL);
+            if (!x.handle) { x.err = std::string("GHIP_RCCL_LIBRARY: ") + (dlerror() ? dlerror() : chosen); return x; }
+        }
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (x.handle) break;
+            x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!x.handle) { x.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return x; }
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
@@ -58,6 +66,7 @@ Rccl &rccl() {
         x.GroupEnd = (decltype(x.GroupEnd))dlsym(x.handle, "ncclGroupEnd");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
         x.CommAbort = (decltype(x.CommAbort))dlsym(x.handle, "ncclCommAbort");
+        x.CommGetAsyncError = (decltype(x.CommGetAsyncError))dlsym(x.handle, "ncclCommGetAsyncError");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
         if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.Send || !x.Recv || !x.GroupStart || !x.GroupEnd || !x.CommDestroy ||
             !x.GetErrorString)
@@ -109,6 +118,12 @@ struct ghip_comm {
     // and unpin the vectors around every copy: the NEXT small device-to-host copy of the caller then stalled 12-24 ms.)
     void *pin_send = nullptr, *pin_recv = nullptr;
     size_t pin_send_bytes = 0, pin_recv_bytes = 0;
+    // RCCL transport, made once at ghip_comm_init_rank so that nothing can fail on one rank between "decided to enter a
+    // collective" and "entered it": the event a rank polls behind every collective, and device + pinned staging of the
+    // SMALL host payloads (status words, sizes, flags: up to HC_BYTES per rank)
+    hipEvent_t wait_ev = nullptr;
+    void *hc_send = nullptr, *hc_recv = nullptr, *hc_pin = nullptr;
+    static constexpr size_t HC_BYTES = 4096;
 };
 
 namespace {
@@ -127,6 +142,51 @@ int rccl_failed(ghip_comm *c, const char *what, ncclResult_t r) {
     if (c->nccl && rccl().CommAbort) { rccl().CommAbort(c->nccl); c->nccl = nullptr; }
     c->dead = true;
     return cerr_(c, GHIP_EHIP, msg);
+}
+
+#define COMM_HIP(c, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return cerr_((c), GHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// Waits for the RCCL work just put on the context's stream WITHOUT handing the thread to hipStreamSynchronize: a peer that died,
+// or never enters the collective, would hold this rank inside it for ever (the status words cover failures BETWEEN collectives,
+// not inside one).  The stream's event is polled next to ncclCommGetAsyncError -- RCCL's own report of a broken link or a
+// remote abort -- and against a deadline (ghip_options.comm_timeout_ms).  Either way out: ncclCommAbort (which also releases
+// the kernel RCCL has on the stream), the communicator is dead, the caller gets GHIP_EPEER.
+int rccl_wait(ghip_comm *c, const char *what) {
+    ghip_ctx *ctx = c->ctx;
+    if (!c->wait_ev) {   // (a communicator made before the event could be: plain wait)
+        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+        return GHIP_OK;
+    }
+    COMM_HIP(c, hipEventRecord(c->wait_ev, ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t limit_ms = ctx->opt.comm_timeout_ms;
+    auto give_up = [&](const std::string &why) {
+        if (c->nccl && rccl().CommAbort) { rccl().CommAbort(c->nccl); c->nccl = nullptr; }
+        c->dead = true;
+        (void)hipStreamSynchronize(ctx->stream);   // the aborted kernel leaves the stream
+        (void)hipGetLastError();
+        return cerr_(c, GHIP_EPEER, std::string(what) + ": " + why + " -- the communicator was aborted");
+    };
+    for (uint64_t spins = 0;; spins++) {
+        const hipError_t q = hipEventQuery(c->wait_ev);
+        if (q == hipSuccess) return GHIP_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return give_up(std::string("the stream reports ") + hipGetErrorString(q)); }
+        (void)hipGetLastError();   // (hipErrorNotReady is sticky in hipGetLastError)
+        if (rccl().CommGetAsyncError && c->nccl && (spins & 15) == 0) {
+            ncclResult_t async = ncclSuccess;
+            const ncclResult_t r = rccl().CommGetAsyncError(c->nccl, &async);
+            if (r != ncclSuccess || (async != ncclSuccess && async != ncclInProgress))
+                return give_up(std::string("RCCL reports ") + rccl().GetErrorString(r != ncclSuccess ? r : async));
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (limit_ms && ms > (double)limit_ms) return give_up("no answer from the peers within " + std::to_string(limit_ms) + " ms (ghip_options.comm_timeout_ms)");
+        if (ms < 2.0) std::this_thread::yield();   // a collective of this path takes 0.05-10 ms: stay close at first
+        else std::this_thread::sleep_for(std::chrono::microseconds(ms < 50.0 ? 50 : 500));
+    }
 }
 
 // tests of the error paths: ghip_options.fault_stage / fault_rank make one rank fail at a named point
@@ -151,12 +211,6 @@ struct PoolBuf {  // device scratch from the context's pool
     void *release() { void *q = p; p = nullptr; return q; }
 };
 
-#define COMM_HIP(c, expr)                                                                                   \
-    do {                                                                                                    \
-        hipError_t _e = (expr);                                                                             \
-        if (_e != hipSuccess) return cerr_((c), GHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-
 // every rank contributes `bytes` from d_send; d_recv (world * bytes) receives the blocks in rank order
 int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t bytes) {
     if (bytes == 0) return GHIP_OK;
@@ -171,8 +225,7 @@ int allgather_device(ghip_comm *c, const void *d_send, void *d_recv, size_t byte
         if (c->dead) return cerr_(c, GHIP_EHIP, "the RCCL communicator was aborted by an earlier failure");
         ncclResult_t r = rccl().AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream);
         if (r != ncclSuccess) return rccl_failed(c, "ncclAllGather", r);
-        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
-        return GHIP_OK;
+        return rccl_wait(c, "ncclAllGather");
     }
     case T_LOCAL: {
         LocalGroup *g = c->group;
@@ -241,8 +294,7 @@ int exchange_device(ghip_comm *c, const void *d_send, const uint64_t *send_off, 
         const ncclResult_t e = rccl().GroupEnd();
         if (r == ncclSuccess) r = e;
         if (r != ncclSuccess) return rccl_failed(c, "ncclSend/ncclRecv", r);
-        COMM_HIP(c, hipStreamSynchronize(ctx->stream));
-        return GHIP_OK;
+        return rccl_wait(c, "ncclSend/ncclRecv");
     }
     case T_LOCAL: {
         LocalGroup *g = c->group;
@@ -315,16 +367,31 @@ int allgather_host(ghip_comm *c, const void *send, size_t bytes, void *recv) {
         if (!g->barrier()) return cerr_(c, GHIP_EHIP, "a peer rank failed");
         return GHIP_OK;
     }
-    case T_RCCL: {  // small host payloads ride the same collective through two pool buffers
+    case T_RCCL: {  // host payloads ride the same collective
         ghip_ctx *ctx = c->ctx;
         const size_t padded = (bytes + 15) / 16 * 16;
-        PoolBuf ds(ctx, padded), dr(ctx, padded * c->world);
-        if (!ds.p || !dr.p) return cerr_(c, GHIP_EHIP, "out of device memory for a host collective");
-        std::vector<uint8_t> hr(padded * c->world);
         COMM_HIP(c, hipSetDevice(ctx->device));
-        if (ghip_copy_to_device(ctx, ds.p, send, bytes) != GHIP_OK) return cerr_(c, GHIP_EHIP, "host collective: upload failed");
-        int rc = allgather_device(c, ds.p, dr.p, padded);
-        if (rc) return rc;
+        if (padded <= ghip_comm::HC_BYTES && c->hc_send) {
+            // small payloads (every status word is one): buffers made with the communicator -- no allocation, hence nothing
+            // that could fail on this rank alone, stands between the call and the collective
+            memcpy(c->hc_pin, send, bytes);
+            COMM_HIP(c, hipMemcpyAsync(c->hc_send, c->hc_pin, padded, hipMemcpyHostToDevice, ctx->stream));
+            int rc = allgather_device(c, c->hc_send, c->hc_recv, padded);
+            if (rc) return rc;
+            COMM_HIP(c, hipMemcpyAsync(c->hc_pin, c->hc_recv, padded * c->world, hipMemcpyDeviceToHost, ctx->stream));
+            COMM_HIP(c, hipStreamSynchronize(ctx->stream));
+            for (uint32_t r = 0; r < c->world; r++) memcpy((char *)recv + (size_t)r * bytes, (const char *)c->hc_pin + (size_t)r * padded, bytes);
+            return GHIP_OK;
+        }
+        // larger ones (a lazy round's answers): the buffers can only be sized now, and a rank that cannot get them says so in a
+        // status word (a small payload: the branch above) before anyone enters the collective
+        PoolBuf ds(ctx, padded), dr(ctx, padded * c->world);
+        int rc = (!ds.p || !dr.p) ? cerr_(c, GHIP_ENOMEM, "out of device memory for a host collective") : GHIP_OK;
+        std::vector<uint8_t> hr;
+        if (!rc) { try { hr.resize(padded * c->world); } catch (const std::bad_alloc &) { rc = cerr_(c, GHIP_ENOMEM, "out of host memory for a host collective"); } }
+        if (!rc && ghip_copy_to_device(ctx, ds.p, send, bytes) != GHIP_OK) rc = cerr_(c, GHIP_EHIP, "host collective: upload failed");
+        if ((rc = agree(c, rc, "the buffers of a host collective"))) return rc;
+        if ((rc = allgather_device(c, ds.p, dr.p, padded))) return rc;
         if (ghip_copy_to_host(ctx, hr.data(), dr.p, hr.size()) != GHIP_OK) return cerr_(c, GHIP_EHIP, "host collective: download failed");
         for (uint32_t r = 0; r < c->world; r++) memcpy((char *)recv + (size_t)r * bytes, hr.data() + (size_t)r * padded, bytes);
         return GHIP_OK;
@@ -448,6 +515,15 @@ extern "C" int ghip_comm_init_rank(ghip_ctx *ctx, uint32_t rank, uint32_t world,
     if (r != ncclSuccess) return ghip_set_error(ctx, GHIP_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
     ghip_comm *c = new ghip_comm();
     c->ctx = ctx; c->rank = rank; c->world = world; c->transport = T_RCCL; c->nccl = nc;
+    // (failures here are local and precede every collective of this communicator: the caller's set-up protocol -- a first probe
+    // all-gather under a watchdog, galah_amd/distributed.py -- is where the ranks find out)
+    const size_t hc = ghip_comm::HC_BYTES;
+    if (hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) != hipSuccess || hipMalloc(&c->hc_send, hc) != hipSuccess ||
+        hipMalloc(&c->hc_recv, hc * world) != hipSuccess || hipHostMalloc(&c->hc_pin, hc * world, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ghip_comm_destroy(c);
+        return ghip_set_error(ctx, GHIP_ENOMEM, "RCCL communicator: no memory for its status-word buffers");
+    }
     *out = c;
     return GHIP_OK;
 }
@@ -494,6 +570,10 @@ extern "C" void ghip_comm_destroy(ghip_comm *c) {
     if (c->nccl) rccl().CommDestroy(c->nccl);
     if (c->pin_send) hipHostFree(c->pin_send);
     if (c->pin_recv) hipHostFree(c->pin_recv);
+    if (c->wait_ev) hipEventDestroy(c->wait_ev);
+    if (c->hc_send) hipFree(c->hc_send);
+    if (c->hc_recv) hipFree(c->hc_recv);
+    if (c->hc_pin) hipHostFree(c->hc_pin);
     if (c->group && --c->group->refs == 0) delete c->group;
     delete c;
 }

@@ -88,6 +88,20 @@ class Comm:
         return c
 
     @classmethod
+    def from_rccl_id(cls, ctx, rank: int, world: int, uid: bytes) -> "Comm":
+        """RCCL transport for a host that ships the 128-byte unique id itself (rank 0: Comm.rccl_unique_id()): the library calls
+        ncclCommInitRank; blocks until every rank has joined."""
+        h = C.c_void_p()
+        check(_lib.lib().ghip_comm_init_rank(ctx._h, rank, world, (C.c_uint8 * 128).from_buffer_copy(uid), C.byref(h)), ctx._h)
+        return cls(h, ctx)
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        uid = (C.c_uint8 * 128)()
+        check(_lib.lib().ghip_comm_unique_id(uid))
+        return bytes(uid)
+
+    @classmethod
     def from_torch_rccl(cls, ctx, rank: int, world: int, timeout_s: float = 180.0) -> "Comm":
         """RCCL transport: rank 0 makes the unique id, torch.distributed (any backend) ships its 128 bytes, the
         library calls ncclCommInitRank itself.  The init runs under a watchdog; raises on failure or timeout."""

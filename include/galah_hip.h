@@ -105,6 +105,8 @@ typedef struct ghip_options {
                                    choice sharing low bucket bits with the first (1: 3 bits for tables of >= 1 024 buckets, 2 below;
                                    2..4: that many) -- fewer LDS bank conflicts.  Takes effect when a matrix's tables are built.
                                    (GHIP_PROBE_ARRANGED) */
+    uint32_t comm_timeout_ms;   /* RCCL transport: how long a rank waits inside one collective for its peers before it aborts the
+                                   communicator and returns GHIP_EPEER, default 60 000; 0: for ever   (GHIP_COMM_TIMEOUT_MS) */
 } ghip_options;
 int ghip_get_options(const ghip_ctx *ctx /* NULL: the process-wide defaults */, ghip_options *out);
 int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const ghip_options *opt);

@@ -21,6 +21,10 @@ if EMU:
     _galah_lib.LIB_PATH = EMU_LIB
 
 
+# tests/emu/cases holds tests that only exist under emulation (the RCCL transport with several ranks in one process)
+collect_ignore_glob = [] if EMU else ["emu/cases/*"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "emu: small enough to also run under the CPU emulator (tests/emu); selected by tests/test_emu.py")

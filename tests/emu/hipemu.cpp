@@ -22,6 +22,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -54,7 +55,6 @@ hipemu_switch:
 
 namespace hipemu {
 
-thread_local ThreadCtx *tl = nullptr;
 
 namespace {
 
@@ -74,8 +74,8 @@ struct Launch {
 };
 
 struct Worker {   // per OS thread
-    char *stacks = nullptr;
-    size_t n_stacks = 0, stack_bytes = 0;
+    char *stack_map = nullptr, *stacks = nullptr;
+    size_t n_stacks = 0, stack_map_bytes = 0;
     std::vector<ThreadCtx> ctx;
     std::vector<State> st;
     std::vector<void *> sp;
@@ -85,7 +85,7 @@ struct Worker {   // per OS thread
     Launch *cur = nullptr;
     uint32_t cur_thread = 0;
     ~Worker() {
-        if (stacks) munmap(stacks, n_stacks * stack_bytes);
+        if (stack_map) munmap(stack_map, stack_map_bytes);
         free(lds);
     }
 };
@@ -114,24 +114,23 @@ size_t env_size(const char *name, size_t dflt) {
 }
 
 void fiber_entry() {
-    Worker *w = tw;
+    Worker *w = static_cast<Worker *>(cur()->worker);
     w->cur->body();
-    w = tw;
+    w = static_cast<Worker *>(cur()->worker);
     w->st[w->cur_thread] = DONE;
     hipemu_switch(&w->sp[w->cur_thread], w->sched_sp);
     __builtin_trap();
 }
 
-inline void to_sched(State s) {
-    Worker *w = tw;
-    const uint32_t t = w->cur_thread;
+inline void to_sched(ThreadCtx *c, State s) {
+    Worker *w = static_cast<Worker *>(c->worker);
+    const uint32_t t = c->flat;
     w->st[t] = s;
     hipemu_switch(&w->sp[t], w->sched_sp);
 }
 
 inline void run_fiber(Worker *w, uint32_t t) {
     w->cur_thread = t;
-    tl = &w->ctx[t];
     hipemu_switch(&w->sched_sp, w->sp[t]);
 }
 
@@ -192,13 +191,14 @@ void start_coresident(Launch *L);
 
 void run_block(Worker *w, Launch *L, uint64_t b) {
     const uint32_t n = L->block.x * L->block.y * L->block.z, nw = (n + 63) / 64;
-    const size_t stack_bytes = env_size("HIPEMU_STACK_KB", 256) * 1024;
-    if (w->n_stacks < n || w->stack_bytes != stack_bytes) {
-        if (w->stacks) munmap(w->stacks, w->n_stacks * w->stack_bytes);
-        w->stacks = (char *)mmap(nullptr, (size_t)n * stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (w->stacks == (char *)MAP_FAILED) { fprintf(stderr, "[hipemu] cannot map %u fibre stacks\n", n); abort(); }
+    const size_t stack_bytes = STACK_BYTES;
+    if (w->n_stacks < n) {
+        if (w->stack_map) munmap(w->stack_map, w->stack_map_bytes);
+        w->stack_map_bytes = (size_t)(n + 1) * stack_bytes;   // one more: the first stack starts at a multiple of its size
+        w->stack_map = (char *)mmap(nullptr, w->stack_map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (w->stack_map == (char *)MAP_FAILED) { fprintf(stderr, "[hipemu] cannot map %u fibre stacks\n", n); abort(); }
+        w->stacks = (char *)(((uintptr_t)w->stack_map + stack_bytes - 1) & ~(uintptr_t)(stack_bytes - 1));
         w->n_stacks = n;
-        w->stack_bytes = stack_bytes;
     }
     if (w->ctx.size() < n) { w->ctx.resize(n); w->st.resize(n); w->sp.resize(n); }
     if (w->lds_cap < L->lds + 64) {
@@ -221,6 +221,8 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         c.lane = t & 63;
         c.wave = t >> 6;
         c.flat = t;
+        c.worker = w;
+        *reinterpret_cast<ThreadCtx **>(w->stacks + (size_t)t * stack_bytes) = &c;   // what cur() finds from the stack pointer
         w->st[t] = READY;
         uint64_t *top = (uint64_t *)(w->stacks + (size_t)(t + 1) * stack_bytes);   // 16-byte aligned (page aligned)
         top[-1] = 0;                          // the return address fiber_entry would see (never used)
@@ -228,7 +230,6 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         for (int i = 3; i <= 8; i++) top[-i] = 0;
         w->sp[t] = top - 8;
     }
-    ThreadCtx *saved_tl = tl;
     for (;;) {
         for (uint32_t wv = 0; wv < nw; wv++) {
             const uint32_t lo = wv * 64, hi = std::min(n, lo + 64);
@@ -263,7 +264,6 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         for (uint32_t t = 0; t < n; t++)   // s_barrier counts the waves that are still alive
             if (w->st[t] == BARRIER) w->st[t] = READY;
     }
-    tl = saved_tl;
     g_stats.blocks++;
 }
 
@@ -345,20 +345,22 @@ std::atomic<size_t> g_mem_now{0}, g_mem_peak{0};
 }  // namespace
 
 uint64_t wave_op(int kind, uint64_t val, int arg, int width, const void *site) {
-    ThreadCtx *c = tl;
+    ThreadCtx *c = cur();
     c->op_kind = kind;
     c->op_val = val;
     c->op_arg = arg;
     c->op_width = width <= 0 || width > 64 ? 64 : width;
     c->op_site = site;
-    to_sched(WAVE_WAIT);
+    to_sched(c, WAVE_WAIT);
     return c->op_res;
 }
-void block_barrier() { to_sched(BARRIER); }
-void yield() { to_sched(YIELDED); }
-unsigned char *dyn_lds() { return tw->lds; }
+void block_barrier() { to_sched(cur(), BARRIER); }
+void yield() { to_sched(cur(), YIELDED); }
+unsigned char *dyn_lds() { return static_cast<Worker *>(cur()->worker)->lds; }
 
-void launch(const char *name, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t, std::function<void()> body) {
+void drain_stream(hipStream_t s);
+void launch(const char *name, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::function<void()> body) {
+    drain_stream(stream);
     const uint64_t threads = (uint64_t)block.x * block.y * block.z, total = (uint64_t)grid.x * grid.y * grid.z;
     size_t allow = 64 * 1024;
     {
@@ -407,8 +409,46 @@ void launch(const char *name, const void *fn, dim3 grid, dim3 block, size_t lds,
 // ------------------------------------------------------------------ the runtime API
 using namespace hipemu;
 
-struct hipemuStream { int id; };
-struct hipemuEvent { double t_ms; };
+// Streams run what they are given at once, in the caller's thread -- except for PENDING work: something outside the
+// emulator (the stand-in for RCCL, tests/emu/fake_rccl) puts a ticket on a stream that completes later, from another thread
+// (the peers of a collective arriving).  Everything put on the stream after a ticket waits for it first; an event recorded
+// behind one is not ready until it is; hipEventQuery is the one call that does not wait.
+struct Pending { std::atomic<int> state{0}; };   // 0 in flight, 1 done, 2 failed
+struct hipemuStream {
+    std::mutex mu;
+    std::vector<std::shared_ptr<Pending>> pending;
+};
+struct hipemuEvent {
+    double t_ms = 0.0;
+    std::vector<std::shared_ptr<Pending>> behind;   // tickets in flight on the stream when the event was recorded
+};
+static hipemuStream g_null_stream;
+static hipemuStream *stream_of(hipStream_t s) { return s ? s : &g_null_stream; }
+static bool all_done(const std::vector<std::shared_ptr<Pending>> &v) {
+    for (auto &p : v) if (p->state.load(std::memory_order_acquire) == 0) return false;
+    return true;
+}
+// waits for the stream's tickets (what the hardware queue does before it runs the next item); returns false if one failed
+static bool drain(hipStream_t s_) {
+    hipemuStream *s = stream_of(s_);
+    std::vector<std::shared_ptr<Pending>> v;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->pending.empty()) return true;
+        v = s->pending;
+    }
+    for (uint64_t spins = 0; !all_done(v); spins++) {
+        if (spins < 200) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    bool ok = true;
+    for (auto &p : v) ok = ok && p->state.load() == 1;
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (auto &p : v) s->pending.erase(std::remove(s->pending.begin(), s->pending.end(), p), s->pending.end());
+    return ok;
+}
+
+namespace hipemu { void drain_stream(hipStream_t s) { (void)drain(s); } }
 
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -439,7 +479,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->l2CacheSize = 4 << 20;
     return hipSuccess;
 }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { drain(nullptr); return hipSuccess; }
 hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 
@@ -478,23 +518,40 @@ hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) {
     return hipSuccess;
 }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
-hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind, hipStream_t) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
-hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_t bytes, hipStream_t) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
-hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t) { if (bytes) memset(dst, value, bytes); return hipSuccess; }
-hipError_t hipMemset(void *dst, int value, size_t bytes) { if (bytes) memset(dst, value, bytes); return hipSuccess; }
+hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind) { drain(nullptr); if (bytes) memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind, hipStream_t s) { drain(s); if (bytes) memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_t bytes, hipStream_t s) { drain(s); if (bytes) memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t s) { drain(s); if (bytes) memset(dst, value, bytes); return hipSuccess; }
+hipError_t hipMemset(void *dst, int value, size_t bytes) { drain(nullptr); if (bytes) memset(dst, value, bytes); return hipSuccess; }
 
-hipError_t hipStreamCreate(hipStream_t *s) { *s = new hipemuStream{1}; return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemuStream{1}; return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemuEvent{0.0}; return hipSuccess; }
-hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new hipemuEvent{0.0}; return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t *s) { *s = new hipemuStream(); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemuStream(); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { drain(s); delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { return drain(s) ? hipSuccess : (t_last_error = hipErrorUnknown); }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) {
+    while (!all_done(e->behind)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemuEvent(); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new hipemuEvent(); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t_ms = now_ms(); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s_) {
+    hipemuStream *s = stream_of(s_);
+    std::lock_guard<std::mutex> lk(s->mu);
+    e->behind.clear();
+    for (auto &p : s->pending) if (p->state.load() == 0) e->behind.push_back(p);
+    e->t_ms = now_ms();
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    while (!all_done(e->behind)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    return hipSuccess;
+}
+hipError_t hipEventQuery(hipEvent_t e) {
+    if (!all_done(e->behind)) return t_last_error = hipErrorNotReady;
+    for (auto &p : e->behind) if (p->state.load() == 2) return t_last_error = hipErrorUnknown;
+    return hipSuccess;
+}
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 hipError_t hipGetLastError() { const hipError_t e = t_last_error; t_last_error = hipSuccess; return e; }
 hipError_t hipPeekAtLastError() { return t_last_error; }
@@ -521,4 +578,17 @@ void hipemu_stats(uint64_t out[8]) {
     out[4] = g_stats.divergent_ops; out[5] = g_stats.inactive_reads; out[6] = g_stats.coresident_launches; out[7] = g_mem_peak;
 }
 int hipemu_is_emulator() { return 1; }
+// a ticket on a stream (see Pending): returns a handle for hipemu_pending_complete; used by tests/emu/fake_rccl
+void *hipemu_pending_new(hipStream_t s_) {
+    hipemuStream *s = stream_of(s_);
+    auto *h = new std::shared_ptr<Pending>(std::make_shared<Pending>());
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->pending.push_back(*h);
+    return h;
+}
+void hipemu_pending_complete(void *h_, int failed) {
+    auto *h = static_cast<std::shared_ptr<Pending> *>(h_);
+    (*h)->state.store(failed ? 2 : 1, std::memory_order_release);
+    delete h;
+}
 }

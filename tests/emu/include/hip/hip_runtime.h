@@ -98,16 +98,26 @@ namespace hipemu {
 struct ThreadCtx {   // one work-item
     dim3 tid, bid, bdim, gdim;
     uint32_t lane, wave, flat;
+    void *worker;   // the emulator's per-OS-thread state
     // the cross-lane operation this lane waits in
     uint64_t op_val, op_res;
     const void *op_site;
     int op_kind, op_arg, op_width;
 };
-extern thread_local ThreadCtx *tl;   // the work-item running on this OS thread right now
+// A fibre's stack is HIPEMU_STACK_BYTES long and aligned to that: the work-item's context pointer sits in its lowest word
+// and is found from the stack pointer (no thread-local lookup at every threadIdx; a stack overflow lands on it first).
+constexpr uintptr_t STACK_BYTES = 256 * 1024;
+inline ThreadCtx *cur() {
+    uintptr_t sp;
+    asm("mov %%rsp, %0" : "=r"(sp));
+    return *reinterpret_cast<ThreadCtx **>(sp & ~(STACK_BYTES - 1));
+}
 
 enum { OP_SHFL = 1, OP_SHFL_UP, OP_SHFL_DOWN, OP_SHFL_XOR, OP_BALLOT, OP_FIRST, OP_WAVE_BARRIER };
-uint64_t wave_op(int kind, uint64_t val, int arg, int width, const void *site);
-void block_barrier();
+// (convergent: what keeps a GPU compiler from duplicating or sinking a cross-lane operation into divergent branches keeps the
+// host compiler from giving one operation two call sites, which the emulator would match separately)
+__attribute__((convergent)) uint64_t wave_op(int kind, uint64_t val, int arg, int width, const void *site);
+__attribute__((convergent)) void block_barrier();
 void yield();   // s_sleep inside a spin loop: lets the other workgroups run
 unsigned char *dyn_lds();
 void launch(const char *name, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::function<void()> body);
@@ -125,17 +135,17 @@ template <class T> inline T from_bits(uint64_t b) {
 }
 }  // namespace hipemu
 
-#define threadIdx (hipemu::tl->tid)
-#define blockIdx (hipemu::tl->bid)
-#define blockDim (hipemu::tl->bdim)
-#define gridDim (hipemu::tl->gdim)
+#define threadIdx (hipemu::cur()->tid)
+#define blockIdx (hipemu::cur()->bid)
+#define blockDim (hipemu::cur()->bdim)
+#define gridDim (hipemu::cur()->gdim)
 static constexpr int warpSize = 64;
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __noinline__ __attribute__((noinline))
+#define __noinline__ __attribute__((noinline, convergent))
 #define __launch_bounds__(...)
 #define __shared__ static thread_local   // one OS thread runs one workgroup at a time: its statics are the group's LDS
 #define __constant__
@@ -162,54 +172,54 @@ static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, 
 static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
 
 // ------------------------------------------------------------------ barriers, fences
-static inline void __syncthreads() { hipemu::block_barrier(); }
+__attribute__((convergent)) static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) hipemu::yield()
-__attribute__((noinline)) static void hipemu_wave_barrier() { (void)hipemu::wave_op(hipemu::OP_WAVE_BARRIER, 0, 0, 64, __builtin_return_address(0)); }
+__attribute__((noinline, convergent)) static void hipemu_wave_barrier() { (void)hipemu::wave_op(hipemu::OP_WAVE_BARRIER, 0, 0, 64, __builtin_return_address(0)); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 
 // ------------------------------------------------------------------ cross-lane operations (wave64)
 // `site` tells apart two operations that lanes of one wave wait in at the same time (divergent code): the emulator lets
 // the group at the lower code address go first -- an if-body or a loop body before the code behind it.
-template <class T> __attribute__((noinline)) T __shfl(T v, int src, int width = 64) {
+template <class T> __attribute__((noinline, convergent)) T __shfl(T v, int src, int width = 64) {
     return hipemu::from_bits<T>(hipemu::wave_op(hipemu::OP_SHFL, hipemu::to_bits(v), src, width, __builtin_return_address(0)));
 }
-template <class T> __attribute__((noinline)) T __shfl_up(T v, unsigned delta, int width = 64) {
+template <class T> __attribute__((noinline, convergent)) T __shfl_up(T v, unsigned delta, int width = 64) {
     return hipemu::from_bits<T>(hipemu::wave_op(hipemu::OP_SHFL_UP, hipemu::to_bits(v), (int)delta, width, __builtin_return_address(0)));
 }
-template <class T> __attribute__((noinline)) T __shfl_down(T v, unsigned delta, int width = 64) {
+template <class T> __attribute__((noinline, convergent)) T __shfl_down(T v, unsigned delta, int width = 64) {
     return hipemu::from_bits<T>(hipemu::wave_op(hipemu::OP_SHFL_DOWN, hipemu::to_bits(v), (int)delta, width, __builtin_return_address(0)));
 }
-template <class T> __attribute__((noinline)) T __shfl_xor(T v, int mask, int width = 64) {
+template <class T> __attribute__((noinline, convergent)) T __shfl_xor(T v, int mask, int width = 64) {
     return hipemu::from_bits<T>(hipemu::wave_op(hipemu::OP_SHFL_XOR, hipemu::to_bits(v), mask, width, __builtin_return_address(0)));
 }
-__attribute__((noinline)) static unsigned long long __ballot(int pred) {
+__attribute__((noinline, convergent)) static unsigned long long __ballot(int pred) {
     return hipemu::wave_op(hipemu::OP_BALLOT, pred != 0, 0, 64, __builtin_return_address(0));
 }
-__attribute__((noinline)) static unsigned long long hipemu_ballot_w64(bool pred) {
+__attribute__((noinline, convergent)) static unsigned long long hipemu_ballot_w64(bool pred) {
     return hipemu::wave_op(hipemu::OP_BALLOT, pred, 0, 64, __builtin_return_address(0));
 }
-__attribute__((noinline)) static int __any(int pred) { return hipemu::wave_op(hipemu::OP_BALLOT, pred != 0, 0, 64, __builtin_return_address(0)) != 0; }
-__attribute__((noinline)) static int __all(int pred) { return hipemu::wave_op(hipemu::OP_BALLOT, pred == 0, 0, 64, __builtin_return_address(0)) == 0; }
-__attribute__((noinline)) static uint32_t hipemu_readfirstlane(uint32_t v) {
+__attribute__((noinline, convergent)) static int __any(int pred) { return hipemu::wave_op(hipemu::OP_BALLOT, pred != 0, 0, 64, __builtin_return_address(0)) != 0; }
+__attribute__((noinline, convergent)) static int __all(int pred) { return hipemu::wave_op(hipemu::OP_BALLOT, pred == 0, 0, 64, __builtin_return_address(0)) == 0; }
+__attribute__((noinline, convergent)) static uint32_t hipemu_readfirstlane(uint32_t v) {
     return (uint32_t)hipemu::wave_op(hipemu::OP_FIRST, v, 0, 64, __builtin_return_address(0));
 }
 #define __builtin_amdgcn_ballot_w64(p) hipemu_ballot_w64(p)
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
 static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {
-    const uint32_t l = hipemu::tl->lane;
+    const uint32_t l = hipemu::cur()->lane;
     return base + (uint32_t)__builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u)));
 }
 static inline uint32_t hipemu_mbcnt_hi(uint32_t mask, uint32_t base) {
-    const uint32_t l = hipemu::tl->lane;
+    const uint32_t l = hipemu::cur()->lane;
     return base + (uint32_t)__builtin_popcount(mask & (l <= 32 ? 0u : ((1u << (l - 32)) - 1u)));
 }
 #define __builtin_amdgcn_mbcnt_lo(m, b) hipemu_mbcnt_lo((m), (b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) hipemu_mbcnt_hi((m), (b))
-static inline uint32_t __lane_id() { return hipemu::tl->lane; }
+static inline uint32_t __lane_id() { return hipemu::cur()->lane; }
 
 // ------------------------------------------------------------------ gfx950 integer builtins the kernels name directly
 static inline uint32_t hipemu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {   // v_alignbit_b32: ({hi, lo} >> sh[4:0])[31:0]

@@ -272,7 +272,7 @@ def test_join_fused_form_equals_exact_form_and_survives_an_outgrown_capacity(ctx
     hashes, lens = random_sketches(rng, n, s, shared_groups=120, min_len=600)
     sk = ctx.sketches_from_host(hashes, lens, 21)
     want = oracle.distances_from_sketches(hashes, lens, np.float32(0.9), threads=32)
-    assert len(want) > 1000
+    assert len(want) > 500
     ctx.profile(True)
     for fused in (0, 1):
         opts(join_fused=fused)
@@ -889,11 +889,11 @@ def test_ingest_forms_agree(ctx, tmp_path, opts):
     # the resident streams are the same whichever way they travelled (IUPAC codes, gaps, the 'N' after a record).  The
     # resident form keeps 2-bit codes + "is it A/C/G/T" per position, so every other stream byte -- 'N', needletail's
     # '-' for gaps -- reads back as 'N'
-    assert streams["pipelined"] == streams["ascii"] == streams["two-phase"]
-    assert b"-" not in streams["pipelined"][0] and streams["pipelined"][0].count(b"N") > 100
+    assert streams["packed"] == streams["ascii"] == streams["two-phase"]
+    assert b"-" not in streams["packed"][0] and streams["packed"][0].count(b"N") > 100
     for i, p in enumerate(paths):   # ... and the host parser's (ghip_fasta_stream, no GPU involved)
         host = galah_amd.fasta_stream(p)[0].tobytes()
-        assert (b"-" in host) == (i < 5) and streams["pipelined"][i] == host.replace(b"-", b"N"), p
+        assert (b"-" in host) == (i < 5) and streams["packed"][i] == host.replace(b"-", b"N"), p
     with pytest.raises(galah_amd.GalahHipError):
         ctx.genomes_from_files([str(tmp_path / "missing.fna")], 1)
     bad = tmp_path / "notfasta.fna"
