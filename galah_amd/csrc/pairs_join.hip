@@ -287,9 +287,11 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_write_kernel(const uint32
     // 32-bit offsets: the host bounds the inputs (n*s < 2^32 elements, < 2^31 records from a 64-bit total)
 }
 
+constexpr uint32_t J_BARRIER_POLLS = 1u << 18;   // polls of the grid barrier before a waiter gives up (an agent-scope load + s_sleep 2: ~1 us each)
+
 // The same scan in ONE launch (fused form): per-tile sums, a grid barrier, the write.  The grid is n_tiles <= 256 blocks of
 // 256 threads with no dynamic LDS -- a fraction of what the chip holds at once, so every block is (or becomes, as soon as a
-// co-running kernel's blocks retire) resident and the barrier cannot starve; the tile sums cross the XCDs through
+// co-running kernel's blocks retire) resident and the barrier is not expected to starve (and gives up if it does: J_BARRIER_POLLS); the tile sums cross the XCDs through
 // agent-scope atomics.  `arrive` is zeroed by the caller (one word per scan of a join call).  hist_b (nullable): a second
 // counter array that is only summed; totals (nullable) = {sum of hist_b, sum of hist} as 64-bit numbers -- what
 // join_totals_kernel delivered in a launch of its own.  The counters are read ONCE (they wait in registers across the barrier).
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_fused_kernel(const uint32
                                                                     uint32_t *__restrict__ tile_sum, uint32_t *__restrict__ tile_max,
                                                                     unsigned long long *__restrict__ tile_sum_b, uint32_t *__restrict__ arrive,
                                                                     uint32_t n_tiles, uint32_t *__restrict__ start, uint32_t *__restrict__ max_out,
-                                                                    unsigned long long *__restrict__ totals) {
+                                                                    unsigned long long *__restrict__ totals, uint32_t *__restrict__ flags) {
     __shared__ uint32_t ws[J_WAVES], wm[J_WAVES], ts[256], tm[256];
     __shared__ unsigned long long wb[J_WAVES];
     const size_t base = (size_t)blockIdx.x * J_SCAN_TILE + threadIdx.x * J_SCAN_PER;
@@ -332,7 +334,15 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_fused_kernel(const uint32
         __hip_atomic_store(&tile_max[blockIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&tile_sum_b[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the three stores above are ordered before it
-        while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_tiles) __builtin_amdgcn_s_sleep(2);
+        // A BOUNDED wait: should a block of this grid not become resident while the others spin -- a co-running
+        // kernel that holds the chip for longer than any of this library's does -- the waiters give up after ~0.3 s of polls,
+        // raise flags bit 3 (what an outgrown capacity raises: the host discards this form's output and repeats the join in
+        // the exact form) and run on with whatever sums there are; the late blocks find `arrive` complete and leave too.
+        uint32_t polls = 0;
+        while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_tiles) {
+            if (++polls > J_BARRIER_POLLS) { atomicOr(flags, 8u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
     }
     __syncthreads();
     ts[threadIdx.x] = threadIdx.x < n_tiles ? __hip_atomic_load(&tile_sum[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -744,7 +754,7 @@ int scan_counters_fused(ghip_ctx *ctx, std::vector<void *> &owned, JoinFused &jf
     uint32_t *d_tile = jalloc<uint32_t>(ctx, owned, 512 + 2 * 256);   // tile sums | tile maxima | 64-bit sums of the second array
     if (!d_tile) return GHIP_EHIP;
     hipLaunchKernelGGL(join_scan_fused_kernel, dim3(n_tiles), dim3(J_THREADS), 0, ctx->stream, d_hist, d_hist_b, d_tile, d_tile + 256,
-                       reinterpret_cast<unsigned long long *>(d_tile + 512), jf.d_arrive + jf.n_arrive, n_tiles, d_start, d_max, d_totals);
+                       reinterpret_cast<unsigned long long *>(d_tile + 512), jf.d_arrive + jf.n_arrive, n_tiles, d_start, d_max, d_totals, jf.d_flags);
     jf.n_arrive++;
     return GHIP_OK;
 }

@@ -44,6 +44,14 @@ for f in ('bench','bench1k'):
 PY
   done | tee $O/forms.txt
 fi
+if has anibin; then
+  # ani_bin alone against next to the pair stage (the claim needs a kept file), 10 000 and 50 000 genomes
+  run() { timeout 600 python bench.py --species $2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$1 genomes=%d' % d['config']['genomes'], round(d['ms_per_step'],1), {k:round(v,2) for k,v in d['stage_ms_per_step'].items()}, {k:round(v['avg_ms'],2) for k,v in d['kernels'].items()})"; }
+  { for SP in 1000 5000; do run overlapped $SP; GHIP_NO_OVERLAP=1 run alone $SP; run overlapped_again $SP; GHIP_NO_OVERLAP=1 run alone_again $SP; done; } | tee $O/r05_ani_bin_alone_vs_overlapped.txt
+fi
 if has prof; then
   cd /tmp
   for J in ${PROF_FORMS:-0 1}; do

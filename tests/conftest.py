@@ -21,6 +21,22 @@ if EMU:
     _galah_lib.LIB_PATH = EMU_LIB
 
 
+# Foreign device memory in the tests is a torch tensor: on the GPU box a "cuda" one; under emulation device memory IS host memory
+DEV = "cpu" if EMU else "cuda"
+
+
+def dev_select(device: int = 0):
+    if not EMU:
+        import torch
+        torch.cuda.set_device(device)
+
+
+def dev_sync():
+    if not EMU:
+        import torch
+        torch.cuda.synchronize()
+
+
 # tests/emu/cases holds tests that only exist under emulation (the RCCL transport with several ranks in one process)
 collect_ignore_glob = [] if EMU else ["emu/cases/*"]
 

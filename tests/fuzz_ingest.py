@@ -4,8 +4,10 @@ through ghip_genomes_from_files in a randomly chosen form (2-bit packed over PCI
 resident streams must equal the host parser's (ghip_fasta_stream) byte for byte and the statistics the oracle's.
 usage: fuzz_ingest.py [rounds=60] [seed=1]"""
 import gzip, os, sys, tempfile, shutil
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import conftest  # noqa: E402,F401  (the test harness' emulator switch, tests/conftest.py: GALAH_TEST_EMU)
 import galah_amd
 import oracle
 

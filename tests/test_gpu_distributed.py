@@ -14,7 +14,7 @@ import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import fasta, never_run_on_hardware
+from conftest import DEV, dev_select, dev_sync, fasta, never_run_on_hardware
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _worker(rank, world, port, q, n=N, length=LENGTH, options=None, min_ani=0.9,
     from galah_amd.distributed import DereplicationJob
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    dev_select(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = galah_amd.Context(0)
     ctx.set_options(**(options or {}))   # ghip_options, per context: how a rank picks the forms of its stages
@@ -321,12 +321,12 @@ def test_exchange_device_ragged_blocks_over_peer_copies(ctx):
     words = lambda r, d: ((r + 2 * d) % 5) * blk
 
     def run(r):
-        send = torch.cat([torch.arange(words(r, d), dtype=torch.int32, device="cuda") + (r * 16 + d) * 1_000_000 for d in range(world)] +
-                         [torch.zeros(1, dtype=torch.int32, device="cuda")])
+        send = torch.cat([torch.arange(words(r, d), dtype=torch.int32, device=DEV) + (r * 16 + d) * 1_000_000 for d in range(world)] +
+                         [torch.zeros(1, dtype=torch.int32, device=DEV)])
         send_off = np.cumsum([0] + [words(r, d) * 4 for d in range(world)])
         recv_off = np.cumsum([0] + [words(s, r) * 4 for s in range(world)]) + 64   # (not at the start of the buffer)
-        recv = torch.full((int(recv_off[-1]) // 4 + 16,), -1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
+        recv = torch.full((int(recv_off[-1]) // 4 + 16,), -1, dtype=torch.int32, device=DEV)
+        dev_sync()
         comms[r].exchange_device(send.data_ptr(), send_off, recv.data_ptr(), recv_off)
         got = recv.cpu().numpy()
         assert (got[:16] == -1).all() and (got[int(recv_off[-1]) // 4:] == -1).all()
@@ -414,20 +414,20 @@ def _rccl_single_rank(port, q):
     from galah_amd.distributed import Comm, DereplicationJob
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    dev_select(0)
     dist.init_process_group("gloo", rank=0, world_size=1)
     ctx = galah_amd.Context(0)
     comm = Comm.from_torch_rccl(ctx, 0, 1)
     assert comm.transport == "rccl" and comm.world == 1
-    src = torch.arange(4096, dtype=torch.int64, device="cuda") * 3 - 7
+    src = torch.arange(4096, dtype=torch.int64, device=DEV) * 3 - 7
     dst = torch.zeros_like(src)
-    torch.cuda.synchronize()
+    dev_sync()
     comm.allgather_device(src.data_ptr(), dst.data_ptr(), src.numel() * 8)
     ok = bool(torch.equal(src, dst))
     ok = ok and comm.allgather_host(np.float32([1.25, 2.5, 3.75])).tolist() == [[1.25, 2.5, 3.75]]
     # grouped ncclSend / ncclRecv (to itself: all a one-rank communicator can do): 1000 words from word 24 to word 100
     dst.zero_()
-    torch.cuda.synchronize()
+    dev_sync()
     comm.exchange_device(src.data_ptr(), [24 * 8, 1024 * 8], dst.data_ptr(), [100 * 8, 1100 * 8])
     ok = ok and bool(torch.equal(dst[100:1100], src[24:1024])) and int(dst[:100].abs().sum()) == 0 and int(dst[1100:].abs().sum()) == 0
     pairs = np.zeros(3, dtype=galah_amd.PAIR_DTYPE); pairs["i"] = [1, 2, 3]; pairs["j"] = [4, 5, 6]

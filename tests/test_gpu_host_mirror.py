@@ -6,8 +6,11 @@ import subprocess
 
 import pytest
 
+from conftest import EMU
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "galah_amd", "csrc", "build", "test_host_mirror")
+# (under emulation: the same program linked against the emulated build of the library, tests/emu/Makefile)
+EXE = os.path.join(ROOT, "tests", "emu", "build", "test_host_mirror_emu") if EMU else os.path.join(ROOT, "galah_amd", "csrc", "build", "test_host_mirror")
 
 
 def test_host_mirror_header_and_test_program_are_built():

@@ -6,7 +6,7 @@ import pytest
 
 import galah_amd
 import oracle
-from conftest import fasta, random_sketches, never_run_on_hardware
+from conftest import DEV, fasta, random_sketches, never_run_on_hardware
 
 pytestmark = pytest.mark.gpu
 
@@ -603,8 +603,8 @@ def test_every_seed_of_dirty_streams(ctx, c):
     for idx in (ctx.ani_index_build(g, 15, c, 5000), ctx.sketch_and_index(g, 21, 1000, 0, 15, c, 5000)[1]):
         lay = idx.layout()
         glen, cap, cnt = idx.meta()
-        code = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device="cuda")
-        loc = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device="cuda")
+        code = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device=DEV)
+        loc = torch.empty(int(lay.n_seed_slots), dtype=torch.int32, device=DEV)
         ctx.memcpy_d2d(code.data_ptr(), lay.d_seed_code, code.numel() * 4)
         ctx.memcpy_d2d(loc.data_ptr(), lay.d_seed_loc, loc.numel() * 4)
         ctx.synchronize()
