@@ -230,20 +230,33 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         for (int i = 3; i <= 8; i++) top[-i] = 0;
         w->sp[t] = top - 8;
     }
+    // HIPEMU_ORDER: the order waves of a workgroup (and lanes of a wave) take their turns in between two meeting points --
+    // "forward" (default), "reverse", or a seed for a fresh random order at every turn.  Any order is a schedule the hardware
+    // may produce; a result that changes with it is a missing barrier (or a reliance on wave lockstep without wave_barrier).
+    static const int order_mode = [] { const char *v = getenv("HIPEMU_ORDER"); return !v || !*v || !strcmp(v, "forward") ? 0 : !strcmp(v, "reverse") ? 1 : 2; }();
+    static const uint64_t order_seed = [] { const char *v = getenv("HIPEMU_ORDER"); return v ? strtoull(v, nullptr, 10) : 0ull; }();
+    uint64_t rng = order_seed * 0x9E3779B97F4A7C15ull + b * 0xD1B54A32D192ED03ull + 1;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    std::vector<uint32_t> wave_turn(nw), lane_turn(64);
     for (;;) {
-        for (uint32_t wv = 0; wv < nw; wv++) {
-            const uint32_t lo = wv * 64, hi = std::min(n, lo + 64);
+        for (uint32_t x = 0; x < nw; x++) wave_turn[x] = order_mode == 1 ? nw - 1 - x : x;
+        if (order_mode == 2) for (uint32_t x = nw; x > 1; x--) std::swap(wave_turn[x - 1], wave_turn[next() % x]);
+        for (uint32_t wx = 0; wx < nw; wx++) {
+            const uint32_t wv = wave_turn[wx];
+            const uint32_t lo = wv * 64, hi = std::min(n, lo + 64), nl = hi - lo;
             for (;;) {
-                bool ran = false;
-                for (uint32_t t = lo; t < hi; t++)
-                    if (w->st[t] == READY) { run_fiber(w, t); ran = true; }
+                for (uint32_t x = 0; x < nl; x++) lane_turn[x] = order_mode == 1 ? nl - 1 - x : x;
+                if (order_mode == 2) for (uint32_t x = nl; x > 1; x--) std::swap(lane_turn[x - 1], lane_turn[next() % x]);
+                for (uint32_t x = 0; x < nl; x++) {
+                    const uint32_t t = lo + lane_turn[x];
+                    if (w->st[t] == READY) run_fiber(w, t);
+                }
+                // every lane has run until it blocked: those that wait in a cross-lane operation exchange and run on; when none
+                // does, the wave stands at a block barrier, sleeps in a spin loop, or is done
                 bool waiting = false;
                 for (uint32_t t = lo; t < hi && !waiting; t++) waiting = w->st[t] == WAVE_WAIT;
-                if (waiting) { resolve_wave(w, L, lo, hi); continue; }
-                if (!ran) break;
-                bool ready = false;
-                for (uint32_t t = lo; t < hi && !ready; t++) ready = w->st[t] == READY;
-                if (!ready) break;
+                if (!waiting) break;
+                resolve_wave(w, L, lo, hi);
             }
         }
         uint32_t n_done = 0, n_bar = 0, n_yield = 0;
