@@ -44,6 +44,7 @@ SIGNATURES = {
     "ghip_profile_enable": (_int, [_vp, _int]),
     "ghip_profile_reset": (_int, [_vp]),
     "ghip_kernel_stats": (_int, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "ghip_ingest_counters": (_int, [_vp, C.POINTER(_u64)]),
     "ghip_selftest_hash_floor": (_int, [_vp, _u64, C.POINTER(C.c_double)]),
     "ghip_genomes_from_files": (_int, [_vp, C.POINTER(C.c_char_p), _sz, _int, _pp]),
     "ghip_genomes_from_host": (_int, [_vp, _vp, _vp, _sz, _pp]),
@@ -140,7 +141,7 @@ class ClusterTimes(C.Structure):
 OPTION_FIELDS = ("struct_size", "pair_form", "join_ranks", "ingest_form", "ingest_groups", "io_threads_plain", "io_threads_gz", "copy_streams",
                  "use_libdeflate", "pipeline_pieces", "overlap_binning", "lazy_flush_below", "cluster_threads", "ani_force_general",
                  "ani_tall_below", "debug", "pair_debug", "fault_stage", "fault_rank", "join_fused", "probe_arranged",
-                 "comm_timeout_ms")
+                 "comm_timeout_ms", "gz_device")
 PAIR_FORMS = {"auto": 0, "join": 1, "probe": 2, "merge": 3}
 JOIN_RANKS = {"hash": 0, "records": 1, "replicate": 2}
 INGEST_FORMS = {"packed": 0, "ascii": 1, "pageable": 2, "two-phase": 3}

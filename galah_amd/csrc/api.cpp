@@ -99,6 +99,9 @@ void ghip_ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     ctx->io.shutdown();
     for (auto &b : ctx->pool) hipFree(b.p);
     for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+    for (auto &sl : ctx->gz_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+    for (uint8_t *p : ctx->gz_results) if (p) hipHostFree(p);
+    for (hipEvent_t e : ctx->gz_ev) if (e) hipEventDestroy(e);
     if (ctx->pin_buf) hipHostFree(ctx->pin_buf);
     if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
     for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
@@ -185,6 +188,7 @@ ghip_options options_from_environment() {
     o.pair_debug = num("GHIP_PAIR_DEBUG", 0);
     o.probe_arranged = num("GHIP_PROBE_ARRANGED", 0);   // (likewise off until measured)
     o.comm_timeout_ms = num("GHIP_COMM_TIMEOUT_MS", 60000);
+    o.gz_device = num("GHIP_GZ_DEVICE", 0);   // (likewise)
     o.join_fused = num("GHIP_JOIN_FUSED", 0);   // (off until a GPU run has shown it byte-identical and faster: profiles/r04*)
     return o;
 }
@@ -323,6 +327,15 @@ extern "C" int ghip_kernel_stats(ghip_ctx *ctx, const char *kernel, uint64_t *la
     auto it = ctx->stats.find(kernel);
     if (launches) *launches = it == ctx->stats.end() ? 0 : it->second.launches;
     if (total_ms) *total_ms = it == ctx->stats.end() ? 0.0 : it->second.total_ms;
+    return GHIP_OK;
+}
+
+extern "C" int ghip_ingest_counters(ghip_ctx *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return GHIP_EINVAL;
+    out[0] = ctx->gz_device_files.load();
+    out[1] = ctx->gz_host_files.load();
+    out[2] = ctx->gz_device_us.load();
+    out[3] = 0;
     return GHIP_OK;
 }
 

@@ -279,6 +279,16 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
             { std::lock_guard<std::mutex> l(smu); sl->state = state; sl->seq = ++slot_seq; }
             scv.notify_one();
         };
+        // The device-side gzip path first (ingest_gz.cpp; ghip_options.gz_device): files named *.gz go to the device
+        // compressed and are inflated, checked, parsed and packed there; gz_done marks the ones it ingested, the workers
+        // below take the rest -- plain files, and whatever that path declined.
+        std::vector<uint8_t> gz_done(n, 0);
+        if (opt.gz_device && n_gz >= opt.gz_device) {
+            std::vector<size_t> cand;
+            for (size_t i = 0; i < n; i++) { const size_t l = strlen(paths[i]); if (l > 3 && !strcmp(paths[i] + l - 3, ".gz")) cand.push_back(i); }
+            const int grc = ghip_ingest_gz_device(ctx, g, paths, cap, cand, threads, gz_done);
+            if (grc != GHIP_OK) { free_genomes_locked(g); return grc; }
+        }
         // work units: a file, or a run of consecutive SMALL files shipped as one group (packed form only)
         std::vector<std::pair<size_t, size_t>> units;
         {
@@ -286,10 +296,11 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
             constexpr size_t GROUP_FILES = 512;
             const bool grouping = packed_mode && n_slots && opt.ingest_groups;
             for (size_t i = 0; i < n;) {
+                if (gz_done[i]) { i++; continue; }
                 size_t j = i + 1;
                 if (grouping && cap[i] <= SMALL_FILE) {
                     uint64_t bases = next_genome_offset(0, cap[i]);
-                    while (j < n && j - i < GROUP_FILES && cap[j] <= SMALL_FILE && bases + next_genome_offset(0, cap[j]) <= std::min<uint64_t>(GROUP_BASES, slot_bytes)) {
+                    while (j < n && !gz_done[j] && j - i < GROUP_FILES && cap[j] <= SMALL_FILE && bases + next_genome_offset(0, cap[j]) <= std::min<uint64_t>(GROUP_BASES, slot_bytes)) {
                         bases += next_genome_offset(0, cap[j]);
                         j++;
                     }

@@ -101,6 +101,14 @@ struct ghip_ctx {
     std::mutex ingest_mu;  // one file ingest at a time per context (it runs with `mu` released, next to kernels of other calls)
     hipStream_t copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_copy_streams = 0;   // streams in use (GHIP_COPY_STREAMS, default 2)
+    // device-side gzip path (ingest_gz.cpp): pinned staging of the compressed images (two slots per reader thread) and of
+    // the results of the two batches in flight, kept for the life of the context; counters for ghip_ingest_counters
+    struct gz_slot { uint8_t *p = nullptr; hipEvent_t ev = nullptr; bool inflight = false; };
+    std::vector<gz_slot> gz_slots;
+    uint8_t *gz_results[2] = {nullptr, nullptr};
+    size_t gz_results_bytes[2] = {0, 0};
+    hipEvent_t gz_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per batch in flight: kernels begin, end, results landed
+    std::atomic<uint64_t> gz_device_files{0}, gz_host_files{0}, gz_device_us{0};
     std::atomic<int> live_handles{0};   // genomes / sketches / ani indexes still alive
     bool destroyed = false; // ghip_destroy called; the struct is deleted with the last handle
 };
@@ -220,6 +228,18 @@ void ghip_prof_begin(ghip_ctx *ctx, const char *name);
 void ghip_prof_end(ghip_ctx *ctx);
 
 // ---- launchers (defined in the .hip files) ----
+// gz_inflate.hip: the device path of gzip input, one batch (struct ghip_gz_job: gz_common.h)
+struct ghip_gz_job;
+size_t ghip_gz_chunks_of(uint64_t text_cap);   // chunk summaries the FASTA pass needs for a text of that many bytes
+size_t ghip_gz_chunk_bytes();
+void ghip_launch_gz_batch(hipStream_t stream, const uint8_t *d_in, uint8_t *d_text, uint8_t *d_stream, ghip_gz_job *d_jobs, uint32_t n_jobs,
+                          uint64_t max_text_cap, const uint32_t *d_chunk_start, void *d_chunks, uint32_t *d_rec_next, uint32_t *d_rec_pool,
+                          uint32_t rec_room, uint32_t *d_packed, uint32_t *d_valid, uint64_t max_stream_cap);
+// ingest_gz.cpp: the .gz files among paths[cand[..]] inflated, parsed and packed on the device into g (whose layout and
+// resident arrays exist); done[i] = 1 for every file it ingested -- the others are the host path's.  Returns GHIP_OK unless
+// the device failed (not: a file it declined).
+int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *paths, const std::vector<uint64_t> &cap, const std::vector<size_t> &cand,
+                          int io_threads, std::vector<uint8_t> &done);
 void ghip_launch_synth(ghip_ctx *ctx, uint32_t *d_packed, uint32_t *d_valid, const uint64_t *d_starts, uint64_t length,
                        uint32_t first, uint32_t count, uint32_t members, uint64_t seed, uint32_t sub_thr);
 

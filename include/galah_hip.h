@@ -107,9 +107,18 @@ typedef struct ghip_options {
                                    (GHIP_PROBE_ARRANGED) */
     uint32_t comm_timeout_ms;   /* RCCL transport: how long a rank waits inside one collective for its peers before it aborts the
                                    communicator and returns GHIP_EPEER, default 60 000; 0: for ever   (GHIP_COMM_TIMEOUT_MS) */
+    uint32_t gz_device;         /* N > 0: a call that ingests at least N files named *.gz inflates, checks (CRC-32, ISIZE), parses and
+                                   packs them ON THE DEVICE, one wavefront per file (gz_inflate.hip); a file that path does not take
+                                   (further members, FHCRC, a damaged stream, ...) goes through the host's inflate as before, which
+                                   alone words the errors.  0 (default until a GPU run has timed it): host inflate   (GHIP_GZ_DEVICE) */
 } ghip_options;
 int ghip_get_options(const ghip_ctx *ctx /* NULL: the process-wide defaults */, ghip_options *out);
 int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const ghip_options *opt);
+
+/* What the file ingest of this context has done so far: out[0] = gzip files inflated on the device, out[1] = gzip files
+ * offered to the device path that went through the host's inflate instead, out[2] = microseconds of device time of the
+ * device path's launches (HIP events), out[3] = 0. */
+int ghip_ingest_counters(ghip_ctx *ctx, uint64_t out[4]);
 
 /* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:
  * "sketch_kmers", "sketch_select", "pair_table_build", "pair_intersect_tile", "ani_seeds", "ani_bin",

@@ -19,7 +19,7 @@ REF_PREFIX = ("src/", "tests/test_cmdline.rs", "tests/data/", "Cargo.toml", "pix
 TOKEN = re.compile(r"`([^`\s]+)`")
 # files that exist only after a run / a build, or are named as patterns of such
 GENERATED = ("gpurun_out/", "oracle/_ref", "galah_amd/libgalah_hip.so", "galah_amd/csrc/build/", "tests/emu/build/", "tests/emu/libgalah_hip_emu.so",
-             "tests/emu/fake_rccl/librccl.so.1", "oracle/libgalah_oracle.so")
+             "tests/emu/fake_rccl/librccl.so.1", "oracle/libgalah_oracle.so", "scripts/ubench/hash_variants", "scripts/ubench/int_ops", "scripts/ubench/host_costs")
 
 
 def line_count(path, cache={}):

@@ -17,6 +17,12 @@ if has fuzz; then
   for f in "fuzz_pairs.py 60 7" "fuzz_ani.py 80 7" "fuzz_sketch.py 30 7" "fuzz_ingest.py 40 7"; do timeout 600 python tests/$f 2>&1 | tail -1; done | tee $O/fuzz_default.txt
   GHIP_JOIN_FUSED=1 GHIP_PROBE_ARRANGED=1 timeout 600 python tests/fuzz_pairs.py 60 9 2>&1 | tail -1 | tee $O/fuzz_pairs_round4_forms.txt
 fi
+if has gz; then
+  # the device-side gzip path: its own tests and fuzzers, then 1 000 and 4 000 x 5 Mb gzip files host-inflated against device-inflated
+  timeout 1200 python -m pytest tests/test_gpu_gz_device.py -m gpu -q -rfEsxX 2>&1 | tail -5 | tee $O/gz_tests.txt
+  for f in "fuzz_gz.py 60 7" "fuzz_ingest.py 60 9"; do timeout 900 python tests/$f 2>&1 | tail -1; done | tee $O/gz_fuzz.txt
+  timeout 1500 python scripts/gz_device_bench.py 2>&1 | tee $O/r05_gz_device_vs_host.txt
+fi
 if has bench; then
   (time timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err) 2>&1 | grep real
   tail -5 $O/bench.err

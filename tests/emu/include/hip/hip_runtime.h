@@ -207,6 +207,10 @@ __attribute__((noinline, convergent)) static int __all(int pred) { return hipemu
 __attribute__((noinline, convergent)) static uint32_t hipemu_readfirstlane(uint32_t v) {
     return (uint32_t)hipemu::wave_op(hipemu::OP_FIRST, v, 0, 64, __builtin_return_address(0));
 }
+__attribute__((noinline, convergent)) static uint32_t hipemu_readlane(uint32_t v, uint32_t lane) {   // v_readlane_b32: lane is uniform
+    return (uint32_t)hipemu::wave_op(hipemu::OP_SHFL, v, (int)(lane & 63u), 64, __builtin_return_address(0));
+}
+#define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
 #define __builtin_amdgcn_ballot_w64(p) hipemu_ballot_w64(p)
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
 static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {

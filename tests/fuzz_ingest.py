@@ -1,6 +1,7 @@
 """Randomised differential test of the file ingest (needs a GPU): random FASTA files -- record counts and lengths, line
 widths, LF / CRLF, lower case, IUPAC codes, gaps, empty records, no final newline, plain / gzip / multi-member gzip -- go
-through ghip_genomes_from_files in a randomly chosen form (2-bit packed over PCIe, ASCII, pageable, two-phase); the
+through ghip_genomes_from_files in a randomly chosen form (2-bit packed over PCIe, ASCII, pageable, two-phase; gzip inflated on
+the host or on the device); the
 resident streams must equal the host parser's (ghip_fasta_stream) byte for byte and the statistics the oracle's.
 usage: fuzz_ingest.py [rounds=60] [seed=1]"""
 import gzip, os, sys, tempfile, shutil
@@ -50,17 +51,18 @@ for rnd in range(rounds):
             paths.append(path)
         want = [galah_amd.fasta_stream(p) for p in paths]
         form = str(rng.choice(["packed", "packed", "ascii", "pageable", "two-phase"]))
-        ctx.set_options(ingest_form=form)
+        gz_device = int(rng.integers(0, 2))   # 1: the .gz files are inflated, parsed and packed on the device (gz_inflate.hip); what it declines (the multi-member ones) goes the host's way
+        ctx.set_options(ingest_form=form, gz_device=gz_device)
         g = ctx.genomes_from_files(paths, int(rng.integers(1, 9)))
         for i, p in enumerate(paths):
             got = g.to_host(i).tobytes()
             # the resident form keeps "is it A/C/G/T" per position (2-bit codes + validity bits): every other stream byte
             # -- 'N', needletail's '-' for gaps -- reads back as 'N'
-            assert got == want[i][0].tobytes().replace(b"-", b"N"), (rnd, form, p, len(got), len(want[i][0]))
-            assert g.stats(i) == tuple(int(x) for x in want[i][1]) == oracle.genome_stats(p), (rnd, form, p)
+            assert got == want[i][0].tobytes().replace(b"-", b"N"), (rnd, form, gz_device, p, len(got), len(want[i][0]))
+            assert g.stats(i) == tuple(int(x) for x in want[i][1]) == oracle.genome_stats(p), (rnd, form, gz_device, p)
             checked += 1
         g.free()
     finally:
         shutil.rmtree(d, ignore_errors=True)
-ctx.set_options(ingest_form="packed")
-print(f"fuzz ok: {rounds} rounds, {checked} files checked")
+ctx.set_options(ingest_form="packed", gz_device=0)
+print(f"fuzz ok: {rounds} rounds, {checked} files checked, {ctx.ingest_counters()['gz_device_files']} of them inflated on the device")
