@@ -145,7 +145,7 @@ OPTION_FIELDS = ("struct_size", "pair_form", "join_ranks", "ingest_form", "inges
 PAIR_FORMS = {"auto": 0, "join": 1, "probe": 2, "merge": 3}
 JOIN_RANKS = {"hash": 0, "records": 1, "replicate": 2}
 INGEST_FORMS = {"packed": 0, "ascii": 1, "pageable": 2, "two-phase": 3}
-FAULT_STAGES = {"none": 0, "sketch": 1, "pairs_stage1": 2, "pairs_stage2": 3, "index_pack": 4, "ani_round": 5}
+FAULT_STAGES = {"none": 0, "sketch": 1, "pairs_stage1": 2, "pairs_stage2": 3, "index_pack": 4, "ani_round": 5, "gz_small_batches": 6}
 _OPTION_ENUMS = {"pair_form": PAIR_FORMS, "join_ranks": JOIN_RANKS, "ingest_form": INGEST_FORMS, "fault_stage": FAULT_STAGES}
 
 

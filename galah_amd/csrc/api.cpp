@@ -200,7 +200,7 @@ int merge_options(ghip_options &dst, const ghip_options *src) {
     memcpy(&o, src, std::min<size_t>(src->struct_size, sizeof(ghip_options)));
     o.struct_size = sizeof(ghip_options);
     if (o.pair_form > GHIP_PAIR_MERGE || o.join_ranks > GHIP_JOIN_REPLICATE || o.ingest_form > GHIP_INGEST_TWO_PHASE || o.copy_streams < 1 ||
-        o.copy_streams > 4 || o.fault_stage > GHIP_FAULT_ANI_ROUND || o.probe_arranged > 4)
+        o.copy_streams > 4 || o.fault_stage > GHIP_FAULT_GZ_SMALL_BATCHES || o.probe_arranged > 4)
         return GHIP_EINVAL;
     dst = o;
     return GHIP_OK;

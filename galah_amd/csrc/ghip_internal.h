@@ -232,9 +232,9 @@ void ghip_prof_end(ghip_ctx *ctx);
 struct ghip_gz_job;
 size_t ghip_gz_chunks_of(uint64_t text_cap);   // chunk summaries the FASTA pass needs for a text of that many bytes
 size_t ghip_gz_chunk_bytes();
-void ghip_launch_gz_batch(hipStream_t stream, const uint8_t *d_in, uint8_t *d_text, uint8_t *d_stream, ghip_gz_job *d_jobs, uint32_t n_jobs,
-                          uint64_t max_text_cap, const uint32_t *d_chunk_start, void *d_chunks, uint32_t *d_rec_next, uint32_t *d_rec_pool,
-                          uint32_t rec_room, uint32_t *d_packed, uint32_t *d_valid, uint64_t max_stream_cap);
+void ghip_launch_gz_batch(hipStream_t stream, const uint8_t *d_in, uint8_t *d_text, ghip_gz_job *d_jobs, uint32_t n_jobs, uint64_t max_text_cap,
+                          const uint32_t *d_chunk_start, void *d_chunks, uint32_t *d_rec_next, uint32_t *d_rec_pool, uint32_t rec_room, uint32_t *d_packed,
+                          uint32_t *d_valid);
 // ingest_gz.cpp: the .gz files among paths[cand[..]] inflated, parsed and packed on the device into g (whose layout and
 // resident arrays exist); done[i] = 1 for every file it ingested -- the others are the host path's.  Returns GHIP_OK unless
 // the device failed (not: a file it declined).

@@ -28,10 +28,10 @@ enum : uint32_t {
 };
 
 // One gzip file of a batch.  The host fills the first block; gz_inflate_kernel the second; gz_crc_kernel crc_got; the FASTA
-// kernels the rest.  All offsets are into the batch's device areas (input images, text, stream bytes).
+// kernels the rest.  in_off / text_off are offsets into the batch's device areas (input images, texts).
 struct ghip_gz_job {
     uint64_t in_off;        // the compressed image (a multiple of 16)
-    uint64_t text_off;      // where its text goes (a multiple of 16); the stream bytes go to the same offset of the stream area
+    uint64_t text_off;      // where its text goes (a multiple of 64)
     uint64_t gbase;         // base offset of the genome in the resident arrays (a multiple of 64)
     uint32_t in_len;        // bytes of the image
     uint32_t text_cap;      // room for the text = the trailer's ISIZE

@@ -24,8 +24,8 @@
 //
 // Behind the inflate: gz_crc_kernel (CRC-32 of the text by spans, combined in GF(2): gz_common.h), the FASTA pass
 // (fasta_chunk / fasta_scan / fasta_emit: the parse of ghip_parse_fasta as two sweeps around a scan over 16 KiB chunks,
-// yielding the stream bytes, the record table and the assembly statistics of reference src/genome_stats.rs:11-51) and
-// gz_pack_kernel (stream bytes -> the resident 2-bit + validity form).  No host round trip between the six launches.
+// yielding the genome in its resident 2-bit + validity form, the record table and the assembly statistics of reference
+// src/genome_stats.rs:11-51).  No host round trip between the five launches.
 #include <hip/hip_runtime.h>
 
 #include "ghip_internal.h"
@@ -593,8 +593,7 @@ __global__ __launch_bounds__(FA_THREADS) void fasta_chunk_kernel(const uint8_t *
 }
 
 // the scan: one wavefront per file over its chunk summaries; the file's totals, its verdicts, its place in the record pool
-__global__ __launch_bounds__(64) void fasta_scan_kernel(const uint8_t *__restrict__ text_area, uint8_t *__restrict__ stream_area, ghip_gz_job *__restrict__ jobs,
-                                                        const uint32_t *__restrict__ chunk_start, ghip_fa_chunk *__restrict__ chunks, uint32_t *__restrict__ rec_next,
+__global__ __launch_bounds__(64) void fasta_scan_kernel(const uint8_t *__restrict__ text_area, ghip_gz_job *__restrict__ jobs, const uint32_t *__restrict__ chunk_start, ghip_fa_chunk *__restrict__ chunks, uint32_t *__restrict__ rec_next,
                                                         uint32_t rec_room, uint32_t n_jobs) {
     if (blockIdx.x >= n_jobs) return;
     ghip_gz_job *job = jobs + blockIdx.x;
@@ -650,22 +649,24 @@ __global__ __launch_bounds__(64) void fasta_scan_kernel(const uint8_t *__restric
         job->ambiguous = amb;
         job->seq_bytes = seq;
         job->rec_off = rec_off;
-        if (status == GHIP_GZ_OK && headers) stream_area[job->text_off + stream_len - 1] = 'N';   // behind the last record
     }
 }
 
-// sweep 2: the stream bytes and the record table
-__global__ __launch_bounds__(FA_THREADS) void fasta_emit_kernel(const uint8_t *__restrict__ text_area, uint8_t *__restrict__ stream_area,
-                                                                const ghip_gz_job *__restrict__ jobs, const uint32_t *__restrict__ chunk_start,
-                                                                const ghip_fa_chunk *__restrict__ chunks, uint32_t *__restrict__ rec_pool) {
+// sweep 2: the genome in its resident form, and the record table.  A work-item's kept bytes are consecutive stream
+// positions (a header start takes one too: the 'N' behind the record in front of it -- an invalid position like every byte
+// other than A, C, G, T, i.e. no bit to set in arrays that start out zero).  The 2-bit codes and validity bits are gathered
+// word by word in registers and OR-ed into place: neighbours share their first and last words.
+__global__ __launch_bounds__(FA_THREADS) void fasta_emit_kernel(const uint8_t *__restrict__ text_area, const ghip_gz_job *__restrict__ jobs,
+                                                                const uint32_t *__restrict__ chunk_start, const ghip_fa_chunk *__restrict__ chunks,
+                                                                uint32_t *__restrict__ rec_pool, uint32_t *__restrict__ packed, uint32_t *__restrict__ valid_bits) {
     __shared__ unsigned long long kinds[2 * (FA_THREADS / 64)];
     __shared__ unsigned long long wave_sum[FA_THREADS / 64];
     const ghip_gz_job *job = jobs + blockIdx.y;
     const uint32_t n = job->text_len;
     if (job->status != GHIP_GZ_OK || (uint64_t)blockIdx.x * FA_CHUNK >= n) return;
     const uint8_t *text = text_area + job->text_off;
-    uint8_t *stream = stream_area + job->text_off;
     uint32_t *rec = rec_pool + job->rec_off;
+    uint32_t *pk = packed + job->gbase / 16, *vd = valid_bits + job->gbase / 32;   // (gbase is a multiple of 64)
     const ghip_fa_chunk ch = chunks[chunk_start[blockIdx.y] + blockIdx.x];
     const uint32_t from = blockIdx.x * FA_CHUNK + threadIdx.x * FA_SPAN, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t w[16] = {};
@@ -696,78 +697,55 @@ __global__ __launch_bounds__(FA_THREADS) void fasta_emit_kernel(const uint8_t *_
     uint32_t kept = ch.kept_before + (uint32_t)(before & 0xfffffu), headers = ch.headers_before + (uint32_t)((before >> 20) & 0xfffffu),
              seq = ch.seq_before + (uint32_t)(before >> 40);
     bool at_start = starts_line, header = in == 1;
+    uint32_t word_p = 0xffffffffu, word_v = 0xffffffffu, acc_p = 0, acc_v = 0;   // the packed / validity word being gathered
 #pragma unroll
     for (uint32_t i = 0; i < FA_SPAN; i++) {   // (unrolled and predicated: w[] stays in registers)
         const uint32_t c = (w[i / 4] >> (8 * (i % 4))) & 0xffu;
         const bool in = i < valid;
         if (in && at_start) {
             header = c == '>';
-            if (header) {
-                if (headers) stream[kept + headers - 1] = 'N';   // behind the record in front of this one
-                rec[headers] = seq;
-                headers++;
-            }
+            if (header) { rec[headers] = seq; headers++; }   // (from the second header on this also passes over the 'N' behind the record in front)
         }
         if (in && !header) {
             if (!fa_space(c)) {
-                const uint32_t u = c & 0xdfu;
-                stream[kept + headers - 1] = (u == 'A' || u == 'C' || u == 'G') ? (uint8_t)u : (u == 'T' || u == 'U') ? (uint8_t)'T' : (uint8_t)'N';
+                const uint32_t u = c & 0xdfu, at = kept + headers - 1;   // stream position (a kept byte has a header in front of it)
+                const bool t = u == 'T' || u == 'U';
+                if (u == 'A' || u == 'C' || u == 'G' || t) {
+                    if ((at >> 4) != word_p) { if (acc_p) atomicOr(&pk[word_p], acc_p); acc_p = 0; word_p = at >> 4; }
+                    if ((at >> 5) != word_v) { if (acc_v) atomicOr(&vd[word_v], acc_v); acc_v = 0; word_v = at >> 5; }
+                    acc_p |= (t ? 3u : ((u >> 1) ^ (u >> 2)) & 3u) << (2 * (at & 15u));   // A0 C1 G2 T3
+                    acc_v |= 1u << (at & 31u);
+                }
                 kept++;
             }
             seq += (c != '\n' && c != '\r') ? 1u : 0u;
         }
         at_start = in && c == '\n';
     }
-}
-
-// the stream bytes into the resident form (sketch.hip: pack_bases_kernel, for a batch and guarded by the jobs' verdicts)
-__global__ __launch_bounds__(256) void gz_pack_kernel(const uint8_t *__restrict__ stream_area, const ghip_gz_job *__restrict__ jobs, uint32_t *__restrict__ packed,
-                                                      uint32_t *__restrict__ valid) {
-    const ghip_gz_job *job = jobs + blockIdx.y;
-    if (job->status != GHIP_GZ_OK) return;
-    const uint32_t n = job->stream_len;
-    const uint8_t *src = stream_area + job->text_off;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; 32 * t < n; t += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t out[2] = {0, 0}, ok = 0;
-        const uint64_t b0 = 32 * t;
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(src + b0), v1 = *reinterpret_cast<const uint4 *>(src + b0 + 16);   // (padded area)
-        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const uint32_t c = b0 + j < n ? (w[j / 4] >> (8 * (j % 4))) & 0xffu : 0u;
-            const bool good = c == 'A' || c == 'C' || c == 'G' || c == 'T';
-            out[j >> 4] |= (good ? (((c >> 1) ^ (c >> 2)) & 3u) : 0u) << (2 * (j & 15));
-            ok |= (good ? 1u : 0u) << j;
-        }
-        const uint64_t at = job->gbase + b0;
-        packed[at >> 4] = out[0];
-        packed[(at >> 4) + 1] = out[1];
-        valid[at >> 5] = ok;
-    }
+    if (acc_p) atomicOr(&pk[word_p], acc_p);
+    if (acc_v) atomicOr(&vd[word_v], acc_v);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
 size_t ghip_gz_chunks_of(uint64_t text_cap) { return (size_t)((text_cap + FA_CHUNK - 1) / FA_CHUNK); }
 size_t ghip_gz_chunk_bytes() { return sizeof(ghip_fa_chunk); }
 
-// the whole device path of one batch on `stream`: inflate, CRC, FASTA pass, pack.  max_text_cap = the largest text_cap of
-// the batch; d_chunk_start[j] = first chunk summary of job j; d_rec_next = one zeroed word; rec_room = entries of d_rec_pool.
-void ghip_launch_gz_batch(hipStream_t stream, const uint8_t *d_in, uint8_t *d_text, uint8_t *d_stream, ghip_gz_job *d_jobs, uint32_t n_jobs,
-                          uint64_t max_text_cap, const uint32_t *d_chunk_start, void *d_chunks, uint32_t *d_rec_next, uint32_t *d_rec_pool,
-                          uint32_t rec_room, uint32_t *d_packed, uint32_t *d_valid, uint64_t max_stream_cap) {
+// the whole device path of one batch on `stream`: inflate, CRC, FASTA pass straight into the resident arrays (which are
+// zero where these genomes go).  max_text_cap = the largest text_cap of the batch; d_chunk_start[j] = first chunk summary of
+// job j; d_rec_next = one zeroed word; rec_room = entries of d_rec_pool.
+void ghip_launch_gz_batch(hipStream_t stream, const uint8_t *d_in, uint8_t *d_text, ghip_gz_job *d_jobs, uint32_t n_jobs, uint64_t max_text_cap,
+                          const uint32_t *d_chunk_start, void *d_chunks, uint32_t *d_rec_next, uint32_t *d_rec_pool, uint32_t rec_room, uint32_t *d_packed,
+                          uint32_t *d_valid) {
     if (n_jobs == 0) return;
     ghip_fa_chunk *chunks = reinterpret_cast<ghip_fa_chunk *>(d_chunks);
     hipLaunchKernelGGL(gz_inflate_kernel, dim3(n_jobs), dim3(64), 0, stream, d_in, d_text, d_jobs, n_jobs);
+    const unsigned n_chunks = (unsigned)ghip_gz_chunks_of(max_text_cap);
     if (max_text_cap) {
         const unsigned crc_blocks = (unsigned)((max_text_cap + (uint64_t)CRC_THREADS * CRC_SPAN - 1) / ((uint64_t)CRC_THREADS * CRC_SPAN));
         hipLaunchKernelGGL(gz_crc_kernel, dim3(crc_blocks, n_jobs), dim3(CRC_THREADS), 0, stream, d_text, d_jobs);
-        hipLaunchKernelGGL(fasta_chunk_kernel, dim3((unsigned)ghip_gz_chunks_of(max_text_cap), n_jobs), dim3(FA_THREADS), 0, stream, d_text, d_jobs, d_chunk_start, chunks);
+        hipLaunchKernelGGL(fasta_chunk_kernel, dim3(n_chunks, n_jobs), dim3(FA_THREADS), 0, stream, d_text, d_jobs, d_chunk_start, chunks);
     }
-    hipLaunchKernelGGL(fasta_scan_kernel, dim3(n_jobs), dim3(64), 0, stream, d_text, d_stream, d_jobs, d_chunk_start, chunks, d_rec_next, rec_room, n_jobs);
-    if (max_text_cap) {
-        hipLaunchKernelGGL(fasta_emit_kernel, dim3((unsigned)ghip_gz_chunks_of(max_text_cap), n_jobs), dim3(FA_THREADS), 0, stream, d_text, d_stream, d_jobs, d_chunk_start,
-                           chunks, d_rec_pool);
-        const uint64_t words = (max_stream_cap + 31) / 32;
-        hipLaunchKernelGGL(gz_pack_kernel, dim3((unsigned)std::min<uint64_t>((words + 255) / 256, 4096), n_jobs), dim3(256), 0, stream, d_stream, d_jobs, d_packed, d_valid);
-    }
+    hipLaunchKernelGGL(fasta_scan_kernel, dim3(n_jobs), dim3(64), 0, stream, d_text, d_jobs, d_chunk_start, chunks, d_rec_next, rec_room, n_jobs);
+    if (max_text_cap)
+        hipLaunchKernelGGL(fasta_emit_kernel, dim3(n_chunks, n_jobs), dim3(FA_THREADS), 0, stream, d_text, d_jobs, d_chunk_start, chunks, d_rec_pool, d_packed, d_valid);
 }

@@ -15,12 +15,16 @@
 #include "api_internal.h"
 #include "gz_common.h"
 
+#include <memory>
+#include <set>
+
 namespace {
 
 constexpr size_t GZ_SLOT_BYTES = 16u << 20;      // a pinned slot; a compressed image larger than this is left to the host
 constexpr size_t GZ_MAX_READERS = 8;
 constexpr size_t GZ_BATCH_FILES = 4096;          // one wavefront each: 16 per CU x 256 CUs
-constexpr uint64_t GZ_BATCH_TEXT = 6ull << 30;   // bytes of text per batch (the stream bytes take as much again)
+constexpr uint64_t GZ_BATCH_TEXT = 24ull << 30;  // bytes of text per batch: 4 096 genomes of 5 Mb (a batch the pool has no room for is halved)
+constexpr size_t GZ_SPLIT_MIN = 64;              // ... down to this many files, below which the host takes them
 constexpr uint32_t GZ_REC_EXTRA = 1u << 20;      // record-table entries of a batch beyond one per file
 
 struct Unit { size_t first, last; uint64_t in_off, bytes; };   // jobs [first, last): their images lie together at in_off
@@ -30,21 +34,21 @@ struct Batch {
     std::vector<ghip_gz_job> jobs;
     std::vector<uint32_t> chunk_start;
     std::vector<Unit> units;
-    uint64_t in_bytes = 0, text_bytes = 0, max_text_cap = 0, max_stream_cap = 0;
+    uint64_t in_bytes = 0, text_bytes = 0, max_text_cap = 0;
     size_t n_chunks = 0;
     uint32_t rec_room = 0;
-    uint8_t *d_in = nullptr, *d_text = nullptr, *d_stream = nullptr;
+    uint8_t *d_in = nullptr, *d_text = nullptr;
     ghip_gz_job *d_jobs = nullptr;
     uint32_t *d_chunk_start = nullptr, *d_rec = nullptr;   // d_rec[0] = entries handed out, the pool from d_rec + 4
     void *d_chunks = nullptr;
     int side = 0;                       // which pinned result buffer / event triple
-    bool launched = false;
+    bool launched = false, no_room = false;
 };
 
 void free_batch(ghip_ctx *ctx, Batch &b) {
-    ghip_pool_free(ctx, b.d_in); ghip_pool_free(ctx, b.d_text); ghip_pool_free(ctx, b.d_stream); ghip_pool_free(ctx, b.d_jobs);
+    ghip_pool_free(ctx, b.d_in); ghip_pool_free(ctx, b.d_text); ghip_pool_free(ctx, b.d_jobs);
     ghip_pool_free(ctx, b.d_chunk_start); ghip_pool_free(ctx, b.d_chunks); ghip_pool_free(ctx, b.d_rec);
-    b.d_in = b.d_text = b.d_stream = nullptr; b.d_jobs = nullptr; b.d_chunk_start = b.d_rec = nullptr; b.d_chunks = nullptr;
+    b.d_in = b.d_text = nullptr; b.d_jobs = nullptr; b.d_chunk_start = b.d_rec = nullptr; b.d_chunks = nullptr;
 }
 
 inline uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -80,14 +84,12 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
     for (hipEvent_t &e : ctx->gz_ev)
         if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; (void)hipGetLastError(); ctx->gz_host_files += take.size(); return GHIP_OK; }
 
-    // ---- batches
-    std::vector<Batch> batches;
-    for (size_t t = 0; t < take.size();) {
+    // ---- batches: runs [lo, hi) of `take`, laid out when their turn comes (a run the pool has no room for is halved)
+    auto lay_out = [&](size_t lo, size_t hi) {
         Batch b;
-        while (t < take.size() && b.files.size() < GZ_BATCH_FILES) {
+        for (size_t t = lo; t < hi; t++) {
             const size_t i = take[t].first;
-            const uint64_t text_cap = cap[i] - 1, slot = up(text_cap, 64) + 64;
-            if (!b.files.empty() && b.text_bytes + slot > GZ_BATCH_TEXT) break;
+            const uint64_t text_cap = cap[i] - 1;
             ghip_gz_job j{};
             j.in_off = b.in_bytes;
             j.text_off = b.text_bytes;
@@ -99,12 +101,10 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
             b.chunk_start.push_back((uint32_t)b.n_chunks);
             b.n_chunks += ghip_gz_chunks_of(text_cap);
             b.in_bytes += up(j.in_len, 16);
-            b.text_bytes += slot;
+            b.text_bytes += up(text_cap, 64) + 64;
             b.max_text_cap = std::max<uint64_t>(b.max_text_cap, text_cap);
-            b.max_stream_cap = std::max<uint64_t>(b.max_stream_cap, j.stream_cap);
             b.files.push_back(i);
             b.jobs.push_back(j);
-            t++;
         }
         for (size_t f = 0; f < b.jobs.size();) {   // groups of consecutive images that fill a pinned slot
             Unit u{f, f, b.jobs[f].in_off, 0};
@@ -113,9 +113,22 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
             f = u.last;
         }
         b.rec_room = (uint32_t)b.jobs.size() + GZ_REC_EXTRA;
-        b.side = (int)(batches.size() & 1);
-        batches.push_back(std::move(b));
+        return b;
+    };
+    const bool small = ctx->opt.fault_stage == GHIP_FAULT_GZ_SMALL_BATCHES;   // (tests: several batches in flight, runs that find no room)
+    const size_t batch_files = small ? 3 : GZ_BATCH_FILES, split_min = small ? 1 : GZ_SPLIT_MIN;
+    const bool pretend_no_room = small && ctx->opt.fault_rank == 1;
+    std::set<std::pair<size_t, size_t>> pretended;
+    std::vector<std::pair<size_t, size_t>> todo;   // a stack: the next run on top
+    for (size_t t = 0; t < take.size();) {
+        size_t hi = t;
+        uint64_t text = 0;
+        while (hi < take.size() && hi - t < batch_files && (hi == t || text + up(cap[take[hi].first] - 1, 64) + 64 <= GZ_BATCH_TEXT)) { text += up(cap[take[hi].first] - 1, 64) + 64; hi++; }
+        todo.push_back({t, hi});
+        t = hi;
     }
+    std::reverse(todo.begin(), todo.end());
+    size_t n_batches = 0;
 
     std::atomic<int> hip_failed{0};
     double t_read = 0, t_wait = 0;
@@ -133,12 +146,11 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
         }
         b.d_in = (uint8_t *)ghip_pool_alloc(ctx, b.in_bytes + 1024);
         b.d_text = (uint8_t *)ghip_pool_alloc(ctx, b.text_bytes + 64);
-        b.d_stream = (uint8_t *)ghip_pool_alloc(ctx, b.text_bytes + 64);
         b.d_jobs = (ghip_gz_job *)ghip_pool_alloc(ctx, jobs_bytes);
         b.d_chunk_start = (uint32_t *)ghip_pool_alloc(ctx, nj * sizeof(uint32_t));
         b.d_chunks = ghip_pool_alloc(ctx, std::max<size_t>(b.n_chunks, 1) * ghip_gz_chunk_bytes());
         b.d_rec = (uint32_t *)ghip_pool_alloc(ctx, rec_bytes);
-        if (!b.d_in || !b.d_text || !b.d_stream || !b.d_jobs || !b.d_chunk_start || !b.d_chunks || !b.d_rec) { free_batch(ctx, b); return; }   // no room: the host path
+        if (!b.d_in || !b.d_text || !b.d_jobs || !b.d_chunk_start || !b.d_chunks || !b.d_rec) { free_batch(ctx, b); b.no_room = true; return; }
         // ---- the images: disk -> pinned slot -> input area
         std::atomic<size_t> next{0};
         std::mutex tmu;
@@ -185,8 +197,8 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
                   hipMemcpyAsync(b.d_chunk_start, b.chunk_start.data(), nj * sizeof(uint32_t), hipMemcpyHostToDevice, ks) == hipSuccess &&
                   hipMemsetAsync(b.d_rec, 0, 16, ks) == hipSuccess && hipEventRecord(ev_begin, ks) == hipSuccess;
         if (ok) {
-            ghip_launch_gz_batch(ks, b.d_in, b.d_text, b.d_stream, b.d_jobs, (uint32_t)nj, b.max_text_cap, b.d_chunk_start, b.d_chunks, b.d_rec, b.d_rec + 4, b.rec_room,
-                                 g->d_packed, g->d_valid, b.max_stream_cap);
+            ghip_launch_gz_batch(ks, b.d_in, b.d_text, b.d_jobs, (uint32_t)nj, b.max_text_cap, b.d_chunk_start, b.d_chunks, b.d_rec, b.d_rec + 4, b.rec_room, g->d_packed,
+                                 g->d_valid);
             ok = hipGetLastError() == hipSuccess && hipEventRecord(ev_end, ks) == hipSuccess &&
                  hipMemcpyAsync(res, b.d_jobs, jobs_bytes, hipMemcpyDeviceToHost, ks) == hipSuccess &&
                  hipMemcpyAsync(res + jobs_bytes, b.d_rec, rec_bytes, hipMemcpyDeviceToHost, ks) == hipSuccess && hipEventRecord(ev_landed, ks) == hipSuccess;
@@ -231,18 +243,38 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
         free_batch(ctx, b);   // (the event behind the results has fired: nothing in flight reads these)
     };
 
-    for (size_t b = 0; b < batches.size(); b++) {
-        stage(batches[b]);
-        if (b > 0) finish(batches[b - 1]);
+    // two batches in flight: the next one is read and shipped while the kernels of the one before it run
+    std::unique_ptr<Batch> flying;
+    int side = 0;
+    while (!todo.empty()) {
+        const std::pair<size_t, size_t> run = todo.back();
+        todo.pop_back();
+        std::unique_ptr<Batch> b(new Batch(lay_out(run.first, run.second)));
+        b->side = side;
+        if (pretend_no_room && run.second - run.first >= 2 && pretended.insert(run).second) b->no_room = true;   // (once per run)
+        else stage(*b);
+        if (b->no_room) {   // (ghip_pool_alloc has left its message in the context: not an error here)
+            if (flying) { finish(*flying); flying.reset(); todo.push_back(run); continue; }   // once more with the other batch's memory back
+            if (run.second - run.first >= 2 * split_min) {
+                const size_t mid = run.first + (run.second - run.first) / 2;
+                todo.push_back({mid, run.second});
+                todo.push_back({run.first, mid});
+                continue;
+            }
+        }
+        if (flying) finish(*flying);
+        flying = std::move(b);
+        side ^= 1;
+        n_batches++;
     }
-    finish(batches.back());
+    if (flying) finish(*flying);
     if (dbg)
         fprintf(stderr, "[ingest gz-device] text %llu bytes in %llu deflate blocks: %llu tokens (%llu matches) in %llu batches, %llu copy rounds\n", (unsigned long long)diag[0],
                 (unsigned long long)diag[5], (unsigned long long)diag[1], (unsigned long long)diag[2], (unsigned long long)diag[3], (unsigned long long)diag[4]);
     if (dbg)
         fprintf(stderr, "[ingest gz-device] %zu files in %zu batches, %zu readers: ok %llu, format %llu, data %llu, unusual %llu, overflow %llu, multi %llu, crc %llu, fasta %llu, "
                         "not run %llu; thread-seconds read %.3f slot wait %.3f; device %.3f s; wall %.3f s\n",
-                take.size(), batches.size(), readers, (unsigned long long)verdicts[0], (unsigned long long)verdicts[1], (unsigned long long)verdicts[2],
+                take.size(), n_batches, readers, (unsigned long long)verdicts[0], (unsigned long long)verdicts[1], (unsigned long long)verdicts[2],
                 (unsigned long long)verdicts[3], (unsigned long long)verdicts[4], (unsigned long long)verdicts[5], (unsigned long long)verdicts[6],
                 (unsigned long long)verdicts[7], (unsigned long long)verdicts[8], t_read, t_wait, ctx->gz_device_us.load() * 1e-6,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());

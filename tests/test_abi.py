@@ -243,7 +243,7 @@ def test_options_struct_round_trip_and_environment_seed():
         assert L.ghip_set_options(None, short) == 0
         now = galah_amd.get_options()
         assert (now["pair_form"], now["join_ranks"], now["lazy_flush_below"]) == (2, 2, 7)
-        for bad in ({"pair_form": 9}, {"join_ranks": 3}, {"ingest_form": 4}, {"copy_streams": 0}, {"fault_stage": 6}):
+        for bad in ({"pair_form": 9}, {"join_ranks": 3}, {"ingest_form": 4}, {"copy_streams": 0}, {"fault_stage": 7}):
             with pytest.raises(galah_amd.GalahHipError):
                 galah_amd.set_options(None, **bad)
         assert L.ghip_set_options(None, (C.c_uint32 * 1)(4)) == 1 and L.ghip_set_options(None, None) == 1 and L.ghip_get_options(None, None) == 1

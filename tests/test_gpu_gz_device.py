@@ -14,9 +14,10 @@ import pytest
 
 import galah_amd
 import oracle
-from conftest import fasta
+from conftest import fasta, never_run_on_hardware
 
-pytestmark = [pytest.mark.gpu, pytest.mark.emu]
+# (never_run_on_hardware: ordering only -- written in a round without GPU access, green under the emulator; runs behind the proven tests)
+pytestmark = [pytest.mark.gpu, pytest.mark.emu, never_run_on_hardware]
 
 
 def _fasta_text(rng, lengths, width=60, eol=b"\n", alphabet=b"ACGT", final_newline=True, name=b"rec"):
@@ -197,6 +198,24 @@ def test_threshold_and_mixed_input(ctx, tmp_path, opts):
             assert g.to_host(i).tobytes() == want[i][0].tobytes().replace(b"-", b"N"), (threshold, p)
             assert g.stats(i) == tuple(int(x) for x in want[i][1]), (threshold, p)
         g.free()
+
+
+def test_several_batches_in_flight_and_runs_that_find_no_room(ctx, tmp_path, opts):
+    """The driver's batch pipeline with a handful of files (fault_stage = gz_small_batches cuts the batches at 3 files): more batches
+    than the two that are in flight at a time; and, with fault_rank = 1, every run of files "finds no room" once -- it is retried
+    when the batch in flight has given its memory back, else halved.  Same genomes and statistics, all from the device."""
+    rng = np.random.default_rng(15)
+    paths = []
+    for i in range(11):
+        p = tmp_path / ("g%02d.fna.gz" % i)
+        p.write_bytes(_gz(_fasta_text(rng, [int(rng.integers(200, 9000)) for _ in range(int(rng.integers(1, 5)))]), int(rng.integers(1, 10))))
+        paths.append(str(p))
+    host = _ingest(ctx, opts, paths, device=False)
+    for no_room in (0, 1):
+        opts(fault_stage="gz_small_batches", fault_rank=no_room)
+        dev = _ingest(ctx, opts, paths, device=True, threads=2)
+        assert dev[0] == host[0] and dev[1] == host[1], no_room
+        assert dev[2]["gz_device_files"] == len(paths) and dev[2]["gz_host_files"] == 0, (no_room, dev[2])
 
 
 def test_a_genome_sized_member(ctx, tmp_path, opts):
