@@ -279,9 +279,9 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
             { std::lock_guard<std::mutex> l(smu); sl->state = state; sl->seq = ++slot_seq; }
             scv.notify_one();
         };
-        // The device-side gzip path first (ingest_gz.cpp; ghip_options.gz_device): files named *.gz go to the device
-        // compressed and are inflated, checked, parsed and packed there; gz_done marks the ones it ingested, the workers
-        // below take the rest -- plain files, and whatever that path declined.
+        // The device-side gzip path first (ingest_gz.cpp; ghip_options.gz_device = N): files named *.gz go to the device
+        // compressed and are inflated, checked, parsed and packed there -- those of which the call holds N files' worth;
+        // gz_done marks the ones it ingested, the workers below take the rest: plain files, and whatever that path declined.
         std::vector<uint8_t> gz_done(n, 0);
         if (opt.gz_device && n_gz >= opt.gz_device) {
             std::vector<size_t> cand;

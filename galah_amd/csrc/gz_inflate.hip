@@ -50,12 +50,10 @@ constexpr uint32_t LL_SYMS = 288, D_SYMS = 32, PRE_SYMS = 19;
 constexpr uint32_t LL_ROOM = 1334, D_ROOM = 402;           // primary + every sub-table a complete code can need (15-bit codes)
 constexpr uint32_t LENS_LL = 0, LENS_D = LL_SYMS, LENS_PRE = LL_SYMS + D_SYMS;
 
-// entry: bits 0-3 code bits to consume, 4-6 kind, 8-11 extra bits (K_SUB: index bits of the sub-table), 16-31 value
-// (literal / base length / base distance / first entry of the sub-table)
-constexpr uint32_t K_BAD = 0, K_LIT = 1, K_BASE = 2, K_EOB = 3, K_SUB = 4;
-__device__ __forceinline__ uint32_t entry(uint32_t kind, uint32_t nbits, uint32_t value, uint32_t extra) {
-    return nbits | (kind << 4) | (extra << 8) | (value << 16);
-}
+// entry: bits 0-3 code bits to consume, 4-7 what it is (one flag; none = not a code), 8-11 extra bits (F_SUB: index bits of the
+// sub-table), 16-31 value (literal / base length / base distance / first entry of the sub-table)
+constexpr uint32_t K_BAD = 0, K_LIT = 1u << 4, K_BASE = 1u << 5, K_SUB = 1u << 6, K_EOB = 1u << 7;
+__device__ __forceinline__ uint32_t entry(uint32_t kind, uint32_t nbits, uint32_t value, uint32_t extra) { return nbits | kind | (extra << 8) | (value << 16); }
 enum { T_PRE = 0, T_LL = 1, T_D = 2 };
 template <int T> __device__ __forceinline__ uint32_t symbol_entry(uint32_t sym, uint32_t nbits) {
     if (T == T_PRE) return entry(K_LIT, nbits, sym, 0);
@@ -78,7 +76,6 @@ template <int T> __device__ __forceinline__ uint32_t symbol_entry(uint32_t sym, 
 struct InflateLds {
     uint32_t ll[LL_ROOM];
     uint32_t dt[D_ROOM];                 // (the precode's 128 entries live here while the code lengths are read)
-    uint32_t tok[64];                    // the batch of decoded tokens: bit 31 match, (length - 3) << 16 | distance - 1; else the literal
     uint32_t count[16], first[16], offs[16];
     uint32_t sub_next, err;
     uint16_t sorted[LL_SYMS];            // symbols by (code length, symbol)
@@ -230,24 +227,30 @@ __device__ __forceinline__ void copy_match(uint8_t *text, uint32_t p, uint32_t l
     }
 }
 
-// The batch L.tok[0, ntok) written to text[pos0 ..]: one token per lane.
-__device__ uint32_t emit_tokens(uint8_t *text, const uint32_t *tok, uint32_t ntok, uint32_t pos0, uint32_t lane, uint32_t &n_matches) {
+// The batch of ntok tokens written to text[pos0 ..]: lane t holds token t (tk: decode_batch).  The lanes finish what the chain
+// left undone -- lengths and distances from their base values and extra bits, the tokens' places, the checks that need them --
+// and copy.  Returns GHIP_GZ_OK and the bytes written, or what is wrong (nothing written then).
+__device__ uint32_t emit_tokens(uint8_t *text, const uint4 tk, uint32_t ntok, uint32_t pos0, uint32_t room, uint32_t lane, uint32_t &written,
+                                uint32_t &n_matches, uint32_t &n_rounds) {
     const bool active = lane < ntok;
-    const uint32_t tk = active ? tok[lane] : 0u;
-    const bool is_match = active && (tk >> 31);
-    const uint32_t len = !active ? 0u : is_match ? ((tk >> 16) & 0xffu) + 3u : 1u, dist = (tk & 0x7fffu) + 1u;
+    const bool is_match = active && (tk.x & K_BASE);
+    const uint32_t len = !active ? 0u : is_match ? (tk.x >> 16) + (tk.y & ((1u << ((tk.x >> 8) & 15u)) - 1u)) : 1u;
+    const uint32_t dist = (tk.z >> 16) + (tk.w & ((1u << ((tk.z >> 8) & 15u)) - 1u));
     uint32_t x = len;
     for (uint32_t d = 1; d < 64; d <<= 1) {
         const uint32_t y = __shfl_up(x, d);
         if (lane >= d) x += y;
     }
+    const uint32_t total = __builtin_amdgcn_readlane(x, 63);
     const uint32_t p = pos0 + x - len;
-    if (active && !is_match) text[p] = (uint8_t)tk;
+    written = 0;
+    if (total > room) return GHIP_GZ_EOVERFLOW;                        // more text than the trailer promised
+    if (__ballot(is_match && dist > p)) return GHIP_GZ_EDATA;          // a distance that reaches in front of the member's first byte
+    if (active && !is_match) text[p] = (uint8_t)(tk.x >> 16);
     uint64_t pending = __ballot(is_match);
-    uint32_t rounds = 0;
     n_matches += (uint32_t)__popcll(pending);
     while (pending) {
-        rounds++;
+        n_rounds++;
         // everything in front of the first unfinished match is complete; a match may go when its source ends there
         const uint32_t frontier = __builtin_amdgcn_readlane(p, (uint32_t)__ffsll((long long)pending) - 1u);
         const bool ready = ((pending >> lane) & 1ull) && p - dist + (len < dist ? len : dist) <= frontier;
@@ -256,10 +259,62 @@ __device__ uint32_t emit_tokens(uint8_t *text, const uint32_t *tok, uint32_t nto
         pending &= ~__ballot(ready);
     }
     text_sync();
-    return rounds;
+    written = total;
+    return GHIP_GZ_OK;
 }
 
 __device__ __forceinline__ uint32_t ld_byte(const uint8_t *in, uint32_t i) { return uni((uint32_t)in[i]); }
+
+// The serial half: up to 64 symbols of the current block off the bit stream, symbol t into LANE t's registers (a compare of
+// the lane number with the token count and one v_cndmask per word: vector instructions, whose issue slots are idle here --
+// no LDS, nothing for the scalar unit).  The chain does the least it can per symbol -- look
+// the code up, pass over it and its extra bits, hand the entry and the stream's bits behind the code to the lane -- since
+// every scalar instruction is a whole issue slot of the wavefront: lengths, distances, positions and the checks on them are
+// the lanes' work (emit_tokens).  tk = (a literal's entry) or (length entry, bits behind the length code, distance entry,
+// bits behind the distance code).
+enum : uint32_t { BATCH_FULL = 0, BATCH_END_OF_BLOCK = 1, BATCH_DAMAGED = 2 };
+__device__ __forceinline__ uint32_t decode_batch(InflateLds &L, Reader &r, uint32_t lane, uint32_t &ntok_out, uint4 &tk) {
+    uint32_t ntok = 0;
+    do {
+        rd_fill(r, lane);
+        uint32_t e = uni(L.ll[(uint32_t)r.bb & ((1u << LL_P) - 1u)]);
+        if (e & K_SUB) {
+            r.bb >>= LL_P;
+            r.bl -= LL_P;
+            e = uni(L.ll[(e >> 16) + ((uint32_t)r.bb & ((1u << ((e >> 8) & 15u)) - 1u))]);
+        }
+        r.bb >>= e & 15u;
+        const bool mine = lane == ntok;
+        tk.x = mine ? e : tk.x;
+        if (e & K_LIT) {
+            r.bl -= e & 15u;
+            ntok++;
+            continue;
+        }
+        const uint32_t xl = (e >> 8) & 15u;
+        tk.y = mine ? (uint32_t)r.bb : tk.y;
+        r.bb >>= xl;
+        r.bl -= (e & 15u) + xl;
+        if (!(e & K_BASE)) { ntok_out = ntok; return (e & K_EOB) ? BATCH_END_OF_BLOCK : BATCH_DAMAGED; }
+        rd_fill(r, lane);
+        uint32_t d = uni(L.dt[(uint32_t)r.bb & ((1u << D_P) - 1u)]);
+        if (d & K_SUB) {
+            r.bb >>= D_P;
+            r.bl -= D_P;
+            d = uni(L.dt[(d >> 16) + ((uint32_t)r.bb & ((1u << ((d >> 8) & 15u)) - 1u))]);
+        }
+        if (!(d & K_BASE)) { ntok_out = ntok; return BATCH_DAMAGED; }
+        r.bb >>= d & 15u;
+        const uint32_t xd = (d >> 8) & 15u;
+        tk.z = mine ? d : tk.z;
+        tk.w = mine ? (uint32_t)r.bb : tk.w;
+        r.bb >>= xd;
+        r.bl -= (d & 15u) + xd;
+        ntok++;
+    } while (ntok < 64);
+    ntok_out = ntok;
+    return BATCH_FULL;
+}
 
 }  // namespace
 
@@ -346,7 +401,7 @@ __global__ __launch_bounds__(64) void gz_inflate_kernel(const uint8_t *__restric
             while (i < total && status == GHIP_GZ_OK) {
                 rd_fill(r, lane);
                 const uint32_t e = uni(L.dt[(uint32_t)r.bb & ((1u << PRE_P) - 1u)]);
-                if (((e >> 4) & 7u) != K_LIT) { status = GHIP_GZ_EDATA; break; }
+                if (!(e & K_LIT)) { status = GHIP_GZ_EDATA; break; }
                 rd_bits(r, e & 15u);
                 const uint32_t sym = e >> 16;
                 uint32_t rep = 1, val = sym;
@@ -373,49 +428,16 @@ __global__ __launch_bounds__(64) void gz_inflate_kernel(const uint8_t *__restric
         // ---- the block's symbols, 64 tokens at a time
         bool eob = false;
         while (!eob && status == GHIP_GZ_OK) {
-            uint32_t ntok = 0, end = pos;
-            while (ntok < 64) {
-                rd_fill(r, lane);
-                uint32_t e = uni(L.ll[(uint32_t)r.bb & ((1u << LL_P) - 1u)]);
-                if (((e >> 4) & 7u) == K_SUB) {
-                    rd_bits(r, LL_P);
-                    e = uni(L.ll[(e >> 16) + ((uint32_t)r.bb & ((1u << ((e >> 8) & 15u)) - 1u))]);
-                }
-                const uint32_t kind = (e >> 4) & 7u;
-                rd_bits(r, e & 15u);
-                if (kind == K_LIT) {
-                    if (end == text_cap) { status = GHIP_GZ_EOVERFLOW; break; }
-                    if (lane == 0) L.tok[ntok] = e >> 16;
-                    ntok++;
-                    end++;
-                    continue;
-                }
-                if (kind == K_EOB) { eob = true; break; }
-                if (kind != K_BASE) { status = GHIP_GZ_EDATA; break; }
-                const uint32_t len = (e >> 16) + rd_bits(r, (e >> 8) & 15u);
-                rd_fill(r, lane);
-                uint32_t d = uni(L.dt[(uint32_t)r.bb & ((1u << D_P) - 1u)]);
-                if (((d >> 4) & 7u) == K_SUB) {
-                    rd_bits(r, D_P);
-                    d = uni(L.dt[(d >> 16) + ((uint32_t)r.bb & ((1u << ((d >> 8) & 15u)) - 1u))]);
-                }
-                if (((d >> 4) & 7u) != K_BASE) { status = GHIP_GZ_EDATA; break; }
-                rd_bits(r, d & 15u);
-                const uint32_t dist = (d >> 16) + rd_bits(r, (d >> 8) & 15u);
-                if (dist > end) { status = GHIP_GZ_EDATA; break; }   // in front of the member's first byte
-                if (len > text_cap - end) { status = GHIP_GZ_EOVERFLOW; break; }
-                if (lane == 0) L.tok[ntok] = 0x80000000u | ((len - 3) << 16) | (dist - 1);
-                ntok++;
-                end += len;
-            }
-            if (rd_byte_pos(r) > in_len + 8) status = status == GHIP_GZ_OK ? GHIP_GZ_EDATA : status;   // ran off the image (zeros behind it)
-            if (status != GHIP_GZ_OK) break;
-            wave_sync();
-            n_rounds += emit_tokens(text, L.tok, ntok, pos, lane, n_matches);
+            uint32_t ntok = 0;
+            uint4 tk = make_uint4(0, 0, 0, 0);
+            const uint32_t how = decode_batch(L, r, lane, ntok, tk);
+            eob = how == BATCH_END_OF_BLOCK;
+            if (how == BATCH_DAMAGED || rd_byte_pos(r) > in_len + 8) { status = GHIP_GZ_EDATA; break; }   // (the latter: ran off the image, zeros behind it)
+            uint32_t written = 0;
+            status = emit_tokens(text, tk, ntok, pos, text_cap - pos, lane, written, n_matches, n_rounds);
             n_tokens += ntok;
             n_batches++;
-            wave_sync();
-            pos = end;
+            pos += written;
         }
     }
     if (status == GHIP_GZ_OK) {   // the trailer: CRC-32 and ISIZE, then nothing

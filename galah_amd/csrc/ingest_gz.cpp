@@ -70,6 +70,20 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
             cap[i] - 1 > (uint64_t)st.st_size * 1032 + 1024) { ctx->gz_host_files++; continue; }
         take.push_back({i, (uint64_t)st.st_size});
     }
+    // One wavefront inflates one file, so a launch takes as long as its largest file (~0.03 us per byte of text, modelled), while the
+    // host's threads take the files one after the other: the device is the better place for a file only when the call holds many
+    // files' worth of it.  gz_device = N: a file goes to the device when the call's device-bound files together hold at least N times
+    // its text (N files of one size: the plain count; a 100 Mb assembly among bacterial genomes: left to the host).
+    {
+        std::sort(take.begin(), take.end(), [&](const std::pair<size_t, uint64_t> &a, const std::pair<size_t, uint64_t> &b) { return cap[a.first] > cap[b.first]; });
+        uint64_t sum = 0;
+        for (auto &tk : take) sum += cap[tk.first];
+        size_t drop = 0;
+        while (drop < take.size() && cap[take[drop].first] * (uint64_t)ctx->opt.gz_device > sum) { sum -= cap[take[drop].first]; drop++; }
+        ctx->gz_host_files += drop;
+        take.erase(take.begin(), take.begin() + drop);
+        std::sort(take.begin(), take.end());   // back to the order of the call (the layout's order: consecutive files, consecutive places)
+    }
     if (take.empty()) return GHIP_OK;
     // ---- pinned memory and events, kept by the context
     const size_t readers = std::min<size_t>(std::max(1, io_threads), GZ_MAX_READERS);

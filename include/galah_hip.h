@@ -109,10 +109,12 @@ typedef struct ghip_options {
                                    (GHIP_PROBE_ARRANGED) */
     uint32_t comm_timeout_ms;   /* RCCL transport: how long a rank waits inside one collective for its peers before it aborts the
                                    communicator and returns GHIP_EPEER, default 60 000; 0: for ever   (GHIP_COMM_TIMEOUT_MS) */
-    uint32_t gz_device;         /* N > 0: a call that ingests at least N files named *.gz inflates, checks (CRC-32, ISIZE), parses and
-                                   packs them ON THE DEVICE, one wavefront per file (gz_inflate.hip); a file that path does not take
-                                   (further members, FHCRC, a damaged stream, ...) goes through the host's inflate as before, which
-                                   alone words the errors.  0 (default until a GPU run has timed it): host inflate   (GHIP_GZ_DEVICE) */
+    uint32_t gz_device;         /* N > 0: gzip input is inflated, checked (CRC-32, ISIZE), parsed and packed ON THE DEVICE, one wavefront per file
+                                   (gz_inflate.hip) -- for every file named *.gz of which the call holds N files' worth (its gzip files together
+                                   have at least N times its text: N files of one size, or more of mixed sizes; a launch takes as long as its
+                                   largest file).  A file that path does not take (too large a share, further members, FHCRC, a damaged
+                                   stream, ...) goes through the host's inflate as before, which alone words the errors.  0 (default until a
+                                   GPU run has timed it): host inflate   (GHIP_GZ_DEVICE) */
 } ghip_options;
 int ghip_get_options(const ghip_ctx *ctx /* NULL: the process-wide defaults */, ghip_options *out);
 int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const ghip_options *opt);

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 EMU = os.environ.get("GALAH_TEST_EMU") == "1"
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "libgalah_hip_emu.so")
+EMU_LIB = os.environ.get("HIPEMU_LIB") or os.path.join(ROOT, "tests", "emu", "libgalah_hip_emu.so")   # (HIPEMU_LIB: a build of the emulated library elsewhere)
 if EMU:
     # tests/test_emu.py (and scripts/emu_suite.sh) run GPU tests in a child process against the library's sources compiled for
     # the host over the wave64 emulator (tests/emu/).  Only the test harness knows this switch: galah_amd never reads it.

@@ -253,6 +253,15 @@ def test_options_struct_round_trip_and_environment_seed():
     assert galah_amd.get_options() == saved
 
 
+def test_gz_crc_algebra_against_zlib(tmp_path):
+    """tests/cpp/test_gz_crc.cpp: the CRC-32 of a text put together from the remainders of its spans (galah_amd/csrc/gz_common.h, the
+    header the kernels of the device-side gzip path compile) equals zlib's crc32 for every text length and span size tried."""
+    exe = str(tmp_path / "test_gz_crc")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_gz_crc.cpp"), "-lz"], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gz crc ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_probe_model_shares_the_kernels_bucket_and_tag_functions(tmp_path):
     """tests/cpp/test_probe_model.cpp: a host-side model of the dense probe form's arranged variant built on the SAME
     bucket / tag functions the kernels compile (galah_amd/csrc/probe_common.h): every hash in one of its two buckets for

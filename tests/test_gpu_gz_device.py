@@ -48,6 +48,19 @@ def _gz(data, level=6, name=None, extra=None, comment=None, hcrc=False):
     return head + body + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data) & 0xffffffff)
 
 
+def _bits(spec):
+    """Bits in stream order ('1 10 0000001': the first bit of the stream first) -> bytes, the way DEFLATE packs them (LSB first)."""
+    bits = [int(c) for c in spec if c in "01"]
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        out[i // 8] |= b << (i % 8)
+    return bytes(out)
+
+
+def _raw_member(deflate, text, isize):
+    return b"\x1f\x8b\x08\0\0\0\0\0\0\x03" + deflate + struct.pack("<II", zlib.crc32(text) & 0xffffffff, isize)
+
+
 def _ingest(ctx, opts, paths, device, threads=3):
     opts(gz_device=1 if device else 0)
     before = ctx.ingest_counters()
@@ -129,6 +142,10 @@ def test_what_the_device_declines_goes_through_the_host(ctx, tmp_path, opts):
         "truncated.fna.gz": good[: len(good) // 2],
         "bit_flip.fna.gz": bytes(flipped),
         "not_fasta.fna.gz": _gz(b"ACGT\nACGT\n", 6),
+        "isize_too_small.fna.gz": good[:-4] + struct.pack("<I", len(text) - 100),     # more text than the trailer promises
+        "distance_before_the_text.fna.gz": _raw_member(_bits("1 10 0000001 00000 0000000"), b"\0\0\0", 3),   # fixed block: a match as the first symbol
+        "block_type_3.fna.gz": _raw_member(_bits("1 11"), b"", 0),
+        "stored_len_mismatch.fna.gz": _raw_member(_bits("1 00 00000") + b"\x05\x00\x00\x00>a\nAC", b">a\nAC", 5),   # NLEN is not ~LEN
     }
     paths = []
     for name, data in fine.items():
@@ -178,26 +195,31 @@ def test_reference_fixtures_through_the_device_path(ctx, opts, golden_sketches):
 
 
 def test_threshold_and_mixed_input(ctx, tmp_path, opts):
-    """gz_device = N takes effect from N files named *.gz on; plain files and small groups next to device-ingested files keep
-    their places in the layout (a group of small plain files must not be shipped over a neighbour the device wrote)."""
+    """gz_device = N sends a gzip file to the device when the call holds N files' worth of it (a launch takes as long as its largest
+    file): three of one size pass at N = 3 and not at N = 4; a fourth, ten times their size, stays with the host at N = 3 and
+    goes along at N = 1.  Plain files and small groups next to device-ingested files keep their places in the layout (a group of
+    small plain files must not be shipped over a neighbour the device wrote)."""
     rng = np.random.default_rng(13)
     paths = []
     for i in range(9):
-        text = _fasta_text(rng, [int(rng.integers(50, 4000)) for _ in range(int(rng.integers(1, 4)))])
         gz = i % 3 == 1
+        text = _fasta_text(rng, [1500, 700] if gz else [int(rng.integers(50, 4000)) for _ in range(int(rng.integers(1, 4)))])
         p = tmp_path / ("f%d.fna%s" % (i, ".gz" if gz else ""))
         p.write_bytes(_gz(text, 6) if gz else text)
         paths.append(str(p))
-    want = [galah_amd.fasta_stream(p) for p in paths]
-    for threshold, device_files in ((4, 0), (3, 3), (1, 3)):
-        opts(gz_device=threshold)
-        before = ctx.ingest_counters()
-        g = ctx.genomes_from_files(paths, 3)
-        assert ctx.ingest_counters()["gz_device_files"] - before["gz_device_files"] == device_files
-        for i, p in enumerate(paths):
-            assert g.to_host(i).tobytes() == want[i][0].tobytes().replace(b"-", b"N"), (threshold, p)
-            assert g.stats(i) == tuple(int(x) for x in want[i][1]), (threshold, p)
-        g.free()
+    big = tmp_path / "big.fna.gz"
+    big.write_bytes(_gz(_fasta_text(rng, [15000, 7000]), 6))
+    for files, cases in ((paths, ((4, 0), (3, 3), (1, 3))), (paths[:5] + [str(big)] + paths[5:], ((3, 3), (1, 4)))):
+        want = [galah_amd.fasta_stream(p) for p in files]
+        for threshold, device_files in cases:
+            opts(gz_device=threshold)
+            before = ctx.ingest_counters()
+            g = ctx.genomes_from_files(files, 3)
+            assert ctx.ingest_counters()["gz_device_files"] - before["gz_device_files"] == device_files, (threshold, len(files))
+            for i, p in enumerate(files):
+                assert g.to_host(i).tobytes() == want[i][0].tobytes().replace(b"-", b"N"), (threshold, p)
+                assert g.stats(i) == tuple(int(x) for x in want[i][1]), (threshold, p)
+            g.free()
 
 
 def test_several_batches_in_flight_and_runs_that_find_no_room(ctx, tmp_path, opts):
