@@ -9,16 +9,18 @@
 // DEFLATE is serial within a member, so the parallelism is ACROSS files: one wavefront per file, thousands of files per
 // launch.  Inside a wavefront:
 //   * the Huffman decoding is one dependent chain and runs on the SCALAR unit: every value of the chain is wave-uniform
-//     (v_readfirstlane behind each LDS look-up), so the compiler keeps bit buffer, positions and table entries in SGPRs;
+//     (v_readfirstlane behind each LDS look-up), so the compiler keeps bit buffer, bit count and table entries in SGPRs;
 //     the input reaches it through a 2 x 64-dword window the 64 lanes hold in two VGPRs (one coalesced load per 256 bytes,
-//     v_readlane per dword);
+//     v_readlane per dword).  Every scalar instruction is a whole issue slot of the wavefront, so the chain only looks the
+//     codes up and passes over them: the table entries and the stream's bits behind each code go to the lanes;
 //   * the decode tables (10-bit litlen + 8-bit distance primaries with sub-tables, 7 KiB) live in LDS and are built by the
-//     64 lanes together; 8.5 KiB of LDS per wavefront = 16 wavefronts per CU;
-//   * the LZ77 copies are the data-parallel half: 64 decoded tokens at a time, positions by a wave prefix sum, every lane
-//     writes its literal or copies its match.  A match whose source lies in front of the batch's unfinished part goes at
-//     once; the others wait for the round in which their source is complete (a match can name bytes of the same batch) --
-//     multi-round resolution, at least one token per round, in practice one or two rounds.  History is read back from the
-//     text in HBM (L2), not kept in LDS: 32 KiB of window per wavefront would leave 4 wavefronts per CU.
+//     64 lanes together; 8 KiB of LDS per wavefront = 16 wavefronts per CU;
+//   * the LZ77 copies are the data-parallel half: 64 tokens at a time, one per lane, which finishes the decoding (base +
+//     extra bits), finds its place by a wave prefix sum and writes its literal or copies its match.  A match whose source
+//     lies in front of the batch's unfinished part goes at once; the others wait for the round in which their source is
+//     complete (a match can name bytes of the same batch) -- multi-round resolution, at least one token per round, two
+//     rounds on average for a genome.  History is read back from the text in HBM (L2), not kept in LDS: 32 KiB of window
+//     per wavefront would leave 4 wavefronts per CU.
 // Anything this path does not take -- further members, FHCRC, an incomplete code, a text that does not start with '>' ... --
 // sets a status and the host path (ingest.cpp) ingests that file instead and alone decides what is an error.
 //
@@ -266,12 +268,11 @@ __device__ uint32_t emit_tokens(uint8_t *text, const uint4 tk, uint32_t ntok, ui
 __device__ __forceinline__ uint32_t ld_byte(const uint8_t *in, uint32_t i) { return uni((uint32_t)in[i]); }
 
 // The serial half: up to 64 symbols of the current block off the bit stream, symbol t into LANE t's registers (a compare of
-// the lane number with the token count and one v_cndmask per word: vector instructions, whose issue slots are idle here --
-// no LDS, nothing for the scalar unit).  The chain does the least it can per symbol -- look
-// the code up, pass over it and its extra bits, hand the entry and the stream's bits behind the code to the lane -- since
-// every scalar instruction is a whole issue slot of the wavefront: lengths, distances, positions and the checks on them are
-// the lanes' work (emit_tokens).  tk = (a literal's entry) or (length entry, bits behind the length code, distance entry,
-// bits behind the distance code).
+// the lane number with the token count and one v_cndmask per word: vector instructions, whose issue slots are idle here -- no
+// LDS, nothing for the scalar unit).  The chain does the least it can per symbol -- look the code up, pass over it and its
+// extra bits, hand the entry and the stream's bits behind the code to the lane -- since every scalar instruction is a whole
+// issue slot of the wavefront: lengths, distances, positions and the checks on them are the lanes' work (emit_tokens).
+// tk = (a literal's entry) or (length entry, bits behind the length code, distance entry, bits behind the distance code).
 enum : uint32_t { BATCH_FULL = 0, BATCH_END_OF_BLOCK = 1, BATCH_DAMAGED = 2 };
 __device__ __forceinline__ uint32_t decode_batch(InflateLds &L, Reader &r, uint32_t lane, uint32_t &ntok_out, uint4 &tk) {
     uint32_t ntok = 0;

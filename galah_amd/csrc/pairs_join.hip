@@ -287,6 +287,7 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_write_kernel(const uint32
     // 32-bit offsets: the host bounds the inputs (n*s < 2^32 elements, < 2^31 records from a 64-bit total)
 }
 
+constexpr uint32_t J_BARRIER_VOID = 0x80000000u;  // in the arrival word of a fused scan: a waiter has given up, the scan is void (the count lives in the bits below)
 constexpr uint32_t J_BARRIER_POLLS = 1u << 18;   // polls of the grid barrier before a waiter gives up (an agent-scope load + s_sleep 2: ~1 us each)
 
 // The same scan in ONE launch (fused form): per-tile sums, a grid barrier, the write.  The grid is n_tiles <= 256 blocks of
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_fused_kernel(const uint32
                                                                     unsigned long long *__restrict__ totals, uint32_t *__restrict__ flags) {
     __shared__ uint32_t ws[J_WAVES], wm[J_WAVES], ts[256], tm[256];
     __shared__ unsigned long long wb[J_WAVES];
+    __shared__ uint32_t void_scan;
     const size_t base = (size_t)blockIdx.x * J_SCAN_TILE + threadIdx.x * J_SCAN_PER;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t v[J_SCAN_PER];
@@ -335,16 +337,40 @@ __global__ __launch_bounds__(J_THREADS) void join_scan_fused_kernel(const uint32
         __hip_atomic_store(&tile_sum_b[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the three stores above are ordered before it
         // A BOUNDED wait: should a block of this grid not become resident while the others spin -- a co-running
-        // kernel that holds the chip for longer than any of this library's does -- the waiters give up after ~0.3 s of polls,
-        // raise flags bit 3 (what an outgrown capacity raises: the host discards this form's output and repeats the join in
-        // the exact form) and run on with whatever sums there are; the late blocks find `arrive` complete and leave too.
-        uint32_t polls = 0;
-        while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_tiles) {
-            if (++polls > J_BARRIER_POLLS) { atomicOr(flags, 8u); break; }
+        // kernel that holds the chip for longer than any of this library's does -- a waiter gives up after ~0.3 s of polls.
+        // Giving up VOIDS the scan for every block, those that have not started included: the waiter marks the arrival word
+        // (J_BARRIER_VOID, by compare-and-swap against the count it saw: a count that completes meanwhile wins and nobody
+        // gives up), no block passes a marked word, every block writes zeros for its offsets -- all buckets empty, so the
+        // kernels queued behind this one find nothing to do instead of offsets made of partial sums -- and flags bit 3 (what an
+        // outgrown capacity raises) has the host discard this form's output and repeat the join in the exact form.
+        uint32_t polls = 0, seen = __hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        while (!(seen & J_BARRIER_VOID) && seen < n_tiles) {
+            if (++polls > J_BARRIER_POLLS) {
+                uint32_t expect = seen;
+                if (__hip_atomic_compare_exchange_strong(arrive, &expect, seen | J_BARRIER_VOID, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+                    atomicOr(flags, 8u);
+                    seen |= J_BARRIER_VOID;
+                    break;
+                }
+                seen = expect;   // the count moved on: look again
+                continue;
+            }
             __builtin_amdgcn_s_sleep(2);
+            seen = __hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        void_scan = (seen & J_BARRIER_VOID) ? 1u : 0u;
     }
     __syncthreads();
+    if (void_scan) {   // (block-uniform: thread 0 wrote it in front of the barrier)
+#pragma unroll
+        for (uint32_t q = 0; q < J_SCAN_PER / 4; q++) reinterpret_cast<uint4 *>(start + base)[q] = make_uint4(0, 0, 0, 0);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            start[(size_t)n_tiles * J_SCAN_TILE] = 0;
+            if (max_out) *max_out = 0;
+            if (totals) { totals[0] = 0; totals[1] = 0; }
+        }
+        return;
+    }
     ts[threadIdx.x] = threadIdx.x < n_tiles ? __hip_atomic_load(&tile_sum[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     tm[threadIdx.x] = threadIdx.x < n_tiles ? __hip_atomic_load(&tile_max[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     __syncthreads();

@@ -70,7 +70,7 @@ struct Launch {
     int refs = 0;   // pool workers inside (under the pool's mutex)
     std::mutex extra_mu;
     std::vector<std::thread> extra;
-    bool coresident = false;
+    std::atomic<bool> coresident{false};
 };
 
 struct Worker {   // per OS thread
@@ -238,6 +238,7 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
     uint64_t rng = order_seed * 0x9E3779B97F4A7C15ull + b * 0xD1B54A32D192ED03ull + 1;
     auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
     std::vector<uint32_t> wave_turn(nw), lane_turn(64);
+    uint64_t yield_turns = 0;
     for (;;) {
         for (uint32_t x = 0; x < nw; x++) wave_turn[x] = order_mode == 1 ? nw - 1 - x : x;
         if (order_mode == 2) for (uint32_t x = nw; x > 1; x--) std::swap(wave_turn[x - 1], wave_turn[next() % x]);
@@ -268,7 +269,11 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         if (n_done == n) break;
         if (n_yield) {   // somebody spins on another workgroup: make sure that one exists, let it run, try again
             start_coresident(L);
-            std::this_thread::yield();
+            // A poll of a spin loop stands for ~1 us of GPU time: a BOUNDED wait (the fused scan's grid barrier gives up after
+            // 2^18 polls) must not run out here just because the host is busy with the other workgroups' fibres -- after the
+            // first thousand turns a turn takes at least 20 us of wall time (2^18 polls: five seconds and more).
+            if (++yield_turns > 1000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            else std::this_thread::yield();
             for (uint32_t t = 0; t < n; t++)
                 if (w->st[t] == YIELDED) w->st[t] = READY;
             continue;
@@ -291,9 +296,12 @@ void block_loop(Launch *L) {
 }
 
 void start_coresident(Launch *L) {
+    // (called at every turn of a spinning workgroup: the common case must not touch the mutex -- the launcher holds it while it
+    // joins the extra threads, and a spinner that blocked on it here would never finish: a deadlock seen once in four runs)
+    if (L->coresident.load(std::memory_order_acquire)) return;
     std::lock_guard<std::mutex> lk(L->extra_mu);
-    if (L->coresident) return;
-    L->coresident = true;
+    if (L->coresident.load(std::memory_order_relaxed)) return;
+    L->coresident.store(true, std::memory_order_release);
     g_stats.coresident_launches++;
     for (;;) {
         const uint64_t b = L->next.fetch_add(1);
@@ -411,8 +419,13 @@ void launch(const char *name, const void *fn, dim3 grid, dim3 block, size_t lds,
         g_pool->active.erase(std::find(g_pool->active.begin(), g_pool->active.end(), &L));
     }
     {
-        std::lock_guard<std::mutex> lk(L.extra_mu);
-        for (auto &t : L.extra) t.join();
+        std::vector<std::thread> extra;
+        {
+            std::lock_guard<std::mutex> lk(L.extra_mu);
+            L.coresident.store(true, std::memory_order_release);   // (nothing left to start: a late spinner need not look)
+            extra.swap(L.extra);
+        }
+        for (auto &t : extra) t.join();   // outside the lock
     }
     while (L.done.load() < L.total) std::this_thread::yield();
 }

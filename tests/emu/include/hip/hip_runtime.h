@@ -327,3 +327,4 @@ template <class T, class U> static inline T atomicMin(T *p, U v) {
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
 #define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), (order))
+#define __hip_atomic_compare_exchange_strong(p, expected, desired, success, failure, scope) __atomic_compare_exchange_n((p), (expected), (desired), false, (success), (failure))

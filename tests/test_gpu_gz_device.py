@@ -101,6 +101,12 @@ def test_device_inflate_equals_host_inflate(ctx, tmp_path, opts):
     with gzip.GzipFile(filename="inner_name.fna", mode="wb", fileobj=buf, compresslevel=6) as f:
         f.write(base)
     files["python_gzipfile.fna.gz"] = buf.getvalue()
+    # what pigz and flushing writers leave in a member: empty stored blocks between the chunks (sync / full flush markers 00 00 ff ff)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = []
+    for j in range(0, len(base), 9973):
+        parts.append(co.compress(base[j:j + 9973]) + co.flush(zlib.Z_FULL_FLUSH if (j // 9973) % 3 == 0 else zlib.Z_SYNC_FLUSH))
+    files["flush_markers.fna.gz"] = b"\x1f\x8b\x08\0\0\0\0\0\0\x03" + b"".join(parts) + co.flush() + struct.pack("<II", zlib.crc32(base) & 0xffffffff, len(base))
     paths = []
     for name, data in files.items():
         p = tmp_path / name
