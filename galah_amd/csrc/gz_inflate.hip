@@ -251,7 +251,8 @@ __device__ uint32_t emit_tokens(uint8_t *text, const uint4 tk, uint32_t ntok, ui
     if (active && !is_match) text[p] = (uint8_t)(tk.x >> 16);
     uint64_t pending = __ballot(is_match);
     n_matches += (uint32_t)__popcll(pending);
-    while (pending) {
+    for (uint32_t round = 0; pending; round++) {
+        if (round == 64) return GHIP_GZ_EDATA;   // (cannot happen: the first unfinished match goes every round -- but no loop of this kernel is left unbounded)
         n_rounds++;
         // everything in front of the first unfinished match is complete; a match may go when its source ends there
         const uint32_t frontier = __builtin_amdgcn_readlane(p, (uint32_t)__ffsll((long long)pending) - 1u);
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(64) void gz_inflate_kernel(const uint8_t *__restric
     if (status == GHIP_GZ_OK) rd_seek(r, at, lane);
     bool last = false;
     while (status == GHIP_GZ_OK && !last) {
+        if (rd_byte_pos(r) > in_len + 8) { status = GHIP_GZ_EDATA; break; }   // ran off the image (empty blocks made of the zeros behind it)
         rd_fill(r, lane);
         last = rd_bits(r, 1) != 0;
         const uint32_t type = rd_bits(r, 2);

@@ -2,7 +2,7 @@
 // ghip_genomes_from_files call go to the device as they are on disk -- a third of the bytes of their text -- in batches of
 // up to 4 096 files, and come back as resident genomes plus their assembly statistics.  Per batch:
 //
-//   reader threads (<= 8, the context's I/O pool)   file -> pinned slot (16 MiB, two per thread) -> hipMemcpyAsync into the
+//   reader threads (<= 12, the context's I/O pool)   file -> pinned slot (16 MiB, two per thread) -> hipMemcpyAsync into the
 //                                                   batch's input area, a group of consecutive files per copy
 //   one stream                                      job table up, the six launches of ghip_launch_gz_batch, job table + record
 //                                                   pool back into pinned memory, an event
@@ -21,7 +21,7 @@
 namespace {
 
 constexpr size_t GZ_SLOT_BYTES = 16u << 20;      // a pinned slot; a compressed image larger than this is left to the host
-constexpr size_t GZ_MAX_READERS = 8;
+constexpr size_t GZ_MAX_READERS = 12;   // (read() of ~1.5 MB files from the page cache: ~3 GB/s per thread; two 16 MiB pinned slots each)
 constexpr size_t GZ_BATCH_FILES = 4096;          // one wavefront each: 16 per CU x 256 CUs
 constexpr uint64_t GZ_BATCH_TEXT = 24ull << 30;  // bytes of text per batch: 4 096 genomes of 5 Mb (a batch the pool has no room for is halved)
 constexpr size_t GZ_SPLIT_MIN = 64;              // ... down to this many files, below which the host takes them
