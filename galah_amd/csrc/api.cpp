@@ -101,6 +101,7 @@ void ghip_ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     for (auto &sl : ctx->ingest_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
     for (auto &sl : ctx->gz_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
     for (uint8_t *p : ctx->gz_results) if (p) hipHostFree(p);
+    if (ctx->gz_rec_host) hipHostFree(ctx->gz_rec_host);
     for (hipEvent_t e : ctx->gz_ev) if (e) hipEventDestroy(e);
     if (ctx->pin_buf) hipHostFree(ctx->pin_buf);
     if (ctx->ingest_stage) hipFree(ctx->ingest_stage);

@@ -107,6 +107,8 @@ struct ghip_ctx {
     std::vector<gz_slot> gz_slots;
     uint8_t *gz_results[2] = {nullptr, nullptr};
     size_t gz_results_bytes[2] = {0, 0};
+    uint8_t *gz_rec_host = nullptr;   // pinned landing place of a batch's record table (grown on demand)
+    size_t gz_rec_host_bytes = 0;
     hipEvent_t gz_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per batch in flight: kernels begin, end, results landed
     std::atomic<uint64_t> gz_device_files{0}, gz_host_files{0}, gz_device_us{0};
     std::atomic<int> live_handles{0};   // genomes / sketches / ani indexes still alive

@@ -664,9 +664,14 @@ __global__ __launch_bounds__(64) void fasta_scan_kernel(const uint8_t *__restric
         uint32_t status = GHIP_GZ_OK, rec_off = 0;
         const uint64_t stream_len = (uint64_t)kept + headers;
         if (stream_len > job->stream_cap) status = GHIP_GZ_EOVERFLOW;
-        else {
-            rec_off = atomicAdd(rec_next, headers);
-            if ((uint64_t)rec_off + headers > rec_room) status = GHIP_GZ_EFASTA;   // the pool is full: the host parser has no such limit
+        else {   // a slice of the record pool -- taken only if it fits, so that a file of very many records costs the others nothing
+            uint32_t seen = *rec_next;
+            for (;;) {
+                if ((uint64_t)seen + headers > rec_room) { status = GHIP_GZ_EFASTA; break; }   // the host parser has no such limit
+                const uint32_t was = atomicCAS(rec_next, seen, seen + headers);
+                if (was == seen) { rec_off = seen; break; }
+                seen = was;
+            }
         }
         job->status = status;
         job->stream_len = (uint32_t)stream_len;

@@ -25,7 +25,8 @@ constexpr size_t GZ_MAX_READERS = 12;   // (read() of ~1.5 MB files from the pag
 constexpr size_t GZ_BATCH_FILES = 4096;          // one wavefront each: 16 per CU x 256 CUs
 constexpr uint64_t GZ_BATCH_TEXT = 24ull << 30;  // bytes of text per batch: 4 096 genomes of 5 Mb (a batch the pool has no room for is halved)
 constexpr size_t GZ_SPLIT_MIN = 64;              // ... down to this many files, below which the host takes them
-constexpr uint32_t GZ_REC_EXTRA = 1u << 20;      // record-table entries of a batch beyond one per file
+constexpr uint64_t GZ_REC_PER_TEXT = 128;        // the record pool of a batch: one entry per file and one per this many bytes of its texts (a fragmented
+                                                 // assembly has a contig per few kb; a file whose records do not fit is the host's) -- 3 % of the texts' memory
 
 struct Unit { size_t first, last; uint64_t in_off, bytes; };   // jobs [first, last): their images lie together at in_off
 
@@ -99,6 +100,7 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
         if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; (void)hipGetLastError(); ctx->gz_host_files += take.size(); return GHIP_OK; }
 
     // ---- batches: runs [lo, hi) of `take`, laid out when their turn comes (a run the pool has no room for is halved)
+    const bool small_pool = ctx->opt.fault_stage == GHIP_FAULT_GZ_SMALL_BATCHES;   // (tests: a record pool that a file of many short records outgrows)
     auto lay_out = [&](size_t lo, size_t hi) {
         Batch b;
         for (size_t t = lo; t < hi; t++) {
@@ -126,7 +128,7 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
             b.units.push_back(u);
             f = u.last;
         }
-        b.rec_room = (uint32_t)b.jobs.size() + GZ_REC_EXTRA;
+        b.rec_room = (uint32_t)std::min<uint64_t>(b.jobs.size() + b.text_bytes / (small_pool ? 4096 : GZ_REC_PER_TEXT), 0x3fffffffull);
         return b;
     };
     const bool small = ctx->opt.fault_stage == GHIP_FAULT_GZ_SMALL_BATCHES;   // (tests: several batches in flight, runs that find no room)
@@ -150,11 +152,11 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
 
     auto stage = [&](Batch &b) {
         const size_t nj = b.jobs.size(), jobs_bytes = nj * sizeof(ghip_gz_job), rec_bytes = (4 + (size_t)b.rec_room) * sizeof(uint32_t);
-        // the pinned landing place of the results
-        if (ctx->gz_results_bytes[b.side] < jobs_bytes + rec_bytes) {
+        // the pinned landing place of the job table and the record pool's head (the pool's used part follows in finish())
+        if (ctx->gz_results_bytes[b.side] < jobs_bytes + 16) {
             if (ctx->gz_results[b.side]) hipHostFree(ctx->gz_results[b.side]);
             ctx->gz_results[b.side] = nullptr; ctx->gz_results_bytes[b.side] = 0;
-            const size_t want = GZ_BATCH_FILES * sizeof(ghip_gz_job) + (4 + GZ_BATCH_FILES + (size_t)GZ_REC_EXTRA) * sizeof(uint32_t);
+            const size_t want = std::max(jobs_bytes, GZ_BATCH_FILES * sizeof(ghip_gz_job)) + 16;
             if (hipHostMalloc((void **)&ctx->gz_results[b.side], want, hipHostMallocDefault) == hipSuccess) ctx->gz_results_bytes[b.side] = want;
             else { ctx->gz_results[b.side] = nullptr; (void)hipGetLastError(); return; }
         }
@@ -215,7 +217,7 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
                                  g->d_valid);
             ok = hipGetLastError() == hipSuccess && hipEventRecord(ev_end, ks) == hipSuccess &&
                  hipMemcpyAsync(res, b.d_jobs, jobs_bytes, hipMemcpyDeviceToHost, ks) == hipSuccess &&
-                 hipMemcpyAsync(res + jobs_bytes, b.d_rec, rec_bytes, hipMemcpyDeviceToHost, ks) == hipSuccess && hipEventRecord(ev_landed, ks) == hipSuccess;
+                 hipMemcpyAsync(res + jobs_bytes, b.d_rec, 16, hipMemcpyDeviceToHost, ks) == hipSuccess && hipEventRecord(ev_landed, ks) == hipSuccess;
         }
         if (!ok) { (void)hipGetLastError(); hip_failed = 1; hipStreamSynchronize(ks); free_batch(ctx, b); return; }
         b.launched = true;
@@ -228,13 +230,28 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
         if (hipEventElapsedTime(&ms, ctx->gz_ev[3 * b.side], ctx->gz_ev[3 * b.side + 1]) == hipSuccess) ctx->gz_device_us += (uint64_t)(ms * 1000.0f);
         const size_t nj = b.jobs.size();
         const ghip_gz_job *jobs = reinterpret_cast<const ghip_gz_job *>(ctx->gz_results[b.side]);
-        const uint32_t *rec = reinterpret_cast<const uint32_t *>(ctx->gz_results[b.side] + nj * sizeof(ghip_gz_job)) + 4;
+        // the used part of the record pool, over the stream the next batch's kernels are NOT queued on (they may be running)
+        const uint32_t rec_used = std::min(reinterpret_cast<const uint32_t *>(ctx->gz_results[b.side] + nj * sizeof(ghip_gz_job))[0], b.rec_room);
+        if (rec_used) {
+            if (ctx->gz_rec_host_bytes < (size_t)rec_used * 4) {
+                if (ctx->gz_rec_host) hipHostFree(ctx->gz_rec_host);
+                ctx->gz_rec_host = nullptr; ctx->gz_rec_host_bytes = 0;
+                const size_t want = std::max<size_t>((size_t)rec_used * 4 * 2, 4u << 20);
+                if (hipHostMalloc((void **)&ctx->gz_rec_host, want, hipHostMallocDefault) == hipSuccess) ctx->gz_rec_host_bytes = want;
+                else { ctx->gz_rec_host = nullptr; (void)hipGetLastError(); }
+            }
+            hipStream_t rs = ctx->n_copy_streams > 1 && ctx->copy_stream[1] ? ctx->copy_stream[1] : ks;
+            if (!ctx->gz_rec_host || hipMemcpyAsync(ctx->gz_rec_host, b.d_rec + 4, (size_t)rec_used * 4, hipMemcpyDeviceToHost, rs) != hipSuccess || hipStreamSynchronize(rs) != hipSuccess) {
+                (void)hipGetLastError(); hip_failed = 1; hipStreamSynchronize(ks); free_batch(ctx, b); return;
+            }
+        }
+        const uint32_t *rec = reinterpret_cast<const uint32_t *>(ctx->gz_rec_host);
         std::vector<uint64_t> lengths;
         for (size_t j = 0; j < nj; j++) {
             const ghip_gz_job &r = jobs[j];
             verdicts[std::min<uint32_t>(r.status, 8)]++;
             diag[0] += r.text_len; diag[1] += r.tokens; diag[2] += r.matches; diag[3] += r.batches; diag[4] += r.rounds; diag[5] += r.blocks;
-            if (r.status != GHIP_GZ_OK || (uint64_t)r.rec_off + r.records > b.rec_room) { ctx->gz_host_files++; continue; }
+            if (r.status != GHIP_GZ_OK || (uint64_t)r.rec_off + r.records > rec_used) { ctx->gz_host_files++; continue; }
             const size_t i = b.files[j];
             g->lens[i] = r.stream_len;
             ghip_genome_stats &st = g->stats[i];

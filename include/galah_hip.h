@@ -79,7 +79,8 @@ enum { GHIP_DEBUG_INGEST = 1, GHIP_DEBUG_PRECLUSTER = 2, GHIP_DEBUG_COMM = 4, GH
 enum { GHIP_FAULT_NONE = 0, GHIP_FAULT_SKETCH = 1, GHIP_FAULT_PAIRS_STAGE1 = 2, GHIP_FAULT_PAIRS_STAGE2 = 3, GHIP_FAULT_INDEX_PACK = 4,
        GHIP_FAULT_ANI_ROUND = 5,
        GHIP_FAULT_GZ_SMALL_BATCHES = 6 /* not a failure: the device-side gzip path cuts its batches at 3 files (several in flight with a handful of
-                                          files); with fault_rank = 1 every run of two or more files also finds "no room" once and is halved */ };
+                                          files) and sizes their record pools for one record per 4 KiB of text; with fault_rank = 1 every run of two or
+                                          more files also finds "no room" once and is halved */ };
 typedef struct ghip_options {
     uint32_t struct_size;       /* sizeof(ghip_options) of the caller */
     uint32_t pair_form;         /* GHIP_PAIR_*: form of the pair stage (AUTO: by n and s; JOIN still declines what it cannot do) */

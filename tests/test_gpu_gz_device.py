@@ -238,12 +238,18 @@ def test_several_batches_in_flight_and_runs_that_find_no_room(ctx, tmp_path, opt
         p = tmp_path / ("g%02d.fna.gz" % i)
         p.write_bytes(_gz(_fasta_text(rng, [int(rng.integers(200, 9000)) for _ in range(int(rng.integers(1, 5)))]), int(rng.integers(1, 10))))
         paths.append(str(p))
+    crumbs = tmp_path / "g11_crumbs.fna.gz"   # 400 records of 300 bp: more than the (test-sized) record pool of its batch holds -> the host's
+    crumbs.write_bytes(_gz(_fasta_text(rng, [300] * 400), 6))
+    paths.append(str(crumbs))
     host = _ingest(ctx, opts, paths, device=False)
     for no_room in (0, 1):
         opts(fault_stage="gz_small_batches", fault_rank=no_room)
         dev = _ingest(ctx, opts, paths, device=True, threads=2)
         assert dev[0] == host[0] and dev[1] == host[1], no_room
-        assert dev[2]["gz_device_files"] == len(paths) and dev[2]["gz_host_files"] == 0, (no_room, dev[2])
+        assert dev[2]["gz_device_files"] == len(paths) - 1 and dev[2]["gz_host_files"] == 1, (no_room, dev[2])
+    opts(fault_stage="none", fault_rank=0)
+    dev = _ingest(ctx, opts, paths, device=True, threads=2)      # with the pool at its real size the crumbs are the device's too
+    assert dev[0] == host[0] and dev[1] == host[1] and dev[2]["gz_device_files"] == len(paths), dev[2]
 
 
 def test_a_genome_sized_member(ctx, tmp_path, opts):
