@@ -336,7 +336,7 @@ extern "C" int ghip_ingest_counters(ghip_ctx *ctx, uint64_t out[4]) {
     out[0] = ctx->gz_device_files.load();
     out[1] = ctx->gz_host_files.load();
     out[2] = ctx->gz_device_us.load();
-    out[3] = 0;
+    out[3] = ctx->ingest_repeats.load();
     return GHIP_OK;
 }
 

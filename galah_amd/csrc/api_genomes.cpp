@@ -504,6 +504,7 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
         if (rc != GHIP_OK || overflow) { free_genomes_locked(g); if (rc != GHIP_OK) return rc; }
         else { *out = g; return GHIP_OK; }
     }
+    ctx->ingest_repeats++;
     return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);  // overflow: exact lengths first
 }
 

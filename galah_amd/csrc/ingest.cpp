@@ -430,15 +430,36 @@ uint64_t ghip_stream_capacity_hint(const char *path) {
     }
     FILE *f = fopen(path, "rb");
     if (!f) return 0;
-    unsigned char magic[2] = {0, 0};
-    size_t got = fread(magic, 1, 2, f);
+    unsigned char head[18] = {0};
+    size_t got = fread(head, 1, 18, f);
     fseek(f, 0, SEEK_END);
     const long size = ftell(f);
     uint64_t cap = size > 0 ? (uint64_t)size : 0;
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && size >= 4) {
+    if (got >= 2 && head[0] == 0x1f && head[1] == 0x8b && size >= 4) {
         unsigned char t[4];
         fseek(f, -4, SEEK_END);
         if (fread(t, 1, 4, f) == 4) cap = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+        // BGZF (bgzip: what an indexed compressed FASTA is written with) is one gzip member per 64 KiB of text, each naming its own
+        // size in an extra field ('B' 'C', SLEN 2, BSIZE = member bytes - 1): the trailer of the LAST member alone says nothing
+        // about the file (the end-of-file marker's ISIZE is 0), and a stream that outgrows its hint sends the whole call through
+        // the two-phase form.  Walking the members -- an 18-byte read and a 4-byte read each -- gives the exact size.
+        if (got == 18 && head[2] == 8 && (head[3] & 4) && head[12] == 'B' && head[13] == 'C' && head[14] == 2 && head[15] == 0 && (head[10] | (head[11] << 8)) == 6) {
+            uint64_t total = 0;
+            long pos = 0;
+            bool ok = true;
+            while (ok && pos < size) {
+                unsigned char h[18];
+                ok = fseek(f, pos, SEEK_SET) == 0 && fread(h, 1, 18, f) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) &&
+                     (h[10] | (h[11] << 8)) == 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+                if (!ok) break;
+                const long member = (long)(h[16] | (h[17] << 8)) + 1;
+                ok = member >= 26 && pos + member <= size && fseek(f, pos + member - 4, SEEK_SET) == 0 && fread(t, 1, 4, f) == 4;
+                if (!ok) break;
+                total += (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+                pos += member;
+            }
+            if (ok && pos == size) cap = total;   // (anything else: the plain gzip guess above stands)
+        }
     }
     fclose(f);
     return cap + 1;  // a file without a final newline still gets its trailing 'N'

@@ -197,7 +197,7 @@ class Context:
         """ghip_ingest_counters: gzip files inflated on the device / left to the host's inflate, device microseconds of that path."""
         out = (C.c_uint64 * 4)()
         check(_lib.lib().ghip_ingest_counters(self._h, out), self._h)
-        return {"gz_device_files": int(out[0]), "gz_host_files": int(out[1]), "gz_device_us": int(out[2])}
+        return {"gz_device_files": int(out[0]), "gz_host_files": int(out[1]), "gz_device_us": int(out[2]), "two_phase_repeats": int(out[3])}
 
     def hash_floor_ms(self, wave_positions: int) -> float:
         """Duration of the MurmurHash3 filter instructions alone for `wave_positions` wave-level evaluations."""

@@ -178,6 +178,48 @@ def test_what_the_device_declines_goes_through_the_host(ctx, tmp_path, opts):
     assert outcome is not None
 
 
+def _bgzf(data, block=60_000):
+    """What bgzip writes: one gzip member per block of text, each with its size in a 'BC' extra field; an empty member last."""
+    out = []
+    for j in list(range(0, len(data), block)) + [len(data)]:
+        chunk = data[j:j + block] if j < len(data) else b""
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        size = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", size - 1) + body + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    return b"".join(out)
+
+
+def test_bgzf_files_are_sized_exactly(ctx, tmp_path, opts):
+    """A BGZF file (bgzip: one member per 64 KiB, the last one empty) names the size of every member in its header: the capacity
+    hint walks them, so the file no longer outgrows the trailer's ISIZE and sends the whole call through the two-phase form -- as a
+    plain concatenation of members still does.  Same streams and statistics either way, with the device path on or off (it leaves
+    multi-member files to the host)."""
+    rng = np.random.default_rng(16)
+    text = _fasta_text(rng, [150_000, 40_000, 900])
+    paths = []
+    for name, data in (("a.fna.gz", _gz(text, 6)), ("bgzf.fna.gz", _bgzf(text)), ("b.fna", text)):
+        (tmp_path / name).write_bytes(data)
+        paths.append(str(tmp_path / name))
+    cat = tmp_path / "cat.fna.gz"
+    cut = text.index(b">rec1")
+    cat.write_bytes(_gz(text[:cut], 6) + _gz(text[cut:], 6))
+    want = galah_amd.fasta_stream(paths[0])
+    for device in (0, 1):
+        opts(gz_device=device)
+        before = ctx.ingest_counters()
+        g = ctx.genomes_from_files(paths, 3)
+        after = ctx.ingest_counters()
+        assert after["two_phase_repeats"] == before["two_phase_repeats"], device
+        for i in range(3):
+            assert g.to_host(i).tobytes() == want[0].tobytes() and g.stats(i) == tuple(int(x) for x in want[1]), (device, i)
+        g.free()
+        g = ctx.genomes_from_files(paths + [str(cat)], 3)
+        assert ctx.ingest_counters()["two_phase_repeats"] == after["two_phase_repeats"] + 1, device
+        assert g.to_host(3).tobytes() == want[0].tobytes() and g.stats(3) == tuple(int(x) for x in want[1])
+        g.free()
+
+
 def test_reference_fixtures_through_the_device_path(ctx, opts, golden_sketches):
     """The reference's FASTA test data (tests/golden/fasta/*.fna.gz, as gzip wrote them) inflated on the device: the sketches of
     tests/golden/sketches.npz, the oracle's statistics."""
