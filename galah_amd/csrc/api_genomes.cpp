@@ -180,6 +180,7 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
         std::atomic<size_t> next{0};
         std::atomic<int> status{GHIP_OK};
         std::atomic<bool> over{false};
+        std::vector<uint8_t> outgrown(n, 0);   // files whose stream is longer than their hint promised (a multi-member gzip that is not BGZF)
         std::mutex emu;
         std::string err;
         struct AtomicD { std::atomic<double> v{0}; void operator+=(double d) { double o = v.load(); while (!v.compare_exchange_weak(o, o + d)) {} } double load() const { return v.load(); } };
@@ -379,7 +380,7 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
                     r = ghip_parse_fasta(raw.data(), raw.size(), paths[i], stream_buf, (size_t)cap[i], &len, g->stats[i], e);
                     t2 = std::chrono::steady_clock::now();
                     if (r != GHIP_OK) { fail(r, e); stop = true; }
-                    else if (len > cap[i]) { over = true; stop = true; }  // capacity hint too small (multi-member gzip): two-phase form
+                    else if (len > cap[i]) { over = true; outgrown[i] = 1; }  // capacity hint too small (multi-member gzip): this file is placed afterwards (below)
                     else {
                         g->lens[i] = len;
                         hipError_t ce = hipSuccess;
@@ -476,7 +477,7 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
                 return false;
             };
             for (;;) {
-                if (status.load() != GHIP_OK || over.load()) break;
+                if (status.load() != GHIP_OK) break;
                 const size_t u = next.fetch_add(1);
                 if (u >= units.size()) break;
                 const size_t first = units[u].first, last = units[u].second;
@@ -493,6 +494,65 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
         overflow = over.load();
         rc = status.load();
         if (rc != GHIP_OK) ghip_set_error(ctx, rc, err);
+        if (rc == GHIP_OK && overflow) {
+            // Some streams outgrew their places.  Only THOSE files are read again (exact lengths first, as the two-phase form does
+            // for every file); the genomes already resident move into a layout made with the exact lengths by device-to-device
+            // copies of whole 64-base groups -- not, as until round 5, the whole call repeated through host vectors (one
+            // concatenated gzip among 10 000 genomes: 50 GB of them).
+            ctx->ingest_repeats++;
+            std::vector<size_t> again;
+            for (size_t i = 0; i < n; i++) if (outgrown[i]) again.push_back(i);
+            std::vector<const char *> again_paths;
+            for (size_t i : again) again_paths.push_back(paths[i]);
+            std::vector<std::vector<uint8_t>> streams;
+            std::vector<ghip_genome_stats> again_stats;
+            std::string e2;
+            rc = ghip_read_fasta_streams(again_paths.data(), again.size(), threads, streams, again_stats, e2);
+            if (rc != GHIP_OK) ghip_set_error(ctx, rc, e2);
+            uint32_t *old_packed = g->d_packed, *old_valid = g->d_valid;
+            std::vector<uint64_t> old_starts = g->starts;
+            if (rc == GHIP_OK) {
+                for (size_t x = 0; x < again.size(); x++) { g->lens[again[x]] = streams[x].size(); g->stats[again[x]] = again_stats[x]; }
+                uint64_t off = 0;
+                for (size_t i = 0; i < n; i++) { g->starts[i] = off; off = next_genome_offset(off, g->lens[i]); }
+                g->total_alloc = off + 256;
+                g->d_packed = nullptr; g->d_valid = nullptr;
+                rc = alloc_bases(ctx, g, fill_stream);
+            }
+            uint64_t *d_runs = nullptr;
+            if (rc == GHIP_OK) {
+                std::vector<uint64_t> runs;   // (source word, destination word, words) of the packed array; the validity bitmap's are half of each
+                for (size_t i = 0; i < n; i++) {
+                    if (outgrown[i] || g->lens[i] == 0) continue;
+                    const uint64_t groups = (g->lens[i] + 63) / 64;
+                    runs.push_back(old_starts[i] / 16); runs.push_back(g->starts[i] / 16); runs.push_back(groups * 4);
+                }
+                const size_t n_runs = runs.size() / 3;
+                for (size_t x = 0; x < 3 * n_runs; x++) runs.push_back(runs[x] / 2);
+                if (n_runs && (rc = dmalloc(ctx, &d_runs, runs.size())) == GHIP_OK && (rc = h2d_on(ctx, fill_stream, d_runs, runs.data(), runs.size())) == GHIP_OK) {
+                    ghip_launch_copy_runs(fill_stream, old_packed, g->d_packed, d_runs, n_runs);
+                    ghip_launch_copy_runs(fill_stream, old_valid, g->d_valid, d_runs + 3 * n_runs, n_runs);
+                    if (hipGetLastError() != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "ingest re-layout failed");
+                }
+            }
+            if (rc == GHIP_OK) {   // the outgrown files into their new places (upload_streams: through one staging buffer)
+                uint64_t longest = 0;
+                for (auto &s : streams) longest = std::max<uint64_t>(longest, s.size());
+                uint8_t *d_stage = nullptr;
+                if (longest && (rc = dmalloc(ctx, &d_stage, longest + 64)) == GHIP_OK) {
+                    for (size_t x = 0; x < again.size() && rc == GHIP_OK; x++) {
+                        if (streams[x].empty()) continue;
+                        if (hipMemcpyAsync(d_stage, streams[x].data(), streams[x].size(), hipMemcpyHostToDevice, fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "base upload failed");
+                        else ghip_launch_pack_bases(fill_stream, d_stage, streams[x].size(), g->starts[again[x]], g->d_packed, g->d_valid);
+                    }
+                }
+                if (hipStreamSynchronize(fill_stream) != hipSuccess || hipGetLastError() != hipSuccess) { if (rc == GHIP_OK) rc = ghip_set_error(ctx, GHIP_EHIP, "ingest re-layout failed"); }
+                ghip_pool_free(ctx, d_stage);
+            } else hipStreamSynchronize(fill_stream);
+            ghip_pool_free(ctx, d_runs);
+            if (old_packed != g->d_packed) { ghip_pool_free(ctx, old_packed); ghip_pool_free(ctx, old_valid); }
+            overflow = false;
+        }
         if (rc == GHIP_OK && !overflow) {
             g->total_bases = 0;
             for (uint64_t l : g->lens) g->total_bases += l;
@@ -504,8 +564,7 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
         if (rc != GHIP_OK || overflow) { free_genomes_locked(g); if (rc != GHIP_OK) return rc; }
         else { *out = g; return GHIP_OK; }
     }
-    ctx->ingest_repeats++;
-    return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);  // overflow: exact lengths first
+    return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);  // (not reached any more: outgrown files are placed above)
 }
 
 extern "C" int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32_t members, uint64_t first,

@@ -122,8 +122,8 @@ int ghip_set_options(ghip_ctx *ctx /* NULL: the process-wide defaults */, const 
 
 /* What the file ingest of this context has done so far: out[0] = gzip files inflated on the device, out[1] = gzip files
  * offered to the device path that went through the host's inflate instead, out[2] = microseconds of device time of the
- * device path's launches (HIP events), out[3] = calls whose streams outgrew a capacity hint (a multi-member gzip that is not
- * BGZF) and were repeated in the two-phase form. */
+ * device path's launches (HIP events), out[3] = calls in which a stream outgrew its capacity hint (a multi-member gzip that is
+ * not BGZF): those files were read a second time and the resident genomes moved into a layout of exact lengths. */
 int ghip_ingest_counters(ghip_ctx *ctx, uint64_t out[4]);
 
 /* Per-kernel HIP-event timing (recorded on the launch stream).  Kernel names:

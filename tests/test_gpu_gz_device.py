@@ -192,8 +192,8 @@ def _bgzf(data, block=60_000):
 
 def test_bgzf_files_are_sized_exactly(ctx, tmp_path, opts):
     """A BGZF file (bgzip: one member per 64 KiB, the last one empty) names the size of every member in its header: the capacity
-    hint walks them, so the file no longer outgrows the trailer's ISIZE and sends the whole call through the two-phase form -- as a
-    plain concatenation of members still does.  Same streams and statistics either way, with the device path on or off (it leaves
+    hint walks them, so the file no longer outgrows the trailer's ISIZE -- as a plain concatenation of members still does (that file
+    is then read a second time and the genomes already resident move into a layout of exact lengths: counted).  Same streams and statistics either way, with the device path on or off (it leaves
     multi-member files to the host)."""
     rng = np.random.default_rng(16)
     text = _fasta_text(rng, [150_000, 40_000, 900])
