@@ -14,13 +14,13 @@
 //     v_readlane per dword).  Every scalar instruction is a whole issue slot of the wavefront, so the chain only looks the
 //     codes up and passes over them: the table entries and the stream's bits behind each code go to the lanes;
 //   * the decode tables (10-bit litlen + 8-bit distance primaries with sub-tables, 7 KiB) live in LDS and are built by the
-//     64 lanes together; 8 KiB of LDS per wavefront = 16 wavefronts per CU;
+//     64 lanes together; with the copy stage 9.9 KiB of LDS per wavefront = 16 wavefronts per CU;
 //   * the LZ77 copies are the data-parallel half: 64 tokens at a time, one per lane, which finishes the decoding (base +
-//     extra bits), finds its place by a wave prefix sum and writes its literal or copies its match.  A match whose source
-//     lies in front of the batch's unfinished part goes at once; the others wait for the round in which their source is
-//     complete (a match can name bytes of the same batch) -- multi-round resolution, at least one token per round, two
-//     rounds on average for a genome.  History is read back from the text in HBM (L2), not kept in LDS: 32 KiB of window
-//     per wavefront would leave 4 wavefronts per CU.
+//     extra bits), finds its place by a wave prefix sum and writes its literal or copies its match.  A match can name bytes
+//     of its own batch: it waits for exactly the tokens that write its source (a mask of lanes), in rounds -- two on average
+//     for a gzip -6 genome, five at gzip -1 -- and the rounds do not go through memory: the batch's bytes are also kept in a
+//     2 KiB stage in LDS, so only sources older than the batch are read from the text (HBM / L2: a 32 KiB window per
+//     wavefront in LDS would leave 4 wavefronts per CU), once, and those bytes were stored a whole decode phase ago.
 // Anything this path does not take -- further members, FHCRC, an incomplete code, a text that does not start with '>' ... --
 // sets a status and the host path (ingest.cpp) ingests that file instead and alone decides what is an error.
 //
@@ -75,11 +75,13 @@ template <int T> __device__ __forceinline__ uint32_t symbol_entry(uint32_t sym, 
     return entry(K_BASE, nbits, 1 + ((2 + (sym & 1)) << e), e);
 }
 
+constexpr uint32_t STAGE_BYTES = 2048;   // (a token writes at most 258 bytes; a batch of a genome ~300)
 struct InflateLds {
     uint32_t ll[LL_ROOM];
     uint32_t dt[D_ROOM];                 // (the precode's 128 entries live here while the code lengths are read)
     uint32_t count[16], first[16], offs[16];
     uint32_t sub_next, err;
+    uint8_t stage[STAGE_BYTES];          // the bytes of the token group being written (emit_tokens): a source inside the group is read here
     uint16_t sorted[LL_SYMS];            // symbols by (code length, symbol)
     uint8_t lens[LL_SYMS + D_SYMS + 32]; // code lengths: litlen, distance, precode
 };
@@ -205,25 +207,38 @@ __device__ __forceinline__ uint32_t rd_byte_pos(const Reader &r) { return r.wpos
 typedef uint64_t __attribute__((aligned(1))) u64_any;   // global loads / stores at any byte address (one instruction on gfx9+)
 typedef uint32_t __attribute__((aligned(1))) u32_any;
 
-// text[p, p + len) = the len bytes that start dist in front of p, LZ77's way (a distance shorter than the length repeats)
-__device__ __forceinline__ void copy_match(uint8_t *text, uint32_t p, uint32_t len, uint32_t dist) {
-    uint8_t *d = text + p;
+// text[p, p + len) = the len bytes that start dist in front of p, LZ77's way (a distance shorter than the length repeats) --
+// and the same bytes into the group's stage (stage[0] = text[group0]), where the later tokens of the group find them.  A
+// source older than the group comes from the text in whole words; one that reaches into the group (or repeats) byte by byte,
+// each byte from where it lives: the text in front of group0, the stage from there on.
+__device__ __forceinline__ void stage_word(uint8_t *at, uint64_t v, uint32_t n) {
+    for (uint32_t k = 0; k < n; k++) at[k] = (uint8_t)(v >> (8 * k));
+}
+__device__ __forceinline__ void copy_match(uint8_t *text, uint8_t *stage, uint32_t group0, uint32_t p, uint32_t len, uint32_t dist) {
+    uint8_t *d = text + p, *g = stage + (p - group0);
     const uint8_t *s = d - dist;
-    if (dist >= len) {   // source and destination apart: whole words, the last one overlapping the one before
+    if (dist >= len && p - dist + len <= group0) {   // apart, and older than the group: whole words, the last one overlapping the one before
         if (len >= 8) {
-            for (uint32_t i = 0; i + 8 <= len; i += 8) *(u64_any *)(d + i) = *(const u64_any *)(s + i);
-            if (len & 7u) *(u64_any *)(d + len - 8) = *(const u64_any *)(s + len - 8);
+            for (uint32_t i = 0; i + 8 <= len; i += 8) { const uint64_t v = *(const u64_any *)(s + i); *(u64_any *)(d + i) = v; stage_word(g + i, v, 8); }
+            if (len & 7u) { const uint64_t v = *(const u64_any *)(s + len - 8); *(u64_any *)(d + len - 8) = v; stage_word(g + len - 8, v, 8); }
         } else if (len >= 4) {
             const uint32_t a = *(const u32_any *)s, b = *(const u32_any *)(s + len - 4);
             *(u32_any *)d = a;
             *(u32_any *)(d + len - 4) = b;
+            stage_word(g, a, 4);
+            stage_word(g + len - 4, b, 4);
         } else {
             const uint8_t a = s[0], b = s[1], c = s[2];   // len == 3
             d[0] = a; d[1] = b; d[2] = c;
+            g[0] = a; g[1] = b; g[2] = c;
         }
-    } else {             // periodic: every byte comes from the dist bytes in front of p
+    } else {
+        const uint32_t src = p - dist;
         for (uint32_t i = 0, j = 0; i < len; i++) {
-            d[i] = s[j];
+            const uint32_t from = src + j;
+            const uint8_t v = from < group0 ? text[from] : stage[from - group0];
+            d[i] = v;
+            g[i] = v;
             if (++j == dist) j = 0;
         }
     }
@@ -232,7 +247,7 @@ __device__ __forceinline__ void copy_match(uint8_t *text, uint32_t p, uint32_t l
 // The batch of ntok tokens written to text[pos0 ..]: lane t holds token t (tk: decode_batch).  The lanes finish what the chain
 // left undone -- lengths and distances from their base values and extra bits, the tokens' places, the checks that need them --
 // and copy.  Returns GHIP_GZ_OK and the bytes written, or what is wrong (nothing written then).
-__device__ uint32_t emit_tokens(uint8_t *text, const uint4 tk, uint32_t ntok, uint32_t pos0, uint32_t room, uint32_t lane, uint32_t &written,
+__device__ uint32_t emit_tokens(uint8_t *text, uint8_t *stage, const uint4 tk, uint32_t ntok, uint32_t pos0, uint32_t room, uint32_t lane, uint32_t &written,
                                 uint32_t &n_matches, uint32_t &n_rounds) {
     const bool active = lane < ntok;
     const bool is_match = active && (tk.x & K_BASE);
@@ -248,12 +263,11 @@ __device__ uint32_t emit_tokens(uint8_t *text, const uint4 tk, uint32_t ntok, ui
     written = 0;
     if (total > room) return GHIP_GZ_EOVERFLOW;                        // more text than the trailer promised
     if (__ballot(is_match && dist > p)) return GHIP_GZ_EDATA;          // a distance that reaches in front of the member's first byte
-    if (active && !is_match) text[p] = (uint8_t)(tk.x >> 16);
     // Which tokens of the batch a match waits for: those that write a byte of its source [src, src_end) -- positions and ends
     // grow with the lane number, so both edges of that run of tokens come from a binary search over the lanes (6 shuffles
     // each).  A source that ends in front of the batch waits for nothing.  (The first version let a match go only when its
     // source ended in front of the first unfinished match: 2.1 rounds per batch on a gzip -6 genome, but 8.8 on gzip -1,
-    // whose matches all name the most recent occurrence -- a chain through the batch.)
+    // whose matches all name the most recent occurrence -- a chain through the batch; this rule: 1.9 and 5.4.)
     const uint32_t src = p - dist, src_end = src + (len < dist ? len : dist), end = p + len;
     uint32_t lo = 0, hi1 = 0;   // tokens [0, lo) end at or in front of src; tokens [0, hi1) start in front of src_end
 #pragma unroll
@@ -267,18 +281,33 @@ __device__ uint32_t emit_tokens(uint8_t *text, const uint4 tk, uint32_t ntok, ui
         if (hi1 > lane) hi1 = lane;   // (only tokens in front of this one: its own bytes are not its source)
         wait_for = hi1 > lo ? ((1ull << hi1) - 1ull) & ~((1ull << lo) - 1ull) : 0ull;
     }
-    uint64_t done = ~__ballot(is_match);   // literals are written, lanes without a token have nothing to do
-    n_matches += (uint32_t)__popcll(~done);
-    for (uint32_t round = 0; ~done; round++) {
-        if (round == 64) return GHIP_GZ_EDATA;   // (cannot happen: the first unfinished match waits for finished tokens only -- but no loop of this kernel is left unbounded)
-        n_rounds++;
-        const bool ready = is_match && !((done >> lane) & 1ull) && !(wait_for & ~done);
-        text_sync();
-        if (ready) copy_match(text, p, len, dist);
-        done |= __ballot(ready);
+    uint64_t done = ~__ballot(active);   // lanes without a token have nothing to do
+    n_matches += (uint32_t)__popcll(__ballot(is_match));
+    // The tokens go in GROUPS of at most STAGE_BYTES of text (a genome's batch is one group), each written to the text AND to
+    // the stage in LDS: the dependency depth of a batch is what it is (5 rounds at gzip -1), but a round whose sources sit in
+    // LDS costs a wave barrier, not a drained store queue and a trip to L2.  Only the group's first step waits for the text
+    // (the stores of the group before: issued a whole decode phase ago).
+    uint32_t emitted = 0;
+    for (uint32_t group = 0; emitted < ntok; group++) {
+        if (group == 64) return GHIP_GZ_EDATA;   // (cannot happen: a group takes at least one token -- but no loop of this kernel is left unbounded)
+        const uint32_t group0 = __builtin_amdgcn_readlane(p, emitted);
+        const bool mine = active && lane >= emitted && end - group0 <= STAGE_BYTES;
+        const uint64_t members = __ballot(mine);
+        emitted += (uint32_t)__popcll(members);
+        text_sync();       // what the group before stored (a whole decode phase ago, as a rule) is in the text
+        if (mine && !is_match) { text[p] = (uint8_t)(tk.x >> 16); stage[p - group0] = (uint8_t)(tk.x >> 16); }
+        done |= members & ~__ballot(is_match);   // (the group's literals)
+        for (uint32_t round = 0; members & ~done; round++) {
+            if (round == 64) return GHIP_GZ_EDATA;   // (cannot happen: the first unfinished match waits for finished tokens only)
+            n_rounds++;
+            wave_sync();   // the stage as the round before left it
+            const bool ready = mine && is_match && !((done >> lane) & 1ull) && !(wait_for & ~done);
+            if (ready) copy_match(text, stage, group0, p, len, dist);
+            done |= __ballot(ready);
+        }
+        wave_sync();       // (the next group writes the stage afresh)
     }
-    text_sync();
-    written = total;
+    written = total;       // (no wait for these stores here: the next group's first step, or the kernel's end, sees to them)
     return GHIP_GZ_OK;
 }
 
@@ -453,7 +482,7 @@ __global__ __launch_bounds__(64) void gz_inflate_kernel(const uint8_t *__restric
             eob = how == BATCH_END_OF_BLOCK;
             if (how == BATCH_DAMAGED || rd_byte_pos(r) > in_len + 8) { status = GHIP_GZ_EDATA; break; }   // (the latter: ran off the image, zeros behind it)
             uint32_t written = 0;
-            status = emit_tokens(text, tk, ntok, pos, text_cap - pos, lane, written, n_matches, n_rounds);
+            status = emit_tokens(text, L.stage, tk, ntok, pos, text_cap - pos, lane, written, n_matches, n_rounds);
             n_tokens += ntok;
             n_batches++;
             pos += written;

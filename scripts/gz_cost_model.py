@@ -2,7 +2,7 @@
 one synthetic genome is written through zlib at several levels, ingested with ghip_options.gz_device on and GHIP_INGEST_DEBUG
 set, and the counters the inflate kernel keeps per file (tokens, matches, batches, copy rounds, deflate blocks) go into
 
-    lone wavefront:  cycles = tokens x (scalar/token x 4 + vector/token x 4 + look-ups/token x LDS) + rounds x ROUND
+    lone wavefront:  cycles = tokens x (scalar/token x 4 + vector/token x 4 + look-ups/token x LDS) + batches x FAR + rounds x ROUND
     saturated:       genomes/s = 1 024 SIMDs x clock / (tokens x scalar/token x 4)
 
 with the instruction counts of profiles/r05_gz_inflate_isa.txt (52 scalar per match, 24 per literal; 12 / 5 vector; 2 / 1
@@ -20,7 +20,9 @@ SCALAR = {"match": 52, "literal": 24}
 VECTOR = {"match": 12, "literal": 5}
 LOOKUPS = {"match": 2, "literal": 1}
 LDS_ROUND_TRIP = 80           # cycles, ds_read + wait + v_readfirstlane
-COPY_ROUND = 1.75e-6          # s: drain of the stores + round trip of the loads (1.5-2 us)
+FAR_LOADS = 0.7e-6            # s per batch: the round trip of the loads of the matches whose source is older than the batch (L2)
+COPY_ROUND = 0.15e-6          # s per round: a wave barrier and the LDS reads / writes of the group's stage (the first version of the kernel, whose
+                              # rounds went through the text: a drained store queue + a round trip of loads, ~1.75e-6)
 SIMDS = 1024
 HOST_TEXT_PER_S = 10.1e9      # libdeflate on the boxes' 16-CPU quota: 0.50 s per 1 000 x 5 Mb of 80-column FASTA (profiles/r04a_bench.json)
 
@@ -72,7 +74,7 @@ for level in levels:
     text, blocks, tokens, matches, batches, rounds = (int(x) for x in m.groups())
     literals = tokens - matches
     cyc = sum(n * (SCALAR[k] * 4 + VECTOR[k] * 4 + LOOKUPS[k] * LDS_ROUND_TRIP) for k, n in (("match", matches), ("literal", literals)))
-    decode_s, copy_s = cyc / CLOCK, rounds * COPY_ROUND
+    decode_s, copy_s = cyc / CLOCK, batches * FAR_LOADS + rounds * COPY_ROUND
     sat = SIMDS * CLOCK / (4 * (matches * SCALAR["match"] + literals * SCALAR["literal"]))
     print(f"  {level}      {int(z.group(1)) / length:.3f}     {blocks:5d}  {tokens:8d} {matches:8d} {literals:8d}   {text / tokens:5.2f}   {batches:7d}     {rounds / max(batches, 1):.2f}      |"
           f" {decode_s:.3f} + {copy_s:.3f} = {decode_s + copy_s:.3f} | {sat * text / 1e9:6.1f} ({sat * text / HOST_TEXT_PER_S:.1f}x)")
