@@ -242,6 +242,18 @@ def test_reference_fixtures_through_the_device_path(ctx, opts, golden_sketches):
     g.free()
 
 
+def test_reference_cli_expectations_with_the_device_inflate(ctx, opts):
+    """The reference's command-line expectations (tests/test_cmdline.rs:36-61, :262-352, :62-216, :1100-1125 as restated in
+    tests/test_gpu_parity.py -- its fixtures are gzip files, :612-629 is the reference's own gz test) with the files inflated on
+    the device: files in -> clusters out, through ghip_sketch_and_index_files, the same clusters and quality order."""
+    import test_gpu_parity
+    opts(gz_device=1)
+    before = ctx.ingest_counters()
+    test_gpu_parity.test_reference_cli_expectations_through_hip(ctx)
+    after = ctx.ingest_counters()
+    assert after["gz_device_files"] - before["gz_device_files"] >= 15 and after["gz_host_files"] == before["gz_host_files"], (before, after)
+
+
 def test_threshold_and_mixed_input(ctx, tmp_path, opts):
     """gz_device = N sends a gzip file to the device when the call holds N files' worth of it (a launch takes as long as its largest
     file): three of one size pass at N = 3 and not at N = 4; a fourth, ten times their size, stays with the host at N = 3 and
