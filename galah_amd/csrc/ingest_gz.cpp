@@ -25,8 +25,9 @@ constexpr size_t GZ_MAX_READERS = 12;   // (read() of ~1.5 MB files from the pag
 constexpr size_t GZ_BATCH_FILES = 4096;          // one wavefront each: 16 per CU x 256 CUs
 constexpr uint64_t GZ_BATCH_TEXT = 24ull << 30;  // bytes of text per batch: 4 096 genomes of 5 Mb (a batch the pool has no room for is halved)
 constexpr size_t GZ_SPLIT_MIN = 64;              // ... down to this many files, below which the host takes them
-constexpr uint64_t GZ_REC_PER_TEXT = 128;        // the record pool of a batch: one entry per file and one per this many bytes of its texts (a fragmented
-                                                 // assembly has a contig per few kb; a file whose records do not fit is the host's) -- 3 % of the texts' memory
+constexpr uint64_t GZ_REC_PER_TEXT = 48;         // the record pool of a batch: four entries per file and one per this many bytes of its text (a fragmented
+                                                 // assembly has a contig per few kb, a file of 30-base primers one per ~50 bytes; a file whose records do
+                                                 // not fit is the host's) -- 8 % of the texts' memory
 
 struct Unit { size_t first, last; uint64_t in_off, bytes; };   // jobs [first, last): their images lie together at in_off
 
@@ -128,7 +129,9 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
             b.units.push_back(u);
             f = u.last;
         }
-        b.rec_room = (uint32_t)std::min<uint64_t>(b.jobs.size() + b.text_bytes / (small_pool ? 4096 : GZ_REC_PER_TEXT), 0x3fffffffull);
+        uint64_t room = 0;
+        for (const ghip_gz_job &j : b.jobs) room += small_pool ? 1 + j.text_cap / 4096 : std::min<uint64_t>(j.text_cap / 2 + 1, 4 + j.text_cap / GZ_REC_PER_TEXT);
+        b.rec_room = (uint32_t)std::min<uint64_t>(room, 0x3fffffffull);
         return b;
     };
     const bool small = ctx->opt.fault_stage == GHIP_FAULT_GZ_SMALL_BATCHES;   // (tests: several batches in flight, runs that find no room)
