@@ -23,11 +23,12 @@ void ghip_ensure_dyn_lds(ghip_ctx *ctx, const void *kernel, size_t bytes) {
 
 // ------------------------------------------------------------------------------------ memory pool
 void *ghip_pool_alloc(ghip_ctx *ctx, size_t bytes) {
-    bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+    const bool exact = ghip_dbg(ctx->opt, GHIP_DEBUG_POOL_EXACT);   // (a memory checker's run: no slack behind any buffer)
+    bytes = exact ? std::max<size_t>(bytes, 1) : std::max<size_t>((bytes + 255) / 256 * 256, 256);
     std::lock_guard<std::mutex> pl(ctx->pool_mu);
     ghip_pool_block *best = nullptr;
     for (auto &b : ctx->pool)
-        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) && (!best || b.bytes < best->bytes)) best = &b;
+        if (!b.used && b.bytes >= bytes && b.bytes <= (exact ? bytes : 2 * bytes + (1u << 20)) && (!best || b.bytes < best->bytes)) best = &b;
     if (best) { best->used = true; return best->p; }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -185,10 +186,11 @@ ghip_options options_from_environment() {
     o.ani_force_general = set("GHIP_ANI_FORCE_GENERAL") ? 1 : 0;
     o.ani_tall_below = num("GHIP_ANI_TALL_BELOW", 200);
     o.debug = (set("GHIP_INGEST_DEBUG") ? GHIP_DEBUG_INGEST : 0) | (set("GHIP_PRECLUSTER_DEBUG") ? GHIP_DEBUG_PRECLUSTER : 0) |
-              (set("GHIP_COMM_DEBUG") ? GHIP_DEBUG_COMM : 0) | (set("GHIP_CLUSTER_DEBUG") ? GHIP_DEBUG_CLUSTER : 0) | (set("GHIP_ANI_DEBUG") ? GHIP_DEBUG_ANI : 0);
+              (set("GHIP_COMM_DEBUG") ? GHIP_DEBUG_COMM : 0) | (set("GHIP_CLUSTER_DEBUG") ? GHIP_DEBUG_CLUSTER : 0) | (set("GHIP_ANI_DEBUG") ? GHIP_DEBUG_ANI : 0) |
+              (set("GHIP_POOL_EXACT") ? GHIP_DEBUG_POOL_EXACT : 0);
     o.pair_debug = num("GHIP_PAIR_DEBUG", 0);
     o.probe_arranged = num("GHIP_PROBE_ARRANGED", 0);   // (likewise off until measured)
-    o.comm_timeout_ms = num("GHIP_COMM_TIMEOUT_MS", 60000);
+    o.comm_timeout_ms = num("GHIP_COMM_TIMEOUT_MS", 0);   // (no deadline unless asked for: it also bounds how late a HEALTHY peer may be, comm.cpp rccl_wait)
     o.gz_device = num("GHIP_GZ_DEVICE", 0);   // (likewise)
     o.join_fused = num("GHIP_JOIN_FUSED", 0);   // (off until a GPU run has shown it byte-identical and faster: profiles/r04*)
     return o;

@@ -101,8 +101,9 @@ static int index_alloc_seeds(ghip_ctx *ctx, ghip_ani_index *idx, const std::vect
     if ((rc = h2d_nosync(ctx, idx->d_seed_start, idx->seed_start.data(), n + 1))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_chunk_start, idx->chunk_start.data(), n + 1))) return rc;
     if ((rc = h2d_nosync(ctx, idx->d_glen, idx->glen.data(), n))) return rc;
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seg_count, 0, std::max<size_t>(n, 1) * GHIP_ANI_SEGMENTS * sizeof(uint32_t), ctx->stream));
-    GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_chunk_total, 0, std::max<uint64_t>(idx->chunk_start[n], 1) * sizeof(uint32_t), ctx->stream));
+    // (exactly what was asked of dmalloc: with no genome the arrays are one element long, not GHIP_ANI_SEGMENTS)
+    if (n) GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_seg_count, 0, n * GHIP_ANI_SEGMENTS * sizeof(uint32_t), ctx->stream));
+    if (idx->chunk_start[n]) GHIP_HIP_CHECK(ctx, hipMemsetAsync(idx->d_chunk_total, 0, idx->chunk_start[n] * sizeof(uint32_t), ctx->stream));
     return GHIP_OK;  // (the host vectors just queued for upload are only rewritten by a retry, i.e. after index_check_seeds has synchronised)
 }
 

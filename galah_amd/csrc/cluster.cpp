@@ -321,7 +321,7 @@ static int cluster_impl(size_t n, const ghip_pair *pairs, size_t n_pairs, const 
     uint32_t *om = (uint32_t *)malloc(std::max<size_t>(out_m.size(), 1) * sizeof(uint32_t));
     uint64_t *oo = (uint64_t *)malloc(out_o.size() * sizeof(uint64_t));
     if (!om || !oo) { free(om); free(oo); return GHIP_ENOMEM; }
-    memcpy(om, out_m.data(), out_m.size() * sizeof(uint32_t));
+    if (!out_m.empty()) memcpy(om, out_m.data(), out_m.size() * sizeof(uint32_t));   // (n = 0: data() may be null, which memcpy may not be given)
     memcpy(oo, out_o.data(), out_o.size() * sizeof(uint64_t));
     *out_members = om;
     *out_offsets = oo;

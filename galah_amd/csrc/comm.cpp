@@ -108,6 +108,7 @@ struct ghip_comm {
     uint32_t rank = 0, world = 1;
     Transport transport = T_SELF;
     ncclComm_t nccl = nullptr;
+    bool arriving = false;         // inside agree(): the collective under way is the one the ranks ARRIVE at (see rccl_wait)
     bool agreed_failure = false;   // the error a call is returning was agreed by every rank (agree(), exchange 1 of the pair stage): the caller must not agree on it again
     bool dead = false;   // an RCCL call failed: the communicator was aborted, every later collective returns an error at once
     LocalGroup *group = nullptr;
@@ -153,8 +154,18 @@ int rccl_failed(ghip_comm *c, const char *what, ncclResult_t r) {
 // Waits for the RCCL work just put on the context's stream WITHOUT handing the thread to hipStreamSynchronize: a peer that died,
 // or never enters the collective, would hold this rank inside it for ever (the status words cover failures BETWEEN collectives,
 // not inside one).  The stream's event is polled next to ncclCommGetAsyncError -- RCCL's own report of a broken link or a
-// remote abort -- and against a deadline (ghip_options.comm_timeout_ms).  Either way out: ncclCommAbort (which also releases
-// the kernel RCCL has on the stream), the communicator is dead, the caller gets GHIP_EPEER.
+// remote abort -- and, when the caller asked for one, against a deadline (ghip_options.comm_timeout_ms; 0, the default: none).
+// Either way out: ncclCommAbort (which also releases the kernel RCCL has on the stream), the communicator is dead, the caller
+// gets GHIP_EPEER.
+//
+// What the deadline means.  It counts from the moment THIS rank entered the collective, so it also bounds how late a healthy
+// peer may be.  Ranks are late for the status-word exchange of a phase boundary (agree()): that is where an uneven shard, a
+// cold page cache under one rank's files or a retry on one rank shows.  They are not late for the data collectives behind
+// it -- every rank has just been seen at the boundary and nothing but a few launches stands between it and the collective.
+// Hence: the data collectives get comm_timeout_ms, the boundary GHIP_COMM_ARRIVAL_FACTOR times that.  With the default of 0
+// nothing is timed: RCCL's own report and the stream's are the failure signals, and a peer that vanished without either is
+// the job launcher's to notice (torchrun and mpirun tear the job down when a rank exits).
+constexpr uint64_t GHIP_COMM_ARRIVAL_FACTOR = 10;
 int rccl_wait(ghip_comm *c, const char *what) {
     ghip_ctx *ctx = c->ctx;
     if (!c->wait_ev) {   // (a communicator made before the event could be: plain wait)
@@ -163,7 +174,7 @@ int rccl_wait(ghip_comm *c, const char *what) {
     }
     COMM_HIP(c, hipEventRecord(c->wait_ev, ctx->stream));
     const auto t0 = std::chrono::steady_clock::now();
-    const uint32_t limit_ms = ctx->opt.comm_timeout_ms;
+    const uint64_t limit_ms = (uint64_t)ctx->opt.comm_timeout_ms * (c->arriving ? GHIP_COMM_ARRIVAL_FACTOR : 1);
     auto give_up = [&](const std::string &why) {
         if (c->nccl && rccl().CommAbort) { rccl().CommAbort(c->nccl); c->nccl = nullptr; }
         c->dead = true;
@@ -183,7 +194,9 @@ int rccl_wait(ghip_comm *c, const char *what) {
                 return give_up(std::string("RCCL reports ") + rccl().GetErrorString(r != ncclSuccess ? r : async));
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (limit_ms && ms > (double)limit_ms) return give_up("no answer from the peers within " + std::to_string(limit_ms) + " ms (ghip_options.comm_timeout_ms)");
+        if (limit_ms && ms > (double)limit_ms)
+            return give_up("no answer from the peers within " + std::to_string(limit_ms) + " ms (ghip_options.comm_timeout_ms" +
+                           (c->arriving ? " x " + std::to_string(GHIP_COMM_ARRIVAL_FACTOR) + " at a phase boundary)" : ")"));
         if (ms < 2.0) std::this_thread::yield();   // a collective of this path takes 0.05-10 ms: stay close at first
         else std::this_thread::sleep_for(std::chrono::microseconds(ms < 50.0 ? 50 : 500));
     }
@@ -450,7 +463,9 @@ int agree(ghip_comm *c, int status, const char *what) {
     struct Word { int32_t status; uint32_t settings; };
     std::vector<Word> all(c->world, Word{0, 0});
     const Word mine{status, settings_word(c)};
+    c->arriving = true;
     const int rc = allgather_host(c, &mine, sizeof(mine), all.data());
+    c->arriving = false;
     if (rc) {
         if (c->transport == T_LOCAL && c->group->failed.load()) {
             c->agreed_failure = true;

@@ -74,7 +74,9 @@ int ghip_memcpy_d2d(ghip_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes
 enum { GHIP_PAIR_AUTO = 0, GHIP_PAIR_JOIN = 1, GHIP_PAIR_PROBE = 2, GHIP_PAIR_MERGE = 3 };       /* GHIP_PAIR_KERNEL=join|probe|merge */
 enum { GHIP_JOIN_HASH = 0, GHIP_JOIN_RECORDS = 1, GHIP_JOIN_REPLICATE = 2 };                     /* GHIP_JOIN_RANKS=records|replicate */
 enum { GHIP_INGEST_PACKED = 0, GHIP_INGEST_ASCII = 1, GHIP_INGEST_PAGEABLE = 2, GHIP_INGEST_TWO_PHASE = 3 };  /* GHIP_INGEST=ascii|pageable|two-phase */
-enum { GHIP_DEBUG_INGEST = 1, GHIP_DEBUG_PRECLUSTER = 2, GHIP_DEBUG_COMM = 4, GHIP_DEBUG_CLUSTER = 8, GHIP_DEBUG_ANI = 16 };  /* GHIP_*_DEBUG: host laps on stderr */
+enum { GHIP_DEBUG_INGEST = 1, GHIP_DEBUG_PRECLUSTER = 2, GHIP_DEBUG_COMM = 4, GHIP_DEBUG_CLUSTER = 8, GHIP_DEBUG_ANI = 16,  /* GHIP_*_DEBUG: host laps on stderr */
+       GHIP_DEBUG_POOL_EXACT = 32 };  /* the device-memory pool recycles a block only for a request of its own size (GHIP_POOL_EXACT): every
+                                         buffer then ends where its request did -- for memory checkers (an address sanitizer, a guard page) */
 /* where ghip_options.fault_stage makes rank fault_rank fail (tests of the multi-rank error paths; 0 = never) */
 enum { GHIP_FAULT_NONE = 0, GHIP_FAULT_SKETCH = 1, GHIP_FAULT_PAIRS_STAGE1 = 2, GHIP_FAULT_PAIRS_STAGE2 = 3, GHIP_FAULT_INDEX_PACK = 4,
        GHIP_FAULT_ANI_ROUND = 5,
@@ -109,7 +111,12 @@ typedef struct ghip_options {
                                    2..4: that many) -- fewer LDS bank conflicts.  Takes effect when a matrix's tables are built.
                                    (GHIP_PROBE_ARRANGED) */
     uint32_t comm_timeout_ms;   /* RCCL transport: how long a rank waits inside one collective for its peers before it aborts the
-                                   communicator and returns GHIP_EPEER, default 60 000; 0: for ever   (GHIP_COMM_TIMEOUT_MS) */
+                                   communicator and returns GHIP_EPEER.  0 (default): for ever -- RCCL's own error report
+                                   (ncclCommGetAsyncError) and the stream's are then the only ways out.  The time counts from this
+                                   rank's own entry, so it also bounds how late a healthy peer may be: the status-word exchange at
+                                   a phase boundary, where uneven shards show, is given 10 times the value, the data collectives
+                                   behind it (every rank was just seen) the value itself.  Choose it above the worst imbalance
+                                   the job may show between two boundaries / 10, e.g. 60 000   (GHIP_COMM_TIMEOUT_MS) */
     uint32_t gz_device;         /* N > 0: gzip input is inflated, checked (CRC-32, ISIZE), parsed and packed ON THE DEVICE, one wavefront per file
                                    (gz_inflate.hip) -- for every file named *.gz of which the call holds N files' worth (its gzip files together
                                    have at least N times its text: N files of one size, or more of mixed sizes; a launch takes as long as its

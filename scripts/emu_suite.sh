@@ -1,10 +1,22 @@
 #!/bin/bash
 # Everything of the -m gpu suite that can run under the CPU emulator (tests/emu), plus the emulation-only RCCL transport tests.
-# ~25 minutes on 8 cores.  usage: bash scripts/emu_suite.sh [output file = profiles/r05_emu_suite.txt]
+# ~25 minutes on 8 cores (about twice that under the sanitizers).
+# usage: [SAN=asan] [HIPEMU_ORDER=reverse|<seed>] bash scripts/emu_suite.sh [output file = profiles/r06_emu_suite.txt]
+#   SAN=asan      the AddressSanitizer + UBSan build of the emulated library (tests/emu/Makefile), the pool handing out blocks of
+#                 exactly the size asked for (GHIP_POOL_EXACT); every report is collected (nothing halts) and counted at the end
+#   HIPEMU_ORDER  the order in which the waves of a workgroup and the lanes of a wave take their turns (tests/emu/hipemu.cpp)
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/r05_emu_suite.txt}
+OUT=${1:-profiles/r06_emu_suite.txt}
 make -C tests/emu > /dev/null || exit 1
-export GALAH_TEST_EMU=1 HIPEMU_LIB=$PWD/tests/emu/libgalah_hip_emu.so GHIP_RCCL_LIBRARY=$PWD/tests/emu/fake_rccl/librccl.so.1
+LIBNAME=libgalah_hip_emu.so
+if [ -n "$SAN" ]; then
+  make -C tests/emu SAN=$SAN > /dev/null || exit 1
+  LIBNAME=libgalah_hip_emu_$SAN.so
+  SANLOGS=$(mktemp -d /tmp/emu_sanlogs.XXXXXX)
+  export LD_PRELOAD=$(make -s -C tests/emu asan-rt) GHIP_POOL_EXACT=1
+  export ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:log_path=$SANLOGS/san UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$SANLOGS/san
+fi
+export GALAH_TEST_EMU=1 HIPEMU_LIB=$PWD/tests/emu/$LIBNAME GHIP_RCCL_LIBRARY=$PWD/tests/emu/fake_rccl/librccl.so.1
 DESELECT=$(python3 - <<'PY'
 import sys; sys.path.insert(0, "tests")
 import test_emu
@@ -12,9 +24,15 @@ print(" ".join("--deselect " + t for t in test_emu.NOT_EMULATABLE))
 PY
 )
 {
-  echo "# $(git rev-parse --short HEAD) $(date -u +%FT%TZ)  -m gpu under tests/emu (deselected: not emulatable, tests/test_emu.py NOT_EMULATABLE)"
-  HIPEMU_THREADS=4 python3 -m pytest tests -m gpu -q -n 2 --timeout 1500 --timeout-method=thread -p no:cacheprovider -rfEsxX --tb=short --durations=25 $DESELECT 2>&1 | grep -v "^\[W\|Gloo\|amdgpu.ids"
+  echo "# $(git rev-parse --short HEAD)$(git diff --quiet HEAD -- galah_amd tests/emu || echo +uncommitted) $(date -u +%FT%TZ)  -m gpu under tests/emu, library $LIBNAME, HIPEMU_ORDER=${HIPEMU_ORDER:-forward} (deselected: not emulatable, tests/test_emu.py NOT_EMULATABLE)"
+  HIPEMU_THREADS=4 python3 -m pytest tests -m gpu -q -n 2 --timeout ${EMU_TEST_TIMEOUT:-3000} --timeout-method=thread -p no:cacheprovider -rfEsxX --tb=short --durations=25 $DESELECT 2>&1 | grep -v "^\[W\|Gloo\|amdgpu.ids"
   echo "# tests/emu/cases (the RCCL transport with thread ranks over the stand-in librccl)"
   python3 -m pytest tests/emu/cases -q -p no:cacheprovider --tb=short 2>&1 | tail -5
+  if [ -n "$SAN" ]; then
+    echo "# sanitizer reports (AddressSanitizer errors, UBSan runtime errors), by kind:"
+    cat $SANLOGS/* 2>/dev/null | grep "runtime error\|ERROR: AddressSanitizer" | sed 's/^==[0-9]*==//; s/0x[0-9a-f]*/0x../g' | sort | uniq -c | sort -rn
+    echo "# total: $(cat $SANLOGS/* 2>/dev/null | grep -c 'runtime error\|ERROR: AddressSanitizer')"
+    mkdir -p gpurun_out && cat $SANLOGS/* > /tmp/emu_san_reports_last.txt 2>/dev/null
+  fi
 } > "$OUT"
 tail -40 "$OUT"

@@ -1,7 +1,7 @@
-# Round 5's GPU work in one gpurun call (usage: bash scripts/r05_validate.sh [stage...]).  Output: gpurun_out/r05v/.
+# Round 6's GPU work in one gpurun call (usage: bash scripts/r06_validate.sh [stage...]).  Output: gpurun_out/r06v/.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05v
+O=$R/gpurun_out/r06v
 mkdir -p $O
 cd $R
 STAGES=${@:-suite}
@@ -21,7 +21,7 @@ if has gz; then
   # the device-side gzip path: its own tests and fuzzers, then 1 000 and 4 000 x 5 Mb gzip files host-inflated against device-inflated
   timeout 1200 python -m pytest tests/test_gpu_gz_device.py -m gpu -q -rfEsxX 2>&1 | tail -5 | tee $O/gz_tests.txt
   for f in "fuzz_gz.py 60 7" "fuzz_ingest.py 60 9"; do timeout 900 python tests/$f 2>&1 | tail -1; done | tee $O/gz_fuzz.txt
-  timeout 1500 python scripts/gz_device_bench.py 2>&1 | tee $O/r05_gz_device_vs_host.txt
+  timeout 1500 python scripts/gz_device_bench.py 2>&1 | tee $O/r06_gz_device_vs_host.txt
 fi
 if has bench; then
   (time timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err) 2>&1 | grep real
@@ -56,18 +56,18 @@ if has anibin; then
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$1 genomes=%d' % d['config']['genomes'], round(d['ms_per_step'],1), {k:round(v,2) for k,v in d['stage_ms_per_step'].items()}, {k:round(v['avg_ms'],2) for k,v in d['kernels'].items()})"; }
-  { for SP in 1000 5000; do run overlapped $SP; GHIP_NO_OVERLAP=1 run alone $SP; run overlapped_again $SP; GHIP_NO_OVERLAP=1 run alone_again $SP; done; } | tee $O/r05_ani_bin_alone_vs_overlapped.txt
+  { for SP in 1000 5000; do run overlapped $SP; GHIP_NO_OVERLAP=1 run alone $SP; run overlapped_again $SP; GHIP_NO_OVERLAP=1 run alone_again $SP; done; } | tee $O/r06_ani_bin_alone_vs_overlapped.txt
 fi
 if has prof; then
   cd /tmp
   for J in ${PROF_FORMS:-0 1}; do
     GHIP_JOIN_FUSED=$J timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace$J -o t -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/trace$J.err
-    find $O/trace$J -name "*kernel_stats.csv" -exec cp {} $O/r05_bench_kernel_stats_join_fused$J.csv \;
+    find $O/trace$J -name "*kernel_stats.csv" -exec cp {} $O/r06_bench_kernel_stats_join_fused$J.csv \;
     rm -rf $O/trace$J
   done
   cd $R
-  GHIP_PROBE_ARRANGED=0 timeout 900 bash scripts/pair_probe_pmc.sh r05_free > $O/probe_pmc_free.txt 2>&1
-  GHIP_PROBE_ARRANGED=1 timeout 900 bash scripts/pair_probe_pmc.sh r05_arranged > $O/probe_pmc_arranged.txt 2>&1
-  cp gpurun_out/pmc_r05_free/r05_free_pair_probe_pmc.json gpurun_out/pmc_r05_arranged/r05_arranged_pair_probe_pmc.json $O/ 2>/dev/null
-  head -14 $O/r05_bench_kernel_stats_join_fused0.csv | cut -c1-90,200-300
+  GHIP_PROBE_ARRANGED=0 timeout 900 bash scripts/pair_probe_pmc.sh r06_free > $O/probe_pmc_free.txt 2>&1
+  GHIP_PROBE_ARRANGED=1 timeout 900 bash scripts/pair_probe_pmc.sh r06_arranged > $O/probe_pmc_arranged.txt 2>&1
+  cp gpurun_out/pmc_r06_free/r06_free_pair_probe_pmc.json gpurun_out/pmc_r06_arranged/r06_arranged_pair_probe_pmc.json $O/ 2>/dev/null
+  head -14 $O/r06_bench_kernel_stats_join_fused0.csv | cut -c1-90,200-300
 fi

@@ -152,6 +152,38 @@ def test_a_peer_that_never_enters_the_collective_costs_a_deadline_not_a_hang():
         assert "aborted" in second and dt2 < 0.1, (second, dt2)
 
 
+def test_no_deadline_by_default_and_a_late_healthy_peer_is_waited_for_at_a_phase_boundary():
+    """the deadline counts from a rank's own entry, so it must not end a job whose peer is merely late.  The default
+    is no deadline; with one set, the status-word exchange of a phase boundary (ghip_comm_agree: where uneven shards show)
+    gets ten times the value, a data collective behind it the value itself."""
+    world = 2
+    assert galah_amd.get_options()["comm_timeout_ms"] == 0
+
+    def body(r, ctx, comm):
+        assert ctx.options()["comm_timeout_ms"] == 0
+        ctx.set_options(comm_timeout_ms=150)
+        comm.allgather_host(np.int64([r]))
+        if r == 1:
+            time.sleep(0.6)                    # four deadlines late for the boundary: healthy, just slow
+        t0 = time.time()
+        comm.agree(0)
+        dt = time.time() - t0
+        if r == 1:
+            time.sleep(0.6)                    # ... and as late for a data collective: that one is not waited for
+        try:
+            comm.allgather_host(np.int64([r]))
+            second = "no error"
+        except galah_amd.GalahHipError as e:
+            second = str(e)
+        return dt, second
+
+    outs = _ranks(world, body)
+    for o in outs:
+        assert not isinstance(o, BaseException), o
+    assert outs[0][0] > 0.4, outs            # rank 0 waited for its peer at the boundary, past comm_timeout_ms
+    assert outs[0][1].startswith("GHIP_EPEER") and "comm_timeout_ms)" in outs[0][1], outs[0]
+
+
 def test_rccl_reports_the_remote_failure_before_the_deadline():
     """With RCCL itself noticing the dead peer (ncclCommGetAsyncError -> ncclRemoteError), the wait ends long before a 20 s
     deadline."""

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(ROOT, "galah_amd", "csrc")
-OUT = os.path.join(ROOT, "tests", "emu", "build", "src")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "src")   # (next to this script: a copy of tests/emu elsewhere under tests/ builds on its own)
 
 DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?unsigned char\s+(\w+)\[\];")
 

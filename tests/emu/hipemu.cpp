@@ -18,6 +18,16 @@
 
 #include <sys/mman.h>
 
+// The sanitizer builds (make SAN=asan: AddressSanitizer + UBSan): device buffers are heap blocks here, so a store past the
+// end of one is a report instead of silent corruption of its neighbour; the fibre switches are announced to the runtime.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -84,8 +94,17 @@ struct Worker {   // per OS thread
     size_t lds_cap = 0;
     Launch *cur = nullptr;
     uint32_t cur_thread = 0;
+#ifdef HIPEMU_ASAN
+    std::vector<void *> fake;           // each fibre's fake-stack handle while it is switched out
+    void *sched_fake = nullptr;
+    const void *sched_bottom = nullptr; // the OS thread's own stack, as the runtime reports it at the first switch
+    size_t sched_size = 0;
+#endif
     ~Worker() {
         if (stack_map) munmap(stack_map, stack_map_bytes);
+#ifdef HIPEMU_ASAN
+        if (lds) ASAN_UNPOISON_MEMORY_REGION(lds, lds_cap);
+#endif
         free(lds);
     }
 };
@@ -115,9 +134,15 @@ size_t env_size(const char *name, size_t dflt) {
 
 void fiber_entry() {
     Worker *w = static_cast<Worker *>(cur()->worker);
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &w->sched_bottom, &w->sched_size);   // first time on this stack
+#endif
     w->cur->body();
     w = static_cast<Worker *>(cur()->worker);
     w->st[w->cur_thread] = DONE;
+#ifdef HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, w->sched_bottom, w->sched_size);   // nullptr: this fibre does not come back
+#endif
     hipemu_switch(&w->sp[w->cur_thread], w->sched_sp);
     __builtin_trap();
 }
@@ -126,12 +151,24 @@ inline void to_sched(ThreadCtx *c, State s) {
     Worker *w = static_cast<Worker *>(c->worker);
     const uint32_t t = c->flat;
     w->st[t] = s;
+#ifdef HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(&w->fake[t], w->sched_bottom, w->sched_size);
+#endif
     hipemu_switch(&w->sp[t], w->sched_sp);
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(w->fake[t], nullptr, nullptr);
+#endif
 }
 
 inline void run_fiber(Worker *w, uint32_t t) {
     w->cur_thread = t;
+#ifdef HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(&w->sched_fake, w->stacks + (size_t)t * STACK_BYTES, STACK_BYTES);
+#endif
     hipemu_switch(&w->sched_sp, w->sp[t]);
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(w->sched_fake, nullptr, nullptr);
+#endif
 }
 
 // the lanes of wave [lo, hi) that wait in a cross-lane operation: the group at the lowest site exchanges and becomes READY
@@ -201,12 +238,19 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         w->n_stacks = n;
     }
     if (w->ctx.size() < n) { w->ctx.resize(n); w->st.resize(n); w->sp.resize(n); }
+#ifdef HIPEMU_ASAN
+    if (w->fake.size() < n) w->fake.resize(n);
+    if (w->lds) ASAN_UNPOISON_MEMORY_REGION(w->lds, w->lds_cap);
+#endif
     if (w->lds_cap < L->lds + 64) {
         free(w->lds);
         w->lds_cap = L->lds + 64;
         if (posix_memalign((void **)&w->lds, 256, w->lds_cap)) abort();
     }
     memset(w->lds, 0xCD, w->lds_cap);   // LDS holds whatever the previous workgroup left: nothing may rely on zeros
+#ifdef HIPEMU_ASAN
+    ASAN_POISON_MEMORY_REGION(w->lds + L->lds, w->lds_cap - L->lds);   // dynamic LDS ends where the launch said it does
+#endif
     w->cur = L;
     dim3 bid;
     bid.x = (uint32_t)(b % L->grid.x);
@@ -229,6 +273,11 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         top[-2] = (uint64_t)&fiber_entry;     // `ret` of the first switch lands here with rsp = top - 8
         for (int i = 3; i <= 8; i++) top[-i] = 0;
         w->sp[t] = top - 8;
+#ifdef HIPEMU_ASAN
+        // the previous fibre on this stack left through fiber_entry's frame without returning: its redzones are still marked
+        ASAN_UNPOISON_MEMORY_REGION((char *)top - 16384, 16384);
+        w->fake[t] = nullptr;
+#endif
     }
     // HIPEMU_ORDER: the order waves of a workgroup (and lanes of a wave) take their turns in between two meeting points --
     // "forward" (default), "reverse", or a seed for a fresh random order at every turn.  Any order is a schedule the hardware
