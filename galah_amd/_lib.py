@@ -32,6 +32,7 @@ _vp, _sz, _u32, _u64, _f32, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint6
 _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "ghip_abi_version": (_int, []),
+    "ghip_ani_definition_version": (C.c_uint32, []),
     "ghip_get_options": (_int, [_vp, _vp]),
     "ghip_set_options": (_int, [_vp, _vp]),
     "ghip_device_count": (_int, []),

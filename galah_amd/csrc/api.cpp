@@ -104,6 +104,7 @@ void ghip_ctx_release(ghip_ctx *ctx) {  // called with ctx->mu NOT held
     for (uint8_t *p : ctx->gz_results) if (p) hipHostFree(p);
     if (ctx->gz_rec_host) hipHostFree(ctx->gz_rec_host);
     for (hipEvent_t e : ctx->gz_ev) if (e) hipEventDestroy(e);
+    if (ctx->gz_stream) hipStreamDestroy(ctx->gz_stream);
     if (ctx->pin_buf) hipHostFree(ctx->pin_buf);
     if (ctx->ingest_stage) hipFree(ctx->ingest_stage);
     for (hipStream_t cs : ctx->copy_stream) if (cs) hipStreamDestroy(cs);
@@ -226,7 +227,18 @@ extern "C" int ghip_set_options(ghip_ctx *ctx, const ghip_options *opt) {
     if (ctx) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         const int rc = merge_options(ctx->opt, opt);
-        return rc ? ghip_set_error(ctx, rc, "ghip_set_options: a field is out of range or struct_size is wrong") : GHIP_OK;
+        if (rc) return ghip_set_error(ctx, rc, "ghip_set_options: a field is out of range or struct_size is wrong");
+        if (ctx->opt.gz_device == 0 && !ctx->gz_slots.empty()) {
+            // the device-side gzip path is off again: its pinned memory (2 x 12 slots of 16 MiB and the result buffers) goes back
+            // to the host; no ingest is under way (this thread holds the context)
+            hipSetDevice(ctx->device);
+            for (auto &sl : ctx->gz_slots) { if (sl.ev) hipEventDestroy(sl.ev); if (sl.p) hipHostFree(sl.p); }
+            ctx->gz_slots.clear();
+            for (int x = 0; x < 2; x++) { if (ctx->gz_results[x]) hipHostFree(ctx->gz_results[x]); ctx->gz_results[x] = nullptr; ctx->gz_results_bytes[x] = 0; }
+            if (ctx->gz_rec_host) hipHostFree(ctx->gz_rec_host);
+            ctx->gz_rec_host = nullptr; ctx->gz_rec_host_bytes = 0;
+        }
+        return GHIP_OK;
     }
     (void)ghip_process_options();   // the environment first
     std::lock_guard<std::mutex> lk(g_opt_mu);

@@ -37,6 +37,8 @@ static void free_index_locked(ghip_ani_index *idx) {  // ctx->mu held
     delete idx;
 }
 
+extern "C" uint32_t ghip_ani_definition_version(void) { return GHIP_ANI_DEFINITION_VERSION; }
+
 extern "C" void ghip_ani_index_free(ghip_ani_index *idx) {
     if (!idx) return;
     ghip_ctx *ctx = idx->ctx;

@@ -502,17 +502,37 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
             ctx->ingest_repeats++;
             std::vector<size_t> again;
             for (size_t i = 0; i < n; i++) if (outgrown[i]) again.push_back(i);
-            std::vector<const char *> again_paths;
-            for (size_t i : again) again_paths.push_back(paths[i]);
-            std::vector<std::vector<uint8_t>> streams;
-            std::vector<ghip_genome_stats> again_stats;
+            // The outgrown files' texts pass through host vectors -- a group of `threads` files at a time, so that a call with
+            // many large concatenated gzips never holds all of them at once.  Their exact lengths come first (the layout needs
+            // every length); texts are kept for the upload while they fit KEEP_BYTES together, the rest is read a second time.
+            const uint64_t KEEP_BYTES = opt.fault_stage == GHIP_FAULT_GZ_SMALL_BATCHES ? 0 : 1ull << 30;   // (tests: every text is read twice)
+            const size_t group = (size_t)std::max(1, threads);
+            std::vector<std::vector<uint8_t>> kept(again.size());
+            std::vector<uint8_t> have(again.size(), 0);
             std::string e2;
-            rc = ghip_read_fasta_streams(again_paths.data(), again.size(), threads, streams, again_stats, e2);
+            auto read_group = [&](size_t lo, size_t hi, std::vector<std::vector<uint8_t>> &streams, std::vector<ghip_genome_stats> &stats) {
+                std::vector<const char *> gp;
+                for (size_t x = lo; x < hi; x++) gp.push_back(paths[again[x]]);
+                return ghip_read_fasta_streams(gp.data(), gp.size(), threads, streams, stats, e2);
+            };
+            {
+                uint64_t kept_bytes = 0;
+                for (size_t lo = 0; lo < again.size() && rc == GHIP_OK; lo += group) {
+                    const size_t hi = std::min(again.size(), lo + group);
+                    std::vector<std::vector<uint8_t>> streams;
+                    std::vector<ghip_genome_stats> stats;
+                    if ((rc = read_group(lo, hi, streams, stats)) != GHIP_OK) break;
+                    for (size_t x = lo; x < hi; x++) {
+                        g->lens[again[x]] = streams[x - lo].size();
+                        g->stats[again[x]] = stats[x - lo];
+                        if (kept_bytes + streams[x - lo].size() <= KEEP_BYTES) { kept_bytes += streams[x - lo].size(); kept[x] = std::move(streams[x - lo]); have[x] = 1; }
+                    }
+                }
+            }
             if (rc != GHIP_OK) ghip_set_error(ctx, rc, e2);
             uint32_t *old_packed = g->d_packed, *old_valid = g->d_valid;
             std::vector<uint64_t> old_starts = g->starts;
             if (rc == GHIP_OK) {
-                for (size_t x = 0; x < again.size(); x++) { g->lens[again[x]] = streams[x].size(); g->stats[again[x]] = again_stats[x]; }
                 uint64_t off = 0;
                 for (size_t i = 0; i < n; i++) { g->starts[i] = off; off = next_genome_offset(off, g->lens[i]); }
                 g->total_alloc = off + 256;
@@ -535,15 +555,29 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
                     if (hipGetLastError() != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "ingest re-layout failed");
                 }
             }
-            if (rc == GHIP_OK) {   // the outgrown files into their new places (upload_streams: through one staging buffer)
+            if (rc == GHIP_OK) {   // the outgrown files into their new places, through one staging buffer
                 uint64_t longest = 0;
-                for (auto &s : streams) longest = std::max<uint64_t>(longest, s.size());
+                for (size_t i : again) longest = std::max<uint64_t>(longest, g->lens[i]);
                 uint8_t *d_stage = nullptr;
+                auto place = [&](size_t x, const std::vector<uint8_t> &text) {
+                    if (text.empty()) return;
+                    if (text.size() != g->lens[again[x]]) { rc = ghip_set_error(ctx, GHIP_EIO, std::string(paths[again[x]]) + ": changed while it was being read"); return; }
+                    // (the staging buffer is reused: the copy before this one has been packed when the stream gets here, and the host
+                    // vector is pageable -- the runtime has taken its bytes when hipMemcpyAsync returns)
+                    if (hipMemcpyAsync(d_stage, text.data(), text.size(), hipMemcpyHostToDevice, fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "base upload failed");
+                    else ghip_launch_pack_bases(fill_stream, d_stage, text.size(), g->starts[again[x]], g->d_packed, g->d_valid);
+                };
                 if (longest && (rc = dmalloc(ctx, &d_stage, longest + 64)) == GHIP_OK) {
-                    for (size_t x = 0; x < again.size() && rc == GHIP_OK; x++) {
-                        if (streams[x].empty()) continue;
-                        if (hipMemcpyAsync(d_stage, streams[x].data(), streams[x].size(), hipMemcpyHostToDevice, fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "base upload failed");
-                        else ghip_launch_pack_bases(fill_stream, d_stage, streams[x].size(), g->starts[again[x]], g->d_packed, g->d_valid);
+                    for (size_t lo = 0; lo < again.size() && rc == GHIP_OK; lo += group) {
+                        const size_t hi = std::min(again.size(), lo + group);
+                        bool all = true;
+                        for (size_t x = lo; x < hi; x++) all = all && have[x];
+                        std::vector<std::vector<uint8_t>> streams;
+                        std::vector<ghip_genome_stats> stats;
+                        if (!all && (rc = read_group(lo, hi, streams, stats)) != GHIP_OK) { ghip_set_error(ctx, rc, e2); break; }
+                        for (size_t x = lo; x < hi && rc == GHIP_OK; x++) place(x, have[x] ? kept[x] : streams[x - lo]);
+                        // a group's re-read vectors die here: their copies must have left the host first
+                        if (!all && hipStreamSynchronize(fill_stream) != hipSuccess) rc = ghip_set_error(ctx, GHIP_EHIP, "base upload failed");
                     }
                 }
                 if (hipStreamSynchronize(fill_stream) != hipSuccess || hipGetLastError() != hipSuccess) { if (rc == GHIP_OK) rc = ghip_set_error(ctx, GHIP_EHIP, "ingest re-layout failed"); }
@@ -564,7 +598,7 @@ int ghip_genomes_from_files_impl(ghip_ctx *ctx, const char *const *paths, size_t
         if (rc != GHIP_OK || overflow) { free_genomes_locked(g); if (rc != GHIP_OK) return rc; }
         else { *out = g; return GHIP_OK; }
     }
-    return genomes_from_files_two_phase(ctx, paths, n, io_threads, out);  // (not reached any more: outgrown files are placed above)
+    return ghip_set_error(ctx, GHIP_EHIP, "ingest: a stream is still marked outgrown after the re-layout (internal error)");   // (not reached)
 }
 
 extern "C" int ghip_genomes_synthetic_range(ghip_ctx *ctx, uint64_t seed, uint32_t members, uint64_t first,

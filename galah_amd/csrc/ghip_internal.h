@@ -110,6 +110,7 @@ struct ghip_ctx {
     uint8_t *gz_rec_host = nullptr;   // pinned landing place of a batch's record table (grown on demand)
     size_t gz_rec_host_bytes = 0;
     hipEvent_t gz_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per batch in flight: kernels begin, end, results landed
+    hipStream_t gz_stream = nullptr;   // the gz kernels' own stream: the readers' copies of batch b + 1 (copy_stream[]) do not queue behind batch b's kernels
     std::atomic<uint64_t> gz_device_files{0}, gz_host_files{0}, gz_device_us{0};
     std::atomic<uint64_t> ingest_repeats{0};   // calls that outgrew a capacity hint and were repeated in the two-phase form
     std::atomic<int> live_handles{0};   // genomes / sketches / ani indexes still alive

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64) void fasta_scan_kernel(const uint8_t *__restric
         const uint64_t stream_len = (uint64_t)kept + headers;
         if (stream_len > job->stream_cap) status = GHIP_GZ_EOVERFLOW;
         else {   // a slice of the record pool -- taken only if it fits, so that a file of very many records costs the others nothing
-            uint32_t seen = *rec_next;
+            uint32_t seen = __hip_atomic_load(rec_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (other workgroups CAS it: not a plain read)
             for (;;) {
                 if ((uint64_t)seen + headers > rec_room) { status = GHIP_GZ_EFASTA; break; }   // the host parser has no such limit
                 const uint32_t was = atomicCAS(rec_next, seen, seen + headers);

@@ -4,12 +4,16 @@
 //
 //   reader threads (<= 12, the context's I/O pool)   file -> pinned slot (16 MiB, two per thread) -> hipMemcpyAsync into the
 //                                                   batch's input area, a group of consecutive files per copy
-//   one stream                                      job table up, the six launches of ghip_launch_gz_batch, job table + record
+//   one stream of its own (ctx->gz_stream)          job table up, the six launches of ghip_launch_gz_batch, job table + record
 //                                                   pool back into pinned memory, an event
 //   host, once the event has fired                  genome lengths, contig counts, ambiguous bases, N50 from the record table;
 //                                                   files with a verdict other than GHIP_GZ_OK stay with the host path
 //
-// Two batches are in flight: batch b + 1 is read and shipped while the kernels of batch b run.  Nothing here decides that a
+// Two batches are in flight: batch b + 1 is read and shipped while the kernels of batch b run -- the readers' copies go over the
+// context's copy streams, the kernels over a stream of their own, so that staging b + 1 (which waits for its copies) does not
+// wait for b's kernels.  A batch's text is bounded by a quarter of the device memory that is free when the call starts (two in
+// flight: half), so that the sketch pass of the previous batch of FILES, which allocates from the same pool on another thread
+// (ghip_sketch_and_index_files), still finds room.  Nothing here decides that a
 // file is bad: whatever the device declines is ingested by ingest.cpp's inflate + parser afterwards, which words the errors
 // (reference behaviour: needletail's reader behind src/finch.rs:69).
 #include "api_internal.h"
@@ -61,8 +65,20 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
                           int io_threads, std::vector<uint8_t> &done) {
     const bool dbg = ghip_dbg(ctx->opt, GHIP_DEBUG_INGEST);
     const auto w0 = std::chrono::steady_clock::now();
-    hipStream_t ks = ctx->copy_stream[0];
-    if (cand.empty() || !ks || ctx->n_copy_streams < 1) return GHIP_OK;
+    if (cand.empty() || !ctx->copy_stream[0] || ctx->n_copy_streams < 1) return GHIP_OK;
+    if (!ctx->gz_stream && hipStreamCreateWithFlags(&ctx->gz_stream, hipStreamNonBlocking) != hipSuccess) { ctx->gz_stream = nullptr; (void)hipGetLastError(); }
+    hipStream_t ks = ctx->gz_stream;
+    if (!ks) { ctx->gz_host_files += cand.size(); return GHIP_OK; }   // (no stream to be had: the host path takes them all)
+    // what a batch may hold: a quarter of what is free now, counting the pool's idle blocks (they are ours to reuse)
+    uint64_t batch_text = GZ_BATCH_TEXT;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t idle = 0;
+            { std::lock_guard<std::mutex> pl(ctx->pool_mu); for (auto &blk : ctx->pool) if (!blk.used) idle += blk.bytes; }
+            batch_text = std::min<uint64_t>(GZ_BATCH_TEXT, std::max<uint64_t>(((uint64_t)free_b + idle) / 4, 256ull << 20));
+        } else (void)hipGetLastError();
+    }
     // ---- what the path takes: a readable image that fits a slot, a text below 4 GiB (the trailer's ISIZE is all there is to go by)
     std::vector<std::pair<size_t, uint64_t>> take;   // (file, bytes on disk)
     for (size_t i : cand) {
@@ -142,7 +158,7 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
     for (size_t t = 0; t < take.size();) {
         size_t hi = t;
         uint64_t text = 0;
-        while (hi < take.size() && hi - t < batch_files && (hi == t || text + up(cap[take[hi].first] - 1, 64) + 64 <= GZ_BATCH_TEXT)) { text += up(cap[take[hi].first] - 1, 64) + 64; hi++; }
+        while (hi < take.size() && hi - t < batch_files && (hi == t || text + up(cap[take[hi].first] - 1, 64) + 64 <= batch_text)) { text += up(cap[take[hi].first] - 1, 64) + 64; hi++; }
         todo.push_back({t, hi});
         t = hi;
     }
@@ -243,7 +259,7 @@ int ghip_ingest_gz_device(ghip_ctx *ctx, ghip_genomes *g, const char *const *pat
                 if (hipHostMalloc((void **)&ctx->gz_rec_host, want, hipHostMallocDefault) == hipSuccess) ctx->gz_rec_host_bytes = want;
                 else { ctx->gz_rec_host = nullptr; (void)hipGetLastError(); }
             }
-            hipStream_t rs = ctx->n_copy_streams > 1 && ctx->copy_stream[1] ? ctx->copy_stream[1] : ks;
+            hipStream_t rs = ctx->copy_stream[0];
             if (!ctx->gz_rec_host || hipMemcpyAsync(ctx->gz_rec_host, b.d_rec + 4, (size_t)rec_used * 4, hipMemcpyDeviceToHost, rs) != hipSuccess || hipStreamSynchronize(rs) != hipSuccess) {
                 (void)hipGetLastError(); hip_failed = 1; hipStreamSynchronize(ks); free_batch(ctx, b); return;
             }

@@ -266,6 +266,11 @@ int ghip_sketch_and_index_files(ghip_ctx *ctx, const char *const *paths, size_t 
                                 uint64_t seed, uint32_t ani_k, uint32_t ani_c, uint32_t ani_chunk, int io_threads,
                                 uint64_t batch_bytes, ghip_sketches **out_sk, ghip_ani_index **out_idx,
                                 uint64_t *out_stats);
+/* The ANI estimator is build-defined (skani's own numbers cannot be reproduced here: INTEGRATION.md section 6), so its
+ * definition carries a version: it changes whenever ghip_ani_pairs would return another value for some input (a run's ANI
+ * values are comparable with another run's only at the same version; a persisted table of them should record it). */
+#define GHIP_ANI_DEFINITION_VERSION 5u
+uint32_t ghip_ani_definition_version(void);
 int ghip_ani_pairs(ghip_ctx *ctx, const ghip_ani_index *idx, const uint32_t *pairs /* [n][2] */,
                    size_t n, float min_aligned_fraction, float *out_ani_percent,
                    float *out_af /* nullable, [n][2] */);

@@ -106,6 +106,8 @@ def lib():
     L.go_ani_sketch_strands.argtypes = [C.c_void_p]
     L.go_ani_sketch_length.restype = C.c_uint64
     L.go_ani_sketch_length.argtypes = [C.c_void_p]
+    L.go_ani_definition_version.restype = C.c_uint32
+    L.go_ani_definition_version.argtypes = []
     L.go_ani_density.restype = C.c_uint32
     L.go_ani_density.argtypes = [C.c_uint64, C.c_uint32]
     L.go_ani_sketch_density.restype = C.c_uint32
@@ -290,6 +292,11 @@ def synth_genome(seed: int, species: int, member: int, length: int, sub_rate: fl
 
 
 # ---------------------------------------------------------------- ANI (parity unpinned)
+def ani_definition_version() -> int:
+    """GO_ANI_DEFINITION_VERSION: changes with every change of what the estimator returns (oracle/galah_oracle.h)."""
+    return int(lib().go_ani_definition_version())
+
+
 class AniSketch:
     def __init__(self, handle):
         self._h = handle

@@ -95,6 +95,12 @@ void go_synth_genome(uint64_t seed, uint32_t species, uint32_t member, uint64_t 
                      double sub_rate, uint8_t *out /* length ASCII bases */);
 
 /* ---- ANI on candidate pairs (skani-equivalent; PARITY UNPINNED, see galah_oracle_ani.c) ---- */
+/* The estimator is build-defined (no skani float exists to pin it), so the definition is VERSIONED: the number changes with
+ * every change of what go_ani_pair returns for some input, and tests/golden/ani_golden.json names the version it freezes
+ * (tests/test_oracle_golden.py::test_ani_definition_is_versioned).  5 = round 5's rule (pooled counts below 9 aligned chunks);
+ * the device's copy is GHIP_ANI_DEFINITION_VERSION (include/galah_hip.h). */
+#define GO_ANI_DEFINITION_VERSION 5
+uint32_t go_ani_definition_version(void);
 typedef struct go_ani_sketch go_ani_sketch;
 go_ani_sketch *go_ani_sketch_bytes(const uint8_t *norm, size_t n, uint32_t k, uint32_t c,
                                    uint32_t chunk);

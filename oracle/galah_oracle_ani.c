@@ -77,6 +77,7 @@
 #define GO_ANI_BAND_SHIFT 12
 #define GO_ANI_MIN_COLINEAR 3
 #define GO_ANI_POOL_BELOW 9     /* fewer aligned chunks than this are pooled instead of taking their median (scripts/ani_few_chunks.py, profiles/r05_ani_few_chunks.txt) */
+uint32_t go_ani_definition_version(void) { return GO_ANI_DEFINITION_VERSION; }
 #define GO_ANI_SEEDS_WANTED 8192   /* a genome shorter than this many seeds' worth of bases is seeded four times denser */
 
 typedef struct { uint32_t code, idx; } code_ref;

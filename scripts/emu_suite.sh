@@ -1,9 +1,11 @@
 #!/bin/bash
 # Everything of the -m gpu suite that can run under the CPU emulator (tests/emu), plus the emulation-only RCCL transport tests.
 # ~25 minutes on 8 cores (about twice that under the sanitizers).
-# usage: [SAN=asan] [HIPEMU_ORDER=reverse|<seed>] bash scripts/emu_suite.sh [output file = profiles/r06_emu_suite.txt]
+# usage: [SAN=asan|wavesan] [HIPEMU_ORDER=reverse|<seed>] bash scripts/emu_suite.sh [output file = profiles/r06_emu_suite.txt]
 #   SAN=asan      the AddressSanitizer + UBSan build of the emulated library (tests/emu/Makefile), the pool handing out blocks of
 #                 exactly the size asked for (GHIP_POOL_EXACT); every report is collected (nothing halts) and counted at the end
+#   SAN=wavesan   the kernels under the wave race detector (tests/emu/wavesan.cpp): a __syncthreads missing between two waves'
+#                 accesses, a hand-over between workgroups without release / acquire; reports symbolized and counted at the end
 #   HIPEMU_ORDER  the order in which the waves of a workgroup and the lanes of a wave take their turns (tests/emu/hipemu.cpp)
 cd "$(dirname "$0")/.."
 OUT=${1:-profiles/r06_emu_suite.txt}
@@ -13,8 +15,12 @@ if [ -n "$SAN" ]; then
   make -C tests/emu SAN=$SAN > /dev/null || exit 1
   LIBNAME=libgalah_hip_emu_$SAN.so
   SANLOGS=$(mktemp -d /tmp/emu_sanlogs.XXXXXX)
+fi
+if [ "$SAN" = asan ]; then
   export LD_PRELOAD=$(make -s -C tests/emu asan-rt) GHIP_POOL_EXACT=1
   export ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:log_path=$SANLOGS/san UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$SANLOGS/san
+elif [ "$SAN" = wavesan ]; then
+  export WAVESAN_LOG=$SANLOGS/ws
 fi
 export GALAH_TEST_EMU=1 HIPEMU_LIB=$PWD/tests/emu/$LIBNAME GHIP_RCCL_LIBRARY=$PWD/tests/emu/fake_rccl/librccl.so.1
 DESELECT=$(python3 - <<'PY'
@@ -28,7 +34,10 @@ PY
   HIPEMU_THREADS=4 python3 -m pytest tests -m gpu -q -n 2 --timeout ${EMU_TEST_TIMEOUT:-3000} --timeout-method=thread -p no:cacheprovider -rfEsxX --tb=short --durations=25 $DESELECT 2>&1 | grep -v "^\[W\|Gloo\|amdgpu.ids"
   echo "# tests/emu/cases (the RCCL transport with thread ranks over the stand-in librccl)"
   python3 -m pytest tests/emu/cases -q -p no:cacheprovider --tb=short 2>&1 | tail -5
-  if [ -n "$SAN" ]; then
+  if [ "$SAN" = wavesan ]; then
+    echo "# wave race detector: reports by source location (scripts/wavesan_symbolize.py)"
+    python3 scripts/wavesan_symbolize.py $SANLOGS/ws.* 2>/dev/null
+  elif [ -n "$SAN" ]; then
     echo "# sanitizer reports (AddressSanitizer errors, UBSan runtime errors), by kind:"
     cat $SANLOGS/* 2>/dev/null | grep "runtime error\|ERROR: AddressSanitizer" | sed 's/^==[0-9]*==//; s/0x[0-9a-f]*/0x../g' | sort | uniq -c | sort -rn
     echo "# total: $(cat $SANLOGS/* 2>/dev/null | grep -c 'runtime error\|ERROR: AddressSanitizer')"

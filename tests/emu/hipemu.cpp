@@ -15,7 +15,9 @@
 //   runtime     streams are synchronous (a valid schedule of any stream program), events are host clock readings,
 //               device memory is host memory (poisoned with 0xA5 at hipMalloc)
 #include <hip/hip_runtime.h>
+#include <hipemu_wavesan.h>
 
+#include <link.h>
 #include <sys/mman.h>
 
 // The sanitizer builds (make SAN=asan: AddressSanitizer + UBSan): device buffers are heap blocks here, so a store past the
@@ -65,17 +67,22 @@ hipemu_switch:
 
 namespace hipemu {
 
+thread_local WaveSanState wavesan_state;
+void wavesan_suppress(int delta) { wavesan_state.suppress += (uint32_t)delta; }
 
 namespace {
+std::atomic<uint32_t> g_launch_serial{0}, g_block_serial{0};
 
 enum State : uint8_t { READY, WAVE_WAIT, BARRIER, YIELDED, DONE };
 
 struct Launch {
     const char *name;
+    const void *fn = nullptr;
     dim3 grid, block;
     size_t lds;
     std::function<void()> body;
     uint64_t total;
+    uint32_t serial = 0;
     std::atomic<uint64_t> next{0}, done{0};
     int refs = 0;   // pool workers inside (under the pool's mutex)
     std::mutex extra_mu;
@@ -162,6 +169,10 @@ inline void to_sched(ThreadCtx *c, State s) {
 
 inline void run_fiber(Worker *w, uint32_t t) {
     w->cur_thread = t;
+    WaveSanState &ws = wavesan_state;
+    ws.wave = t >> 6;
+    ws.lane = t & 63;
+    ws.in_kernel = true;
 #ifdef HIPEMU_ASAN
     __sanitizer_start_switch_fiber(&w->sched_fake, w->stacks + (size_t)t * STACK_BYTES, STACK_BYTES);
 #endif
@@ -169,6 +180,7 @@ inline void run_fiber(Worker *w, uint32_t t) {
 #ifdef HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(w->sched_fake, nullptr, nullptr);
 #endif
+    ws.in_kernel = false;
 }
 
 // the lanes of wave [lo, hi) that wait in a cross-lane operation: the group at the lowest site exchanges and becomes READY
@@ -252,6 +264,38 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
     ASAN_POISON_MEMORY_REGION(w->lds + L->lds, w->lds_cap - L->lds);   // dynamic LDS ends where the launch said it does
 #endif
     w->cur = L;
+    {
+        WaveSanState &ws = wavesan_state;
+        ws.launch = L->serial;
+        ws.block = g_block_serial.fetch_add(1) + 1;
+        ws.epoch = 0;
+        ws.kernel = L->name;
+        ws.stack_lo = (uintptr_t)w->stack_map;
+        ws.stack_len = w->stack_map_bytes;
+        ws.ctx_lo = (uintptr_t)w->ctx.data();
+        ws.ctx_len = w->ctx.size() * sizeof(ThreadCtx);
+        ws.dyn_lds_lo = (uintptr_t)w->lds;
+        ws.dyn_lds_len = w->lds_cap;
+        if (!ws.static_lds_len) {   // this thread's block of the thread_local statics of the module the kernels live in
+            struct Q { const void *fn; uintptr_t lo, len; } q{(const void *)L->fn, 0, 0};
+            dl_iterate_phdr([](dl_phdr_info *info, size_t, void *qp) {
+                Q *q = (Q *)qp;
+                bool here = false;
+                uintptr_t tls_len = 0;
+                for (int i = 0; i < info->dlpi_phnum; i++) {
+                    const auto &ph = info->dlpi_phdr[i];
+                    if (ph.p_type == PT_LOAD && (uintptr_t)q->fn - (info->dlpi_addr + ph.p_vaddr) < ph.p_memsz) here = true;
+                    if (ph.p_type == PT_TLS) tls_len = ph.p_memsz;
+                }
+                if (!here) return 0;
+                q->lo = (uintptr_t)info->dlpi_tls_data;
+                q->len = q->lo ? tls_len : 0;
+                return 1;
+            }, &q);
+            ws.static_lds_lo = q.lo;
+            ws.static_lds_len = q.len ? q.len : 1;   // (1: looked, found none)
+        }
+    }
     dim3 bid;
     bid.x = (uint32_t)(b % L->grid.x);
     bid.y = (uint32_t)((b / L->grid.x) % L->grid.y);
@@ -330,6 +374,7 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         if (n_bar + n_done != n) { fprintf(stderr, "[hipemu] %s: scheduler found nothing to run\n", L->name); abort(); }
         for (uint32_t t = 0; t < n; t++)   // s_barrier counts the waves that are still alive
             if (w->st[t] == BARRIER) w->st[t] = READY;
+        wavesan_state.epoch++;
     }
     g_stats.blocks++;
 }
@@ -450,11 +495,13 @@ void launch(const char *name, const void *fn, dim3 grid, dim3 block, size_t lds,
     g_stats.launches++;
     Launch L;
     L.name = name;
+    L.fn = fn;
     L.grid = grid;
     L.block = block;
     L.lds = lds;
     L.body = std::move(body);
     L.total = total;
+    L.serial = g_launch_serial.fetch_add(1) + 1;
     const bool shared = total > 1 && !g_pool->threads.empty();
     if (shared) {
         std::lock_guard<std::mutex> lk(g_pool->mu);
@@ -585,6 +632,12 @@ hipError_t hipFree(void *p) {
         g_allocs.erase(it);
     }
     free(p);
+    return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes) {
+    const size_t limit = env_size("HIPEMU_MEM_MB", 48 * 1024) << 20, now = g_mem_now.load();
+    *total_bytes = limit;
+    *free_bytes = now < limit ? limit - now : 0;
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) {

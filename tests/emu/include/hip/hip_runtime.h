@@ -58,6 +58,7 @@ hipError_t hipDeviceCanAccessPeer(int *can, int d, int peer);
 hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
 hipError_t hipMalloc(void **p, size_t bytes);
 hipError_t hipFree(void *p);
+hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes);
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void *p);
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);

@@ -12,6 +12,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <hipemu_wavesan.h>
+
 namespace hipemu_gcn {
 
 struct Bind {   // a named operand: %[name]
@@ -117,6 +119,7 @@ struct Machine {
 
 // runs `text` with the named inputs bound; leaves the machine for the caller to read named outputs / fixed registers from
 inline void run(const char *text, const Bind *binds, int n_binds, Machine &m) {
+    hipemu::WaveSanSuppress not_the_kernels_memory;   // (the parsed program, its cache: the interpreter's own; the instructions touch registers only)
     static std::mutex mu;
     static std::unordered_map<const char *, Program *> cache;
     static thread_local const char *last_text[2] = {nullptr, nullptr};

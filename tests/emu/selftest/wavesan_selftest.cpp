@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE -- proves that the wave race detector (make SAN=wavesan, tests/emu/wavesan.cpp) reports what it is there
+// to report and nothing else: a __syncthreads missing behind a producer wave (in LDS and in global memory), a flag handed
+// between workgroups without release / acquire fences -- and stays silent on the same kernels written correctly.
+// usage: wavesan_selftest <mode>; prints the detector's counts (tests/test_emu.py::test_wave_race_detector_reports_what_it_should).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+extern "C" void hipemu_wavesan_counts(uint64_t out[4]);
+
+// wave 0 produces, wave 1 consumes
+__global__ void lds_handover(uint32_t *out, int barrier) {
+    __shared__ uint32_t buf[64];
+    if (threadIdx.x < 64) buf[threadIdx.x] = threadIdx.x * 3u;
+    if (barrier) __syncthreads();
+    if (threadIdx.x >= 64) out[blockIdx.x * 64 + threadIdx.x - 64] = buf[threadIdx.x - 64];
+}
+__global__ void global_handover(uint32_t *scratch, uint32_t *out, int barrier) {
+    uint32_t *mine = scratch + blockIdx.x * 64;
+    if (threadIdx.x < 64) mine[threadIdx.x] = threadIdx.x * 5u;
+    if (barrier) __syncthreads();
+    if (threadIdx.x >= 64) out[blockIdx.x * 64 + threadIdx.x - 64] = mine[127 - threadIdx.x];
+}
+// every wave writes its own part of LDS, atomics on a shared counter: nothing to report
+__global__ void disjoint_and_atomic(uint32_t *out) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t count;
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    part[threadIdx.x] = threadIdx.x;
+    atomicAdd(&count, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = count + part[255];
+}
+// workgroup 0 publishes a value for workgroup 1 through a flag
+__global__ void flag_handover(uint32_t *data, uint32_t *flag, uint32_t *out, int fences) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            data[0] = 42u;
+            if (fences) __threadfence();
+            atomicAdd(flag, 1u);
+        }
+    } else if (threadIdx.x == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+        if (fences) __threadfence();
+        out[0] = data[0];
+    }
+}
+
+int main(int argc, char **argv) {
+    const char *mode = argc > 1 ? argv[1] : "ok";
+    auto is = [&](const char *m) { return !strcmp(mode, m); };
+    uint32_t *a = nullptr, *b = nullptr, *f = nullptr;
+    hipMalloc((void **)&a, 4096);
+    hipMalloc((void **)&b, 4096);
+    hipMalloc((void **)&f, 64);
+    hipMemset(f, 0, 64);
+    hipLaunchKernelGGL(lds_handover, dim3(3), dim3(128), 0, nullptr, b, is("lds") ? 0 : 1);
+    hipLaunchKernelGGL(global_handover, dim3(3), dim3(128), 0, nullptr, a, b, is("global") ? 0 : 1);
+    hipLaunchKernelGGL(disjoint_and_atomic, dim3(3), dim3(256), 0, nullptr, b);
+    hipLaunchKernelGGL(flag_handover, dim3(2), dim3(64), 0, nullptr, a, f, b, is("flag") ? 0 : 1);
+    hipDeviceSynchronize();
+    uint64_t c[4];
+    hipemu_wavesan_counts(c);
+    printf("wavesan_selftest %s: write-write %llu read-write %llu inter-block %llu (accesses checked: %llu)\n", mode, (unsigned long long)c[0],
+           (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[3]);
+    return 0;
+}

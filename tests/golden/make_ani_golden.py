@@ -57,7 +57,7 @@ def build():
         as_ += s
     ask = [oracle.AniSketch.from_bytes(np.concatenate([s, np.frombuffer(b"N", dtype=np.uint8)])) for s in as_]
     anchors = {n: {"length": int(s.length), "density": int(s.density), "seeds": int(s.nseeds)} for n, s in zip(an, ask)}
-    return {"k": 15, "c": 125, "chunk": 20000, "min_aligned_fraction": MIN_AF, "source": "oracle-derived (no reference float exists)",
+    return {"definition_version": oracle.ani_definition_version(), "k": 15, "c": 125, "chunk": 20000, "min_aligned_fraction": MIN_AF, "source": "oracle-derived (no reference float exists)",
             "genomes": genomes, "genome_pairs": rows_of(GENOMES, sk), "contigs": contigs, "contig_pairs": rows_of(cn, csk),
             "anchor_contigs": anchors, "anchor_contig_pairs": rows_of(an, ask)}
 

@@ -4,7 +4,7 @@ instruction by instruction, a stand-in librccl whose ranks are threads), driven 
 (`-m gpu`), against the same oracle.  This file runs the quick ones as part of the CPU suite, each group in a child process
 (GALAH_TEST_EMU=1 makes tests/conftest.py point galah_amd at the emulated library; the product never reads that switch and
 has no CPU path of its own).  scripts/emu_suite.sh runs everything that can be emulated (~25 minutes on 8 cores); its last
-output is kept as profiles/r05_emu_suite.txt.
+output is kept as profiles/r06_emu_suite.txt (and, under the two checked builds of round 6, r06_emu_suite_asan.txt / _wavesan.txt).
 
 What a green run here says: indexing, LDS layout, barriers, cross-lane data flow, atomics protocols, launch geometry, LDS
 allowances and the host orchestration of every kernel produce the oracle's bytes.  What it cannot say: anything about time,
@@ -59,17 +59,38 @@ SLOW = [
 ]
 
 
-def emu_env():
+def emu_env(san=None, logs=None):
+    """The environment of a child process that runs GPU tests against the emulated library -- plain, or one of its checked
+    builds (tests/emu/Makefile): "asan" = AddressSanitizer + UBSan, with the device-memory pool handing out blocks of exactly
+    the size asked for; "wavesan" = the wave race detector.  Reports go to files under `logs` (nothing halts: every report of
+    a run is collected, and the caller asserts that there is none)."""
     env = dict(os.environ)
-    env.update(GALAH_TEST_EMU="1", HIPEMU_LIB=os.path.join(EMU_DIR, "libgalah_hip_emu.so"),
+    env.update(GALAH_TEST_EMU="1", HIPEMU_LIB=os.path.join(EMU_DIR, "libgalah_hip_emu%s.so" % ("_" + san if san else "")),
                GHIP_RCCL_LIBRARY=os.path.join(EMU_DIR, "fake_rccl", "librccl.so.1"))
+    if san == "asan":
+        rt = subprocess.check_output(["make", "-s", "-C", EMU_DIR, "asan-rt"], text=True).strip()
+        env.update(LD_PRELOAD=rt, GHIP_POOL_EXACT="1",
+                   ASAN_OPTIONS="detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:log_path=%s/san" % logs,
+                   UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0:log_path=%s/san" % logs)
+    elif san == "wavesan":
+        env.update(WAVESAN_LOG="%s/ws" % logs)
     return env
 
 
-def run_emulated(args, timeout):
+def reports_in(logs):
+    """The sanitizer / race-detector reports the children left under `logs`, one line each."""
+    out = []
+    for f in sorted(os.listdir(logs)):
+        for line in open(os.path.join(logs, f), errors="replace"):
+            if "ERROR: AddressSanitizer" in line or "runtime error" in line or line.startswith("WAVESAN"):
+                out.append(line.strip()[:400])
+    return out
+
+
+def run_emulated(args, timeout, env=None):
     """pytest in a child process against the emulated library -> (passed, other outcomes as text)."""
     cmd = [sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "--tb=short", "-rfEsxX"] + args
-    r = subprocess.run(cmd, cwd=ROOT, env=emu_env(), capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(cmd, cwd=ROOT, env=env or emu_env(), capture_output=True, text=True, timeout=timeout)
     tail = r.stdout[-6000:] + r.stderr[-2000:]
     m = re.search(r"(\d+) passed", r.stdout)
     assert r.returncode == 0 and m, tail
@@ -103,6 +124,81 @@ def test_quick_gpu_tests_under_emulation(emulator):
         deselect += ["--deselect", t]
     passed, summary = run_emulated(["tests", "-m", "gpu", "-n", "4", "--timeout", "600"] + deselect, timeout=1500)
     assert passed >= 60, summary
+
+
+# ------------------------------------------------------------------ the checked builds (round 6)
+# One test per kernel family and per host path that sizes device buffers, quick enough for the CPU suite under both checked
+# builds; scripts/emu_suite.sh SAN=asan / SAN=wavesan runs everything emulatable (profiles/r06_emu_suite_{asan,wavesan}.txt).
+CORE = [
+    "tests/test_gpu_parity.py::test_reference_golden_through_hip",
+    "tests/test_gpu_parity.py::test_empty_and_single_inputs",
+    "tests/test_gpu_parity.py::test_pairs_random_sketches_vs_oracle",
+    "tests/test_gpu_parity.py::test_merge_path_kernel_also_matches_oracle",
+    "tests/test_gpu_parity.py::test_probe_kernel_arranged_form_matches_oracle",
+    "tests/test_gpu_parity.py::test_join_form_takes_over_at_scale_with_awkward_families",
+    "tests/test_gpu_parity.py::test_ingest_forms_agree",
+    "tests/test_gpu_parity.py::test_ani_pairs_both_workgroup_shapes",
+    "tests/test_gpu_gz_device.py::test_reference_fixtures_through_the_device_path",
+]
+
+
+@pytest.fixture(scope="module")
+def checked_builds(emulator):
+    for san in ("asan", "wavesan"):
+        subprocess.check_call(["make", "-C", EMU_DIR, "SAN=" + san], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", EMU_DIR, "SAN=asan", "build/san_selftest"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", EMU_DIR, "SAN=wavesan", "build/wavesan_selftest"], stdout=subprocess.DEVNULL)
+    return EMU_DIR
+
+
+def test_sanitizer_build_reports_what_it_should(checked_builds):
+    """The ASan + UBSan build of the emulator sees what it is there for -- kernels that store past a device buffer, past the
+    dynamic LDS the launch asked for, read a freed buffer, load a vector at a misaligned address, shift by the type's width --
+    and says nothing when the same kernels stay inside the bounds."""
+    exe = os.path.join(EMU_DIR, "build", "san_selftest")
+    want = {"ok": None, "heap": "heap-buffer-overflow", "lds": "use-after-poison", "freed": "heap-use-after-free",
+            "align": "misaligned address", "shift": "shift exponent 32 is too large"}
+    for mode, text in want.items():
+        r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+                                                                                                UBSAN_OPTIONS="halt_on_error=1"))
+        if text is None:
+            assert r.returncode == 0 and "nothing reported" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        else:
+            assert r.returncode != 0 and text in r.stderr, (mode, r.stderr[-2000:])
+
+
+def test_wave_race_detector_reports_what_it_should(checked_builds):
+    """The wave race detector (tests/emu/wavesan.cpp) reports a __syncthreads missing behind a producer wave -- in LDS and in
+    global memory, whichever wave the schedule runs first -- and a flag handed between workgroups without release / acquire
+    fences; it says nothing about the same kernels written correctly (waves on disjoint parts, atomics, fenced hand-over)."""
+    exe = os.path.join(EMU_DIR, "build", "wavesan_selftest")
+    for order in ("forward", "reverse", "7"):
+        for mode, want in (("ok", (0, 0, 0)), ("lds", (0, 1, 0)), ("global", (0, 1, 0)), ("flag", (0, 0, 1))):
+            r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIPEMU_ORDER=order))
+            m = re.search(r"write-write (\d+) read-write (\d+) inter-block (\d+)", r.stdout)
+            assert r.returncode == 0 and m, r.stdout + r.stderr
+            assert tuple(int(x) for x in m.groups()) == want, (order, mode, r.stdout, r.stderr[-1500:])
+            if mode == "lds":
+                assert "missing barrier" in r.stderr and "lds_handover" in r.stderr
+            if mode == "flag":
+                assert "no release/acquire between" in r.stderr and "flag_handover" in r.stderr
+
+
+@pytest.mark.parametrize("san", ["asan", "wavesan"])
+def test_smoke_and_core_gpu_tests_under_the_checked_builds(checked_builds, tmp_path, san):
+    """smoke() and one test per kernel family under AddressSanitizer + UBSan (device buffers are heap blocks there, the pool
+    hands out exact sizes: a store past the end of one is a report, not a silent write into its neighbour) and under the wave
+    race detector: green, and not one report."""
+    logs = str(tmp_path)
+    env = emu_env(san, logs)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import conftest; import __graft_entry__ as g; g.smoke()"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    passed, summary = run_emulated(CORE + ["-m", "gpu", "-n", "3", "--timeout", "1200"], timeout=2400, env=env)
+    assert passed >= len(CORE), summary
+    found = reports_in(logs)
+    assert not found, "\n".join(found[:20])
 
 
 def test_rccl_transport_with_thread_ranks_under_emulation(emulator):

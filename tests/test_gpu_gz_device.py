@@ -218,6 +218,18 @@ def test_bgzf_files_are_sized_exactly(ctx, tmp_path, opts):
         assert ctx.ingest_counters()["two_phase_repeats"] == after["two_phase_repeats"] + 1, device
         assert g.to_host(3).tobytes() == want[0].tobytes() and g.stats(3) == tuple(int(x) for x in want[1])
         g.free()
+    # several outgrown files, their texts NOT kept between the pass that finds their lengths and the pass that places them
+    # (fault stage 6 = the tests' small limits: what a call with more than 1 GiB of such texts does), more of them than reader threads
+    cats = []
+    for x in range(5):
+        c = tmp_path / f"cat{x}.fna.gz"
+        c.write_bytes(_gz(text[:cut], 6) + _gz(text[cut:], 1 + x))
+        cats.append(str(c))
+    opts(gz_device=0, fault_stage=6)
+    g = ctx.genomes_from_files([paths[2]] + cats + [paths[0]], 2)
+    for i in range(7):
+        assert g.to_host(i).tobytes() == want[0].tobytes() and g.stats(i) == tuple(int(x) for x in want[1]), i
+    g.free()
 
 
 def test_reference_fixtures_through_the_device_path(ctx, opts, golden_sketches):

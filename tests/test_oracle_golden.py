@@ -270,3 +270,39 @@ def test_reference_cli_representative_list_and_github7():
     got = _finch_plus_ani(["set1_1mbp", "set1_500kb", "abisko_S1D21", "abisko_S2M16"], 95.0, 0.15)
     assert sorted(sorted(c) for c in got) == [[0, 1], [2, 3]]
     assert _finch_plus_ani(["antonio_MAG52", "antonio_MAG189"], 95.0, 0.6) == [[0, 1]]
+
+
+# sha256 of tests/golden/ani_golden.json's content (everything but "definition_version", as canonical JSON), by version of the
+# ANI estimator's definition.  ADD an entry when the definition changes on purpose; never edit an old one.
+ANI_GOLDEN_DIGESTS = {
+    5: "707b9da04eba047a9f1a65f96be703b71d23535e7642d7fefe2397fd938d7e43",   # round 5: pooled counts below 9 aligned chunks
+}
+
+
+def test_ani_definition_is_versioned():
+    """the oracle IS the definition of the ANI estimator (no skani float exists to pin it), so the definition
+    must stop moving silently.  Oracle, device library and golden file name one version; the golden file's digest is recorded per
+    version -- a regenerated file with other numbers fails here until GO_ANI_DEFINITION_VERSION (oracle/galah_oracle.h) and
+    GHIP_ANI_DEFINITION_VERSION (include/galah_hip.h) are bumped and the new version's digest is added above."""
+    import hashlib
+    import json
+    import os
+    import re
+    from conftest import GOLDEN, ROOT
+    from galah_amd import _lib
+    with open(os.path.join(GOLDEN, "ani_golden.json")) as f:
+        d = json.load(f)
+    v = oracle.ani_definition_version()
+    assert v == d["definition_version"] == int(_lib.lib().ghip_ani_definition_version()), "oracle, golden file and device library name different versions"
+    assert v == max(ANI_GOLDEN_DIGESTS), "a new version needs its digest recorded in ANI_GOLDEN_DIGESTS"
+    rows = {k: x for k, x in d.items() if k != "definition_version"}
+    digest = hashlib.sha256(json.dumps(rows, sort_keys=True, separators=(",", ":")).encode()).hexdigest()
+    assert digest == ANI_GOLDEN_DIGESTS[v], ("tests/golden/ani_golden.json changed but the ANI definition's version did not: bump GO_ANI_DEFINITION_VERSION and "
+                                             "GHIP_ANI_DEFINITION_VERSION, regenerate with tests/golden/make_ani_golden.py, add the new digest")
+    # the constants of the definition that oracle and device each spell out are the same numbers
+    osrc = open(os.path.join(ROOT, "oracle", "galah_oracle_ani.c")).read()
+    dsrc = open(os.path.join(ROOT, "galah_amd", "csrc", "ghip_internal.h")).read()
+    for name in ("POOL_BELOW", "SEEDS_WANTED"):
+        o = re.search(r"#define GO_ANI_%s (\d+)" % name, osrc)
+        g = re.search(r"#define GHIP_ANI_%s (\d+)u" % name, dsrc)
+        assert o and g and o.group(1) == g.group(1), name

@@ -94,3 +94,21 @@ def test_synth_genome_identity():
     assert 0.94 < ident < 0.96
     assert float(np.mean(a == c)) < 0.3
     assert set(np.unique(a)) <= set(b"ACGT")
+
+
+def test_ani_error_does_not_jump_at_the_seam_between_pooled_counts_and_the_median():
+    """below GO_ANI_POOL_BELOW = 9 listed chunks the estimator pools the counts, from 9 on it takes the lower median --
+    a discontinuity by construction.  Pairs either side of it (the shorter record 160 kb = 8 chunks / 180 kb = 9 chunks, ~95 %
+    identity): the value stays within 0.15 points of the counted identity on both sides and the error moves by <= 0.15 across
+    the seam.  (The device runs the same rows: tests/test_gpu_ani_fidelity.py::test_the_seam_between_pooled_counts_and_the_median.)"""
+    from test_gpu_ani_fidelity import boundary_pairs   # (tests/ is on sys.path under pytest's rootdir conftest)
+    errs, chunks = [], []
+    for a, b, truth, want_chunks in boundary_pairs():
+        ani, _, _, d = oracle.ani_pair_detail(oracle.AniSketch.from_bytes(a), oracle.AniSketch.from_bytes(b), 0.15)
+        assert int(d[2]) == want_chunks
+        errs.append(float(ani) - truth)
+        chunks.append(want_chunks)
+    errs = np.asarray(errs)
+    assert chunks[0::2] == [8] * 6 and chunks[1::2] == [9] * 6
+    assert np.abs(errs).max() <= 0.15, errs
+    assert np.abs(errs[0::2] - errs[1::2]).max() <= 0.15, errs
