@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no other configs, wall clock, probes)")
     ap.add_argument("--leg", default=None, help="(internal) run ONE extra leg in this process and print its JSON object: wall_clock_10k")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: 4 per CPU of the cgroup quota)")
+    ap.add_argument("--cpu-serial-rows", type=int, default=100, help="rows of the serial (B1) pair loop timed at the headline size (100 rows of 10 000 genomes: ~1e6 pairs, seconds)")
     ap.add_argument("--contigs", type=int, default=100_000, help="contigs of the configs[3] leg")
     ap.add_argument("--big-species", type=int, default=5000, help="species (x members genomes) of the configs[4] leg")
     return ap.parse_args()
@@ -313,16 +314,49 @@ class CpuWhole:
                 "pair_stage_only_pairs_per_s": {"serial": self.n_pairs / self.t_pairs_serial, "parallel": self.n_pairs / self.t_pairs_par},
                 "parity_checked": f"all {self.n} sketches, all {self.n_pairs} pair results, all {self.n_cand} ANI values and the clusters equal the GPU's, bit for bit"}
 
+    def pair_loop_at_headline(self, args, hashes, lens, min_ani, gpu_pairs, serial_rows):
+        """The pair loop of src/finch.rs:74-96 TIMED at the headline size instead of scaled up from configs[1]:
+        on the device-made sketches of the headline workload, B2 (rows in parallel on every thread) in full -- whose result is
+        also the full-size parity check of the headline's pair list -- and B1 (the reference's serial loop) on a bounded sample,
+        the first `serial_rows` rows of its outer index."""
+        import oracle
+        n = hashes.shape[0]
+        t0 = time.perf_counter()
+        par = oracle.distances_from_sketches(hashes, lens, min_ani, args.kmer, threads=self.threads)
+        self.h_t_pairs_par = time.perf_counter() - t0
+        assert par.tobytes() == gpu_pairs.tobytes(), "GPU precluster pairs of the headline workload differ from the CPU oracle's"
+        rows = max(1, min(int(serial_rows), n))
+        t0 = time.perf_counter()
+        hits, looked = oracle.distances_rows(hashes, lens, min_ani, args.kmer, 0, rows)
+        t_rows = time.perf_counter() - t0
+        assert hits.tobytes() == par[par["i"] < rows].tobytes()
+        self.h_n, self.h_pairs, self.h_serial_rows, self.h_serial_looked, self.h_t_serial_rows = n, n * (n - 1) // 2, rows, looked, t_rows
+        self.h_serial_rate = looked / t_rows
+
     def scaled(self, n, n_pairs, n_cand):
-        """The same measured stage times scaled to a larger run of the same generator (a bounded sample of that workload)."""
+        """The CPU figure for a larger run of the same generator.  Sketching, ANI and clustering are configs[1]'s measured stage
+        times SCALED to this size (a bounded sample of the workload: sketching a genome, or one pair's ANI, costs the same in a
+        run of any size); the pair loop is MEASURED at this size when pair_loop_at_headline has run (B2 in full, B1 from a
+        sample of rows), and scaled too otherwise."""
         g, p, c = n / self.n, n_pairs / self.n_pairs, n_cand / max(self.n_cand, 1)
-        t_b2 = (self.t_sketch + self.t_ani_sketch) * g + self.t_pairs_par * p + self.t_ani_pairs * c + self.t_cluster * g
-        t_b1 = t_b2 - self.t_pairs_par * p + self.t_pairs_serial * p
-        return {"value": n_pairs / t_b2, "unit": "genome-pairs/s", "cores": self.cores, "threads": self.threads, "kind": "port",
-                "sample": (f"bounded sample = the whole configs[1] workload ({self.n} of the {n} genomes, {self.n_pairs} pairs, {self.n_cand} ANI pairs; "
-                           f"{self.t_sketch + self.t_ani_sketch + self.t_pairs_par + self.t_ani_pairs:.1f}s of CPU work on {self.threads} threads under a quota of "
-                           f"{self.quota} CPUs), its stage times scaled to this workload: sketching x{g:.0f}, pair loop x{p:.1f}, ANI pairs x{c:.1f}"),
-                "seconds_projected": t_b2, "host_cgroup_cpu_quota": self.quota, "b1_faithful_serial_pair_loop_value": n_pairs / t_b1}
+        measured = getattr(self, "h_n", None) == n
+        t_par = self.h_t_pairs_par if measured else self.t_pairs_par * p
+        t_ser = n_pairs / self.h_serial_rate if measured else self.t_pairs_serial * p
+        t_b2 = (self.t_sketch + self.t_ani_sketch) * g + t_par + self.t_ani_pairs * c + self.t_cluster * g
+        t_b1 = t_b2 - t_par + t_ser
+        pair_part = (f"the {n_pairs}-pair loop MEASURED at this size on the headline's own sketches: B2 (rows in parallel, {self.threads} threads) in full "
+                     f"{t_par:.2f}s, its result equal to the GPU's pair list byte for byte; B1 (serial, as src/finch.rs:75-76) on a sample of the first "
+                     f"{self.h_serial_rows} rows = {self.h_serial_looked} pairs in {self.h_t_serial_rows:.2f}s -> {t_ser:.1f}s for all of them"
+                     if measured else f"pair loop scaled x{p:.1f}")
+        out = {"value": n_pairs / t_b2, "unit": "genome-pairs/s", "cores": self.cores, "threads": self.threads, "kind": "port",
+               "sample": (f"{pair_part}; sketching (x{g:.0f}), ANI pairs (x{c:.1f}) and clustering (x{g:.0f}) PROJECTED from the whole configs[1] workload "
+                          f"({self.n} of the {n} genomes, {self.n_cand} ANI pairs; {self.t_sketch + self.t_ani_sketch + self.t_ani_pairs:.1f}s of CPU work on "
+                          f"{self.threads} threads under a quota of {self.quota} CPUs)"),
+               "seconds_projected": t_b2, "host_cgroup_cpu_quota": self.quota, "b1_faithful_serial_pair_loop_value": n_pairs / t_b1,
+               "parts": {"pair_loop": "measured" if measured else "scaled", "sketching": "scaled", "ani": "scaled", "clustering": "scaled"}}
+        if measured:
+            out["pair_stage_only_pairs_per_s"] = {"serial_sampled": self.h_serial_rate, "parallel_measured": n_pairs / t_par}
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ extra legs (N = 1)
@@ -794,6 +828,9 @@ def main_single(args, ctx, json_fd):
         "stage_ms_per_step": head["stage_ms_per_step"], "result": head["result"],
     }
     head_pairs, n_cand = result["pairs"], int(result["n_pairs"])
+    # the headline's own sketches, for the CPU baseline's pair loop at this size (80 MB at 10 000 genomes)
+    head_sketches = job.sketches_to_host() if not args.no_cpu_baseline and n > 1000 else None
+    head_min_ani = job.min_ani
     job = result = None
     if not args.no_extras or not args.no_cpu_baseline:
         gc.unfreeze()
@@ -811,6 +848,8 @@ def main_single(args, ctx, json_fd):
                 c1["speedup_vs_cpu_b2"] = c1["value"] / c1["cpu_baseline"]["value"]
                 if is_north_star:
                     whole.check_leading_block(head_pairs)
+                if head_sketches is not None:
+                    whole.pair_loop_at_headline(args, head_sketches[0], head_sketches[1], head_min_ani, head_pairs, args.cpu_serial_rows)
                 out["cpu_baseline"] = whole.scaled(n, head["pairs"], n_cand)
                 out["speedup_vs_cpu_b2"] = out["value"] / out["cpu_baseline"]["value"]
                 out["target_10x_met"] = bool(out["value"] >= 10.0 * out["cpu_baseline"]["value"])   # north_star: >= 10x the CPU baseline

@@ -196,6 +196,25 @@ def distances_from_sketches(sk: np.ndarray, lens: np.ndarray, min_ani: float, k:
         cap = int(m)
 
 
+def distances_rows(sk: np.ndarray, lens: np.ndarray, min_ani: float, k: int, row_lo: int, row_hi: int) -> Tuple[np.ndarray, int]:
+    """Rows [row_lo, row_hi) of the outer index of finch::distances' pair loop (src/finch.rs:74-96), serial -> (hits, pairs compared)."""
+    sk = np.ascontiguousarray(sk, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n, s = sk.shape
+    L = lib()
+    L.go_distances_rows.restype = C.c_size_t
+    L.go_distances_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_float, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_uint64)]
+    cap = 1 << 16
+    while True:
+        out = np.empty(cap, dtype=PAIR_DTYPE)
+        looked = C.c_uint64(0)
+        m = L.go_distances_rows(sk.ctypes.data, lens.ctypes.data, n, s, k, np.float32(min_ani), row_lo, row_hi, out.ctypes.data, cap, C.byref(looked))
+        if m <= cap:
+            return out[:m].copy(), int(looked.value)
+        cap = int(m)
+
+
 def distances(paths: Sequence[str], min_ani: float, num_kmers: int = 1000, kmer_length: int = 21,
               threads: int = 1) -> np.ndarray:
     """finch::distances(genome_fasta_paths, min_ani, num_kmers, kmer_length) (src/finch.rs:48-97)."""

@@ -340,6 +340,33 @@ double go_mash_ani(uint64_t common, uint64_t total, uint32_t k) {
     return 1.0 - mash;
 }
 
+/* The same loop (src/finch.rs:74-96) over the rows row_lo <= i < row_hi of its outer index only, serial: a bounded SAMPLE of the
+ * faithful (serial) pair loop at a size where the whole of it would take minutes (bench.py's cpu_baseline at 10 000 genomes).
+ * Returns the hits (written up to cap); *compared = the pairs it looked at. */
+size_t go_distances_rows(const uint64_t *sk, const uint32_t *lens, size_t n, uint32_t s, uint32_t k, float min_ani, size_t row_lo,
+                         size_t row_hi, go_pair *out, size_t cap, uint64_t *compared) {
+    double thr = (double)min_ani;
+    size_t m = 0;
+    uint64_t looked = 0;
+    for (size_t i = row_lo; i < row_hi && i < n; i++)
+        for (size_t j = i + 1; j < n; j++) {
+            uint64_t c, t;
+            go_raw_distance(sk + i * s, lens[i], sk + j * s, lens[j], &c, &t);
+            double ani = go_mash_ani(c, t, k);
+            looked++;
+            if (ani >= thr) {
+                if (m < cap) {
+                    out[m].i = (uint32_t)i; out[m].j = (uint32_t)j;
+                    out[m].common = (uint32_t)c; out[m].total = (uint32_t)t;
+                    out[m].ani = (float)ani;
+                }
+                m++;
+            }
+        }
+    if (compared) *compared = looked;
+    return m;
+}
+
 /* src/finch.rs:74-96: for i<j (row-major), keep if ANI(f64) >= (min_ani as f64), store f32. */
 size_t go_distances(const uint64_t *sk, const uint32_t *lens, size_t n, uint32_t s,
                     uint32_t k, float min_ani, go_pair *out, size_t cap, int threads) {

@@ -60,6 +60,8 @@ typedef struct {
 
 /* finch::distances pair loop (src/finch.rs:74-96).  threads==1: the reference's serial
  * loop; threads>1: parallel over i (the "fair" baseline B2), same output order. */
+size_t go_distances_rows(const uint64_t *sketches, const uint32_t *lens, size_t n, uint32_t s, uint32_t k, float min_ani, size_t row_lo,
+                         size_t row_hi, go_pair *out, size_t cap, uint64_t *compared);   /* rows [row_lo, row_hi) of the same loop, serial */
 size_t go_distances(const uint64_t *sk, const uint32_t *lens, size_t n, uint32_t s,
                     uint32_t k, float min_ani, go_pair *out, size_t cap, int threads);
 

@@ -24,6 +24,8 @@ NOT_EMULATABLE = {
     "tests/test_gpu_configs.py::test_bench_line_contract": "runs bench.py, which drives torch.cuda itself",
     "tests/test_gpu_configs.py::test_config2_1000_full_length_genomes_sketch_stage_sampled": "5 Gbases through the sketch pass",
     "tests/test_gpu_e2e_scale.py::test_10k_genomes_end_to_end_against_the_oracle": "2 Gbases + 5e7 pairs",
+    "tests/test_gpu_distributed.py::test_rccl_deadline_against_the_real_library": "torch.cuda streams and the real librccl (the stand-in's version: "
+                                                                                   "tests/emu/cases/test_rccl_transport.py)",
     "tests/test_gpu_distributed.py::test_rccl_transport_on_one_rank": "builds its communicator through torch.distributed + the real librccl "
                                                                       "(tests/emu/cases/test_rccl_transport.py covers the transport with 2-4 ranks)",
 }

@@ -14,7 +14,7 @@ import pytest
 
 import galah_amd
 import oracle
-from conftest import GOLDEN, fasta, fasta_records
+from conftest import GOLDEN, fasta, fasta_records, never_run_on_hardware
 
 pytestmark = pytest.mark.gpu
 
@@ -257,6 +257,7 @@ def boundary_pairs():
 
 
 @pytest.mark.emu
+@never_run_on_hardware
 def test_the_seam_between_pooled_counts_and_the_median(ctx):
     """GO_ANI_POOL_BELOW = 9: the estimator changes rule between 8 and 9 listed chunks.  Either side of the seam the device
     value is the oracle's and within 0.15 points of the counted identity, and the ERROR does not jump by more than 0.15

@@ -441,6 +441,79 @@ def _rccl_single_rank(port, q):
     ctx.close()
 
 
+def _rccl_deadline_rank(port, q):
+    """A one-rank RCCL communicator whose stream is held busy by a long kernel AHEAD of the collective: the collective cannot
+    complete within comm_timeout_ms, so rccl_wait (comm.cpp) must abort the communicator (ncclCommAbort), drain the stream
+    (hipStreamSynchronize right after the abort: the assumption VERDICT r5 weak 8 names as unproven against the real library),
+    return GHIP_EPEER, refuse every later call at once -- and the process must still exit cleanly."""
+    import time
+
+    import torch
+
+    import galah_amd
+    from galah_amd.distributed import Comm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev_select(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    ctx = galah_amd.Context(0)
+    comm = Comm.from_torch_rccl(ctx, 0, 1)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    out = {"works": comm.allgather_host(np.int64([7])).tolist() == [[7]]}
+    # how many of torch's sleep cycles make a second on this box
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        t0 = time.time()
+        torch.cuda._sleep(200_000_000)
+        stream.synchronize()
+        per_s = 200_000_000 / max(time.time() - t0, 1e-3)
+    ctx.set_options(comm_timeout_ms=250)
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(int(2.0 * per_s))      # two seconds of GPU time in front of the collective
+    t0 = time.time()
+    try:
+        comm.allgather_host(np.int64([7]))
+        out["first"] = "no error"
+    except galah_amd.GalahHipError as e:
+        out["first"] = str(e)
+    out["dt_first"] = time.time() - t0
+    t0 = time.time()
+    try:
+        comm.allgather_host(np.int64([7]))
+        out["second"] = "no error"
+    except galah_amd.GalahHipError as e:
+        out["second"] = str(e)
+    out["dt_second"] = time.time() - t0
+    # the context itself is alive: a kernel of the library still runs on the same stream
+    g = ctx.genomes_synthetic(3, 1, 2, 50_000, 0.02)
+    hashes, lens = ctx.sketch_genomes(g, 21, 1000, 0).to_host()
+    out["context_alive"] = bool(lens[0] == 1000)
+    g.free()
+    q.put(out)
+    comm.close()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@never_run_on_hardware
+def test_rccl_deadline_against_the_real_library(ctx):
+    """rccl_wait's give-up path against the REAL librccl (the emulated suite has only a stand-in): GHIP_EPEER
+    within comm_timeout_ms plus the rest of the kernel that held the stream, a dead communicator afterwards, a clean exit."""
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_rccl_deadline_rank, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0, p.exitcode
+    assert got["works"]
+    assert got["first"].startswith("GHIP_EPEER") and "comm_timeout_ms" in got["first"] and "aborted" in got["first"], got
+    assert 0.2 < got["dt_first"] < 6.0, got          # the deadline, then the drain of the two-second kernel
+    assert "aborted" in got["second"] and got["dt_second"] < 0.5, got
+    assert got["context_alive"], got
+
+
 def test_rccl_transport_on_one_rank(ctx):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
