@@ -257,7 +257,7 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
 // NS x 64 slots per sketch, slot t * 64 + lane, 2^64 - 1 = hole) and the second bucket is the constrained one, so the 32
 // lanes of a ds_read_b64 group read 32 different bank pairs.  The loops are turned inside out with respect to the kernel
 // above: a GROUP of four row slots is fetched (the next group travels meanwhile), its tags and bucket offsets are worked
-// out once, and all 8 A-sets are probed with them -- 12 registers of row state instead of 3 NS: 82 VGPRs and no spills (the
+// out once, and all 8 A-sets are probed with them -- 12 registers of row state instead of 3 NS: 83 / 65 VGPRs and no spills (the
 // row-major order of the kernel above holds 128 with 7 spilled at 16 slots per lane).
 template <int NS>
 __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void pair_probe_arranged_kernel(
@@ -267,7 +267,9 @@ __global__ __launch_bounds__(PROBE_THREADS) __attribute__((amdgpu_waves_per_eu(4
     ghip_pair *__restrict__ out, unsigned long long *__restrict__ out_count, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr uint32_t SET_BYTES = (NS > 4 ? 1024u : 256u) * 8u;
-    constexpr int GROUP = 4;
+    // (four slots per lane are two groups of two: as ONE group of four the group loop has a single turn, the compiler drops it, hoists
+    // every set's LDS reads to the top and spills 176 bytes per lane at 128 VGPRs -- two turns: 65 VGPRs, no scratch; round 6, static)
+    constexpr int GROUP = NS > 4 ? 4 : 2;
     static_assert(NS % GROUP == 0, "slots per lane");
     uint64_t *samp = reinterpret_cast<uint64_t *>(smem_raw + PROBE_TA * SET_BYTES);     // [TA][64]
     uint64_t *a_max = samp + PROBE_TA * 64;                                             // [TA]
