@@ -3,7 +3,7 @@
 cfef442 = round 4's call "r04a", and the work tree)?  Both trees' .hip files are compiled to device assembly (hipcc -S
 --offload-device-only), every kernel's body is cut out and compared after dropping labels' numbering and comments.  A kernel
 whose ISA is identical carries its measurements over; one that differs is new code as far as the GPU is concerned.
-usage: isa_diff.py [old-commit] [--write profiles/r05_isa_vs_last_hardware_run.txt]"""
+usage: isa_diff.py [old-commit] [--write profiles/r06_isa_vs_last_hardware_run.txt]"""
 import hashlib
 import os
 import re
@@ -13,7 +13,7 @@ import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["sketch.hip", "pairs.hip", "pairs_probe.hip", "pairs_join.hip", "ani.hip"]
+FILES = ["sketch.hip", "pairs.hip", "pairs_probe.hip", "pairs_join.hip", "ani.hip", "gz_inflate.hip"]
 
 
 def kernels_of(tree, f):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static resource usage of every gfx950 kernel of the library, as hipcc reports it (-Rpass-analysis=kernel-resource-usage):
 VGPRs, AGPRs, SGPRs, scratch bytes per lane (spills), LDS bytes, occupancy in waves per SIMD.  No GPU needed.
-usage: kernel_resources.py [--write profiles/r05_kernel_resources.txt]"""
+usage: kernel_resources.py [--write profiles/r06_kernel_resources.txt]"""
 import os
 import re
 import subprocess
@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "galah_amd", "csrc")
-FILES = ["sketch.hip", "pairs.hip", "pairs_probe.hip", "pairs_join.hip", "ani.hip"]
+FILES = ["sketch.hip", "pairs.hip", "pairs_probe.hip", "pairs_join.hip", "ani.hip", "gz_inflate.hip"]
 FIELDS = [("Function Name", "name"), ("VGPRs", "vgprs"), ("AGPRs", "agprs"), ("SGPRs", "sgprs"), ("ScratchSize [bytes/lane]", "scratch"),
           ("Occupancy [waves/SIMD]", "occupancy"), ("LDS Size [bytes/block]", "lds")]
 

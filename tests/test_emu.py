@@ -142,6 +142,10 @@ CORE = [
     "tests/test_gpu_parity.py::test_ani_pairs_both_workgroup_shapes",
     "tests/test_gpu_gz_device.py::test_reference_fixtures_through_the_device_path",
 ]
+# under the race detector every load and store of a kernel is a call: the two heaviest of the list are replaced by smaller tests of
+# the same kernels (the inflate + FASTA kernels on a 190 kb text; ani_pairs runs in smoke())
+CORE_SWAPS = {"wavesan": {"tests/test_gpu_gz_device.py::test_reference_fixtures_through_the_device_path": "tests/test_gpu_gz_device.py::test_bgzf_files_are_sized_exactly",
+                          "tests/test_gpu_parity.py::test_ani_pairs_both_workgroup_shapes": None}}
 
 
 @pytest.fixture(scope="module")
@@ -197,8 +201,10 @@ def test_smoke_and_core_gpu_tests_under_the_checked_builds(checked_builds, tmp_p
             % (ROOT, os.path.join(ROOT, "tests")))
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    passed, summary = run_emulated(CORE + ["-m", "gpu", "-n", "3", "--timeout", "1200"], timeout=2400, env=env)
-    assert passed >= len(CORE), summary
+    core = [CORE_SWAPS.get(san, {}).get(t, t) for t in CORE]
+    core = [t for t in core if t]
+    passed, summary = run_emulated(core + ["-m", "gpu", "-n", "4", "--timeout", "1200"], timeout=2400, env=env)
+    assert passed >= len(core), summary
     found = reports_in(logs)
     assert not found, "\n".join(found[:20])
 
