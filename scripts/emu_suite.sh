@@ -6,6 +6,7 @@
 #                 exactly the size asked for (GHIP_POOL_EXACT); every report is collected (nothing halts) and counted at the end
 #   SAN=wavesan   the kernels under the wave race detector (tests/emu/wavesan.cpp): a __syncthreads missing between two waves'
 #                 accesses, a hand-over between workgroups without release / acquire; reports symbolized and counted at the end
+#   EMU_EXTRA     further pytest arguments (deselections of the longest tests under the race detector)
 #   HIPEMU_ORDER  the order in which the waves of a workgroup and the lanes of a wave take their turns (tests/emu/hipemu.cpp)
 #   The suite runs in a SNAPSHOT of the tree (a copy under /tmp, built there): it takes hours, and a file of the tree edited meanwhile --
 #   galah_amd/_lib.py gaining a symbol the running build lacks -- otherwise fails every test that starts a fresh process (the first
@@ -43,7 +44,7 @@ PY
 )
 {
   echo "# $HEAD_NAME $(date -u +%FT%TZ)  -m gpu under tests/emu, library $LIBNAME, HIPEMU_ORDER=${HIPEMU_ORDER:-forward} (deselected: not emulatable, tests/test_emu.py NOT_EMULATABLE)"
-  HIPEMU_THREADS=${HIPEMU_THREADS:-4} python3 -m pytest ${EMU_TESTS:-tests} -m gpu -q -n ${EMU_WORKERS:-2} --timeout ${EMU_TEST_TIMEOUT:-3000} --timeout-method=thread -p no:cacheprovider -rfEsxX --tb=short --durations=25 $DESELECT 2>&1 | grep -v "^\[W\|Gloo\|amdgpu.ids"
+  HIPEMU_THREADS=${HIPEMU_THREADS:-4} python3 -m pytest ${EMU_TESTS:-tests} -m gpu -q -n ${EMU_WORKERS:-2} --timeout ${EMU_TEST_TIMEOUT:-3000} --timeout-method=thread -p no:cacheprovider -rfEsxX --tb=short --durations=25 $DESELECT $EMU_EXTRA 2>&1 | grep -v "^\[W\|Gloo\|amdgpu.ids"
   if [ -z "$EMU_TESTS" ] || [ -n "$EMU_CASES" ]; then
     echo "# tests/emu/cases (the RCCL transport with thread ranks over the stand-in librccl)"
     python3 -m pytest tests/emu/cases -q -p no:cacheprovider --tb=short 2>&1 | tail -5
