@@ -6,6 +6,9 @@ build compiles: the text is the product's, with the three constructs a host comp
                                           executes the same instruction text; operands are read off the statement)
   "../../include/galah_hip.h"        ->  "galah_hip.h" (found through -I)
   __attribute__((amdgpu_waves_per_eu(..)))  ->  dropped (an occupancy hint)
+  __launch_bounds__(EXPR) ... NAME(...) {  ->  the same, and `hipemu::check_launch_bound((EXPR), "NAME");` as the body's first statement:
+                                          a launch with more work-items per workgroup than the kernel was compiled for fails on the GPU
+                                          (the bound may depend on template parameters, hence a check inside the kernel)
 """
 import os
 import re
@@ -15,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SRC = os.path.join(ROOT, "galah_amd", "csrc")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "src")   # (next to this script: a copy of tests/emu elsewhere under tests/ builds on its own)
 
+LAUNCH_BOUND_CHECKS = {}
 DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?unsigned char\s+(\w+)\[\];")
 
 
@@ -47,6 +51,42 @@ def operands_to_emu(text):
     return "{" + ", ".join(binds) + "}", " ".join(assigns)
 
 
+def balanced(text, at):
+    """text[at] == '(' -> index just past its closing parenthesis."""
+    depth = 0
+    for i in range(at, len(text)):
+        if text[i] == "(":
+            depth += 1
+        elif text[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return i + 1
+    raise AssertionError("unbalanced parentheses")
+
+
+def check_launch_bounds(name, text):
+    """Inserts the launch-bound check at the top of every kernel that declares one -> (text, number of kernels)."""
+    out, at, n = "", 0, 0
+    for m in re.finditer(r"__launch_bounds__\(", text):
+        if m.start() < at:
+            continue
+        e_end = balanced(text, m.end() - 1)
+        expr = text[m.end():e_end - 1]
+        k = re.compile(r"(\w+)\s*\(").search(text, e_end)   # the kernel's name: the next identifier in front of a parameter list
+        while k and k.group(1) in ("__attribute__", "amdgpu_waves_per_eu", "aligned"):
+            k = re.compile(r"(\w+)\s*\(").search(text, balanced(text, k.end() - 1))
+        assert k, (name, expr)
+        p_end = balanced(text, k.end() - 1)
+        rest = re.compile(r"\s*(\{|;)").match(text, p_end)
+        assert rest, (name, k.group(1))
+        if rest.group(1) == ";":
+            continue   # a declaration
+        out += text[at:rest.end()] + f' hipemu::check_launch_bound(({expr}), "{k.group(1)}");'
+        at = rest.end()
+        n += 1
+    return out + text[at:], n
+
+
 def transform(name, text):
     text = DYN.sub(lambda m: f"unsigned char *const {m.group(1)} = hipemu::dyn_lds();", text)
     text = text.replace('"../../include/galah_hip.h"', '"galah_hip.h"')
@@ -68,6 +108,9 @@ def transform(name, text):
         text = text.replace("#undef GHIP_MURMUR21_OPERANDS\n", "")
         text = text.replace("#include <hip/hip_runtime.h>", "#include <hip/hip_runtime.h>\n#include <hipemu_gcn_asm.h>")
     assert "GHIP_MURMUR21_OPERANDS" not in text
+    if name.endswith(".hip"):
+        text, n_bounds = check_launch_bounds(name, text)
+        LAUNCH_BOUND_CHECKS[name] = n_bounds
     # any inline assembly left must be the empty scheduling fence of seed_common.h
     for m in re.finditer(r"asm volatile\(([^;]*)\);", text):
         assert m.group(1).strip() == '""', (name, m.group(0))
@@ -86,6 +129,7 @@ def main():
             continue   # keep the timestamp: make rebuilds only what changed
         with open(out, "w") as fh:
             fh.write(text)
+    assert sum(LAUNCH_BOUND_CHECKS.values()) >= 39, LAUNCH_BOUND_CHECKS   # the kernels that declare a launch bound (round 6: 39)
 
 
 if __name__ == "__main__":

@@ -459,6 +459,11 @@ std::atomic<size_t> g_mem_now{0}, g_mem_peak{0};
 
 }  // namespace
 
+void launch_bound_exceeded(const char *kernel, unsigned threads, unsigned bound) {
+    fprintf(stderr, "[hipemu] %s launched with %u work-items per workgroup but declares __launch_bounds__(%u): the GPU refuses this launch\n", kernel, threads, bound);
+    abort();
+}
+
 uint64_t wave_op(int kind, uint64_t val, int arg, int width, const void *site) {
     ThreadCtx *c = cur();
     c->op_kind = kind;

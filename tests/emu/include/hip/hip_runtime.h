@@ -114,6 +114,14 @@ inline ThreadCtx *cur() {
     return *reinterpret_cast<ThreadCtx **>(sp & ~(STACK_BYTES - 1));
 }
 
+// a kernel compiled for at most `bound` work-items per workgroup that is launched with more: the GPU refuses the launch
+[[noreturn]] void launch_bound_exceeded(const char *kernel, unsigned threads, unsigned bound);
+inline void check_launch_bound(unsigned bound, const char *kernel) {
+    const dim3 &b = cur()->bdim;
+    const unsigned t = b.x * b.y * b.z;
+    if (__builtin_expect(t > bound, 0)) launch_bound_exceeded(kernel, t, bound);
+}
+
 enum { OP_SHFL = 1, OP_SHFL_UP, OP_SHFL_DOWN, OP_SHFL_XOR, OP_BALLOT, OP_FIRST, OP_WAVE_BARRIER };
 // (convergent: what keeps a GPU compiler from duplicating or sinking a cross-lane operation into divergent branches keeps the
 // host compiler from giving one operation two call sites, which the emulator would match separately)
@@ -147,7 +155,7 @@ static constexpr int warpSize = 64;
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline, convergent))
-#define __launch_bounds__(...)
+#define __launch_bounds__(...)   // (gen_sources.py turns the bound into a check at the top of the kernel: hipemu::check_launch_bound)
 #define __shared__ static thread_local   // one OS thread runs one workgroup at a time: its statics are the group's LDS
 #define __constant__
 

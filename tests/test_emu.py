@@ -163,7 +163,7 @@ def test_sanitizer_build_reports_what_it_should(checked_builds):
     and says nothing when the same kernels stay inside the bounds."""
     exe = os.path.join(EMU_DIR, "build", "san_selftest")
     want = {"ok": None, "heap": "heap-buffer-overflow", "lds": "use-after-poison", "freed": "heap-use-after-free",
-            "align": "misaligned address", "shift": "shift exponent 32 is too large"}
+            "align": "misaligned address", "shift": "shift exponent 32 is too large", "bounds": "declares __launch_bounds__(64)"}
     for mode, text in want.items():
         r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
                                                                                                 UBSAN_OPTIONS="halt_on_error=1"))
