@@ -69,6 +69,7 @@ namespace hipemu {
 
 thread_local WaveSanState wavesan_state;
 void wavesan_suppress(int delta) { wavesan_state.suppress += (uint32_t)delta; }
+void wavesan_scope(bool sub_agent) { wavesan_state.sub_agent = sub_agent; }
 
 namespace {
 std::atomic<uint32_t> g_launch_serial{0}, g_block_serial{0};

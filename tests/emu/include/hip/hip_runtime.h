@@ -182,9 +182,17 @@ static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long lon
 
 // ------------------------------------------------------------------ barriers, fences
 __attribute__((convergent)) static inline void __syncthreads() { hipemu::block_barrier(); }
-static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// Every fence is a full host fence; what the race detector build (wavesan.cpp) additionally learns is the SCOPE the kernel named: a
+// fence or atomic of workgroup / wavefront scope orders nothing another CU can observe, so it does not count as the release or
+// acquire of a hand-over between workgroups (MI355X: per-XCD L2s, a CU's L1 never refreshed by another CU's stores).
+namespace hipemu { void wavesan_scope(bool sub_agent); }
+static inline void hipemu_fence(const char *scope) {
+    hipemu::wavesan_scope(scope[0] == 'w');   // "workgroup", "wavefront"; "agent" and "" (system) are seen by every CU
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+static inline void __threadfence() { hipemu_fence("agent"); }
+static inline void __threadfence_block() { hipemu_fence("workgroup"); }
+#define __builtin_amdgcn_fence(order, scope) hipemu_fence(scope)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) hipemu::yield()
 __attribute__((noinline, convergent)) static void hipemu_wave_barrier() { (void)hipemu::wave_op(hipemu::OP_WAVE_BARRIER, 0, 0, 64, __builtin_return_address(0)); }
@@ -331,9 +339,11 @@ template <class T, class U> static inline T atomicMin(T *p, U v) {
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
-#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
-#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
-#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
-#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
-#define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), (order))
-#define __hip_atomic_compare_exchange_strong(p, expected, desired, success, failure, scope) __atomic_compare_exchange_n((p), (expected), (desired), false, (success), (failure))
+#define HIPEMU_SCOPE(scope) hipemu::wavesan_scope((scope) < __HIP_MEMORY_SCOPE_AGENT)
+#define __hip_atomic_load(p, order, scope) (HIPEMU_SCOPE(scope), __atomic_load_n((p), (order)))
+#define __hip_atomic_store(p, v, order, scope) (HIPEMU_SCOPE(scope), __atomic_store_n((p), (v), (order)))
+#define __hip_atomic_fetch_add(p, v, order, scope) (HIPEMU_SCOPE(scope), __atomic_fetch_add((p), (v), (order)))
+#define __hip_atomic_fetch_or(p, v, order, scope) (HIPEMU_SCOPE(scope), __atomic_fetch_or((p), (v), (order)))
+#define __hip_atomic_exchange(p, v, order, scope) (HIPEMU_SCOPE(scope), __atomic_exchange_n((p), (v), (order)))
+#define __hip_atomic_compare_exchange_strong(p, expected, desired, success, failure, scope) \
+    (HIPEMU_SCOPE(scope), __atomic_compare_exchange_n((p), (expected), (desired), false, (success), (failure)))

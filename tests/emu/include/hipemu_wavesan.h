@@ -6,6 +6,7 @@
 namespace hipemu {
 struct WaveSanState {
     bool in_kernel = false;        // a work-item's fibre is running (not the scheduler, not host code)
+    bool sub_agent = false;        // the atomic / fence about to execute names a scope below "agent" (workgroup, wavefront): nothing another CU can observe
     uint32_t suppress = 0;         // > 0: the emulator's own code runs inside the work-item (the interpreter of the inline assembly)
     uint32_t launch = 0;           // serial number of the launch
     uint32_t block = 0;            // serial number of the workgroup (unique over the process: never 0)
@@ -20,6 +21,7 @@ struct WaveSanState {
 };
 extern thread_local WaveSanState wavesan_state;
 void wavesan_suppress(int delta);   // (hipemu.cpp: not instrumented)
+void wavesan_scope(bool sub_agent); // the scope of the next atomic / fence of this work-item (consumed by it)
 struct WaveSanSuppress {   // for the duration of a scope: what runs is the emulator's, its memory not the kernel's
     WaveSanSuppress() { wavesan_suppress(1); }
     ~WaveSanSuppress() { wavesan_suppress(-1); }

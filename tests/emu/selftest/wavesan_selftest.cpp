@@ -34,16 +34,19 @@ __global__ void disjoint_and_atomic(uint32_t *out) {
     if (threadIdx.x == 0) out[blockIdx.x] = count + part[255];
 }
 // workgroup 0 publishes a value for workgroup 1 through a flag
+// fences: 0 none, 1 agent scope (right), 2 workgroup scope (a full fence on x86, nothing another CU observes on the GPU)
 __global__ void flag_handover(uint32_t *data, uint32_t *flag, uint32_t *out, int fences) {
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             data[0] = 42u;
-            if (fences) __threadfence();
+            if (fences == 1) __threadfence();
+            if (fences == 2) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             atomicAdd(flag, 1u);
         }
     } else if (threadIdx.x == 0) {
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
-        if (fences) __threadfence();
+        if (fences == 1) __threadfence();
+        if (fences == 2) __threadfence_block();
         out[0] = data[0];
     }
 }
@@ -59,7 +62,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(lds_handover, dim3(3), dim3(128), 0, nullptr, b, is("lds") ? 0 : 1);
     hipLaunchKernelGGL(global_handover, dim3(3), dim3(128), 0, nullptr, a, b, is("global") ? 0 : 1);
     hipLaunchKernelGGL(disjoint_and_atomic, dim3(3), dim3(256), 0, nullptr, b);
-    hipLaunchKernelGGL(flag_handover, dim3(2), dim3(64), 0, nullptr, a, f, b, is("flag") ? 0 : 1);
+    hipLaunchKernelGGL(flag_handover, dim3(2), dim3(64), 0, nullptr, a, f, b, is("flag") ? 0 : is("scope") ? 2 : 1);
     hipDeviceSynchronize();
     uint64_t c[4];
     hipemu_wavesan_counts(c);

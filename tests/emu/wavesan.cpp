@@ -17,7 +17,8 @@
 //     workgroups, at least one a write, not both atomic, are a race UNLESS the later one is ordered behind the earlier one
 //     the way the HSA memory model requires at agent scope: the earlier workgroup executed a release (a __threadfence, or an
 //     atomic of release order or stronger) after its access and then an atomic; the later workgroup executed an atomic after
-//     that and an acquire (a __threadfence, or an atomic of acquire order or stronger) before its access.  This is what the
+//     that and an acquire (a __threadfence, or an atomic of acquire order or stronger) before its access -- fences and orders
+//     of AGENT scope or wider only: a workgroup-scope fence is nothing another CU can observe.  This is what the
 //     fused scan's grid barrier and the "last block reduces" idiom do; a relaxed flag without the fences passes on x86 and
 //     reads stale lines out of another XCD's L2 on the GPU.  (An approximation built on a global sequence number of atomic
 //     operations, not vector clocks: it cannot prove a protocol right, it shows the ones that have no fence at all.)
@@ -201,7 +202,16 @@ inline void access(const volatile void *p, size_t size, bool write, bool atomic,
 }
 
 // memory orders as the instrumentation passes them: 0 relaxed, 1 consume, 2 acquire, 3 release, 4 acq_rel, 5 seq_cst
+// the scope note of the operation that is executing (hip_runtime.h sets it in front of every fence and scoped atomic): consumed here
+inline bool took_sub_agent_scope() {
+    auto &s = const_cast<hipemu::WaveSanState &>(wavesan_state);
+    const bool local = s.sub_agent;
+    s.sub_agent = false;
+    return local;
+}
+
 inline void did_fence(int mo) {
+    if (took_sub_agent_scope()) return;   // a workgroup / wavefront fence: nothing another CU can observe
     if (!wavesan_state.in_kernel) return;
     if (!g_ready.load(std::memory_order_acquire)) { std::call_once(g_once, init); g_ready.store(true, std::memory_order_release); }
     enter_block();
@@ -210,6 +220,7 @@ inline void did_fence(int mo) {
     if (mo == 2 || mo >= 4 || mo == 1) t_mine.acquired_at = now;
 }
 inline void did_atomic(int mo) {
+    if (took_sub_agent_scope()) mo = 0;   // its order holds inside the workgroup only: between workgroups it is a relaxed atomic
     if (!wavesan_state.in_kernel) return;
     if (!g_ready.load(std::memory_order_acquire)) return;   // (the access() before it has made the tables)
     enter_block();

@@ -179,14 +179,14 @@ def test_wave_race_detector_reports_what_it_should(checked_builds):
     fences; it says nothing about the same kernels written correctly (waves on disjoint parts, atomics, fenced hand-over)."""
     exe = os.path.join(EMU_DIR, "build", "wavesan_selftest")
     for order in ("forward", "reverse", "7"):
-        for mode, want in (("ok", (0, 0, 0)), ("lds", (0, 1, 0)), ("global", (0, 1, 0)), ("flag", (0, 0, 1))):
+        for mode, want in (("ok", (0, 0, 0)), ("lds", (0, 1, 0)), ("global", (0, 1, 0)), ("flag", (0, 0, 1)), ("scope", (0, 0, 1))):
             r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIPEMU_ORDER=order))
             m = re.search(r"write-write (\d+) read-write (\d+) inter-block (\d+)", r.stdout)
             assert r.returncode == 0 and m, r.stdout + r.stderr
             assert tuple(int(x) for x in m.groups()) == want, (order, mode, r.stdout, r.stderr[-1500:])
             if mode == "lds":
                 assert "missing barrier" in r.stderr and "lds_handover" in r.stderr
-            if mode == "flag":
+            if mode in ("flag", "scope"):   # (scope: fences of WORKGROUP scope on both sides -- full fences on x86, nothing another CU observes)
                 assert "no release/acquire between" in r.stderr and "flag_handover" in r.stderr
 
 
