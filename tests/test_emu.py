@@ -120,11 +120,11 @@ def test_smoke_under_emulation(emulator):
     assert divergent == 0 and inactive == 0, (divergent, inactive)
 
 
-def test_quick_gpu_tests_under_emulation(emulator):
+def _quick_group():
     deselect = []
     for t in list(NOT_EMULATABLE) + SLOW:
         deselect += ["--deselect", t]
-    passed, summary = run_emulated(["tests", "-m", "gpu", "-n", "4", "--timeout", "600"] + deselect, timeout=1500)
+    passed, summary = run_emulated(["tests", "-m", "gpu", "-n", "3", "--timeout", "900"] + deselect, timeout=2400)
     assert passed >= 60, summary
 
 
@@ -190,25 +190,49 @@ def test_wave_race_detector_reports_what_it_should(checked_builds):
                 assert "no release/acquire between" in r.stderr and "flag_handover" in r.stderr
 
 
-@pytest.mark.parametrize("san", ["asan", "wavesan"])
-def test_smoke_and_core_gpu_tests_under_the_checked_builds(checked_builds, tmp_path, san):
-    """smoke() and one test per kernel family under AddressSanitizer + UBSan (device buffers are heap blocks there, the pool
-    hands out exact sizes: a store past the end of one is a report, not a silent write into its neighbour) and under the wave
-    race detector: green, and not one report."""
-    logs = str(tmp_path)
+def _smoke_and_core(san, logs):
     env = emu_env(san, logs)
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import conftest; import __graft_entry__ as g; g.smoke()"
             % (ROOT, os.path.join(ROOT, "tests")))
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     core = [CORE_SWAPS.get(san, {}).get(t, t) for t in CORE]
     core = [t for t in core if t]
-    passed, summary = run_emulated(core + ["-m", "gpu", "-n", "4", "--timeout", "1200"], timeout=2400, env=env)
+    passed, summary = run_emulated(core + ["-m", "gpu", "-n", "2", "--timeout", "1800"], timeout=3000, env=env)
     assert passed >= len(core), summary
     found = reports_in(logs)
     assert not found, "\n".join(found[:20])
 
 
-def test_rccl_transport_with_thread_ranks_under_emulation(emulator):
-    passed, summary = run_emulated([os.path.join("tests", "emu", "cases")], timeout=900)
-    assert passed >= 8, summary
+def _rccl_cases():
+    passed, summary = run_emulated([os.path.join("tests", "emu", "cases")], timeout=1800)
+    assert passed >= 9, summary
+
+
+@pytest.fixture(scope="module")
+def emulated_runs(checked_builds, tmp_path_factory):
+    """The four long children of this file -- the quick group, the two checked builds' smoke + core, the RCCL transport cases --
+    started TOGETHER (they are independent processes; one after the other they were 5 of the CPU suite's 8 minutes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    ex = ThreadPoolExecutor(4)
+    jobs = {"quick": ex.submit(_quick_group), "rccl": ex.submit(_rccl_cases)}
+    for san in ("asan", "wavesan"):
+        jobs[san] = ex.submit(_smoke_and_core, san, str(tmp_path_factory.mktemp("logs_" + san)))
+    yield jobs
+    ex.shutdown(wait=True)
+
+
+def test_quick_gpu_tests_under_emulation(emulated_runs):
+    emulated_runs["quick"].result()
+
+
+@pytest.mark.parametrize("san", ["asan", "wavesan"])
+def test_smoke_and_core_gpu_tests_under_the_checked_builds(emulated_runs, san):
+    """smoke() and one test per kernel family under AddressSanitizer + UBSan (device buffers are heap blocks there, the pool
+    hands out exact sizes: a store past the end of one is a report, not a silent write into its neighbour) and under the wave
+    race detector: green, and not one report."""
+    emulated_runs[san].result()
+
+
+def test_rccl_transport_with_thread_ranks_under_emulation(emulated_runs):
+    emulated_runs["rccl"].result()
