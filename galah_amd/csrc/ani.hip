@@ -314,7 +314,7 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
         ro_base = reinterpret_cast<uint16_t *>(list + (nchq + nchr));
         for (uint32_t i = threadIdx.x; i < (nchq + nchr) * ANI_VOTE_WORDS; i += blockDim.x) vq[i] = 0;
     }
-    if (threadIdx.x < 6) red[threadIdx.x] = 0;
+    if (threadIdx.x < 6) red[threadIdx.x] = threadIdx.x == 4 ? ~0ull : 0ull;   // red[4]: the minimum the rank selection's atomicMin starts from
     if (threadIdx.x == 0) n_al = 0;
     __syncthreads();
 
@@ -498,7 +498,9 @@ __global__ __launch_bounds__(ANI_PAIR_WAVES * 64) __attribute__((amdgpu_waves_pe
     __syncthreads();
     const uint32_t n = n_al;
     PH(7);   // collect
-    if (threadIdx.x == 0) { red[3] = n; red[4] = ~0ull; }
+    // (red[4] = ~0 was written HERE by thread 0 until round 6, with no barrier between it and the other waves' atomicMin in the
+    // cross-multiplication branch below -- a wave that got there first had its minimum overwritten; found by tests/emu/wavesan.cpp)
+    if (threadIdx.x == 0) red[3] = n;
     const uint32_t target = n ? (n - 1) / 2 : 0;
     // Exact order of the fractions M_c/T_c through f64 keys: the quotient is correctly rounded, hence monotone, and
     // two different fractions with T < 2^26 differ by more than an ulp, so key order == cross-multiplied order and

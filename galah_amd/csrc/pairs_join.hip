@@ -498,7 +498,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_big_kernel(uint64_t
             const uint64_t ka = k[a];
             const uint32_t ga = v[a];
             if (join_in_long_run(k, cnt, a, ka)) {
-                if (!EMIT) { big[ga] = 1; marked = true; }
+                if (!EMIT) { __hip_atomic_store(&big[ga], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); marked = true; }   // (several workgroups may mark one genome)
                 continue;
             }
             for (uint32_t b = a + 1; b < cnt && k[b] == ka; b++) {
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(J_THREADS) void join_elem_pairs_kernel(uint64_t *__
         const uint64_t ka = k[a];
         const uint32_t ga = v[a];
         if (big && join_in_long_run(k, cnt, a, ka)) {   // a hash of a very large family: its genomes are marked, it emits nothing
-            if (!EMIT) { big[ga] = 1; marked = true; }
+            if (!EMIT) { __hip_atomic_store(&big[ga], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); marked = true; }   // (several workgroups may mark one genome)
             continue;
         }
         for (uint32_t b = a + 1; b < cnt && k[b] == ka; b++) {
