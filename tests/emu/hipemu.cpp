@@ -102,6 +102,7 @@ struct Worker {   // per OS thread
     size_t lds_cap = 0;
     Launch *cur = nullptr;
     uint32_t cur_thread = 0;
+    std::vector<uint32_t> wave_barriers;   // per wave of the running workgroup: wave_barriers passed (the race detector's lane rule)
 #ifdef HIPEMU_ASAN
     std::vector<void *> fake;           // each fibre's fake-stack handle while it is switched out
     void *sched_fake = nullptr;
@@ -173,6 +174,7 @@ inline void run_fiber(Worker *w, uint32_t t) {
     WaveSanState &ws = wavesan_state;
     ws.wave = t >> 6;
     ws.lane = t & 63;
+    ws.wave_epoch = w->wave_barriers[t >> 6];
     ws.in_kernel = true;
 #ifdef HIPEMU_ASAN
     __sanitizer_start_switch_fiber(&w->sched_fake, w->stacks + (size_t)t * STACK_BYTES, STACK_BYTES);
@@ -200,6 +202,7 @@ void resolve_wave(Worker *w, Launch *L, uint32_t lo, uint32_t hi) {
     for (uint32_t t = lo; t < hi; t++)
         if (w->st[t] == WAVE_WAIT && w->ctx[t].op_site == site) { mask |= 1ull << (t - lo); kind = w->ctx[t].op_kind; }
     g_stats.wave_ops++;
+    if (kind == OP_WAVE_BARRIER) w->wave_barriers[lo >> 6]++;
     if (__builtin_popcountll(mask) != (int)(hi - lo) || hi - lo != 64) g_stats.partial_ops++;
     uint64_t ballot = 0, first = 0;
     if (kind == OP_BALLOT)
@@ -251,6 +254,7 @@ void run_block(Worker *w, Launch *L, uint64_t b) {
         w->n_stacks = n;
     }
     if (w->ctx.size() < n) { w->ctx.resize(n); w->st.resize(n); w->sp.resize(n); }
+    w->wave_barriers.assign(nw, 0);
 #ifdef HIPEMU_ASAN
     if (w->fake.size() < n) w->fake.resize(n);
     if (w->lds) ASAN_UNPOISON_MEMORY_REGION(w->lds, w->lds_cap);

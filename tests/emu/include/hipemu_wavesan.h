@@ -12,6 +12,7 @@ struct WaveSanState {
     uint32_t block = 0;            // serial number of the workgroup (unique over the process: never 0)
     uint32_t wave = 0, lane = 0;   // of the running work-item
     uint32_t epoch = 0;            // how many __syncthreads this workgroup has passed
+    uint32_t wave_epoch = 0;       // how many wave_barriers the running work-item's wave has passed (in this workgroup)
     const char *kernel = "";
     uintptr_t stack_lo = 0, stack_len = 0;   // the fibre stacks of this thread: lane-private memory
     uintptr_t ctx_lo = 0, ctx_len = 0;       // the work-items' own records (threadIdx, blockIdx, ...): registers on the GPU

@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstring>
 
-extern "C" void hipemu_wavesan_counts(uint64_t out[4]);
+extern "C" void hipemu_wavesan_counts(uint64_t out[5]);
 
 // wave 0 produces, wave 1 consumes
 __global__ void lds_handover(uint32_t *out, int barrier) {
@@ -21,6 +21,14 @@ __global__ void global_handover(uint32_t *scratch, uint32_t *out, int barrier) {
     if (threadIdx.x < 64) mine[threadIdx.x] = threadIdx.x * 5u;
     if (barrier) __syncthreads();
     if (threadIdx.x >= 64) out[blockIdx.x * 64 + threadIdx.x - 64] = mine[127 - threadIdx.x];
+}
+// neighbouring lanes of one wave exchange through LDS: right with a wavefront fence + wave_barrier between store and load; without,
+// the compiler may emit the load first (lds[t] and lds[t ^ 1] never alias for one work-item) -- the opt-in lane rule (WAVESAN_LANES=1)
+__global__ void lane_exchange(uint32_t *out, int sync) {
+    __shared__ uint32_t buf[64];
+    buf[threadIdx.x] = threadIdx.x * 7u;
+    if (sync) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x ^ 1u];
 }
 // every wave writes its own part of LDS, atomics on a shared counter: nothing to report
 __global__ void disjoint_and_atomic(uint32_t *out) {
@@ -61,12 +69,13 @@ int main(int argc, char **argv) {
     hipMemset(f, 0, 64);
     hipLaunchKernelGGL(lds_handover, dim3(3), dim3(128), 0, nullptr, b, is("lds") ? 0 : 1);
     hipLaunchKernelGGL(global_handover, dim3(3), dim3(128), 0, nullptr, a, b, is("global") ? 0 : 1);
+    hipLaunchKernelGGL(lane_exchange, dim3(2), dim3(64), 0, nullptr, b, is("lanes") ? 0 : 1);
     hipLaunchKernelGGL(disjoint_and_atomic, dim3(3), dim3(256), 0, nullptr, b);
     hipLaunchKernelGGL(flag_handover, dim3(2), dim3(64), 0, nullptr, a, f, b, is("flag") ? 0 : is("scope") ? 2 : 1);
     hipDeviceSynchronize();
-    uint64_t c[4];
+    uint64_t c[5];
     hipemu_wavesan_counts(c);
-    printf("wavesan_selftest %s: write-write %llu read-write %llu inter-block %llu (accesses checked: %llu)\n", mode, (unsigned long long)c[0],
-           (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[3]);
+    printf("wavesan_selftest %s: write-write %llu read-write %llu inter-block %llu lanes %llu (accesses checked: %llu)\n", mode, (unsigned long long)c[0],
+           (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[4], (unsigned long long)c[3]);
     return 0;
 }

@@ -47,7 +47,8 @@ using hipemu::wavesan_state;
 
 struct Access {
     uint32_t launch, block, epoch;
-    uint8_t wave, mask, atomic, spare;
+    uint8_t wave, mask, atomic, lane;
+    uint32_t wave_epoch;
     uint64_t seq;                        // global atomic-operation count when the access was made
     const void *pc;
 };
@@ -83,10 +84,10 @@ thread_local Mine t_mine;
 
 std::mutex g_rep_mu;
 std::set<std::tuple<std::string, int, const void *, const void *>> g_seen;
-std::atomic<uint64_t> g_reports[3];   // distinct reports by kind: 0 intra write-write, 1 intra read/write, 2 inter-block
+std::atomic<uint64_t> g_reports[4];   // distinct reports by kind: 0 intra write-write, 1 intra read/write, 2 inter-block, 3 lanes of one wave
 std::atomic<uint64_t> g_checked{0};
 FILE *g_log = nullptr;
-int g_inter = 1;
+int g_inter = 1, g_lanes = 0;   // (the lane rule is opt-in: WAVESAN_LANES=1)
 
 void init() {
     g_cells = (Cell *)mmap(nullptr, CELLS * sizeof(Cell), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -100,6 +101,7 @@ void init() {
     }
     if (!g_log) g_log = stderr;
     if (const char *v = getenv("WAVESAN_INTER_BLOCK")) g_inter = atoi(v);
+    if (const char *v = getenv("WAVESAN_LANES")) g_lanes = atoi(v);
 }
 
 std::string where(const void *pc) {
@@ -141,6 +143,20 @@ inline void one(uintptr_t granule, uint8_t mask, bool write, bool atomic, const 
     const uint64_t seq = g_seq.load(std::memory_order_relaxed);
     const uintptr_t addr = granule << 3;
     const bool shared_memory = addr - s.dyn_lds_lo >= s.dyn_lds_len && addr - s.static_lds_lo >= s.static_lds_len;   // (LDS addresses are reused here, not there)
+    // rule 0 (LDS only): the same wave, different lanes, no wave_barrier between -- the lanes run in lockstep, but the COMPILER orders a
+    // work-item's own LDS store and load only if they may alias; lds[lane] = x; y = lds[lane ^ 1] may be emitted load-first unless a
+    // wavefront fence + wave_barrier (wave_sync()) stands between them
+    if (g_lanes && !shared_memory) {
+        if (c.w.block == s.block && c.w.epoch == s.epoch && c.w.wave == s.wave && c.w.lane != s.lane && c.w.wave_epoch == s.wave_epoch && (c.w.mask & mask) &&
+            !(c.w.atomic && atomic))
+            report(3, write ? "missing wave barrier (write after another lane's write)" : "missing wave barrier (read after another lane's write)", c.w, true, pc,
+                   write, atomic, addr);
+        if (write)
+            for (const Access &r : c.r)
+                if ((r.mask & mask) && !(r.atomic && atomic) && r.block == s.block && r.epoch == s.epoch && r.wave == s.wave && r.lane != s.lane &&
+                    r.wave_epoch == s.wave_epoch)
+                    report(3, "missing wave barrier (write after another lane's read)", r, false, pc, write, atomic, addr);
+    }
     // rule 1: same workgroup, same barrier interval, different waves
     if (c.w.block == s.block && c.w.epoch == s.epoch && c.w.wave != s.wave && (c.w.mask & mask) && !(c.w.atomic && atomic))
         report(write ? 0 : 1, write ? "missing barrier (write after write)" : "missing barrier (read after write)", c.w, true, pc, write, atomic, addr);
@@ -157,18 +173,18 @@ inline void one(uintptr_t granule, uint8_t mask, bool write, bool atomic, const 
                 report(2, "inter-block (write after read, no release/acquire between)", r, false, pc, write, atomic, addr);
         }
     if (write) {
-        if (c.w.block == s.block && c.w.epoch == s.epoch && c.w.wave == s.wave) { c.w.mask |= mask; c.w.atomic &= (uint8_t)atomic; }
-        else c.w = Access{s.launch, s.block, s.epoch, (uint8_t)s.wave, mask, (uint8_t)atomic, 0, seq, pc};
+        if (c.w.block == s.block && c.w.epoch == s.epoch && c.w.wave == s.wave && (!g_lanes || (c.w.lane == s.lane && c.w.wave_epoch == s.wave_epoch))) { c.w.mask |= mask; c.w.atomic &= (uint8_t)atomic; }
+        else c.w = Access{s.launch, s.block, s.epoch, (uint8_t)s.wave, mask, (uint8_t)atomic, (uint8_t)s.lane, s.wave_epoch, seq, pc};
         c.w.seq = seq;
         c.w.pc = pc;
     } else {
         Access *mine = nullptr, *stale = nullptr;
         for (Access &r : c.r) {
-            if (r.block == s.block && r.epoch == s.epoch && r.wave == s.wave) mine = &r;
+            if (r.block == s.block && r.epoch == s.epoch && r.wave == s.wave && (!g_lanes || (r.lane == s.lane && r.wave_epoch == s.wave_epoch))) mine = &r;
             else if (r.block != s.block || r.epoch != s.epoch) stale = &r;
         }
         if (mine) { mine->mask |= mask; mine->atomic &= (uint8_t)atomic; mine->seq = seq; }
-        else *(stale ? stale : &c.r[1]) = Access{s.launch, s.block, s.epoch, (uint8_t)s.wave, mask, (uint8_t)atomic, 0, seq, pc};
+        else *(stale ? stale : &c.r[1]) = Access{s.launch, s.block, s.epoch, (uint8_t)s.wave, mask, (uint8_t)atomic, (uint8_t)s.lane, s.wave_epoch, seq, pc};
     }
     c.lock.store(0, std::memory_order_release);
 }
@@ -290,8 +306,8 @@ void __tsan_atomic_signal_fence(int) { __atomic_signal_fence(__ATOMIC_SEQ_CST); 
 ATOMICS(8, uint8_t) ATOMICS(16, uint16_t) ATOMICS(32, uint32_t) ATOMICS(64, uint64_t)
 #undef ATOMICS
 
-// what the detector saw: distinct reports of rule 1 (write/write), rule 1 (read/write), rule 2 (inter-block); accesses checked
-void hipemu_wavesan_counts(uint64_t out[4]) {
-    out[0] = g_reports[0]; out[1] = g_reports[1]; out[2] = g_reports[2]; out[3] = g_checked;
+// what the detector saw: distinct reports of rule 1 (write/write), rule 1 (read/write), rule 2 (inter-block); accesses checked; rule 0 (lanes)
+void hipemu_wavesan_counts(uint64_t out[5]) {
+    out[0] = g_reports[0]; out[1] = g_reports[1]; out[2] = g_reports[2]; out[3] = g_checked; out[4] = g_reports[3];
 }
 }

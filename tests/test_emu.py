@@ -180,7 +180,7 @@ def test_wave_race_detector_reports_what_it_should(checked_builds):
     exe = os.path.join(EMU_DIR, "build", "wavesan_selftest")
     for order in ("forward", "reverse", "7"):
         for mode, want in (("ok", (0, 0, 0)), ("lds", (0, 1, 0)), ("global", (0, 1, 0)), ("flag", (0, 0, 1)), ("scope", (0, 0, 1))):
-            r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIPEMU_ORDER=order))
+            r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIPEMU_ORDER=order, WAVESAN_LANES="0"))
             m = re.search(r"write-write (\d+) read-write (\d+) inter-block (\d+)", r.stdout)
             assert r.returncode == 0 and m, r.stdout + r.stderr
             assert tuple(int(x) for x in m.groups()) == want, (order, mode, r.stdout, r.stderr[-1500:])
@@ -207,6 +207,18 @@ def _smoke_and_core(san, logs):
 def _rccl_cases():
     passed, summary = run_emulated([os.path.join("tests", "emu", "cases")], timeout=1800)
     assert passed >= 9, summary
+
+
+def test_wave_race_detector_lane_rule(checked_builds):
+    """The opt-in lane rule (WAVESAN_LANES=1): neighbouring lanes of one wave exchanging through LDS with no wavefront fence +
+    wave_barrier between the store and the load are reported (the compiler may emit the load first); with them, silence."""
+    exe = os.path.join(EMU_DIR, "build", "wavesan_selftest")
+    for mode, want in (("ok", 0), ("lanes", 1)):
+        r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=dict(os.environ, WAVESAN_LANES="1"))
+        m = re.search(r"lanes (\d+)", r.stdout)
+        assert r.returncode == 0 and m and (int(m.group(1)) >= 1) == bool(want), (mode, r.stdout, r.stderr[-1500:])
+        if want:
+            assert "missing wave barrier" in r.stderr and "lane_exchange" in r.stderr
 
 
 @pytest.fixture(scope="module")
