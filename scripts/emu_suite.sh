@@ -7,6 +7,7 @@
 #   SAN=wavesan   the kernels under the wave race detector (tests/emu/wavesan.cpp): a __syncthreads missing between two waves'
 #                 accesses, a hand-over between workgroups without release / acquire; reports symbolized and counted at the end
 #   EMU_EXTRA     further pytest arguments (deselections of the longest tests under the race detector)
+#   SAN=cov       the kernel files with edge coverage (tests/emu/covrt.cpp): ends with the lines of device code no test executed
 #   HIPEMU_ORDER  the order in which the waves of a workgroup and the lanes of a wave take their turns (tests/emu/hipemu.cpp)
 #   The suite runs in a SNAPSHOT of the tree (a copy under /tmp, built there): it takes hours, and a file of the tree edited meanwhile --
 #   galah_amd/_lib.py gaining a symbol the running build lacks -- otherwise fails every test that starts a fresh process (the first
@@ -34,6 +35,8 @@ if [ "$SAN" = asan ]; then
   export ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:log_path=$SANLOGS/san UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$SANLOGS/san
 elif [ "$SAN" = wavesan ]; then
   export WAVESAN_LOG=$SANLOGS/ws
+elif [ "$SAN" = cov ]; then
+  export HIPEMU_COV_OUT=$SANLOGS/cov
 fi
 export GALAH_TEST_EMU=1 HIPEMU_LIB=$PWD/tests/emu/$LIBNAME GHIP_RCCL_LIBRARY=$PWD/tests/emu/fake_rccl/librccl.so.1
 DESELECT=$(python3 - <<'PY'
@@ -49,7 +52,10 @@ PY
     echo "# tests/emu/cases (the RCCL transport with thread ranks over the stand-in librccl)"
     python3 -m pytest tests/emu/cases -q -p no:cacheprovider --tb=short 2>&1 | tail -5
   fi
-  if [ "$SAN" = wavesan ]; then
+  if [ "$SAN" = cov ]; then
+    echo "# which lines of the kernel files the run above executed (scripts/emu_coverage.py)"
+    python3 scripts/emu_coverage.py $SANLOGS/cov.*
+  elif [ "$SAN" = wavesan ]; then
     echo "# wave race detector: reports by source location (scripts/wavesan_symbolize.py)"
     python3 scripts/wavesan_symbolize.py $SANLOGS/ws.* 2>/dev/null
   elif [ -n "$SAN" ]; then
