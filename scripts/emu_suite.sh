@@ -30,6 +30,7 @@ if [ -n "$SAN" ]; then
   LIBNAME=libgalah_hip_emu_$SAN.so
   SANLOGS=$(mktemp -d /tmp/emu_sanlogs.XXXXXX)
 fi
+[ -n "$SAN" ] && export GALAH_TEST_SLOW=5   # (the multi-process tests' own "a rank hangs" timeouts are sized for the plain emulator)
 if [ "$SAN" = asan ]; then
   export LD_PRELOAD=$(make -s -C tests/emu asan-rt) GHIP_POOL_EXACT=1
   export ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:log_path=$SANLOGS/san UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$SANLOGS/san

@@ -92,7 +92,9 @@ def _run(world, **kw):
         # (a fault run that hangs must cost three minutes, not the suite: its ranks are killed, and the fault cases after it
         # do not start -- _FAULT_HUNG)
         # (the first answer also waits for the ranks to start and run a clean pass; the others follow it within seconds)
-        got = [q.get(timeout=180 if r == 0 else 60) for r in range(world)] if kw.get("fault") is not None else q.get(timeout=900)
+        # (GALAH_TEST_SLOW: the emulated suite under a sanitizer runs 3-10 times slower than the emulator alone -- scripts/emu_suite.sh)
+        slow = float(os.environ.get("GALAH_TEST_SLOW", "1"))
+        got = [q.get(timeout=slow * (180 if r == 0 else 60)) for r in range(world)] if kw.get("fault") is not None else q.get(timeout=slow * 900)
     except queue.Empty:
         for p in procs:
             p.terminate()
